@@ -1,0 +1,80 @@
+"""ctypes binding of libeffort_hip.so (include/effort_hip.h).
+
+There is NO fallback: if the HIP library is missing or a call fails, this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libeffort_hip.so")
+
+ERRORS = {
+    -1: "EFFORT_ERR_ARG", -2: "EFFORT_ERR_SHAPE", -3: "EFFORT_ERR_EFFORT", -4: "EFFORT_ERR_HIP",
+    -5: "EFFORT_ERR_KIND", -6: "EFFORT_ERR_CONVERT", -7: "EFFORT_ERR_BLAS",
+}
+
+
+class EffortError(RuntimeError):
+    def __init__(self, code: int, where: str, detail: str = ""):
+        self.code = code
+        super().__init__(f"{where}: {ERRORS.get(code, code)} {detail}".strip())
+
+
+def build(verbose: bool = False) -> str:
+    """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j8"]
+    res = subprocess.run(cmd, capture_output=not verbose, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("building libeffort_hip.so failed:\n" + (res.stdout or "") + (res.stderr or ""))
+    return LIB_PATH
+
+
+_P = C.c_void_p
+_SIGS = {
+    "effort_create": (_P, [C.c_int, _P]),
+    "effort_destroy": (None, [_P]),
+    "effort_set_stream": (C.c_int, [_P, _P]),
+    "effort_sync": (C.c_int, [_P]),
+    "effort_last_error": (C.c_char_p, [_P]),
+    "effort_version": (C.c_char_p, []),
+    "effort_weights_fp16": (_P, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "effort_weights_q4": (_P, [_P, _P, _P, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_int]),
+    "effort_weights_free": (None, [_P]),
+    "effort_bucketmul": (C.c_int, [_P, _P, _P, _P, _P, C.c_double]),
+    "effort_bucketmul_q4": (C.c_int, [_P, _P, _P, _P, _P, C.c_double]),
+    "effort_dense_gemv": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int]),
+    "effort_last_dispatch_count": (C.c_int, [_P, C.POINTER(C.c_uint32)]),
+    "effort_last_cutoff": (C.c_int, [_P, C.POINTER(C.c_float)]),
+    "effort_calc_dispatch": (C.c_int, [_P, _P, _P, _P, C.c_double, _P, _P]),
+    "effort_convert_fp16": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P]),
+    "effort_cosine": (C.c_int, [_P, _P, _P, C.c_int, C.POINTER(C.c_float)]),
+    "effort_set_tuning": (C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
+    "effort_enable_kernel_timing": (C.c_int, [_P, C.c_int]),
+    "effort_kernel_timing": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built "
+                "(run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C effort_amd/csrc`). "
+                "effort_amd has no CPU fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(l, name)        # AttributeError if the ABI and the header drifted apart
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def exported_symbols() -> list[str]:
+    return sorted(_SIGS)

@@ -1,0 +1,358 @@
+// C ABI of libeffort_hip.so (include/effort_hip.h): contexts, weight handles, launch orchestration.
+// Host-side equivalent of class BucketMul / BucketMulQ4 (bucketMul.swift:18-90, bucketMulQ4.swift:18-87)
+// and of the slice of class Gpu they use (helpers/gpu.swift:109-196).
+#include <rocblas/rocblas.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "../../include/effort_hip.h"
+#include "effort_internal.h"
+
+using namespace effort;
+
+struct effort_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int numCU = 256;
+    // scratch owned by the context (the reference's singleton state)
+    float* d_cutoff = nullptr;        // BucketMul.cutoff
+    uint32_t* d_count = nullptr;      // dispatch.size
+    float* d_slabs = nullptr;         // partial tiles (replaces tmpMulVec)
+    size_t slabBytes = 0;
+    uint32_t* d_blockScratch = nullptr;
+    uint16_t* d_vhalf = nullptr;      // v.asFloat16() for the dense baseline
+    size_t vhalfElems = 0;
+    float* d_cos = nullptr;
+    uint16_t* d_convVals = nullptr;   // converter scratch (transposed matrix)
+    size_t convElems = 0;
+    int* d_status = nullptr;
+    rocblas_handle blas = nullptr;
+    // tuning overrides (0 = heuristic)
+    int tuneW = 0, tuneE = 0, tuneS = 0;
+    // optional per-kernel timing
+    bool timing = false;
+    static constexpr int kMaxSamples = 4096;
+    hipEvent_t* ev = nullptr;         // 4 events per sample
+    int nSamples = 0;
+    char err[256] = {0};
+};
+
+struct effort_w {
+    effort_ctx* ctx = nullptr;
+    Format fmt = kFp16;
+    const uint16_t* buckets = nullptr;
+    const void* stats = nullptr;
+    const uint16_t* probes = nullptr;
+    uint32_t inDim = 0, outDim = 0, rowsPerIn = 0, numExperts = 1, cols = 0;
+    // Q4 outliers
+    uint64_t nOutliers = 0;
+    uint32_t* olRowPtr = nullptr;
+    uint32_t* olInIdx = nullptr;
+    float* olValue = nullptr;
+};
+
+static int fail(effort_ctx* c, int code, const char* what, hipError_t e = hipSuccess) {
+    if (c) {
+        if (e != hipSuccess) snprintf(c->err, sizeof(c->err), "%s: %s", what, hipGetErrorString(e));
+        else snprintf(c->err, sizeof(c->err), "%s", what);
+    }
+    return code;
+}
+#define HIP_TRY(ctx, call)                                                   \
+    do {                                                                     \
+        hipError_t e_ = (call);                                              \
+        if (e_ != hipSuccess) return fail((ctx), EFFORT_ERR_HIP, #call, e_); \
+    } while (0)
+
+extern "C" const char* effort_version(void) { return "effort-hip 0.1 (gfx950)"; }
+extern "C" const char* effort_last_error(effort_ctx* c) { return c ? c->err : "null context"; }
+
+extern "C" effort_ctx* effort_create(int device, void* stream) {
+    if (hipSetDevice(device) != hipSuccess) return nullptr;
+    effort_ctx* c = new (std::nothrow) effort_ctx();
+    if (!c) return nullptr;
+    c->device = device;
+    c->stream = reinterpret_cast<hipStream_t>(stream);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->numCU = prop.multiProcessorCount;
+    c->slabBytes = (size_t)64 << 20;
+    bool ok = hipMalloc(&c->d_cutoff, 16) == hipSuccess && hipMalloc(&c->d_count, 16) == hipSuccess &&
+              hipMalloc(&c->d_slabs, c->slabBytes) == hipSuccess && hipMalloc(&c->d_blockScratch, 4096 * 4) == hipSuccess &&
+              hipMalloc(&c->d_cos, 16) == hipSuccess && hipMalloc(&c->d_status, 16) == hipSuccess;
+    if (!ok) { effort_destroy(c); return nullptr; }
+    hipMemset(c->d_cutoff, 0, 16);
+    hipMemset(c->d_count, 0, 16);
+    hipMemset(c->d_status, 0, 16);
+    return c;
+}
+
+extern "C" void effort_destroy(effort_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    if (c->blas) rocblas_destroy_handle(c->blas);
+    if (c->ev) { for (int i = 0; i < effort_ctx::kMaxSamples * 4; i++) hipEventDestroy(c->ev[i]); delete[] c->ev; }
+    hipFree(c->d_cutoff); hipFree(c->d_count); hipFree(c->d_slabs); hipFree(c->d_blockScratch);
+    hipFree(c->d_vhalf); hipFree(c->d_cos); hipFree(c->d_convVals); hipFree(c->d_status);
+    delete c;
+}
+
+extern "C" int effort_set_stream(effort_ctx* c, void* stream) {
+    if (!c) return EFFORT_ERR_ARG;
+    c->stream = reinterpret_cast<hipStream_t>(stream);
+    if (c->blas) rocblas_set_stream(c->blas, c->stream);
+    return EFFORT_OK;
+}
+
+extern "C" int effort_sync(effort_ctx* c) {
+    if (!c) return EFFORT_ERR_ARG;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return EFFORT_OK;
+}
+
+// ---- weights ------------------------------------------------------------------------------------
+static int check_shape(uint32_t inDim, uint32_t outDim) {
+    // bucketMul.swift:73-76 (outDim%16, (outDim/16)%4), :52 tmpMulVec 16384 wide; probes need 4096 inputs (:36)
+    if (inDim < (uint32_t)kProbes || outDim == 0 || outDim % 16 || (outDim / 16) % 4 || outDim > 16384) return EFFORT_ERR_SHAPE;
+    return EFFORT_OK;
+}
+
+extern "C" effort_w* effort_weights_fp16(effort_ctx* c, const void* buckets, const void* stats, const void* probes,
+                                         int inDim, int outDim, int percentLoad, int numExperts) {
+    if (!c || !buckets || !stats || !probes) { fail(c, EFFORT_ERR_ARG, "effort_weights_fp16: null argument"); return nullptr; }
+    if (inDim <= 0 || outDim <= 0 || percentLoad < 1 || percentLoad > 16 || numExperts < 1 || check_shape(inDim, outDim) != EFFORT_OK ||
+        inDim > 65535) { fail(c, EFFORT_ERR_SHAPE, "effort_weights_fp16: unsupported shape"); return nullptr; }
+    effort_w* w = new (std::nothrow) effort_w();
+    if (!w) return nullptr;
+    w->ctx = c; w->fmt = kFp16;
+    w->buckets = static_cast<const uint16_t*>(buckets); w->stats = stats; w->probes = static_cast<const uint16_t*>(probes);
+    w->inDim = inDim; w->outDim = outDim; w->rowsPerIn = percentLoad; w->numExperts = numExperts; w->cols = outDim / 16;
+    return w;
+}
+
+extern "C" effort_w* effort_weights_q4(effort_ctx* c, const void* buckets, const void* stats, const void* probes,
+                                       const void* outliers, int64_t nOutliers, int inDim, int outDim, int numExperts) {
+    if (!c || !buckets || !stats || !probes) { fail(c, EFFORT_ERR_ARG, "effort_weights_q4: null argument"); return nullptr; }
+    if (inDim <= 0 || outDim <= 0 || numExperts < 1 || check_shape(inDim, outDim) != EFFORT_OK || outDim % 32 || inDim > 65535 ||
+        nOutliers < 0) { fail(c, EFFORT_ERR_SHAPE, "effort_weights_q4: unsupported shape"); return nullptr; }
+    effort_w* w = new (std::nothrow) effort_w();
+    if (!w) return nullptr;
+    w->ctx = c; w->fmt = kQ4;
+    w->buckets = static_cast<const uint16_t*>(buckets); w->stats = stats; w->probes = static_cast<const uint16_t*>(probes);
+    w->inDim = inDim; w->outDim = outDim; w->rowsPerIn = 8; w->numExperts = numExperts; w->cols = outDim / 32;
+    if (outliers && nOutliers > 0) {
+        hipSetDevice(c->device);
+        uint32_t* cursor = nullptr;
+        w->nOutliers = (uint64_t)nOutliers;
+        bool ok = hipMalloc(&w->olRowPtr, (size_t)(outDim + 1) * 4) == hipSuccess && hipMalloc(&w->olInIdx, (size_t)nOutliers * 4) == hipSuccess &&
+                  hipMalloc(&w->olValue, (size_t)nOutliers * 4) == hipSuccess && hipMalloc(&cursor, ((size_t)outDim + nOutliers) * 4) == hipSuccess;
+        if (ok) ok = launch_build_outlier_index(static_cast<const float*>(outliers), w->nOutliers, outDim, w->olRowPtr, w->olInIdx,
+                                                w->olValue, cursor, c->stream) == hipSuccess;
+        if (ok) ok = hipStreamSynchronize(c->stream) == hipSuccess;
+        hipFree(cursor);
+        if (!ok) { fail(c, EFFORT_ERR_HIP, "effort_weights_q4: outlier index"); effort_weights_free(w); return nullptr; }
+    }
+    return w;
+}
+
+extern "C" void effort_weights_free(effort_w* w) {
+    if (!w) return;
+    hipFree(w->olRowPtr); hipFree(w->olInIdx); hipFree(w->olValue);
+    delete w;
+}
+
+// ---- launch geometry ----------------------------------------------------------------------------
+static bool supported(int W, int E) {
+    return (W == 16 && (E == 1 || E == 2)) || ((W == 8 || W == 4) && (E == 1 || E == 2 || E == 4));
+}
+
+static int choose_geom(const effort_ctx* c, const effort_w* w, MulGeom* g, int* Wout, int* Eout) {
+    const int W = c->tuneW ? c->tuneW : 16;
+    const int E = c->tuneE ? c->tuneE : 1;
+    if (!supported(W, E)) return EFFORT_ERR_ARG;
+    const uint32_t nacc = w->fmt == kFp16 ? 16 : 32;
+    g->inDim = w->inDim; g->outDim = w->outDim; g->cols = w->cols; g->rowsPerIn = w->rowsPerIn;
+    g->expertRows = w->rowsPerIn * w->inDim;
+    g->tiles = (w->cols + 64 * E - 1) / (64 * E);
+    g->tileFloats = nacc * E * 64;
+    const size_t ldsMax = 160 * 1024;
+    uint32_t S;
+    if (c->tuneS) S = c->tuneS;
+    else {
+        // fill the chip: about two workgroups per CU when the accumulator tiles allow it
+        const size_t accBytes = (size_t)W * g->tileFloats * 4;
+        const uint32_t perCU = accBytes * 2 + 16384 <= ldsMax ? 2u : 1u;
+        S = (c->numCU * perCU + g->tiles - 1) / g->tiles;
+    }
+    S = (S + 7) / 8 * 8;
+    if (S > w->inDim) S = w->inDim / 8 * 8;
+    if (S < 8) S = 8;
+    for (;;) {
+        g->sliceRows = (w->inDim + S - 1) / S;
+        g->slices = (w->inDim + g->sliceRows - 1) / g->sliceRows;
+        const size_t lds = bucket_mul_lds_bytes(w->fmt, W, E, g->sliceRows, g->rowsPerIn);
+        const bool fits = lds <= ldsMax && g->sliceRows <= (w->fmt == kFp16 ? 4096u : 8192u);
+        const size_t slab = (size_t)g->slices * g->tiles * g->tileFloats * 4;
+        if (fits && slab <= c->slabBytes) break;
+        if (!fits) { S += 8; if (S > w->inDim + 8) return EFFORT_ERR_SHAPE; }
+        else return EFFORT_ERR_SHAPE;
+    }
+    *Wout = W; *Eout = E;
+    return EFFORT_OK;
+}
+
+static int ensure_timing(effort_ctx* c) {
+    if (c->ev) return EFFORT_OK;
+    c->ev = new (std::nothrow) hipEvent_t[effort_ctx::kMaxSamples * 4];
+    if (!c->ev) return EFFORT_ERR_HIP;
+    for (int i = 0; i < effort_ctx::kMaxSamples * 4; i++) HIP_TRY(c, hipEventCreate(&c->ev[i]));
+    return EFFORT_OK;
+}
+
+static int do_bucketmul(effort_ctx* c, const effort_w* w, Format fmt, const float* v, const uint32_t* expNo, float* out, double effort) {
+    if (!c || !w || !v || !out) return fail(c, EFFORT_ERR_ARG, "bucketmul: null argument");
+    if (w->fmt != fmt) return fail(c, EFFORT_ERR_KIND, "bucketmul: weight handle of the wrong kind");
+    if (!(effort >= 0.0 && effort <= 1.0)) return fail(c, EFFORT_ERR_EFFORT, "bucketmul: effort outside [0,1]");
+    MulGeom g; int W, E;
+    int rc = choose_geom(c, w, &g, &W, &E);
+    if (rc != EFFORT_OK) return fail(c, rc, "bucketmul: no launch geometry for this shape/tuning");
+    const uint32_t q = (uint32_t)(int)((double)(kProbes - 1) * (1.0 - effort));      // bucketMul.swift:39
+    const bool tm = c->timing && c->nSamples < effort_ctx::kMaxSamples;
+    hipEvent_t* ev = tm ? c->ev + 4 * c->nSamples : nullptr;
+
+    if (tm) HIP_TRY(c, hipEventRecord(ev[0], c->stream));
+    HIP_TRY(c, launch_find_cutoff(v, w->probes, expNo, q, c->d_cutoff, c->d_count, c->stream));
+    if (tm) HIP_TRY(c, hipEventRecord(ev[1], c->stream));
+    MulArgs a;
+    a.buckets = w->buckets; a.stats = w->stats; a.v = v; a.expNo = expNo; a.cutoff = c->d_cutoff;
+    a.slabs = c->d_slabs; a.dispatchCount = c->d_count; a.g = g;
+    HIP_TRY(c, launch_bucket_mul(fmt, W, E, a, c->stream));
+    if (tm) HIP_TRY(c, hipEventRecord(ev[2], c->stream));
+    OutlierIndex ol{w->olRowPtr, w->olInIdx, w->olValue};
+    HIP_TRY(c, launch_integrate(fmt, E, c->d_slabs, g, out, (fmt == kQ4 && w->olRowPtr) ? &ol : nullptr, v, c->stream));
+    if (tm) { HIP_TRY(c, hipEventRecord(ev[3], c->stream)); c->nSamples++; }
+    return EFFORT_OK;
+}
+
+extern "C" int effort_bucketmul(effort_ctx* c, const effort_w* w, const float* v, const uint32_t* expNo, float* out, double effort) {
+    return do_bucketmul(c, w, kFp16, v, expNo, out, effort);
+}
+extern "C" int effort_bucketmul_q4(effort_ctx* c, const effort_w* w, const float* v, const uint32_t* expNo, float* out, double effort) {
+    return do_bucketmul(c, w, kQ4, v, expNo, out, effort);
+}
+
+extern "C" int effort_calc_dispatch(effort_ctx* c, const effort_w* w, const float* v, const uint32_t* expNo, double effort,
+                                    float* dispatch, uint32_t* count) {
+    if (!c || !w || !v || !dispatch) return fail(c, EFFORT_ERR_ARG, "calc_dispatch: null argument");
+    if (!(effort >= 0.0 && effort <= 1.0)) return fail(c, EFFORT_ERR_EFFORT, "calc_dispatch: effort outside [0,1]");
+    MulGeom g; int W, E;
+    int rc = choose_geom(c, w, &g, &W, &E);
+    if (rc != EFFORT_OK) return fail(c, rc, "calc_dispatch: geometry");
+    const uint32_t q = (uint32_t)(int)((double)(kProbes - 1) * (1.0 - effort));
+    HIP_TRY(c, launch_find_cutoff(v, w->probes, expNo, q, c->d_cutoff, c->d_count, c->stream));
+    HIP_TRY(c, launch_calc_dispatch(w->fmt, w->stats, v, expNo, c->d_cutoff, g, dispatch, count, c->d_count, c->d_blockScratch, c->stream));
+    return EFFORT_OK;
+}
+
+extern "C" int effort_last_dispatch_count(effort_ctx* c, uint32_t* host_out) {
+    if (!c || !host_out) return EFFORT_ERR_ARG;
+    HIP_TRY(c, hipMemcpyAsync(host_out, c->d_count, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return EFFORT_OK;
+}
+extern "C" int effort_last_cutoff(effort_ctx* c, float* host_out) {
+    if (!c || !host_out) return EFFORT_ERR_ARG;
+    HIP_TRY(c, hipMemcpyAsync(host_out, c->d_cutoff, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return EFFORT_OK;
+}
+
+// ---- dense baseline ------------------------------------------------------------------------------
+extern "C" int effort_dense_gemv(effort_ctx* c, const void* W, const float* v, float* out, int inDim, int outDim) {
+    if (!c || !W || !v || !out || inDim <= 0 || outDim <= 0) return fail(c, EFFORT_ERR_ARG, "dense_gemv: bad argument");
+    if (inDim % 16) return fail(c, EFFORT_ERR_SHAPE, "dense_gemv: inDim % 16 != 0 (helpers/mps.swift:18)");
+    if (!c->blas) {
+        if (rocblas_create_handle(&c->blas) != rocblas_status_success) return fail(c, EFFORT_ERR_BLAS, "rocblas_create_handle");
+        rocblas_set_stream(c->blas, c->stream);
+        rocblas_set_pointer_mode(c->blas, rocblas_pointer_mode_host);
+    }
+    if ((size_t)inDim > c->vhalfElems) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        hipFree(c->d_vhalf); c->d_vhalf = nullptr; c->vhalfElems = 0;
+        HIP_TRY(c, hipMalloc(&c->d_vhalf, (size_t)inDim * 2));
+        c->vhalfElems = inDim;
+    }
+    HIP_TRY(c, launch_f32_to_f16(v, c->d_vhalf, inDim, c->stream));                  // v.asFloat16(), mps.swift:19
+    // W is [outDim][inDim] row-major == column-major inDim x outDim with lda = inDim: y = A^T x
+    const float alpha = 1.0f, beta = 0.0f;
+    rocblas_status s = rocblas_hssgemv_strided_batched(c->blas, rocblas_operation_transpose, inDim, outDim, &alpha,
+                                                       static_cast<const rocblas_half*>(W), inDim, 0,
+                                                       reinterpret_cast<const rocblas_half*>(c->d_vhalf), 1, 0, &beta, out, 1, 0, 1);
+    if (s != rocblas_status_success) return fail(c, EFFORT_ERR_BLAS, "rocblas_hssgemv_strided_batched");
+    return EFFORT_OK;
+}
+
+// ---- converter -----------------------------------------------------------------------------------
+extern "C" int effort_convert_fp16(effort_ctx* c, const void* W, int outDim, int inDim, void* buckets, void* stats, void* probes) {
+    if (!c || !W || !buckets || !stats || !probes) return fail(c, EFFORT_ERR_ARG, "convert_fp16: null argument");
+    // convert.swift:210-215,239 + the 16384-wide limit of the multiply (bucketMul.swift:52)
+    if (outDim <= 0 || inDim < kProbes || !(outDim >= kProbes || kProbes % outDim == 0) || outDim > 16384 || inDim > 32000 ||
+        outDim % 16 || (outDim / 16) % 4)
+        return fail(c, EFFORT_ERR_CONVERT, "convert_fp16: bucketize preconditions violated");
+    const size_t elems = (size_t)outDim * inDim;
+    if (elems > c->convElems) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        hipFree(c->d_convVals); c->d_convVals = nullptr; c->convElems = 0;
+        HIP_TRY(c, hipMalloc(&c->d_convVals, elems * 2));
+        c->convElems = elems;
+    }
+    HIP_TRY(c, launch_convert_fp16(static_cast<const uint16_t*>(W), outDim, inDim, static_cast<uint16_t*>(buckets),
+                                   static_cast<uint16_t*>(stats), static_cast<uint16_t*>(probes), c->d_convVals, c->d_status, c->stream));
+    return EFFORT_OK;
+}
+
+extern "C" int effort_cosine(effort_ctx* c, const float* a, const float* b, int n, float* host_out) {
+    if (!c || !a || !b || !host_out || n <= 0) return EFFORT_ERR_ARG;
+    HIP_TRY(c, launch_cosine(a, b, n, c->d_cos, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(host_out, c->d_cos, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return EFFORT_OK;
+}
+
+// ---- tuning / timing -----------------------------------------------------------------------------
+extern "C" int effort_set_tuning(effort_ctx* c, int W, int E, int S) {
+    if (!c) return EFFORT_ERR_ARG;
+    if ((W || E) && !supported(W ? W : 16, E ? E : 1)) return fail(c, EFFORT_ERR_ARG, "set_tuning: unsupported (waves, elems)");
+    if (S < 0) return EFFORT_ERR_ARG;
+    c->tuneW = W; c->tuneE = E; c->tuneS = S;
+    return EFFORT_OK;
+}
+
+extern "C" int effort_enable_kernel_timing(effort_ctx* c, int enable) {
+    if (!c) return EFFORT_ERR_ARG;
+    if (enable) { int rc = ensure_timing(c); if (rc != EFFORT_OK) return rc; }
+    c->timing = enable != 0;
+    c->nSamples = 0;
+    return EFFORT_OK;
+}
+
+extern "C" int effort_kernel_timing(effort_ctx* c, double* mul_us, double* cutoff_us, double* integrate_us, int* n) {
+    if (!c) return EFFORT_ERR_ARG;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    double a = 0, b = 0, d = 0;
+    for (int i = 0; i < c->nSamples; i++) {
+        float ms;
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[4 * i + 0], c->ev[4 * i + 1])); a += ms;
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[4 * i + 1], c->ev[4 * i + 2])); b += ms;
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[4 * i + 2], c->ev[4 * i + 3])); d += ms;
+    }
+    const int ns = c->nSamples ? c->nSamples : 1;
+    if (cutoff_us) *cutoff_us = a * 1000.0 / ns;
+    if (mul_us) *mul_us = b * 1000.0 / ns;
+    if (integrate_us) *integrate_us = d * 1000.0 / ns;
+    if (n) *n = c->nSamples;
+    c->nSamples = 0;
+    return EFFORT_OK;
+}

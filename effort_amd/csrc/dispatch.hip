@@ -1,0 +1,175 @@
+// Materialised dispatch list (BucketMul.calcDispatch, bucketMul.swift:34-47) and small helper kernels.
+//
+// The fused multiply kernel never writes a global dispatch list; this file produces one, in the
+// reference's float2 format {value, float(row*cols)} (bucketMul.metal:74, bucketMulQ4.metal:52), for
+// the parity tests and for callers that inspect BucketMul.shared.dispatch.  Order: ascending bucket
+// row (the reference's atomic append order is unspecified).  Three small launches: per-block counts
+// (ballot + popcount), one-block exclusive scan, ordered write.
+#include "effort_internal.h"
+
+namespace effort {
+
+constexpr int kDispBlock = 1024;
+
+template <int FMT>
+__device__ __forceinline__ bool keep_row(const void* stats, const float* v, uint32_t e, uint32_t r, const MulGeom& g,
+                                         float cutoff, float* value) {
+    const size_t i = (size_t)e * g.expertRows + r;               // bucket row incl. expert offset (:58-59)
+    float mean, x;
+    if (FMT == kFp16) {
+        mean = half_bits_to_float(reinterpret_cast<const uint16_t*>(stats)[i * 4 + 3]);
+        x = v[r % g.inDim];                                       // v[i % rowsCount], expertSize % inDim == 0
+        *value = x;
+    } else {
+        mean = reinterpret_cast<const float*>(stats)[i * 2 + 1];
+        x = v[r / 8u];                                            // v[i / 8] (expert 0)
+        *value = x * mean;
+    }
+    return cutoff < (kCutoffScale * mean) * fabsf(x);
+}
+
+template <int FMT>
+__global__ __launch_bounds__(kDispBlock) void disp_count_kernel(const void* stats, const float* v, const uint32_t* expNo,
+                                                                const float* cutoff, const MulGeom g, uint32_t* blockCounts) {
+    __shared__ uint32_t s_w[16];
+    const uint32_t r = blockIdx.x * kDispBlock + threadIdx.x;
+    const uint32_t e = expNo ? expNo[0] : 0u;
+    float val;
+    const bool keep = r < g.expertRows && keep_row<FMT>(stats, v, e, r, g, cutoff[0], &val);
+    const unsigned long long m = __ballot(keep);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t t = 0; for (int i = 0; i < 16; i++) t += s_w[i]; blockCounts[blockIdx.x] = t; }
+}
+
+__global__ __launch_bounds__(256) void disp_scan_kernel(uint32_t* blockCounts, uint32_t nBlocks, uint32_t* count, uint32_t* ctxCount) {
+    // nBlocks <= 229376*2/1024 = 448: one thread walks it (a few hundred adds)
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (uint32_t i = 0; i < nBlocks; i++) { const uint32_t c = blockCounts[i]; blockCounts[i] = run; run += c; }
+        if (count) count[0] = run;
+        ctxCount[0] = run;
+    }
+}
+
+template <int FMT>
+__global__ __launch_bounds__(kDispBlock) void disp_write_kernel(const void* stats, const float* v, const uint32_t* expNo,
+                                                                const float* cutoff, const MulGeom g,
+                                                                const uint32_t* blockOffsets, float2* dispatch) {
+    __shared__ uint32_t s_w[16];
+    const uint32_t r = blockIdx.x * kDispBlock + threadIdx.x;
+    const uint32_t e = expNo ? expNo[0] : 0u;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float val = 0.0f;
+    const bool keep = r < g.expertRows && keep_row<FMT>(stats, v, e, r, g, cutoff[0], &val);
+    const unsigned long long m = __ballot(keep);
+    const uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    if (lane == 0) s_w[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int i = 0; i < wave; i++) woff += s_w[i];
+    if (keep) {
+        const uint32_t i = e * g.expertRows + r;
+        dispatch[blockOffsets[blockIdx.x] + woff + pre] = make_float2(val, (float)(uint32_t)(i * g.cols));
+    }
+}
+
+hipError_t launch_calc_dispatch(Format fmt, const void* stats, const float* v, const uint32_t* expNo,
+                                const float* cutoff, const MulGeom& g, float* dispatch, uint32_t* count,
+                                uint32_t* ctxCount, uint32_t* blockScratch, hipStream_t st) {
+    const uint32_t nBlocks = (g.expertRows + kDispBlock - 1) / kDispBlock;
+    if (fmt == kFp16) hipLaunchKernelGGL(disp_count_kernel<kFp16>, dim3(nBlocks), dim3(kDispBlock), 0, st, stats, v, expNo, cutoff, g, blockScratch);
+    else hipLaunchKernelGGL(disp_count_kernel<kQ4>, dim3(nBlocks), dim3(kDispBlock), 0, st, stats, v, expNo, cutoff, g, blockScratch);
+    hipLaunchKernelGGL(disp_scan_kernel, dim3(1), dim3(256), 0, st, blockScratch, nBlocks, count, ctxCount);
+    if (fmt == kFp16) hipLaunchKernelGGL(disp_write_kernel<kFp16>, dim3(nBlocks), dim3(kDispBlock), 0, st, stats, v, expNo, cutoff, g, blockScratch, reinterpret_cast<float2*>(dispatch));
+    else hipLaunchKernelGGL(disp_write_kernel<kQ4>, dim3(nBlocks), dim3(kDispBlock), 0, st, stats, v, expNo, cutoff, g, blockScratch, reinterpret_cast<float2*>(dispatch));
+    return hipGetLastError();
+}
+
+// ---- v.asFloat16() (helpers/mps.swift:19) -----------------------------------------------------
+__global__ void f32_to_f16_kernel(const float* in, uint16_t* out, uint32_t n) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) out[i] = __half_as_ushort(__float2half_rn(in[i]));
+}
+hipError_t launch_f32_to_f16(const float* in, uint16_t* out, uint32_t n, hipStream_t st) {
+    hipLaunchKernelGGL(f32_to_f16_kernel, dim3((n + 255) / 256), dim3(256), 0, st, in, out, n);
+    return hipGetLastError();
+}
+
+// ---- cosineSimilarityTo (aux.metal:293-312): dot, |a|^2, |b|^2 in f32; one block, fixed order ----
+__global__ __launch_bounds__(1024) void cosine_kernel(const float* a, const float* b, uint32_t n, float* out3) {
+    __shared__ float s[3][16];
+    float d = 0, ma = 0, mb = 0;
+    for (uint32_t i = threadIdx.x; i < n; i += 1024) { const float x = a[i], y = b[i]; d += x * y; ma += x * x; mb += y * y; }
+    for (int off = 32; off >= 1; off >>= 1) { d += __shfl_xor(d, off); ma += __shfl_xor(ma, off); mb += __shfl_xor(mb, off); }
+    if ((threadIdx.x & 63) == 0) { s[0][threadIdx.x >> 6] = d; s[1][threadIdx.x >> 6] = ma; s[2][threadIdx.x >> 6] = mb; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float D = 0, A = 0, Bq = 0;
+        for (int i = 0; i < 16; i++) { D += s[0][i]; A += s[1][i]; Bq += s[2][i]; }
+        out3[0] = D / (sqrtf(A) * sqrtf(Bq)); out3[1] = A; out3[2] = Bq;
+    }
+}
+hipError_t launch_cosine(const float* a, const float* b, uint32_t n, float* out3, hipStream_t st) {
+    hipLaunchKernelGGL(cosine_kernel, dim3(1), dim3(1024), 0, st, a, b, n, out3);
+    return hipGetLastError();
+}
+
+// ---- Q4 outliers -> by-output CSR (registration time, keeps table order inside each output) -----
+// outliers float4 = (value, inIdx, outIdx, 0) (q4_draft.py:58-67).  Pass 1 counts per output, a
+// one-block scan makes rowPtr, pass 2 places each outlier at rowPtr[out] + (number of earlier table
+// entries with the same output) -- computed with a per-output ordered walk so the order is the table's.
+__global__ void ol_count_kernel(const float4* ol, uint64_t n, uint32_t* rowPtr) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i < n) atomicAdd(&rowPtr[(uint32_t)ol[i].z + 1], 1u);
+}
+__global__ __launch_bounds__(1024) void ol_scan_kernel(uint32_t* rowPtr, uint32_t outDim) {
+    __shared__ uint32_t s_part[1024];
+    // inclusive scan of rowPtr[1..outDim] in place (rowPtr[0] = 0): thread t owns a contiguous chunk
+    const uint32_t per = (outDim + 1023) / 1024, lo = 1 + threadIdx.x * per, hi = min(outDim + 1, lo + per);
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi; i++) sum += rowPtr[i];
+    s_part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t run = 0; for (int i = 0; i < 1024; i++) { const uint32_t c = s_part[i]; s_part[i] = run; run += c; } rowPtr[0] = 0; }
+    __syncthreads();
+    uint32_t run = s_part[threadIdx.x];
+    for (uint32_t i = lo; i < hi; i++) { run += rowPtr[i]; rowPtr[i] = run; }
+}
+// Placement uses an atomic cursor (arbitrary order inside an output's segment); ol_sort_segments_kernel
+// then restores table order inside each (short, ~2 % of inDim) segment.
+__global__ void ol_place_kernel(const float4* ol, uint64_t n, const uint32_t* rowPtr, uint32_t* cursor,
+                                uint32_t* inIdx, float* value, uint32_t* tableIdx) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float4 o = ol[i];
+    const uint32_t out = (uint32_t)o.z;
+    const uint32_t p = rowPtr[out] + atomicAdd(&cursor[out], 1u);
+    inIdx[p] = (uint32_t)o.y; value[p] = o.x; tableIdx[p] = (uint32_t)i;
+}
+__global__ void ol_sort_segments_kernel(const uint32_t* rowPtr, uint32_t outDim, uint32_t* inIdx, float* value, uint32_t* tableIdx) {
+    const uint32_t out = blockIdx.x * 256u + threadIdx.x;
+    if (out >= outDim) return;
+    const uint32_t lo = rowPtr[out], hi = rowPtr[out + 1];
+    for (uint32_t i = lo + 1; i < hi; i++) {                      // insertion sort by table index
+        const uint32_t ti = tableIdx[i], ii = inIdx[i]; const float vv = value[i];
+        uint32_t k = i;
+        while (k > lo && tableIdx[k - 1] > ti) { tableIdx[k] = tableIdx[k - 1]; inIdx[k] = inIdx[k - 1]; value[k] = value[k - 1]; k--; }
+        tableIdx[k] = ti; inIdx[k] = ii; value[k] = vv;
+    }
+}
+hipError_t launch_build_outlier_index(const float* outliers, uint64_t n, uint32_t outDim, uint32_t* rowPtr,
+                                      uint32_t* inIdx, float* value, uint32_t* cursor, hipStream_t st) {
+    // cursor doubles as [outDim] atomic cursors followed by [n] table indices
+    hipError_t e = hipMemsetAsync(rowPtr, 0, (size_t)(outDim + 1) * 4, st); if (e != hipSuccess) return e;
+    e = hipMemsetAsync(cursor, 0, (size_t)outDim * 4, st); if (e != hipSuccess) return e;
+    const float4* ol = reinterpret_cast<const float4*>(outliers);
+    const uint32_t nb = (uint32_t)((n + 255) / 256);
+    hipLaunchKernelGGL(ol_count_kernel, dim3(nb), dim3(256), 0, st, ol, n, rowPtr);
+    hipLaunchKernelGGL(ol_scan_kernel, dim3(1), dim3(1024), 0, st, rowPtr, outDim);
+    hipLaunchKernelGGL(ol_place_kernel, dim3(nb), dim3(256), 0, st, ol, n, rowPtr, cursor, inIdx, value, cursor + outDim);
+    hipLaunchKernelGGL(ol_sort_segments_kernel, dim3((outDim + 255) / 256), dim3(256), 0, st, rowPtr, outDim, inIdx, value, cursor + outDim);
+    return hipGetLastError();
+}
+
+}  // namespace effort

@@ -1,0 +1,78 @@
+// Internal declarations shared by the HIP translation units of libeffort_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+namespace effort {
+
+constexpr int kWave = 64;            // CDNA4 wavefront
+constexpr int kProbes = 4096;        // bucketMul.swift:17
+constexpr float kCutoffScale = 100000.0f;   // CUTOFF_SCALE, bucketMul.metal:33
+
+enum Format : int { kFp16 = 0, kQ4 = 1 };
+
+// Geometry of one multiply launch (see DESIGN.md "bucket_mul kernel").
+struct MulGeom {
+    uint32_t inDim;        // GEMV input size
+    uint32_t outDim;       // GEMV output size held by this handle (a column shard in multi-GPU)
+    uint32_t cols;         // u16 columns per bucket row: outDim/16 (FP16) or outDim/32 (Q4)
+    uint32_t rowsPerIn;    // bucket rows per input row that are present: percentLoad (FP16) or 8 (Q4)
+    uint32_t expertRows;   // rowsPerIn * inDim  (= expertSize, loader.swift:50)
+    uint32_t tiles;        // T: column tiles of 64*E u16 columns
+    uint32_t slices;       // S: row slices actually used (every slice owns sliceRows input rows)
+    uint32_t sliceRows;    // B: input rows per slice
+    uint32_t tileFloats;   // accumulators per tile = NACC*E*64
+};
+
+struct MulArgs {
+    const uint16_t* buckets;
+    const void* stats;         // f16x4 (FP16) or f32x2 (Q4) per bucket row
+    const float* v;
+    const uint32_t* expNo;     // nullable
+    const float* cutoff;
+    float* slabs;              // [slices][tiles][tileFloats]
+    uint32_t* dispatchCount;
+    MulGeom g;
+};
+
+// ---- device helpers -------------------------------------------------------------------------
+__device__ __forceinline__ float half_bits_to_float(uint16_t h) { return __half2float(__ushort_as_half(h)); }
+
+// f32 -> bfloat (round to nearest even) -> f32; bit-for-bit what Metal's bfloat() conversion does.
+__device__ __forceinline__ float bf16_round(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) u |= 0x00400000u;       // quiet NaN, keep payload top bits
+    else u += 0x7FFFu + ((u >> 16) & 1u);
+    return __uint_as_float(u & 0xFFFF0000u);
+}
+
+// ---- launchers (one per translation unit) ---------------------------------------------------
+hipError_t launch_find_cutoff(const float* v, const uint16_t* probes, const uint32_t* expNo, uint32_t q,
+                              float* cutoff, uint32_t* dispatchCount, hipStream_t st);
+
+// Returns hipErrorInvalidValue for unsupported (fmt, W, E).
+hipError_t launch_bucket_mul(Format fmt, int wavesPerGroup, int elemsPerLane, const MulArgs& a, hipStream_t st);
+size_t bucket_mul_lds_bytes(Format fmt, int wavesPerGroup, int elemsPerLane, uint32_t sliceRows, uint32_t rowsPerIn);
+
+struct OutlierIndex {          // by-output CSR of the Q4 outliers, built at registration
+    const uint32_t* rowPtr;    // [outDim+1]
+    const uint32_t* inIdx;     // [n]
+    const float* value;        // [n]
+};
+hipError_t launch_integrate(Format fmt, int elemsPerLane, const float* slabs, const MulGeom& g, float* out,
+                            const OutlierIndex* outliers, const float* v, hipStream_t st);
+
+hipError_t launch_calc_dispatch(Format fmt, const void* stats, const float* v, const uint32_t* expNo,
+                                const float* cutoff, const MulGeom& g, float* dispatch, uint32_t* count,
+                                uint32_t* ctxCount, uint32_t* blockScratch, hipStream_t st);
+
+hipError_t launch_convert_fp16(const uint16_t* W, uint32_t outDim, uint32_t inDim, uint16_t* buckets,
+                               uint16_t* stats, uint16_t* probes, uint16_t* scratchVals, int* status, hipStream_t st);
+
+hipError_t launch_f32_to_f16(const float* in, uint16_t* out, uint32_t n, hipStream_t st);
+hipError_t launch_cosine(const float* a, const float* b, uint32_t n, float* out3, hipStream_t st);
+hipError_t launch_build_outlier_index(const float* outliers, uint64_t n, uint32_t outDim, uint32_t* rowPtr,
+                                      uint32_t* inIdx, float* value, uint32_t* cursor, hipStream_t st);
+
+}  // namespace effort

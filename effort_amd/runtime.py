@@ -1,0 +1,92 @@
+"""Host-side mirror of ``class Gpu`` (helpers/gpu.swift:19-222), reduced to what the bucketMul path uses.
+
+The reference enqueues kernels into one serial compute encoder and runs them at ``gpu.eval()``
+(helpers/gpu.swift:109-119).  Here work is enqueued on a HIP stream (PyTorch's current stream for the
+device, so torch ops and bucketMul calls interleave in order) and ``eval()`` waits for it.
+PyTorch is used only for device memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+class Gpu:
+    def __init__(self, device: int | None = None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("effort_amd needs an AMD GPU (torch.cuda.is_available() is False); there is no CPU fallback")
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        self._lib = _lib.lib()
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            self.ctx = self._lib.effort_create(self.device, C.c_void_p(stream))
+        if not self.ctx:
+            raise RuntimeError("effort_create failed")
+        self._stream = stream
+
+    # -- helpers ---------------------------------------------------------------------------------
+    def _bind_stream(self):
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        if stream != self._stream:
+            self._lib.effort_set_stream(self.ctx, C.c_void_p(stream))
+            self._stream = stream
+
+    def check(self, rc: int, where: str):
+        if rc != 0:
+            detail = self._lib.effort_last_error(self.ctx)
+            raise _lib.EffortError(rc, where, detail.decode() if detail else "")
+
+    # -- reference surface -------------------------------------------------------------------------
+    def eval(self):
+        """gpu.eval(): commit + waitUntilCompleted."""
+        self.check(self._lib.effort_sync(self.ctx), "gpu.eval")
+
+    # -- extras ------------------------------------------------------------------------------------
+    def set_tuning(self, waves: int = 0, elems: int = 0, slices: int = 0):
+        self.check(self._lib.effort_set_tuning(self.ctx, waves, elems, slices), "set_tuning")
+
+    def enable_kernel_timing(self, on: bool = True):
+        self.check(self._lib.effort_enable_kernel_timing(self.ctx, int(on)), "enable_kernel_timing")
+
+    def kernel_timing(self):
+        mul, cut, integ, n = C.c_double(), C.c_double(), C.c_double(), C.c_int()
+        self.check(self._lib.effort_kernel_timing(self.ctx, C.byref(mul), C.byref(cut), C.byref(integ), C.byref(n)), "kernel_timing")
+        return {"mul_us": mul.value, "cutoff_us": cut.value, "integrate_us": integ.value, "samples": n.value}
+
+    def last_dispatch_count(self) -> int:
+        n = C.c_uint32()
+        self.check(self._lib.effort_last_dispatch_count(self.ctx, C.byref(n)), "last_dispatch_count")
+        return int(n.value)
+
+    def last_cutoff(self) -> float:
+        x = C.c_float()
+        self.check(self._lib.effort_last_cutoff(self.ctx, C.byref(x)), "last_cutoff")
+        return float(x.value)
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self._lib.effort_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_gpus: dict[int, Gpu] = {}
+
+
+def gpu(device: int | None = None) -> Gpu:
+    """The process-wide ``gpu`` object of the reference (helpers/gpu.swift:17), one per device."""
+    if not torch.cuda.is_available():
+        raise RuntimeError("effort_amd needs an AMD GPU (torch.cuda.is_available() is False); there is no CPU fallback")
+    d = torch.cuda.current_device() if device is None else int(device)
+    g = _gpus.get(d)
+    if g is None:
+        g = _gpus[d] = Gpu(d)
+    return g

@@ -1,0 +1,100 @@
+"""Multi-GPU bucketMul: bucket-column (output) sharding + one RCCL all-gather.
+
+The reference is single-device (helpers/gpu.swift:36-38); sharding is new.  One process per GPU
+(torch.distributed, backend "nccl" == RCCL over xGMI).  Rank g holds bucket columns
+[g*C/G, (g+1)*C/G) of every bucket row of a matrix, plus the FULL stats and probes -- those are
+row-global (convert.metal:105-119), so every rank computes the identical cutoff and selects the identical
+rows, and the concatenation of the per-rank outputs is exactly the single-GPU result.  The only exchange
+is an all-gather of outDim/G f32 per rank (KB-scale: latency-bound over xGMI, never bandwidth-bound), so
+matrices that share an input vector (Wq|Wk|Wv, W1|W3) are gathered together in ONE collective.
+"""
+from __future__ import annotations
+
+from typing import Callable, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def shard_columns(buckets: torch.Tensor, rank: int, world: int) -> torch.Tensor:
+    """Columns [rank*C/world, (rank+1)*C/world) of a [..., rows, C] bucket tensor (any device)."""
+    C = buckets.shape[-1]
+    if C % world:
+        raise ValueError(f"{C} bucket columns do not divide across {world} ranks")
+    per = C // world
+    return buckets[..., rank * per:(rank + 1) * per].contiguous()
+
+
+def shard_outliers(outliers: torch.Tensor | None, rank: int, world: int, outDim: int):
+    """Q4 outliers (value, inIdx, outIdx, 0) whose output falls in this rank's slice, re-based to it."""
+    if outliers is None:
+        return None
+    per = outDim // world
+    lo, hi = rank * per, (rank + 1) * per
+    m = (outliers[:, 2] >= lo) & (outliers[:, 2] < hi)
+    ol = outliers[m].clone()
+    ol[:, 2] -= lo
+    return ol
+
+
+class ShardedExpertWeights:
+    """This rank's column shard of one matrix.  ``local`` is whatever the multiply backend consumes: an
+    ``effort_amd.ExpertWeights`` on the GPU path."""
+
+    def __init__(self, local, outSize: int, rank: int, world: int):
+        self.local = local
+        self.outSize = int(outSize)                  # full (gathered) output size
+        self.rank, self.world = int(rank), int(world)
+        if self.outSize % self.world:
+            raise ValueError("outSize must divide across ranks")
+        self.localOut = self.outSize // self.world
+
+    @classmethod
+    def from_full(cls, full, rank: int | None = None, world: int | None = None):
+        """Shard a full GPU ExpertWeights (every rank holds or builds the same full bundle, keeps its slice)."""
+        rank = dist.get_rank() if rank is None else rank
+        world = dist.get_world_size() if world is None else world
+        return cls(full.column_shard(rank, world), full.outSize, rank, world)
+
+
+def _default_mul(v, by, out, effort, expNo):
+    from .bucket_mul import expertMul
+    expertMul(v, by, out, effort, expNo)
+
+
+def shardedExpertMulGroup(v: torch.Tensor, bys: Sequence[ShardedExpertWeights], outs: Sequence[torch.Tensor], effort: float = 0.25,
+                          expNo: torch.Tensor | None = None, group=None,
+                          mul: Callable = _default_mul, scratch: dict | None = None):
+    """expertMul for several matrices sharing the input ``v`` with a single all-gather.
+
+    Each rank multiplies its column shards into one contiguous send buffer [sum(localOut)], the collective
+    gathers [world, sum(localOut)], and the slices are scattered to ``outs`` (each f32 [outSize])."""
+    world = bys[0].world
+    total = sum(b.localOut for b in bys)
+    key = (v.device, total, world)
+    sc = scratch if scratch is not None else _SCRATCH
+    if key not in sc:
+        sc[key] = (torch.empty(total, dtype=torch.float32, device=v.device),
+                   torch.empty((world, total), dtype=torch.float32, device=v.device))
+    send, recv = sc[key]
+    off = 0
+    for b in bys:
+        mul(v, b.local, send[off:off + b.localOut], effort, expNo)
+        off += b.localOut
+    if world == 1:
+        recv[0].copy_(send)
+    else:
+        dist.all_gather_into_tensor(recv.view(-1), send, group=group)
+    off = 0
+    for b, out in zip(bys, outs):
+        out.view(world, b.localOut).copy_(recv[:, off:off + b.localOut])
+        off += b.localOut
+
+
+def shardedExpertMul(v: torch.Tensor, by: ShardedExpertWeights, out: torch.Tensor, effort: float = 0.25,
+                     expNo: torch.Tensor | None = None, group=None, mul: Callable = _default_mul):
+    """Sharded drop-in for expertMul(v:by:out:effort:) (expertMul.swift:20-38)."""
+    shardedExpertMulGroup(v, [by], [out], effort, expNo, group, mul)
+
+
+_SCRATCH: dict = {}

@@ -1,0 +1,124 @@
+"""``ExpertWeights`` -- the per-matrix weight bundle of the reference (loader.swift:46-167).
+
+Same fields and meaning: ``buckets`` [E, inSize*percentLoad, cols], ``stats`` [E, inSize*percentLoad, 4]
+(Q4: f32 [E, inSize*8, 2]), ``probes`` [E, 4096], optional ``outliers`` f32 [n, 4] and dense ``core``
+f16 [outSize, inSize]; ``expertSize = percentLoad*inSize`` (loader.swift:50).  Tensors live in HBM as
+torch CUDA tensors (device memory plumbing only); the C-ABI handle borrows their pointers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .runtime import gpu as _gpu
+
+
+def _ptr(t: torch.Tensor | None):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class ExpertWeights:
+    def __init__(self, buckets: torch.Tensor, stats: torch.Tensor, probes: torch.Tensor, inSize: int, outSize: int,
+                 percentLoad: int | None = None, numExperts: int = 1, outliers: torch.Tensor | None = None,
+                 core: torch.Tensor | None = None, q4: bool = False):
+        self.q4 = bool(q4)                                    # goQ4 (main.swift:47) per bundle
+        self.inSize = int(inSize)
+        self.outSize = int(outSize)
+        self.percentLoad = int(percentLoad) if percentLoad is not None else (8 if q4 else 16)   # loader.swift:64
+        self.numExperts = int(numExperts)
+        self.core = core
+        self.outliers = outliers
+        self.bucketsLoaded = True
+        dev = buckets.device
+        if dev.type != "cuda":
+            raise ValueError("ExpertWeights tensors must be on the GPU")
+        cols = self.outSize // 32 if q4 else self.outSize // 16
+        rows = self.inSize * self.percentLoad
+        # Matrix3D shapes of loader.swift:70,76 (bit-level dtype: 16-bit words / f16x4 or f32x2 stats)
+        self.buckets = buckets.contiguous().view(torch.int16).reshape(self.numExperts, rows, cols)
+        if q4:
+            self.stats = stats.contiguous().to(torch.float32).reshape(self.numExperts, rows, 2)
+        else:
+            self.stats = stats.contiguous().view(torch.int16).reshape(self.numExperts, rows, 4)
+        self.probes = probes.contiguous().view(torch.int16).reshape(self.numExperts, 4096)
+        if outliers is not None:
+            self.outliers = outliers.contiguous().to(torch.float32).reshape(-1, 4)
+        self._gpu = _gpu(dev.index)
+        self._handle = None
+
+    @property
+    def expertSize(self) -> int:
+        return self.percentLoad * self.inSize
+
+    @property
+    def handle(self):
+        """effort_w* registered with the context (lazily, once)."""
+        if self._handle is None:
+            g, lib = self._gpu, _lib.lib()
+            g._bind_stream()
+            if self.q4:
+                n = 0 if self.outliers is None else self.outliers.shape[0]
+                h = lib.effort_weights_q4(g.ctx, _ptr(self.buckets), _ptr(self.stats), _ptr(self.probes), _ptr(self.outliers),
+                                          n, self.inSize, self.outSize, self.numExperts)
+            else:
+                h = lib.effort_weights_fp16(g.ctx, _ptr(self.buckets), _ptr(self.stats), _ptr(self.probes),
+                                            self.inSize, self.outSize, self.percentLoad, self.numExperts)
+            if not h:
+                detail = lib.effort_last_error(g.ctx)
+                raise _lib.EffortError(-2, "ExpertWeights", detail.decode() if detail else "")
+            self._handle = h
+        return self._handle
+
+    def __del__(self):
+        try:
+            if self._handle is not None:
+                _lib.lib().effort_weights_free(self._handle)
+                self._handle = None
+        except Exception:
+            pass
+
+    # -- constructors ------------------------------------------------------------------------------
+    @classmethod
+    def from_core(cls, core: torch.Tensor) -> "ExpertWeights":
+        """Dense f16 matrix [outSize, inSize] -> FP16 bundle via the GPU converter (= bucketize())."""
+        from .convert import bucketize
+        tensors: dict[str, torch.Tensor] = {}
+        bucketize(core, "", tensors, goQ8=False)
+        return cls(tensors["buckets"], tensors["bucket.stats"], tensors["probes"], inSize=core.shape[1],
+                   outSize=core.shape[0], core=core)
+
+    @classmethod
+    def stack(cls, experts: list["ExpertWeights"]) -> "ExpertWeights":
+        """Mixtral-style expert stacking: all experts in one buffer, selected by expNo (loader.swift:113-166)."""
+        e0 = experts[0]
+        return cls(torch.cat([e.buckets for e in experts]), torch.cat([e.stats for e in experts]),
+                   torch.cat([e.probes for e in experts]), e0.inSize, e0.outSize, e0.percentLoad,
+                   numExperts=sum(e.numExperts for e in experts), outliers=e0.outliers, q4=e0.q4)
+
+    def truncated(self, percentLoad: int) -> "ExpertWeights":
+        """Load only the first ``percentLoad`` rank slices (loader.swift:157-159, copyFrom(mySize: true))."""
+        assert not self.q4 and 1 <= percentLoad <= self.percentLoad
+        rows = self.inSize * percentLoad
+        return ExpertWeights(self.buckets[:, :rows].contiguous(), self.stats[:, :rows].contiguous(), self.probes,
+                             self.inSize, self.outSize, percentLoad, self.numExperts, core=self.core)
+
+    def column_shard(self, rank: int, world: int) -> "ExpertWeights":
+        """Bucket-column (output) shard for multi-GPU: columns [rank*C/G, (rank+1)*C/G) of every bucket row,
+        stats and probes replicated (they are row-global), so every rank selects the same rows."""
+        cols = self.buckets.shape[2]
+        assert cols % world == 0, "bucket columns must divide evenly across ranks"
+        per = cols // world
+        unit = 32 if self.q4 else 16
+        assert ((per * unit) // 16) % 4 == 0, "shard violates (outDim/16) % 4 == 0 (bucketMul.swift:76)"
+        b = self.buckets[:, :, rank * per:(rank + 1) * per].contiguous()
+        ol = None
+        if self.outliers is not None:
+            lo, hi = rank * per * unit, (rank + 1) * per * unit
+            m = (self.outliers[:, 2] >= lo) & (self.outliers[:, 2] < hi)
+            ol = self.outliers[m].clone()
+            ol[:, 2] -= lo
+        core = None if self.core is None else self.core[rank * per * unit:(rank + 1) * per * unit]
+        return ExpertWeights(b, self.stats, self.probes, self.inSize, per * unit, self.percentLoad, self.numExperts,
+                             outliers=ol, core=core, q4=self.q4)

@@ -1,0 +1,146 @@
+/*
+ * effort_hip.h -- C ABI of the MI355X (gfx950) implementation of Effort's bucketMul hot path.
+ *
+ * This is the drop-in boundary: every entry point below replaces one piece of the reference's
+ * Swift/Metal interface for the path (file:line relative to kolinko/effort @ 2024_08_07).  A
+ * Swift shim that keeps `bucketMul(v:by:expNo:out:effort:)` / `bucketMulQ4(...)` and forwards
+ * here is shown in INTEGRATION.md.  Plain pointers and sizes only; all `*_dev` pointers are
+ * device (HBM) addresses owned by the caller.  Nothing here depends on PyTorch.
+ *
+ * Conventions (reference: helpers/gpu.swift:109-196)
+ *   - Calls ENQUEUE work on the context's HIP stream and return; results are valid after
+ *     effort_sync() (= gpu.eval(), helpers/gpu.swift:109-119) or any later work on that stream.
+ *   - The reference aborts on violated preconditions (assert/precondition); this ABI returns a
+ *     negative error code instead and enqueues nothing.
+ *   - One effort_ctx per host thread / stream (the reference's BucketMul.shared singleton,
+ *     bucketMul.swift:24, is not re-entrant; a context is its re-entrant equivalent and owns the
+ *     same scratch: cutoff, dispatch counter, partial tiles).
+ */
+#ifndef EFFORT_HIP_H
+#define EFFORT_HIP_H
+
+#include <stdint.h>
+
+#if defined(__GNUC__)
+#define EFFORT_API __attribute__((visibility("default")))
+#else
+#define EFFORT_API
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct effort_ctx effort_ctx;
+typedef struct effort_w effort_w;      /* = class ExpertWeights, loader.swift:46-167 */
+
+enum {
+    EFFORT_OK = 0,
+    EFFORT_ERR_ARG = -1,          /* null pointer / bad handle                                        */
+    EFFORT_ERR_SHAPE = -2,        /* outDim%16, (outDim/16)%4, outDim<=16384 (bucketMul.swift:52,73-76) */
+    EFFORT_ERR_EFFORT = -3,       /* effort outside [0,1]                                              */
+    EFFORT_ERR_HIP = -4,          /* a HIP runtime call failed (see effort_last_error)                 */
+    EFFORT_ERR_KIND = -5,         /* FP16 weights passed to the Q4 call or vice versa                  */
+    EFFORT_ERR_CONVERT = -6,      /* bucketize() preconditions (convert.swift:210-215,239)             */
+    EFFORT_ERR_BLAS = -7          /* rocBLAS failure in effort_dense_gemv                              */
+};
+
+/* ---- context = class Gpu + the BucketMul / BucketMulQ4 singletons ------------------------------ */
+
+/* helpers/gpu.swift:36-60 (device, queue) + bucketMul.swift:24-32 (scratch).  `stream` is a
+ * hipStream_t (NULL = the default stream).  Returns NULL on failure. */
+EFFORT_API effort_ctx* effort_create(int device, void* stream);
+EFFORT_API void effort_destroy(effort_ctx* ctx);
+EFFORT_API int effort_set_stream(effort_ctx* ctx, void* stream);
+/* gpu.eval() -- helpers/gpu.swift:109-119: block until everything enqueued so far has finished. */
+EFFORT_API int effort_sync(effort_ctx* ctx);
+EFFORT_API const char* effort_last_error(effort_ctx* ctx);
+EFFORT_API const char* effort_version(void);
+
+/* ---- weights = ExpertWeights ------------------------------------------------------------------- */
+
+/* FP16 bundle (loader.swift:46-167, layout written by convert.swift:209-260):
+ *   buckets f16 [numExperts][inDim*percentLoad][outDim/16]   rank-major bucket rows, low 4 mantissa
+ *                                                            bits of each weight = output position
+ *   stats   f16 [numExperts][inDim*percentLoad][4]           mean|row| in all four lanes (.w is read)
+ *   probes  f16 [numExperts][4096]
+ * percentLoad (1..16) = rank slices present per expert (loader.swift:50, expertSize = percentLoad*inDim).
+ * Pointers are BORROWED: the caller keeps the buffers alive while the handle is in use. */
+EFFORT_API effort_w* effort_weights_fp16(effort_ctx* ctx, const void* buckets_dev, const void* stats_dev,
+                              const void* probes_dev, int inDim, int outDim, int percentLoad,
+                              int numExperts);
+
+/* Q4 bundle (layout written by q4_draft.py:70-322; loaded by loader.swift:70,98,124):
+ *   buckets  u16 [numExperts][inDim*8][outDim/32]   4 nibbles per word, nibble = sign<<3 | pos,
+ *                                                   bucket row i = inRow*8 + rank (input-major)
+ *   stats    f32 [numExperts][inDim*8][2]           (mean|row|, same); .y is read
+ *   probes   f16 [numExperts][4096]
+ *   outliers f32 [nOutliers][4]                     (value, inIdx, outIdx, 0); may be NULL / 0
+ * Borrowed like the FP16 bundle.  Registration builds a by-output index of the outliers in HBM. */
+EFFORT_API effort_w* effort_weights_q4(effort_ctx* ctx, const void* buckets_dev, const void* stats_dev,
+                            const void* probes_dev, const void* outliers_dev, int64_t nOutliers,
+                            int inDim, int outDim, int numExperts);
+EFFORT_API void effort_weights_free(effort_w* w);
+
+/* ---- the hot path ------------------------------------------------------------------------------ */
+
+/* func bucketMul(v:by:expNo:out:effort:) -- bucketMul.swift:11-15 -> BucketMul.fullMul (:54-70):
+ * findCutoff32 + prepareDispatch + roundUp/zeroRange32 + bucketMul + bucketIntegrate
+ * (bucketMul.metal:11-247).  v_dev f32[inDim], out_dev f32[outDim] (fully overwritten),
+ * expNo_dev = device u32 expert index (NULL = expert 0; expertMul.swift:18-22), effort in [0,1]. */
+EFFORT_API int effort_bucketmul(effort_ctx* ctx, const effort_w* w, const float* v_dev, const uint32_t* expNo_dev,
+                     float* out_dev, double effort);
+
+/* func bucketMulQ4(...) -- bucketMulQ4.swift:11-17 -> fullMul (:54-63), INCLUDING the caller's
+ * out.zero() (expertMul.swift:27) and the calcOutliers pass (bucketMulQ4.metal:13-21). */
+EFFORT_API int effort_bucketmul_q4(effort_ctx* ctx, const effort_w* w, const float* v_dev, const uint32_t* expNo_dev,
+                        float* out_dev, double effort);
+
+/* func basicMul(v:by:out:) -- helpers/mps.swift:14-47: dense out = W * f16(v), W f16 [outDim,inDim]
+ * row-major, f32 result.  rocBLAS (the MPS equivalent); the "100 % effort dense" baseline. */
+EFFORT_API int effort_dense_gemv(effort_ctx* ctx, const void* W_f16_dev, const float* v_dev, float* out_dev,
+                      int inDim, int outDim);
+
+/* ---- reference-visible state / test hooks ------------------------------------------------------ */
+
+/* dispatch.size after calcDispatch (bucketMul.swift:46-47): number of bucket rows selected by the most
+ * recent effort_bucketmul / _q4 / effort_calc_dispatch, before padding.  Synchronises the stream. */
+EFFORT_API int effort_last_dispatch_count(effort_ctx* ctx, uint32_t* host_out);
+/* BucketMul.shared.cutoff (bucketMul.swift:22).  Synchronises the stream. */
+EFFORT_API int effort_last_cutoff(effort_ctx* ctx, float* host_out);
+
+/* BucketMul.calcDispatch (bucketMul.swift:34-47) materialised in the reference's format: float2
+ * entries {v[row % inDim] (Q4: v[row/8]*mean), float(row*cols)} in ASCENDING bucket-row order (the
+ * reference's atomic append order is unspecified), count written to *count_dev.  dispatch_dev must
+ * hold 2*inDim*percentLoad floats.  Not used by the fused hot path; kept for parity tests. */
+EFFORT_API int effort_calc_dispatch(effort_ctx* ctx, const effort_w* w, const float* v_dev, const uint32_t* expNo_dev,
+                         double effort, float* dispatch_dev, uint32_t* count_dev);
+
+/* ---- weight layout converter ------------------------------------------------------------------- */
+
+/* func bucketize(_:outTensorsPref:tensors:goQ8:false) -- convert.swift:209-260 with kernels getProbes,
+ * prepareValsIdxs, idxsBitonicSortAbs, preBucketize, bucketize, makeStats (convert.metal:14-119,
+ * 315-342).  W_f16_dev is the HF matrix [outDim, inDim]; outputs as in effort_weights_fp16 with
+ * percentLoad 16, one expert.  Runs on the GPU (all device pointers), enqueued on the stream. */
+EFFORT_API int effort_convert_fp16(effort_ctx* ctx, const void* W_f16_dev, int outDim, int inDim,
+                        void* buckets_dev, void* stats_dev, void* probes_dev);
+
+/* VectorFloat.cosineSimilarityTo (model.swift:511-519; aux.metal:293-312).  Synchronises. */
+EFFORT_API int effort_cosine(effort_ctx* ctx, const float* a_dev, const float* b_dev, int n, float* host_out);
+
+/* ---- tuning knobs (not part of the reference surface) ------------------------------------------ */
+
+/* Override the launch geometry heuristics of the multiply kernel: waves per workgroup (4, 8 or 16),
+ * elements per lane (1, 2 or 4) and number of row slices (0 = heuristic).  Returns EFFORT_ERR_ARG
+ * for unsupported combinations. */
+EFFORT_API int effort_set_tuning(effort_ctx* ctx, int wavesPerGroup, int elemsPerLane, int rowSlices);
+/* Timing hook: average duration in microseconds of the multiply kernel alone over the launches
+ * since the last call (HIP events recorded on the context's stream when enabled). */
+EFFORT_API int effort_enable_kernel_timing(effort_ctx* ctx, int enable);
+EFFORT_API int effort_kernel_timing(effort_ctx* ctx, double* mul_us_avg, double* cutoff_us_avg,
+                         double* integrate_us_avg, int* n_samples);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EFFORT_HIP_H */
