@@ -1,0 +1,293 @@
+#!/usr/bin/env python
+"""bench.py -- bucketMul throughput on MI355X (driver contract: see README/DESIGN.md "Measurement").
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+Workload (BASELINE.json configs[1]): Mistral-7B-FFN-shaped matrix 4096 x 11008, fp16 buckets, bucketMul
+at 25 % effort (the north-star operating point), plus an effort sweep 10..100 % reported in the same JSON
+line.  One STEP = one pass of the hot path over one batch of synthetic input = 32 bucketMul calls, one per
+DISTINCT converted matrix (rotation i % 32 exactly like benchmarks/benchmark.swift:206,255 -- 2.9 GB of
+buckets, so reads come from HBM, not the 256 MB Infinity Cache), all on the same input vector, outputs
+written to 32 separate vectors.  Inputs are resident in HBM before the timed region.  The 32 calls of a
+step are replayed from one hipGraph (96 kernels), so the host is not in the timed path -- the reference's
+timeIt (helpers/timeit.swift:10-34) likewise enqueues everything and waits once.
+
+value            = effective (dense-equivalent) GB/s = 2*inDim*outDim bytes per call / time per call,
+                   whole job over all ranks.
+tokens_per_s     = the reference's projection 1/(t_call * 4 * 32) (helpers/timeit.swift:26,33-34).
+roofline         = dominant kernel (bucket_mul_kernel): algorithmic bytes per launch / its duration.
+cpu_baseline     = the CPU oracle (a port: the reference ships no CPU path) on the host cores, bounded sample.
+
+N > 1 (one process per GPU, RCCL): independent matrices are partitioned across the ranks (every rank owns
+32 distinct matrices; weak scaling) and the output vectors of a step are exchanged with ONE all-gather
+(north_star: "partition independent weight matrices ... RCCL all-gather of the output vectors").
+`--partition columns` runs the bucket-column sharding of SURVEY 8e instead (strong scaling).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+IN_DIM, OUT_DIM = 4096, 11008
+N_MATS = 32
+SWEEP = [0.10, 0.15, 0.20, 0.25, 0.30, 0.40, 0.50, 0.60, 0.70, 0.80, 0.90, 1.00]
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def algorithmic_bytes(D: int, inDim: int, outDim: int) -> int:
+    """SURVEY 8d / BASELINE.md: bucket rows + stats + probes + v + out.  (The fused kernel writes no global
+    dispatch list, so the reference formula's 8*D term is dropped.)"""
+    return D * (outDim // 16) * 2 + 16 * inDim * 8 + 4096 * 2 + 4 * inDim + 4 * outDim
+
+
+def mul_kernel_bytes(D: int, inDim: int, outDim: int) -> int:
+    """What ONE bucket_mul_kernel launch must move: the kept bucket rows, the stats column it tests, v."""
+    return D * (outDim // 16) * 2 + 16 * inDim * 8 + 4 * inDim
+
+
+def make_weights(ea, n, inDim, outDim, seed0, dev, keep_core=True):
+    ews = []
+    gen = torch.Generator(device=dev)
+    for k in range(n):
+        gen.manual_seed(seed0 + k)
+        W = (torch.randn((outDim, inDim), generator=gen, device=dev, dtype=torch.float32) * 0.02).to(torch.float16)
+        ew = ea.ExpertWeights.from_core(W)
+        if not keep_core:
+            ew.core = None
+        ew.handle
+        ews.append(ew)
+    ea.gpu().eval()
+    return ews
+
+
+def capture_step(ea, v, ews, outs, effort):
+    for ew, o in zip(ews, outs):                      # warm: handles, function attributes
+        ea.bucketMul(v, ew, None, o, effort)
+    ea.gpu().eval()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for ew, o in zip(ews, outs):
+            ea.bucketMul(v, ew, None, o, effort)
+    ea.gpu()._bind_stream()
+    return g
+
+
+def time_replays(g, steps, warmup, barrier=None):
+    for _ in range(warmup):
+        g.replay()
+    if barrier:
+        barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        g.replay()
+    torch.cuda.synchronize()
+    if barrier:
+        barrier()
+    return (time.perf_counter() - t0) / steps
+
+
+def cpu_baseline(ews, v, effort, inDim, outDim, budget_s=12.0):
+    """CPU oracle ("port") on the host cores: same converted weights (4 of the matrices), same v, same effort."""
+    from oracle import cpu
+    import numpy as np
+    mats = []
+    for ew in ews[:4]:
+        mats.append((ew.buckets[0].cpu().numpy().view(np.float16), ew.stats[0].cpu().numpy().view(np.float16),
+                     ew.probes[0].cpu().numpy().view(np.float16)))
+    vh = v.cpu().numpy()
+    sc = cpu.Scratch(inDim * 16)
+    cpu.bucket_mul(vh, *mats[0], inDim, outDim, effort, scratch=sc)                # warm
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        out, D, _ = cpu.bucket_mul(vh, *mats[n % 4], inDim, outDim, effort, scratch=sc)
+        n += 1
+    dt = (time.perf_counter() - t0) / n
+    return {"value": round(2 * inDim * outDim / dt / 1e9, 3), "unit": "GB/s", "cores": os.cpu_count(),
+            "kind": "port", "us_per_call": round(dt * 1e6, 1),
+            "sample": f"{n} bucketMul calls at effort {effort} over 4 of the {N_MATS} converted {inDim}x{outDim} matrices "
+                      f"(OpenMP over bucket columns, {os.cpu_count()} threads), {budget_s:.0f} s budget"}, out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--effort", type=float, default=0.25)
+    ap.add_argument("--partition", choices=["matrices", "columns"], default="matrices")
+    ap.add_argument("--no-sweep", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--tune", default="", help="waves,elems,slices override for the multiply kernel")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import effort_amd as ea
+    g = ea.gpu(local)
+    if args.tune:
+        w_, e_, s_ = (int(x) for x in args.tune.split(","))
+        g.set_tuning(w_, e_, s_)
+
+    inDim, outDim = IN_DIM, OUT_DIM
+    t_setup = time.perf_counter()
+    columns = world > 1 and args.partition == "columns"
+    seed0 = 1234 if (columns or world == 1) else 1234 + rank * N_MATS
+    ews_full = make_weights(ea, N_MATS, inDim, outDim, seed0, dev, keep_core=(rank == 0))
+    if columns:
+        from effort_amd.sharded import ShardedExpertWeights
+        ews = [ShardedExpertWeights.from_full(e, rank, world).local for e in ews_full]
+        localOut = outDim // world
+    else:
+        ews, localOut = ews_full, outDim
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(42)
+    v = torch.randn(inDim, generator=gen, device=dev, dtype=torch.float32)
+    outs_all = torch.zeros((N_MATS, localOut), device=dev)
+    outs = [outs_all[k] for k in range(N_MATS)]
+    gathered = torch.zeros((world, N_MATS * localOut), device=dev) if world > 1 else None
+    log(f"[rank {rank}] setup {time.perf_counter() - t_setup:.1f} s: {N_MATS} matrices {inDim}x{outDim} converted on the GPU")
+
+    def barrier():
+        if dist:
+            dist.barrier()
+
+    # ---------------- the timed job: K steps at the headline effort --------------------------------
+    graph = capture_step(ea, v, ews, outs, args.effort)
+    D = g.last_dispatch_count()
+
+    def run_steps(n):
+        for _ in range(n):
+            graph.replay()
+            if dist:   # the exchange step: one all-gather of this step's output vectors
+                dist.all_gather_into_tensor(gathered.view(-1), outs_all.view(-1))
+
+    run_steps(args.warmup)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_steps(args.steps)
+    torch.cuda.synchronize()
+    barrier()
+    dt = (time.perf_counter() - t0) / args.steps
+    if dist:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    calls_per_step = N_MATS * (world if not columns else 1)          # whole job
+    t_call = dt / N_MATS                                            # per-rank time per bucketMul call
+    eff_bytes = 2 * inDim * outDim
+    value = calls_per_step * eff_bytes / dt / 1e9
+
+    result = {
+        "metric": "effective GB/s + tokens/s vs effort %, Mistral-7B FFN 4096x11008 fp16",
+        "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt * 1e3, 5), "higher_is_better": True, "scaling": "strong" if columns else "weak",
+        "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+        "config": {"workload": f"bucketMul {inDim}x{outDim} fp16 buckets, effort {args.effort}, {N_MATS} distinct matrices rotated "
+                               f"(one call each per step), f32 accumulate", "effort": args.effort, "matrices_per_step": N_MATS,
+                   "inDim": inDim, "outDim": outDim, "partition": ("columns" if columns else "matrices") if world > 1 else "none",
+                   "dispatch_rows": D},
+        "us_per_call": round(t_call * 1e6, 3),
+        "tokens_per_s": round(1.0 / (t_call * 4 * 32), 2),
+    }
+
+    if rank == 0 and world == 1:
+        # ---------------- roofline of the dominant kernel -------------------------------------------
+        kb = mul_kernel_bytes(D, inDim, outDim)
+        g.enable_kernel_timing(2)                        # device wall clock inside the kernel (graph safe)
+        gt = capture_step(ea, v, ews, outs, args.effort)
+        for _ in range(5):
+            gt.replay()
+        g.kernel_clock()
+        for _ in range(20):
+            gt.replay()
+        clk = g.kernel_clock()
+        g.enable_kernel_timing(1)                        # HIP events on the launch stream, queue pre-filled
+        torch.cuda._sleep(20_000_000)                    # keep the GPU busy while the host enqueues
+        for r in range(4):
+            for ew, o in zip(ews, outs):
+                ea.bucketMul(v, ew, None, o, args.effort)
+        evt = g.kernel_timing()
+        g.enable_kernel_timing(0)
+        kus = clk["mul_us"]
+        result["roofline"] = {
+            "bound": "hbm", "kernel": "bucket_mul_kernel", "achieved": round(kb / kus / 1e3, 1), "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s", "frac": round(kb / kus / 1e3 / HBM_PEAK_GBPS, 4), "traffic": None,
+            "bytes_per_launch": kb, "kernel_us": round(kus, 3), "kernel_us_source": "device wall clock, first workgroup start -> last end",
+            "kernel_us_hip_events": round(evt["mul_us"], 3), "cutoff_us_hip_events": round(evt["cutoff_us"], 3),
+            "integrate_us_hip_events": round(evt["integrate_us"], 3),
+            "call_achieved_GBps": round(algorithmic_bytes(D, inDim, outDim) / t_call / 1e9, 1),
+            "call_frac": round(algorithmic_bytes(D, inDim, outDim) / t_call / 1e9 / HBM_PEAK_GBPS, 4),
+        }
+        # ---------------- dense rocBLAS baseline (basicMul over the rotating cores) -------------------
+        dense_out = torch.zeros(outDim, device=dev)
+        ea.basicMul(v, ews[0].core, dense_out)
+        gd = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gd):
+            for ew in ews:
+                ea.basicMul(v, ew.core, dense_out)
+        g._bind_stream()
+        td = time_replays(gd, 50, 10) / N_MATS
+        result["dense_rocblas"] = {"us_per_call": round(td * 1e6, 3), "GBps": round(eff_bytes / td / 1e9, 1),
+                                   "speedup_at_effort": round(td / t_call, 3)}
+        # ---------------- effort sweep ----------------------------------------------------------------
+        if not args.no_sweep:
+            sweep = []
+            for e in SWEEP:
+                ge = capture_step(ea, v, ews, outs, e)
+                De = g.last_dispatch_count()
+                te = time_replays(ge, 40, 10) / N_MATS
+                ea.basicMul(v, ews[N_MATS - 1].core, dense_out)
+                cs = ea.cosineSimilarityTo(outs[N_MATS - 1], dense_out)
+                sweep.append({"effort": e, "dispatch_rows": De, "us_per_call": round(te * 1e6, 3),
+                              "effective_GBps": round(eff_bytes / te / 1e9, 1),
+                              "achieved_GBps": round(algorithmic_bytes(De, inDim, outDim) / te / 1e9, 1),
+                              "tokens_per_s": round(1.0 / (te * 4 * 32), 1), "cos_vs_dense": round(cs, 5)})
+                del ge
+            result["sweep"] = sweep
+        # ---------------- CPU baseline -----------------------------------------------------------------
+        if not args.no_cpu:
+            try:
+                cb, cpu_out = cpu_baseline(ews, v, args.effort, inDim, outDim)
+                import numpy as np
+                graph.replay()
+                torch.cuda.synchronize()
+                hip = outs[(int(cb["sample"].split()[0]) - 1) % 4].cpu().numpy()      # matrix of the last CPU call
+                cb["gpu_vs_cpu_max_rel_err"] = float(np.abs(hip - cpu_out).max() / (np.abs(cpu_out).max() + 1e-30))
+                result["cpu_baseline"] = cb
+            except Exception as ex:  # the oracle is optional infrastructure for the bench
+                result["cpu_baseline"] = {"error": repr(ex)}
+
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -53,6 +53,7 @@ _SIGS = {
     "effort_cosine": (C.c_int, [_P, _P, _P, C.c_int, C.POINTER(C.c_float)]),
     "effort_set_tuning": (C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
     "effort_enable_kernel_timing": (C.c_int, [_P, C.c_int]),
+    "effort_kernel_clock": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "effort_kernel_timing": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
 }
 

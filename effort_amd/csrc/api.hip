@@ -28,11 +28,14 @@ struct effort_ctx {
     uint16_t* d_convVals = nullptr;   // converter scratch (transposed matrix)
     size_t convElems = 0;
     int* d_status = nullptr;
+    unsigned long long* d_tstamp = nullptr;   // device-clock stamps of the multiply kernel (timing mode)
+    double wallClockKHz = 100000.0;
     rocblas_handle blas = nullptr;
     // tuning overrides (0 = heuristic)
     int tuneW = 0, tuneE = 0, tuneS = 0;
     // optional per-kernel timing
-    bool timing = false;
+    bool timing = false;          // HIP events around each kernel
+    bool clock = false;           // device wall-clock stamps inside the multiply kernel
     static constexpr int kMaxSamples = 4096;
     hipEvent_t* ev = nullptr;         // 4 events per sample
     int nSamples = 0;
@@ -80,8 +83,12 @@ extern "C" effort_ctx* effort_create(int device, void* stream) {
     c->slabBytes = (size_t)64 << 20;
     bool ok = hipMalloc(&c->d_cutoff, 16) == hipSuccess && hipMalloc(&c->d_count, 16) == hipSuccess &&
               hipMalloc(&c->d_slabs, c->slabBytes) == hipSuccess && hipMalloc(&c->d_blockScratch, 4096 * 4) == hipSuccess &&
-              hipMalloc(&c->d_cos, 16) == hipSuccess && hipMalloc(&c->d_status, 16) == hipSuccess;
+              hipMalloc(&c->d_cos, 16) == hipSuccess && hipMalloc(&c->d_status, 16) == hipSuccess &&
+              hipMalloc(&c->d_tstamp, 32) == hipSuccess;
     if (!ok) { effort_destroy(c); return nullptr; }
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0) c->wallClockKHz = khz;
+    hipMemset(c->d_tstamp, 0, 32);
     hipMemset(c->d_cutoff, 0, 16);
     hipMemset(c->d_count, 0, 16);
     hipMemset(c->d_status, 0, 16);
@@ -95,7 +102,7 @@ extern "C" void effort_destroy(effort_ctx* c) {
     if (c->blas) rocblas_destroy_handle(c->blas);
     if (c->ev) { for (int i = 0; i < effort_ctx::kMaxSamples * 4; i++) hipEventDestroy(c->ev[i]); delete[] c->ev; }
     hipFree(c->d_cutoff); hipFree(c->d_count); hipFree(c->d_slabs); hipFree(c->d_blockScratch);
-    hipFree(c->d_vhalf); hipFree(c->d_cos); hipFree(c->d_convVals); hipFree(c->d_status);
+    hipFree(c->d_vhalf); hipFree(c->d_cos); hipFree(c->d_convVals); hipFree(c->d_status); hipFree(c->d_tstamp);
     delete c;
 }
 
@@ -222,16 +229,17 @@ static int do_bucketmul(effort_ctx* c, const effort_w* w, Format fmt, const floa
     const bool tm = c->timing && c->nSamples < effort_ctx::kMaxSamples;
     hipEvent_t* ev = tm ? c->ev + 4 * c->nSamples : nullptr;
 
+    unsigned long long* ts = c->clock ? c->d_tstamp : nullptr;
     if (tm) HIP_TRY(c, hipEventRecord(ev[0], c->stream));
-    HIP_TRY(c, launch_find_cutoff(v, w->probes, expNo, q, c->d_cutoff, c->d_count, c->stream));
+    HIP_TRY(c, launch_find_cutoff(v, w->probes, expNo, q, c->d_cutoff, c->d_count, ts, c->stream));
     if (tm) HIP_TRY(c, hipEventRecord(ev[1], c->stream));
     MulArgs a;
     a.buckets = w->buckets; a.stats = w->stats; a.v = v; a.expNo = expNo; a.cutoff = c->d_cutoff;
-    a.slabs = c->d_slabs; a.dispatchCount = c->d_count; a.g = g;
+    a.slabs = c->d_slabs; a.dispatchCount = c->d_count; a.tstamp = ts; a.g = g;
     HIP_TRY(c, launch_bucket_mul(fmt, W, E, a, c->stream));
     if (tm) HIP_TRY(c, hipEventRecord(ev[2], c->stream));
     OutlierIndex ol{w->olRowPtr, w->olInIdx, w->olValue};
-    HIP_TRY(c, launch_integrate(fmt, E, c->d_slabs, g, out, (fmt == kQ4 && w->olRowPtr) ? &ol : nullptr, v, c->stream));
+    HIP_TRY(c, launch_integrate(fmt, E, c->d_slabs, g, out, (fmt == kQ4 && w->olRowPtr) ? &ol : nullptr, v, ts, c->stream));
     if (tm) { HIP_TRY(c, hipEventRecord(ev[3], c->stream)); c->nSamples++; }
     return EFFORT_OK;
 }
@@ -251,7 +259,7 @@ extern "C" int effort_calc_dispatch(effort_ctx* c, const effort_w* w, const floa
     int rc = choose_geom(c, w, &g, &W, &E);
     if (rc != EFFORT_OK) return fail(c, rc, "calc_dispatch: geometry");
     const uint32_t q = (uint32_t)(int)((double)(kProbes - 1) * (1.0 - effort));
-    HIP_TRY(c, launch_find_cutoff(v, w->probes, expNo, q, c->d_cutoff, c->d_count, c->stream));
+    HIP_TRY(c, launch_find_cutoff(v, w->probes, expNo, q, c->d_cutoff, c->d_count, nullptr, c->stream));
     HIP_TRY(c, launch_calc_dispatch(w->fmt, w->stats, v, expNo, c->d_cutoff, g, dispatch, count, c->d_count, c->d_blockScratch, c->stream));
     return EFFORT_OK;
 }
@@ -332,9 +340,22 @@ extern "C" int effort_set_tuning(effort_ctx* c, int W, int E, int S) {
 
 extern "C" int effort_enable_kernel_timing(effort_ctx* c, int enable) {
     if (!c) return EFFORT_ERR_ARG;
-    if (enable) { int rc = ensure_timing(c); if (rc != EFFORT_OK) return rc; }
-    c->timing = enable != 0;
+    if (enable == 1) { int rc = ensure_timing(c); if (rc != EFFORT_OK) return rc; }
+    c->timing = enable == 1;      // 1: events + device clock, 2: device clock only (graph-capture safe)
+    c->clock = enable != 0;
     c->nSamples = 0;
+    HIP_TRY(c, hipMemsetAsync(c->d_tstamp, 0, 32, c->stream));
+    return EFFORT_OK;
+}
+
+extern "C" int effort_kernel_clock(effort_ctx* c, double* mul_us_avg, int* n_launches) {
+    if (!c) return EFFORT_ERR_ARG;
+    unsigned long long h[4] = {0, 0, 0, 0};
+    HIP_TRY(c, hipMemcpyAsync(h, c->d_tstamp, 32, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (mul_us_avg) *mul_us_avg = h[3] ? (double)h[2] / (double)h[3] * 1000.0 / c->wallClockKHz : 0.0;
+    if (n_launches) *n_launches = (int)h[3];
+    HIP_TRY(c, hipMemsetAsync(c->d_tstamp, 0, 32, c->stream));
     return EFFORT_OK;
 }
 

@@ -74,6 +74,7 @@ __global__ __launch_bounds__(64 * W) void bucket_mul_kernel(const MulArgs a) {
     if (s >= g.slices) return;
 
     const int tid = threadIdx.x, lane = tid & 63;
+    if (a.tstamp && tid == 0) atomicMin(&a.tstamp[0], (unsigned long long)wall_clock64());
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t B = g.sliceRows;
     uint32_t offV, offC, offL, offD;
@@ -204,6 +205,7 @@ __global__ __launch_bounds__(64 * W) void bucket_mul_kernel(const MulArgs a) {
         for (int w2 = 1; w2 < W; w2++) sum += acc[w2 * TILE_F + o];
         slab[o] = sum;
     }
+    if (a.tstamp && tid == 0) atomicMax(&a.tstamp[1], (unsigned long long)wall_clock64());
 }
 
 // integrate: out[(col)*NACC + slot] = sum over slices of slab[slice][tile][slot][j][lane]; Q4 adds the
@@ -211,10 +213,12 @@ __global__ __launch_bounds__(64 * W) void bucket_mul_kernel(const MulArgs a) {
 template <int FMT, int E>
 __global__ __launch_bounds__(256) void integrate_kernel(const float* __restrict__ slabs, const MulGeom g,
                                                         float* __restrict__ out, const OutlierIndex ol,
-                                                        const float* __restrict__ v, int hasOutliers) {
+                                                        const float* __restrict__ v, int hasOutliers,
+                                                        unsigned long long* __restrict__ tstamp) {
     constexpr int NACC = Fmt<FMT>::kAcc;
     constexpr int TILE_F = NACC * E * 64;
     const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
+    if (tstamp && gid == 0 && tstamp[1] > tstamp[0]) { tstamp[2] += tstamp[1] - tstamp[0]; tstamp[3] += 1; }
     if (gid >= g.tiles * TILE_F) return;
     const uint32_t t = gid / TILE_F, o = gid % TILE_F;
     const uint32_t lane = o & 63u, sj = o >> 6, j = sj % E, slot = sj / E;
@@ -282,12 +286,12 @@ size_t bucket_mul_lds_bytes(Format fmt, int W, int E, uint32_t B, uint32_t rowsP
 }
 
 hipError_t launch_integrate(Format fmt, int E, const float* slabs, const MulGeom& g, float* out,
-                            const OutlierIndex* ol, const float* v, hipStream_t st) {
+                            const OutlierIndex* ol, const float* v, unsigned long long* tstamp, hipStream_t st) {
     OutlierIndex o = ol ? *ol : OutlierIndex{nullptr, nullptr, nullptr};
     const int has = ol && ol->rowPtr ? 1 : 0;
     const uint32_t total = g.tiles * g.tileFloats;
     const dim3 grid((total + 255) / 256), block(256);
-#define EFFORT_CASE(f, e) if (fmt == f && E == e) { hipLaunchKernelGGL((integrate_kernel<f, e>), grid, block, 0, st, slabs, g, out, o, v, has); return hipGetLastError(); }
+#define EFFORT_CASE(f, e) if (fmt == f && E == e) { hipLaunchKernelGGL((integrate_kernel<f, e>), grid, block, 0, st, slabs, g, out, o, v, has, tstamp); return hipGetLastError(); }
     EFFORT_CASE(kFp16, 1) EFFORT_CASE(kFp16, 2) EFFORT_CASE(kFp16, 4)
     EFFORT_CASE(kQ4, 1) EFFORT_CASE(kQ4, 2) EFFORT_CASE(kQ4, 4)
 #undef EFFORT_CASE

@@ -16,7 +16,8 @@ __global__ __launch_bounds__(256) void find_cutoff_kernel(const float* __restric
                                                           const uint16_t* __restrict__ probes,
                                                           const uint32_t* __restrict__ expNo, uint32_t q,
                                                           float* __restrict__ cutoff,
-                                                          uint32_t* __restrict__ dispatchCount) {
+                                                          uint32_t* __restrict__ dispatchCount,
+                                                          unsigned long long* __restrict__ tstamp) {
     __shared__ float s_min[4], s_max[4];
     __shared__ uint32_t s_cnt[2][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -68,12 +69,13 @@ __global__ __launch_bounds__(256) void find_cutoff_kernel(const float* __restric
     if (tid == 0) {
         cutoff[0] = newBound;
         dispatchCount[0] = 0;      // dispatch.size.zero(), bucketMul.swift:38
+        if (tstamp) { tstamp[0] = ~0ull; tstamp[1] = 0ull; }
     }
 }
 
 hipError_t launch_find_cutoff(const float* v, const uint16_t* probes, const uint32_t* expNo, uint32_t q,
-                              float* cutoff, uint32_t* dispatchCount, hipStream_t st) {
-    hipLaunchKernelGGL(find_cutoff_kernel, dim3(1), dim3(256), 0, st, v, probes, expNo, q, cutoff, dispatchCount);
+                              float* cutoff, uint32_t* dispatchCount, unsigned long long* tstamp, hipStream_t st) {
+    hipLaunchKernelGGL(find_cutoff_kernel, dim3(1), dim3(256), 0, st, v, probes, expNo, q, cutoff, dispatchCount, tstamp);
     return hipGetLastError();
 }
 

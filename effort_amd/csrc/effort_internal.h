@@ -33,6 +33,7 @@ struct MulArgs {
     const float* cutoff;
     float* slabs;              // [slices][tiles][tileFloats]
     uint32_t* dispatchCount;
+    unsigned long long* tstamp;   // nullable: [0]=min start, [1]=max end (wall clock ticks), [2]=sum, [3]=launches
     MulGeom g;
 };
 
@@ -49,7 +50,7 @@ __device__ __forceinline__ float bf16_round(float f) {
 
 // ---- launchers (one per translation unit) ---------------------------------------------------
 hipError_t launch_find_cutoff(const float* v, const uint16_t* probes, const uint32_t* expNo, uint32_t q,
-                              float* cutoff, uint32_t* dispatchCount, hipStream_t st);
+                              float* cutoff, uint32_t* dispatchCount, unsigned long long* tstamp, hipStream_t st);
 
 // Returns hipErrorInvalidValue for unsupported (fmt, W, E).
 hipError_t launch_bucket_mul(Format fmt, int wavesPerGroup, int elemsPerLane, const MulArgs& a, hipStream_t st);
@@ -61,7 +62,7 @@ struct OutlierIndex {          // by-output CSR of the Q4 outliers, built at reg
     const float* value;        // [n]
 };
 hipError_t launch_integrate(Format fmt, int elemsPerLane, const float* slabs, const MulGeom& g, float* out,
-                            const OutlierIndex* outliers, const float* v, hipStream_t st);
+                            const OutlierIndex* outliers, const float* v, unsigned long long* tstamp, hipStream_t st);
 
 hipError_t launch_calc_dispatch(Format fmt, const void* stats, const float* v, const uint32_t* expNo,
                                 const float* cutoff, const MulGeom& g, float* dispatch, uint32_t* count,

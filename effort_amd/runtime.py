@@ -48,8 +48,15 @@ class Gpu:
     def set_tuning(self, waves: int = 0, elems: int = 0, slices: int = 0):
         self.check(self._lib.effort_set_tuning(self.ctx, waves, elems, slices), "set_tuning")
 
-    def enable_kernel_timing(self, on: bool = True):
-        self.check(self._lib.effort_enable_kernel_timing(self.ctx, int(on)), "enable_kernel_timing")
+    def enable_kernel_timing(self, mode: int = 1):
+        """1: HIP events + device clock, 2: device clock only (graph safe), 0: off."""
+        self._bind_stream()
+        self.check(self._lib.effort_enable_kernel_timing(self.ctx, int(mode)), "enable_kernel_timing")
+
+    def kernel_clock(self):
+        us, n = C.c_double(), C.c_int()
+        self.check(self._lib.effort_kernel_clock(self.ctx, C.byref(us), C.byref(n)), "kernel_clock")
+        return {"mul_us": us.value, "launches": n.value}
 
     def kernel_timing(self):
         mul, cut, integ, n = C.c_double(), C.c_double(), C.c_double(), C.c_int()

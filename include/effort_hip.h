@@ -134,9 +134,14 @@ EFFORT_API int effort_cosine(effort_ctx* ctx, const float* a_dev, const float* b
  * elements per lane (1, 2 or 4) and number of row slices (0 = heuristic).  Returns EFFORT_ERR_ARG
  * for unsupported combinations. */
 EFFORT_API int effort_set_tuning(effort_ctx* ctx, int wavesPerGroup, int elemsPerLane, int rowSlices);
-/* Timing hook: average duration in microseconds of the multiply kernel alone over the launches
- * since the last call (HIP events recorded on the context's stream when enabled). */
+/* Timing hooks.  enable = 1: HIP events are recorded on the context's stream around each of the three
+ * kernels of a call (not capturable into a graph) AND the multiply kernel stamps the device wall clock
+ * at its first workgroup's start / last workgroup's end; enable = 2: device clock only (works inside
+ * hipGraph replays); 0: off.  effort_kernel_timing returns event-to-event averages in microseconds
+ * (they include the launch gap in front of each kernel); effort_kernel_clock returns the multiply
+ * kernel's own average duration (first start -> last end).  Both reset their accumulators. */
 EFFORT_API int effort_enable_kernel_timing(effort_ctx* ctx, int enable);
+EFFORT_API int effort_kernel_clock(effort_ctx* ctx, double* mul_us_avg, int* n_launches);
 EFFORT_API int effort_kernel_timing(effort_ctx* ctx, double* mul_us_avg, double* cutoff_us_avg,
                          double* integrate_us_avg, int* n_samples);
 

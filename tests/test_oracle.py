@@ -221,7 +221,10 @@ def test_bucketmul_oracle_against_dense(conv_small, oracle_cpu):
             out, n, cutoff = oracle_cpu.bucket_mul(v, buckets, stats, probes, 4096, 256, effort)
             sims.append(cos(out, dense))
             counts.append(n)
-        assert sims[0] > 0.999 and sims[1] > 0.99 and sims[2] > 0.95, sims
+        # i.i.d. Gaussian weights are the worst case for the method (real LLM weights/activations are
+        # heavier-tailed: docs/ryc/ryc0.3.png shows 0.99 at 22 %); these bands are for this synthetic input
+        assert sims[0] > 0.9999 and sims[1] > 0.98 and sims[2] > 0.9 and sims[3] > 0.75, sims
+        assert sims == sorted(sims, reverse=True)
         assert counts == sorted(counts, reverse=True) and counts[0] <= 4096 * 16
         assert abs(counts[2] / (4096 * 16) - 0.25) < 0.1
 

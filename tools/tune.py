@@ -1,0 +1,76 @@
+#!/usr/bin/env python
+"""Sweep the multiply kernel's launch geometry (waves/workgroup, elements/lane, row slices) on one GPU.
+
+    python tools/tune.py [--shape 4096x11008] [--efforts 0.25,1.0] [--mats 16]
+
+Prints one line per configuration: per-call time from hipGraph replays over rotating matrices, and the
+multiply kernel's own duration from the device wall clock.  Used to pick the heuristics in api.hip.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shape", default="4096x11008")
+    ap.add_argument("--efforts", default="0.25,1.0")
+    ap.add_argument("--mats", type=int, default=16)
+    ap.add_argument("--configs", default="16,1,0;16,1,24;16,1,32;16,1,64;16,2,0;16,2,32;8,1,0;8,1,48;8,1,96;8,2,0;8,2,48;8,4,0;8,4,32;4,1,0;4,2,0;4,4,0")
+    args = ap.parse_args()
+    inDim, outDim = (int(x) for x in args.shape.split("x"))
+    import effort_amd as ea
+    from bench import make_weights, mul_kernel_bytes
+    dev = torch.device("cuda", 0)
+    g = ea.gpu(0)
+    ews = make_weights(ea, args.mats, inDim, outDim, 1234, dev, keep_core=False)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(42)
+    v = torch.randn(inDim, generator=gen, device=dev)
+    outs = [torch.zeros(outDim, device=dev) for _ in ews]
+    rows = []
+    for effort in (float(x) for x in args.efforts.split(",")):
+        for cfg in args.configs.split(";"):
+            W, E, S = (int(x) for x in cfg.split(","))
+            try:
+                g.set_tuning(W, E, S)
+                g.enable_kernel_timing(2)
+                for ew, o in zip(ews, outs):
+                    ea.bucketMul(v, ew, None, o, effort)
+                g.eval()
+                D = g.last_dispatch_count()
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr):
+                    for ew, o in zip(ews, outs):
+                        ea.bucketMul(v, ew, None, o, effort)
+                g._bind_stream()
+                for _ in range(5):
+                    gr.replay()
+                g.kernel_clock()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(30):
+                    gr.replay()
+                torch.cuda.synchronize()
+                t = (time.perf_counter() - t0) / 30 / len(ews)
+                clk = g.kernel_clock()
+                kb = mul_kernel_bytes(D, inDim, outDim)
+                row = {"shape": args.shape, "effort": effort, "W": W, "E": E, "S": S, "D": D, "call_us": round(t * 1e6, 2),
+                       "mul_us": round(clk["mul_us"], 2), "mul_GBps": round(kb / clk["mul_us"] / 1e3, 0),
+                       "eff_GBps": round(2 * inDim * outDim / t / 1e9, 0)}
+            except Exception as ex:
+                row = {"shape": args.shape, "effort": effort, "W": W, "E": E, "S": S, "error": repr(ex)[:100]}
+            rows.append(row)
+            print(json.dumps(row), flush=True)
+    g.set_tuning(0, 0, 0)
+    g.enable_kernel_timing(0)
+
+
+if __name__ == "__main__":
+    main()
