@@ -53,6 +53,7 @@ _SIGS = {
     "effort_cosine": (C.c_int, [_P, _P, _P, C.c_int, C.POINTER(C.c_float)]),
     "effort_set_tuning": (C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
     "effort_enable_kernel_timing": (C.c_int, [_P, C.c_int]),
+    "effort_debug_stamps": (C.c_int, [_P, C.POINTER(C.c_ulonglong)]),
     "effort_kernel_clock": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "effort_kernel_timing": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
 }
@@ -68,6 +69,11 @@ def lib() -> C.CDLL:
                 f"{LIB_PATH} is missing: the HIP extension has not been built "
                 "(run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C effort_amd/csrc`). "
                 "effort_amd has no CPU fallback.")
+        # PyTorch-ROCm wheels bundle their own libamdhip64 / librocblas.  Import torch FIRST so that this
+        # library's NEEDED entries resolve to the copies torch already mapped (same SONAMEs): one HIP
+        # runtime per process, so torch's device pointers and streams are valid here.  (A non-Python host
+        # -- the Swift shim of INTEGRATION.md -- simply uses the system ROCm.)
+        import torch  # noqa: F401
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
             fn = getattr(l, name)        # AttributeError if the ABI and the header drifted apart

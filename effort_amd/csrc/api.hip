@@ -28,6 +28,10 @@ struct effort_ctx {
     uint16_t* d_convVals = nullptr;   // converter scratch (transposed matrix)
     size_t convElems = 0;
     int* d_status = nullptr;
+    uint32_t* d_counters = nullptr;   // per-tile arrival tickets (zero between calls)
+    uint32_t* d_sliceCounts = nullptr;
+    uint32_t lastSlices = 0;
+    static constexpr uint32_t kMaxTiles = 1024, kMaxSlices = 4096;
     unsigned long long* d_tstamp = nullptr;   // device-clock stamps of the multiply kernel (timing mode)
     double wallClockKHz = 100000.0;
     rocblas_handle blas = nullptr;
@@ -84,11 +88,15 @@ extern "C" effort_ctx* effort_create(int device, void* stream) {
     bool ok = hipMalloc(&c->d_cutoff, 16) == hipSuccess && hipMalloc(&c->d_count, 16) == hipSuccess &&
               hipMalloc(&c->d_slabs, c->slabBytes) == hipSuccess && hipMalloc(&c->d_blockScratch, 4096 * 4) == hipSuccess &&
               hipMalloc(&c->d_cos, 16) == hipSuccess && hipMalloc(&c->d_status, 16) == hipSuccess &&
-              hipMalloc(&c->d_tstamp, 32) == hipSuccess;
+              hipMalloc(&c->d_tstamp, 256) == hipSuccess && hipMalloc(&c->d_counters, effort_ctx::kMaxTiles * 4) == hipSuccess &&
+              hipMalloc(&c->d_sliceCounts, effort_ctx::kMaxSlices * 4) == hipSuccess;
     if (!ok) { effort_destroy(c); return nullptr; }
     int khz = 0;
     if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0) c->wallClockKHz = khz;
-    hipMemset(c->d_tstamp, 0, 32);
+    hipMemset(c->d_tstamp, 0, 256);
+    hipMemset(c->d_counters, 0, effort_ctx::kMaxTiles * 4);
+    hipMemset(c->d_sliceCounts, 0, effort_ctx::kMaxSlices * 4);
+    { unsigned long long init[2] = {~0ull, 0ull}; hipMemcpy(c->d_tstamp, init, 16, hipMemcpyHostToDevice); }
     hipMemset(c->d_cutoff, 0, 16);
     hipMemset(c->d_count, 0, 16);
     hipMemset(c->d_status, 0, 16);
@@ -102,7 +110,7 @@ extern "C" void effort_destroy(effort_ctx* c) {
     if (c->blas) rocblas_destroy_handle(c->blas);
     if (c->ev) { for (int i = 0; i < effort_ctx::kMaxSamples * 4; i++) hipEventDestroy(c->ev[i]); delete[] c->ev; }
     hipFree(c->d_cutoff); hipFree(c->d_count); hipFree(c->d_slabs); hipFree(c->d_blockScratch);
-    hipFree(c->d_vhalf); hipFree(c->d_cos); hipFree(c->d_convVals); hipFree(c->d_status); hipFree(c->d_tstamp);
+    hipFree(c->d_vhalf); hipFree(c->d_cos); hipFree(c->d_convVals); hipFree(c->d_status); hipFree(c->d_tstamp); hipFree(c->d_counters); hipFree(c->d_sliceCounts);
     delete c;
 }
 
@@ -130,7 +138,8 @@ extern "C" effort_w* effort_weights_fp16(effort_ctx* c, const void* buckets, con
                                          int inDim, int outDim, int percentLoad, int numExperts) {
     if (!c || !buckets || !stats || !probes) { fail(c, EFFORT_ERR_ARG, "effort_weights_fp16: null argument"); return nullptr; }
     if (inDim <= 0 || outDim <= 0 || percentLoad < 1 || percentLoad > 16 || numExperts < 1 || check_shape(inDim, outDim) != EFFORT_OK ||
-        inDim > 65535) { fail(c, EFFORT_ERR_SHAPE, "effort_weights_fp16: unsupported shape"); return nullptr; }
+        inDim > 65535 || (size_t)numExperts * percentLoad * inDim * (outDim / 16) * 2 > 0xFFFFFFFFull) {
+        fail(c, EFFORT_ERR_SHAPE, "effort_weights_fp16: unsupported shape (or buckets >= 4 GiB)"); return nullptr; }
     effort_w* w = new (std::nothrow) effort_w();
     if (!w) return nullptr;
     w->ctx = c; w->fmt = kFp16;
@@ -143,7 +152,8 @@ extern "C" effort_w* effort_weights_q4(effort_ctx* c, const void* buckets, const
                                        const void* outliers, int64_t nOutliers, int inDim, int outDim, int numExperts) {
     if (!c || !buckets || !stats || !probes) { fail(c, EFFORT_ERR_ARG, "effort_weights_q4: null argument"); return nullptr; }
     if (inDim <= 0 || outDim <= 0 || numExperts < 1 || check_shape(inDim, outDim) != EFFORT_OK || outDim % 32 || inDim > 65535 ||
-        nOutliers < 0) { fail(c, EFFORT_ERR_SHAPE, "effort_weights_q4: unsupported shape"); return nullptr; }
+        nOutliers < 0 || (size_t)numExperts * 8 * inDim * (outDim / 32) * 2 > 0xFFFFFFFFull) {
+        fail(c, EFFORT_ERR_SHAPE, "effort_weights_q4: unsupported shape (or buckets >= 4 GiB)"); return nullptr; }
     effort_w* w = new (std::nothrow) effort_w();
     if (!w) return nullptr;
     w->ctx = c; w->fmt = kQ4;
@@ -172,35 +182,40 @@ extern "C" void effort_weights_free(effort_w* w) {
 
 // ---- launch geometry ----------------------------------------------------------------------------
 static bool supported(int W, int E) {
-    return (W == 16 && (E == 1 || E == 2)) || ((W == 8 || W == 4) && (E == 1 || E == 2 || E == 4));
+    // must match EFFORT_GEOMS in bucket_mul.hip
+    return (W == 16 && (E == 1 || E == 2)) || (W == 8 && (E == 1 || E == 2 || E == 4)) ||
+           (W == 4 && (E == 1 || E == 2 || E == 4 || E == 8)) || (W == 2 && (E == 4 || E == 8));
 }
 
 static int choose_geom(const effort_ctx* c, const effort_w* w, MulGeom* g, int* Wout, int* Eout) {
+    // defaults: 16 waves per workgroup with 128 KiB of private accumulator tiles (FP16: 2 columns per lane,
+    // Q4: 1 word = 4 sub-buckets per lane)
     const int W = c->tuneW ? c->tuneW : 16;
-    const int E = c->tuneE ? c->tuneE : 1;
+    const int E = c->tuneE ? c->tuneE : (w->fmt == kFp16 ? 2 : 1);
     if (!supported(W, E)) return EFFORT_ERR_ARG;
     const uint32_t nacc = w->fmt == kFp16 ? 16 : 32;
     g->inDim = w->inDim; g->outDim = w->outDim; g->cols = w->cols; g->rowsPerIn = w->rowsPerIn;
-    g->expertRows = w->rowsPerIn * w->inDim;
+    g->expertRows = w->rowsPerIn * w->inDim; g->numExperts = w->numExperts;
     g->tiles = (w->cols + 64 * E - 1) / (64 * E);
     g->tileFloats = nacc * E * 64;
     const size_t ldsMax = 160 * 1024;
+    const size_t accBytes = (size_t)W * g->tileFloats * 4;
+    if (accBytes + 4096 > ldsMax) return EFFORT_ERR_ARG;
     uint32_t S;
-    if (c->tuneS) S = c->tuneS;
+    if (c->tuneS) S = (c->tuneS + 7) / 8 * 8;
     else {
-        // fill the chip: about two workgroups per CU when the accumulator tiles allow it
-        const size_t accBytes = (size_t)W * g->tileFloats * 4;
+        // fill the chip: as many workgroups per CU as the private accumulator tiles leave room for (<= 2)
         const uint32_t perCU = accBytes * 2 + 16384 <= ldsMax ? 2u : 1u;
-        S = (c->numCU * perCU + g->tiles - 1) / g->tiles;
+        S = (c->numCU * perCU) / g->tiles / 8 * 8;        // one round of workgroups: tiles*S <= resident capacity
     }
-    S = (S + 7) / 8 * 8;
     if (S > w->inDim) S = w->inDim / 8 * 8;
     if (S < 8) S = 8;
     for (;;) {
         g->sliceRows = (w->inDim + S - 1) / S;
         g->slices = (w->inDim + g->sliceRows - 1) / g->sliceRows;
         const size_t lds = bucket_mul_lds_bytes(w->fmt, W, E, g->sliceRows, g->rowsPerIn);
-        const bool fits = lds <= ldsMax && g->sliceRows <= (w->fmt == kFp16 ? 4096u : 8192u);
+        const bool fits = lds <= ldsMax && g->sliceRows <= (w->fmt == kFp16 ? 4096u : 8192u) &&
+                          g->rowsPerIn * g->sliceRows <= bucket_mul_max_candidates(W);
         const size_t slab = (size_t)g->slices * g->tiles * g->tileFloats * 4;
         if (fits && slab <= c->slabBytes) break;
         if (!fits) { S += 8; if (S > w->inDim + 8) return EFFORT_ERR_SHAPE; }
@@ -228,19 +243,18 @@ static int do_bucketmul(effort_ctx* c, const effort_w* w, Format fmt, const floa
     const uint32_t q = (uint32_t)(int)((double)(kProbes - 1) * (1.0 - effort));      // bucketMul.swift:39
     const bool tm = c->timing && c->nSamples < effort_ctx::kMaxSamples;
     hipEvent_t* ev = tm ? c->ev + 4 * c->nSamples : nullptr;
+    if (g.tiles + 1 > effort_ctx::kMaxTiles || g.slices > effort_ctx::kMaxSlices) return fail(c, EFFORT_ERR_SHAPE, "bucketmul: geometry exceeds scratch");
 
-    unsigned long long* ts = c->clock ? c->d_tstamp : nullptr;
-    if (tm) HIP_TRY(c, hipEventRecord(ev[0], c->stream));
-    HIP_TRY(c, launch_find_cutoff(v, w->probes, expNo, q, c->d_cutoff, c->d_count, ts, c->stream));
-    if (tm) HIP_TRY(c, hipEventRecord(ev[1], c->stream));
     MulArgs a;
-    a.buckets = w->buckets; a.stats = w->stats; a.v = v; a.expNo = expNo; a.cutoff = c->d_cutoff;
-    a.slabs = c->d_slabs; a.dispatchCount = c->d_count; a.tstamp = ts; a.g = g;
+    a.buckets = w->buckets; a.stats = w->stats; a.probes = w->probes; a.v = v; a.expNo = expNo; a.out = out;
+    a.slabs = c->d_slabs; a.counters = c->d_counters; a.sliceCounts = c->d_sliceCounts; a.cutoffOut = c->d_cutoff;
+    a.tstamp = c->clock ? c->d_tstamp : nullptr;
+    a.ol = OutlierIndex{fmt == kQ4 ? w->olRowPtr : nullptr, w->olInIdx, w->olValue};
+    a.q = q; a.g = g;
+    if (tm) HIP_TRY(c, hipEventRecord(ev[0], c->stream));
     HIP_TRY(c, launch_bucket_mul(fmt, W, E, a, c->stream));
-    if (tm) HIP_TRY(c, hipEventRecord(ev[2], c->stream));
-    OutlierIndex ol{w->olRowPtr, w->olInIdx, w->olValue};
-    HIP_TRY(c, launch_integrate(fmt, E, c->d_slabs, g, out, (fmt == kQ4 && w->olRowPtr) ? &ol : nullptr, v, ts, c->stream));
-    if (tm) { HIP_TRY(c, hipEventRecord(ev[3], c->stream)); c->nSamples++; }
+    if (tm) { HIP_TRY(c, hipEventRecord(ev[1], c->stream)); c->nSamples++; }
+    c->lastSlices = g.slices;                      // dispatch.size = sum of the per-slice counts
     return EFFORT_OK;
 }
 
@@ -261,13 +275,23 @@ extern "C" int effort_calc_dispatch(effort_ctx* c, const effort_w* w, const floa
     const uint32_t q = (uint32_t)(int)((double)(kProbes - 1) * (1.0 - effort));
     HIP_TRY(c, launch_find_cutoff(v, w->probes, expNo, q, c->d_cutoff, c->d_count, nullptr, c->stream));
     HIP_TRY(c, launch_calc_dispatch(w->fmt, w->stats, v, expNo, c->d_cutoff, g, dispatch, count, c->d_count, c->d_blockScratch, c->stream));
+    c->lastSlices = 0;                             // dispatch.size is the scalar written by the scan kernel
     return EFFORT_OK;
 }
 
 extern "C" int effort_last_dispatch_count(effort_ctx* c, uint32_t* host_out) {
     if (!c || !host_out) return EFFORT_ERR_ARG;
-    HIP_TRY(c, hipMemcpyAsync(host_out, c->d_count, 4, hipMemcpyDeviceToHost, c->stream));
+    if (c->lastSlices == 0) {
+        HIP_TRY(c, hipMemcpyAsync(host_out, c->d_count, 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        return EFFORT_OK;
+    }
+    static thread_local uint32_t h[effort_ctx::kMaxSlices];
+    HIP_TRY(c, hipMemcpyAsync(h, c->d_sliceCounts, (size_t)c->lastSlices * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    uint32_t n = 0;
+    for (uint32_t i = 0; i < c->lastSlices; i++) n += h[i];
+    *host_out = n;
     return EFFORT_OK;
 }
 extern "C" int effort_last_cutoff(effort_ctx* c, float* host_out) {
@@ -344,7 +368,15 @@ extern "C" int effort_enable_kernel_timing(effort_ctx* c, int enable) {
     c->timing = enable == 1;      // 1: events + device clock, 2: device clock only (graph-capture safe)
     c->clock = enable != 0;
     c->nSamples = 0;
-    HIP_TRY(c, hipMemsetAsync(c->d_tstamp, 0, 32, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_tstamp, 0, 256, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_tstamp, 0xFF, 8, c->stream));
+    return EFFORT_OK;
+}
+
+extern "C" int effort_debug_stamps(effort_ctx* c, unsigned long long* host16) {
+    if (!c || !host16) return EFFORT_ERR_ARG;
+    HIP_TRY(c, hipMemcpyAsync(host16, c->d_tstamp + 8, 128, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     return EFFORT_OK;
 }
 
@@ -355,7 +387,7 @@ extern "C" int effort_kernel_clock(effort_ctx* c, double* mul_us_avg, int* n_lau
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (mul_us_avg) *mul_us_avg = h[3] ? (double)h[2] / (double)h[3] * 1000.0 / c->wallClockKHz : 0.0;
     if (n_launches) *n_launches = (int)h[3];
-    HIP_TRY(c, hipMemsetAsync(c->d_tstamp, 0, 32, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_tstamp + 2, 0, 16, c->stream));
     return EFFORT_OK;
 }
 
@@ -365,9 +397,7 @@ extern "C" int effort_kernel_timing(effort_ctx* c, double* mul_us, double* cutof
     double a = 0, b = 0, d = 0;
     for (int i = 0; i < c->nSamples; i++) {
         float ms;
-        HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[4 * i + 0], c->ev[4 * i + 1])); a += ms;
-        HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[4 * i + 1], c->ev[4 * i + 2])); b += ms;
-        HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[4 * i + 2], c->ev[4 * i + 3])); d += ms;
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[4 * i + 0], c->ev[4 * i + 1])); b += ms;   // the one fused kernel
     }
     const int ns = c->nSamples ? c->nSamples : 1;
     if (cutoff_us) *cutoff_us = a * 1000.0 / ns;

@@ -1,60 +1,97 @@
-// bucket_mul -- the hot kernel.  Replaces prepareDispatch + roundUp + zeroRange32 + bucketMul
-// (bucketMul.metal:11-117) and prepareDispatchQ4 + bucketMulQ4 (bucketMulQ4.metal:25-92) with ONE
-// fused launch; bucketIntegrate (bucketMul.metal:122-137) becomes the small `integrate` kernel below.
+// bucket_mul -- the hot path as ONE kernel launch per bucketMul call.
+// Replaces the reference's six launches: findCutoff32, prepareDispatch, roundUp, zeroRange32, bucketMul,
+// bucketIntegrate (bucketMul.metal:11-247) and, for Q4, prepareDispatchQ4, bucketMulQ4, calcOutliers
+// (bucketMulQ4.metal:13-92).  On MI355X a dependent kernel boundary costs 1.5-5 us and the whole call moves
+// ~23 MB (2.8 us of HBM time), so the call is a latency chain first and a bandwidth problem second: the design
+// goal is one launch, one memory round trip per dependent step, and no host involvement.
 //
 // Work decomposition (MI355X-first, not the reference's [cols x 32] grid of 32-thread groups):
-//   grid   = T column tiles x S row slices, one workgroup of W wave64 each (W = 16 by default),
-//            block id -> (tile, slice) remapped so all tiles of a slice sit on one XCD (same L2:
-//            they share the stats lines and the 128-B lines that straddle two tiles).
-//   slice  = a contiguous block of B input rows (all ranks of them) -> its kept bucket rows are
-//            neighbours in HBM within each rank plane.
-//   tile   = 64*E u16 columns; lane l of every wave owns columns l*E .. l*E+E-1 of the tile, so one
-//            wave load instruction reads one contiguous 128*E-byte piece of one bucket row.
+//   grid   = T column tiles x S row slices, one workgroup of W wave64 each; tiles*S <= resident capacity so
+//            the grid is one round of workgroups; block id -> (tile, slice) remapped so all tiles of a slice sit
+//            on one XCD (same L2: they share the stats lines and the 128-B lines that straddle two tiles).
+//   slice  = a contiguous block of B input rows (all ranks of them) -> its kept bucket rows are neighbours in
+//            HBM within each rank plane.
+//   tile   = 64*E u16 columns; lane l of every wave owns columns l*E .. l*E+E-1 of the tile, so one wave load
+//            instruction reads one contiguous 128*E-byte piece of one bucket row.
 // Per workgroup:
-//   1. test its 16*B (Q4: 8*B) candidate rows against the cutoff exactly as prepareDispatch does
-//      (cutoff < (1e5*mean)*|v|) and compact the survivors, in ascending bucket-row order, into an
-//      LDS list with wave ballots + mbcnt prefix (no global atomics, deterministic);
-//   2. waves take list entries round-robin and stream those rows from HBM (16 loads in flight per
-//      lane), scattering each product into a PRIVATE per-wave LDS accumulator tile with ds_add_f32:
-//      acc[slot][j][lane], slot = the 4 position bits of the f16 weight (Q4: sub-bucket*8 + the 3
-//      position bits of the nibble).  The layout puts lane l on LDS bank l%32 whatever the slot, so
-//      the scatter is bank-conflict free; private tiles make the f32 summation order fixed.
-//   3. the W private tiles are summed in wave order and written as one partial "slab".
-// `integrate` then sums the S slabs per output in slice order (and, for Q4, adds the outliers in
-// table order) and writes out[] -- deterministic end to end.
-#include "effort_internal.h"
+//   A. every thread issues ALL the loads the selection needs up front -- its share of v and the probes, its
+//      slice of v, the stats of the candidate rows it will test -- one memory round trip; the private
+//      accumulator tiles are zeroed while those loads fly.
+//   B. the cutoff is evaluated redundantly by every workgroup (cutoff_device.h: bit-exact findCutoff32), which
+//      is cheaper than a kernel boundary or a cross-workgroup flag.
+//   C. the 16*B (Q4: 8*B) candidate rows are tested exactly as prepareDispatch does (cutoff < (1e5*mean)*|v|)
+//      and the survivors compacted, in ascending bucket-row order, into an LDS list (wave ballots + mbcnt
+//      prefix; no global atomics, deterministic).
+//   D. waves take list entries round-robin and stream those rows from HBM: two batches of 16 buffer loads in
+//      flight per lane, the row offset in an SGPR (v_readlane of the decoded entry -> buffer soffset, no per-row
+//      address VALU).  Each product is added into a PRIVATE per-wave LDS accumulator tile acc[slot][j][lane]
+//      (slot = the 4 position bits of the f16 weight; Q4: sub-bucket*8 + the 3 position bits of the nibble) by a
+//      plain ds_read / v_add / ds_write: the LDS float atomic (ds_add_f32) measured 0.5 elements/clk/CU on
+//      MI355X against 6.8 for read-add-write and 2.1 for a 16-way register select chain (tools/microbench.hip).
+//      The layout puts lane l on LDS bank l%32 whatever the slot, so the scatter is bank-conflict free; the E
+//      (Q4: 4E) slots one lane touches for one row are distinct by construction, so their read-add-writes are
+//      issued together; rows are processed in order, which fixes the f32 summation order.
+//   E. the W private tiles are summed in wave order into one partial "slab", stored write-through; the workgroup
+//      takes a ticket on its tile's arrival counter, and the LAST workgroup of each tile sums the S slabs in
+//      slice order (and, for Q4, adds that output's outliers in table order) and writes out[].  The result does
+//      not depend on arrival order: deterministic end to end.
+#include "cutoff_device.h"
 
 namespace effort {
 
-constexpr int kBatch = 16;   // bucket rows in flight per wave (one VGPR-resident load each)
+constexpr int kBatch = 16;   // bucket rows per batch; two batches in flight per wave
+constexpr int kPre = 4;      // candidate rows per thread whose stats are preloaded into registers
+
+// Ablation builds for profiling (-DEFFORT_ABLATE_NOSCATTER=1 / -DEFFORT_ABLATE_NOLOAD=1); never shipped.
+#ifndef EFFORT_ABLATE_NOSCATTER
+#define EFFORT_ABLATE_NOSCATTER 0
+#endif
+#ifndef EFFORT_ABLATE_NOLOAD
+#define EFFORT_ABLATE_NOLOAD 0
+#endif
+
+constexpr int kSc1 = 16;     // buffer aux bit: sc1 = write-through store / L1-bypassing load (cross-XCD visible)
 
 template <int FMT> struct Fmt;
 template <> struct Fmt<kFp16> { static constexpr int kAcc = 16; };
 template <> struct Fmt<kQ4> { static constexpr int kAcc = 32; };
 
-template <int E> struct LoadT;
-template <> struct LoadT<1> { using type = uint16_t; };
-template <> struct LoadT<2> { using type = uint32_t; };
-template <> struct LoadT<4> { using type = uint2; };
-
-__device__ __forceinline__ uint32_t word_of(uint16_t w, int) { return w; }
-__device__ __forceinline__ uint32_t word_of(uint32_t w, int j) { return (w >> (16 * j)) & 0xFFFFu; }
-__device__ __forceinline__ uint32_t word_of(uint2 w, int j) { return ((j < 2 ? w.x : w.y) >> (16 * (j & 1))) & 0xFFFFu; }
-
-__device__ __forceinline__ void lds_add(float* p, float x) {
-    // wave-private slot: a plain LDS read-modify-write instruction (ds_add_f32), no return value
-    __hip_atomic_fetch_add(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-}
+// One lane's piece of a bucket row: E u16 words.
+template <int E> struct Piece;
+template <> struct Piece<1> {
+    uint32_t w;
+    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) { w = __builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, 0); }
+    __device__ __forceinline__ uint32_t word(int) const { return w & 0xFFFFu; }
+};
+template <> struct Piece<2> {
+    uint32_t w;
+    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) { w = __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0); }
+    __device__ __forceinline__ uint32_t word(int j) const { return (w >> (16 * j)) & 0xFFFFu; }
+};
+template <> struct Piece<4> {
+    uint32_t w[2];
+    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+        auto t = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0); w[0] = t[0]; w[1] = t[1];
+    }
+    __device__ __forceinline__ uint32_t word(int j) const { return (w[j >> 1] >> (16 * (j & 1))) & 0xFFFFu; }
+};
+template <> struct Piece<8> {
+    uint32_t w[4];
+    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+        auto t = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0); w[0] = t[0]; w[1] = t[1]; w[2] = t[2]; w[3] = t[3];
+    }
+    __device__ __forceinline__ uint32_t word(int j) const { return (w[j >> 1] >> (16 * (j & 1))) & 0xFFFFu; }
+};
 
 __host__ __device__ inline uint32_t align_up(uint32_t x, uint32_t a) { return (x + a - 1) / a * a; }
 
-// LDS carve (bytes): [W][tileFloats] f32 | vblk[B] f32 | wcnt[2][16] u32 | list[rows*B] u16 | dlist (Q4) f32
+// LDS carve (bytes): [W][tileFloats] f32 | vblk[B] f32 | misc 256 B | list[rows*B] u16 | dlist (Q4) f32
 template <int FMT, int E, int W>
 __host__ __device__ inline uint32_t lds_layout(uint32_t B, uint32_t rowsPerIn, uint32_t* offV, uint32_t* offC,
                                                uint32_t* offL, uint32_t* offD) {
     uint32_t o = (uint32_t)W * Fmt<FMT>::kAcc * E * 64 * 4;
     *offV = o; o += align_up(B * 4, 16);
-    *offC = o; o += 2 * 16 * 4;
+    *offC = o; o += 256;                                   // [0..63] cutoff scratch, [64..191] wave counts, [192] flags
     *offL = o; o += align_up(rowsPerIn * B * 2, 16);
     *offD = o; if (FMT == kQ4) o += align_up(rowsPerIn * B * 4, 16);
     return o;
@@ -64,7 +101,8 @@ template <int FMT, int E, int W>
 __global__ __launch_bounds__(64 * W) void bucket_mul_kernel(const MulArgs a) {
     constexpr int NACC = Fmt<FMT>::kAcc;
     constexpr int TILE_F = NACC * E * 64;
-    using LT = typename LoadT<E>::type;
+    constexpr int NT = 64 * W;
+    constexpr int VPT = 4096 / NT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const MulGeom& g = a.g;
@@ -75,172 +113,250 @@ __global__ __launch_bounds__(64 * W) void bucket_mul_kernel(const MulArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     if (a.tstamp && tid == 0) atomicMin(&a.tstamp[0], (unsigned long long)wall_clock64());
+    const bool stamp = a.tstamp && blockIdx.x == 0 && tid == 0;      // phase stamps of workgroup 0 (profiling aid)
+    if (stamp) a.tstamp[16] = wall_clock64();
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t B = g.sliceRows;
     uint32_t offV, offC, offL, offD;
     lds_layout<FMT, E, W>(B, g.rowsPerIn, &offV, &offC, &offL, &offD);
     float* acc = reinterpret_cast<float*>(smem);
     float* vblk = reinterpret_cast<float*>(smem + offV);
-    uint32_t* wcnt = reinterpret_cast<uint32_t*>(smem + offC);
+    uint32_t* wcnt = reinterpret_cast<uint32_t*>(smem + offC + 64);          // [2][16]
+    uint32_t* flags = reinterpret_cast<uint32_t*>(smem + offC + 192);
     uint16_t* list = reinterpret_cast<uint16_t*>(smem + offL);
     float* dlist = reinterpret_cast<float*>(smem + offD);
     float* myacc = acc + wave * TILE_F + lane;
 
     const uint32_t j0 = s * B;
     const uint32_t nb = min(B, g.inDim - j0);
+    const uint32_t NC = g.rowsPerIn * nb;                       // candidate rows of this slice
     const uint32_t e = a.expNo ? a.expNo[0] : 0u;
-    const float cutoff = a.cutoff[0];
 
+    // ---- A. everything the selection needs, in one round trip --------------------------------
+    float vj[VPT]; uint16_t prj[VPT];
+    const uint16_t* pr = a.probes + (size_t)e * kProbes;
 #pragma unroll
-    for (int i = 0; i < NACC * E; i++) myacc[i * 64] = 0.0f;
-    for (uint32_t jl = tid; jl < nb; jl += 64 * W) vblk[jl] = a.v[j0 + jl];
-    __syncthreads();
-
-    // ---- 1. dispatch: keep test + ordered compaction into LDS ---------------------------------
-    const uint32_t NC = g.rowsPerIn * nb;
-    uint32_t n = 0;
-    int round = 0;
-    for (uint32_t c0 = 0; c0 < NC; c0 += 64 * W, round++) {
-        const uint32_t c = c0 + tid;
-        bool keep = false;
-        uint32_t code = 0;
-        float dval = 0.0f;
+    for (int i = 0; i < VPT; i++) { vj[i] = a.v[tid + NT * i]; prj[i] = pr[tid + NT * i]; }
+    // candidate c: FP16 -> rank = c / nb, jl = c % nb (rank-major, convert.metal:83-100; v index = row % inDim)
+    //              Q4   -> jl = c / 8,  rank = c % 8  (input-major, bucketMulQ4.metal:46)
+    float mean[kPre];
+    uint32_t codes[kPre];
+#pragma unroll
+    for (int r = 0; r < kPre; r++) {
+        const uint32_t c = r * NT + tid;
+        mean[r] = 0.0f; codes[r] = 0;
         if (c < NC) {
             if (FMT == kFp16) {
-                // bucket row i = rank*inDim + j (rank-major, convert.metal:83-100); v index = i % inDim
                 const uint32_t rank = c / nb, jl = c - rank * nb;
                 const size_t row = (size_t)e * g.expertRows + (size_t)rank * g.inDim + j0 + jl;
-                const float mean = half_bits_to_float(reinterpret_cast<const uint16_t*>(a.stats)[row * 4 + 3]);
-                const float x = vblk[jl];
-                keep = cutoff < (kCutoffScale * mean) * fabsf(x);         // bucketMul.metal:69
-                code = (rank << 12) | jl;
+                mean[r] = half_bits_to_float(reinterpret_cast<const uint16_t*>(a.stats)[row * 4 + 3]);
+                codes[r] = (rank << 12) | jl;
             } else {
-                // bucket row i = j*8 + rank (input-major, bucketMulQ4.metal:46); entry value = v*mean (:52)
                 const uint32_t jl = c >> 3, rank = c & 7u;
                 const size_t row = (size_t)e * g.expertRows + (size_t)(j0 + jl) * 8u + rank;
-                const float mean = reinterpret_cast<const float*>(a.stats)[row * 2 + 1];
-                const float x = vblk[jl];
-                keep = cutoff < (kCutoffScale * mean) * fabsf(x);         // bucketMulQ4.metal:47
-                dval = x * mean;
-                code = (jl << 3) | rank;
+                mean[r] = reinterpret_cast<const float*>(a.stats)[row * 2 + 1];
+                codes[r] = (jl << 3) | rank;
             }
         }
-        const unsigned long long m = __ballot(keep);
-        const uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-        if (lane == 0) wcnt[(round & 1) * 16 + wave] = (uint32_t)__popcll(m);
-        __syncthreads();
-        uint32_t woff = 0, tot = 0;
+    }
+    for (uint32_t jl = tid; jl < nb; jl += NT) vblk[jl] = a.v[j0 + jl];
 #pragma unroll
-        for (int w2 = 0; w2 < W; w2++) {
-            const uint32_t cw = wcnt[(round & 1) * 16 + w2];
-            woff += (w2 < wave) ? cw : 0u;
-            tot += cw;
+    for (int i = 0; i < NACC * E; i++) myacc[i * 64] = 0.0f;
+    if (stamp) a.tstamp[17] = wall_clock64();
+
+    // ---- B. cutoff (findCutoff32), redundantly per workgroup; its first barrier also publishes vblk ------
+    const float cutoff = block_find_cutoff<NT>(vj, prj, a.q, smem + offC, stamp ? a.tstamp + 8 : nullptr);
+    if (blockIdx.x == 0 && tid == 0) a.cutoffOut[0] = cutoff;        // BucketMul.cutoff (bucketMul.swift:22)
+    if (stamp) a.tstamp[18] = wall_clock64();
+
+    // ---- C. keep test (bucketMul.metal:69 / bucketMulQ4.metal:47) + ordered compaction -----------
+    uint32_t n = 0;
+#pragma unroll
+    for (int r = 0; r < kPre; r++) {
+        if ((uint32_t)(r * NT) < NC) {                          // uniform
+            const uint32_t c = r * NT + tid;
+            const uint32_t jl = FMT == kFp16 ? (codes[r] & 4095u) : (codes[r] >> 3);
+            const float x = (c < NC) ? vblk[jl] : 0.0f;
+            const bool keep = (c < NC) && (cutoff < (kCutoffScale * mean[r]) * fabsf(x));
+            const unsigned long long m = __ballot(keep);
+            const uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (lane == 0) wcnt[(r & 1) * 16 + wave] = (uint32_t)__popcll(m);
+            __syncthreads();
+            uint32_t woff = 0, tot = 0;
+#pragma unroll
+            for (int w2 = 0; w2 < W; w2++) {
+                const uint32_t cw = wcnt[(r & 1) * 16 + w2];
+                woff += (w2 < wave) ? cw : 0u;
+                tot += cw;
+            }
+            if (keep) {
+                list[n + woff + pre] = (uint16_t)codes[r];
+                if (FMT == kQ4) dlist[n + woff + pre] = x * mean[r];          // entry value = v*mean (:52)
+            }
+            n += tot;
         }
-        if (keep) {
-            list[n + woff + pre] = (uint16_t)code;
-            if (FMT == kQ4) dlist[n + woff + pre] = dval;
-        }
-        n += tot;
     }
     __syncthreads();
-    if (t == 0 && tid == 0 && n) atomicAdd(a.dispatchCount, n);   // dispatch.size (test hook)
+    if (t == 0 && tid == 0) a.sliceCounts[s] = n;                  // dispatch.size = sum over slices (test hook)
+    if (stamp) a.tstamp[19] = wall_clock64();
 
-    // ---- 2. stream the kept rows, scatter-accumulate into the private LDS tile ----------------
+    // ---- D. stream the kept rows, scatter-accumulate into the private LDS tile ----------------
     const uint32_t col = t * (64u * E) + (uint32_t)lane * E;
-    const bool colOK = col < g.cols;
-    const uint16_t* __restrict__ wbase = a.buckets + (colOK ? col : 0u);
+    const bool colOK = col < g.cols;                               // a piece past the last column is skipped whole
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint16_t*>(a.buckets), 0, (int)min((size_t)0xFFFFFFFFu, (size_t)g.numExperts * g.expertRows * g.cols * 2u), 0x00020000);
+    const uint32_t voff = (colOK ? col : 0u) * 2u;                 // lanes past the last column re-read column 0
     const uint32_t myRows = (n > (uint32_t)wave) ? (n - wave + W - 1) / W : 0u;   // entries wave, wave+W, ...
 
-    for (uint32_t i0 = 0; i0 < myRows; i0 += kBatch) {
-        // lane u of the wave decodes entry i0+u; the row loop below reads it back with v_readlane.
-        // A short last batch re-reads its last valid row (an L1/L2 hit) so that all kBatch loads stay
-        // unconditional -- a branch around a load makes hipcc drain vmcnt(0) per load.
-        const uint32_t nv = min((uint32_t)kBatch, myRows - i0);
-        uint32_t eoff = 0; float dv = 0.0f;
-        if (lane < kBatch) {
-            const uint32_t kk = wave + W * (i0 + min((uint32_t)lane, nv - 1u));
+    // Software pipeline: the loads of batch k+1 are issued before batch k is accumulated, so a wave keeps
+    // up to 2*kBatch row pieces in flight.  Loads are never predicated: a batch that runs past the wave's
+    // last row re-reads that last row (an L1/L2 hit) -- a branch around a load makes hipcc drain
+    // vmcnt(0) -- and the accumulate step skips the surplus with a wave-uniform test.
+    auto decode = [&](uint32_t i0, uint32_t& boff, float& dv) {
+        // lane u decodes list entry i0+u (clamped); the row loops read it back with v_readlane into SGPRs
+        boff = 0; dv = 0.0f;
+        if (lane < kBatch && myRows) {
+            const uint32_t kk = wave + W * min(i0 + (uint32_t)lane, myRows - 1u);
             const uint32_t code = list[kk];
             uint32_t rowIdx;
             if (FMT == kFp16) { const uint32_t rank = code >> 12, jl = code & 4095u; rowIdx = rank * g.inDim + j0 + jl; dv = vblk[jl]; }
             else { const uint32_t jl = code >> 3, rank = code & 7u; rowIdx = (j0 + jl) * 8u + rank; dv = dlist[kk]; }
-            eoff = (e * g.expertRows + rowIdx) * g.cols;
+            boff = (e * g.expertRows + rowIdx) * g.cols * 2u;       // byte offset of the bucket row (< 4 GiB, checked at registration)
         }
-        LT wreg[kBatch];
+    };
+    auto issue = [&](Piece<E> (&piece)[kBatch], uint32_t boff) {
 #pragma unroll
-        for (int u = 0; u < kBatch; u++) {
-            const uint32_t ro = __builtin_amdgcn_readlane(eoff, u);
-            wreg[u] = *reinterpret_cast<const LT*>(wbase + (size_t)ro);     // lanes past the last column read column 0
-        }
+        for (int u = 0; u < kBatch; u++) piece[u].load(rsrc, voff, EFFORT_ABLATE_NOLOAD ? 0u : __builtin_amdgcn_readlane(boff, u));
+    };
+    auto accumulate = [&](const Piece<E> (&piece)[kBatch], float dv, uint32_t nv) {
 #pragma unroll
         for (int u = 0; u < kBatch; u++) {
             const float dd = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(dv), u));
-            if ((uint32_t)u < nv && colOK) {
+            if (EFFORT_ABLATE_NOSCATTER) {   // ablation build: keep the loads live, skip the LDS scatter
+                asm volatile("" ::"v"(piece[u].word(E - 1)), "v"(dd));
+            } else if ((uint32_t)u < nv && colOK) {
+                if (FMT == kFp16) {
+                    // bucketMul.metal:100-106: v = d.x*float(w) with the position bits left in w; acc[pos] += v
+                    float val[E], old[E]; float* p[E];
 #pragma unroll
-                for (int j = 0; j < E; j++) {
-                    const uint32_t x = word_of(wreg[u], j);
-                    if (FMT == kFp16) {
-                        // bucketMul.metal:100-106: v = d.x*float(w) with the position bits left in w
-                        const float val = dd * half_bits_to_float((uint16_t)x);
-                        lds_add(myacc + ((x & 15u) * E + j) * 64, val);
-                    } else {
-                        // bucketMulQ4.metal:76-81: low nibble first <-> sub-bucket 3,2,1,0
+                    for (int j = 0; j < E; j++) {
+                        const uint32_t x = piece[u].word(j);
+                        val[j] = dd * half_bits_to_float((uint16_t)x);
+                        p[j] = myacc + ((x & 15u) * E + j) * 64;
+                    }
+#pragma unroll
+                    for (int j = 0; j < E; j++) old[j] = *p[j];
+#pragma unroll
+                    for (int j = 0; j < E; j++) *p[j] = old[j] + val[j];
+                } else {
+                    // bucketMulQ4.metal:76-81: low nibble first <-> sub-bucket 3,2,1,0; acc += (n&8) ? -d : d
+                    float val[4 * E], old[4 * E]; float* p[4 * E];
+#pragma unroll
+                    for (int j = 0; j < E; j++) {
+                        const uint32_t x = piece[u].word(j);
 #pragma unroll
                         for (int q = 0; q < 4; q++) {
                             const uint32_t nib = (x >> (4 * q)) & 15u;
-                            const float val = (nib & 8u) ? -dd : dd;
-                            lds_add(myacc + (((3 - q) * 8 + (nib & 7u)) * E + j) * 64, val);
+                            val[4 * j + q] = (nib & 8u) ? -dd : dd;
+                            p[4 * j + q] = myacc + (((3 - q) * 8 + (nib & 7u)) * E + j) * 64;
                         }
                     }
+#pragma unroll
+                    for (int i = 0; i < 4 * E; i++) old[i] = *p[i];
+#pragma unroll
+                    for (int i = 0; i < 4 * E; i++) *p[i] = old[i] + val[i];
                 }
             }
         }
+    };
+
+    if (myRows) {
+        Piece<E> pa[kBatch], pb[kBatch];
+        uint32_t boffA, boffB; float dvA, dvB;
+        decode(0, boffA, dvA);
+        issue(pa, boffA);
+        for (uint32_t i0 = 0; i0 < myRows; i0 += 2 * kBatch) {
+            decode(i0 + kBatch, boffB, dvB);
+            issue(pb, boffB);
+            accumulate(pa, dvA, min((uint32_t)kBatch, myRows - i0));
+            decode(i0 + 2 * kBatch, boffA, dvA);
+            issue(pa, boffA);
+            accumulate(pb, dvB, i0 + kBatch < myRows ? min((uint32_t)kBatch, myRows - i0 - kBatch) : 0u);
+        }
     }
     __syncthreads();
+    if (stamp) a.tstamp[20] = wall_clock64();
 
-    // ---- 3. sum the W private tiles in wave order -> one slab (native [slot][j][lane] order) ---
-    float* slab = a.slabs + ((size_t)s * g.tiles + t) * TILE_F;
-    for (int o = tid; o < TILE_F; o += 64 * W) {
-        float sum = acc[o];
+    // ---- E. W private tiles -> one slab (native [slot][j][lane] order), write-through; ticket; last arriver
+    //         of the tile reduces the S slabs in slice order and writes out[] -------------------------------
+    const size_t slabBytes = (size_t)g.slices * g.tiles * TILE_F * 4;
+    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(a.slabs, 0, (int)slabBytes, 0x00020000);
+    const uint32_t slabOff = (s * g.tiles + t) * (uint32_t)(TILE_F * 4);
+    for (int o = tid * 2; o < TILE_F; o += NT * 2) {
+        float s0 = acc[o], s1 = acc[o + 1];
 #pragma unroll
-        for (int w2 = 1; w2 < W; w2++) sum += acc[w2 * TILE_F + o];
-        slab[o] = sum;
+        for (int w2 = 1; w2 < W; w2++) { s0 += acc[w2 * TILE_F + o]; s1 += acc[w2 * TILE_F + o + 1]; }
+        typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+        u2 pk; pk[0] = __float_as_uint(s0); pk[1] = __float_as_uint(s1);
+        __builtin_amdgcn_raw_buffer_store_b64(pk, srs, (uint32_t)o * 4u, slabOff, kSc1);
     }
     if (a.tstamp && tid == 0) atomicMax(&a.tstamp[1], (unsigned long long)wall_clock64());
-}
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's slab stores have left the CU
+    if (stamp) { a.tstamp[21] = wall_clock64(); a.tstamp[22] = n; }
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t ticket = __hip_atomic_fetch_add(&a.counters[t], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        flags[0] = (ticket == g.slices - 1u) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (flags[0] == 0u) return;
 
-// integrate: out[(col)*NACC + slot] = sum over slices of slab[slice][tile][slot][j][lane]; Q4 adds the
-// outliers of that output afterwards (calcOutliers, bucketMulQ4.metal:13-21) in table order.
-template <int FMT, int E>
-__global__ __launch_bounds__(256) void integrate_kernel(const float* __restrict__ slabs, const MulGeom g,
-                                                        float* __restrict__ out, const OutlierIndex ol,
-                                                        const float* __restrict__ v, int hasOutliers,
-                                                        unsigned long long* __restrict__ tstamp) {
-    constexpr int NACC = Fmt<FMT>::kAcc;
-    constexpr int TILE_F = NACC * E * 64;
-    const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
-    if (tstamp && gid == 0 && tstamp[1] > tstamp[0]) { tstamp[2] += tstamp[1] - tstamp[0]; tstamp[3] += 1; }
-    if (gid >= g.tiles * TILE_F) return;
-    const uint32_t t = gid / TILE_F, o = gid % TILE_F;
-    const uint32_t lane = o & 63u, sj = o >> 6, j = sj % E, slot = sj / E;
-    const uint32_t col = t * (64u * E) + lane * E + j;
-    if (col >= g.cols) return;
-    const float* p = slabs + (size_t)t * TILE_F + o;
-    const size_t stride = (size_t)g.tiles * TILE_F;
-    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-    uint32_t sl = 0;
-    for (; sl + 4 <= g.slices; sl += 4) {
-        s0 += p[(size_t)(sl + 0) * stride];
-        s1 += p[(size_t)(sl + 1) * stride];
-        s2 += p[(size_t)(sl + 2) * stride];
-        s3 += p[(size_t)(sl + 3) * stride];
+    // last arriver of tile t: every slab of the tile was stored write-through (sc1) and drained before its ticket;
+    // read them past L1 (sc1), sum in slice order, un-permute, add the Q4 outliers, write out[]
+    const uint32_t sliceStride = g.tiles * (uint32_t)(TILE_F * 4);
+    for (int o = tid; o < TILE_F; o += NT) {
+        const uint32_t lane2 = o & 63u, sj = (uint32_t)o >> 6, j = sj % E, slot = sj / E;
+        const uint32_t c2 = t * (64u * E) + lane2 * E + j;
+        const uint32_t vo = t * (uint32_t)(TILE_F * 4) + (uint32_t)o * 4u;
+        // 16 loads in flight per lane (each is a fabric round trip); partial sums combined in a fixed order
+        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+        for (uint32_t sl = 0; sl < g.slices; sl += 16) {
+            uint32_t r[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+                r[i] = __builtin_amdgcn_raw_buffer_load_b32(srs, vo, min(sl + i, g.slices - 1u) * sliceStride, kSc1);
+#pragma unroll
+            for (int i = 0; i < 16; i += 4) {
+                if (sl + i + 0 < g.slices) s0 += __uint_as_float(r[i + 0]);
+                if (sl + i + 1 < g.slices) s1 += __uint_as_float(r[i + 1]);
+                if (sl + i + 2 < g.slices) s2 += __uint_as_float(r[i + 2]);
+                if (sl + i + 3 < g.slices) s3 += __uint_as_float(r[i + 3]);
+            }
+        }
+        float sum = (s0 + s1) + (s2 + s3);
+        if (c2 < g.cols) {
+            const uint32_t oi = c2 * NACC + slot;
+            if (FMT == kQ4 && a.ol.rowPtr) {                                   // calcOutliers, bucketMulQ4.metal:13-21
+                for (uint32_t q = a.ol.rowPtr[oi]; q < a.ol.rowPtr[oi + 1]; q++) sum += a.v[a.ol.inIdx[q]] * a.ol.value[q];
+            }
+            a.out[oi] = sum;
+        }
     }
-    for (; sl < g.slices; sl++) s0 += p[(size_t)sl * stride];
-    float sum = (s0 + s1) + (s2 + s3);
-    const uint32_t oi = col * NACC + slot;
-    if (FMT == kQ4 && hasOutliers) {
-        for (uint32_t q = ol.rowPtr[oi]; q < ol.rowPtr[oi + 1]; q++) sum += v[ol.inIdx[q]] * ol.value[q];
+    if (tid == 0) {
+        __hip_atomic_store(&a.counters[t], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next call
+        if (a.tstamp) {
+            atomicMax(&a.tstamp[1], (unsigned long long)wall_clock64());
+            const uint32_t done = __hip_atomic_fetch_add(&a.counters[g.tiles], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (done == g.tiles - 1u) {                                        // whole kernel finished: fold the stamps
+                const unsigned long long t0 = __hip_atomic_load(&a.tstamp[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long t1 = __hip_atomic_load(&a.tstamp[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                a.tstamp[2] += t1 - t0; a.tstamp[3] += 1;
+                __hip_atomic_store(&a.tstamp[0], ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&a.tstamp[1], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&a.counters[g.tiles], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     }
-    out[oi] = sum;
 }
 
 // ---- host side ------------------------------------------------------------------------------
@@ -255,16 +371,18 @@ static hipError_t launch_mul_t(const MulArgs& a, hipStream_t st) {
         if (err != hipSuccess) return err;
         maxSet = lds;
     }
+    if (a.g.rowsPerIn * a.g.sliceRows > (uint32_t)kPre * 64 * W) return hipErrorInvalidValue;   // candidates must fit the preload
     const uint32_t grid = a.g.tiles * align_up(a.g.slices, 8);
     hipLaunchKernelGGL((bucket_mul_kernel<FMT, E, W>), dim3(grid), dim3(64 * W), lds, st, a);
     return hipGetLastError();
 }
 
+#define EFFORT_GEOMS(X) X(16, 1) X(16, 2) X(8, 1) X(8, 2) X(8, 4) X(4, 1) X(4, 2) X(4, 4) X(4, 8) X(2, 4) X(2, 8)
+
 template <int FMT>
 static hipError_t launch_mul_fmt(int W, int E, const MulArgs& a, hipStream_t st) {
 #define EFFORT_CASE(w, e) if (W == w && E == e) return launch_mul_t<FMT, e, w>(a, st);
-    EFFORT_CASE(16, 1) EFFORT_CASE(16, 2) EFFORT_CASE(8, 1) EFFORT_CASE(8, 2) EFFORT_CASE(8, 4)
-    EFFORT_CASE(4, 1) EFFORT_CASE(4, 2) EFFORT_CASE(4, 4)
+    EFFORT_GEOMS(EFFORT_CASE)
 #undef EFFORT_CASE
     return hipErrorInvalidValue;
 }
@@ -279,23 +397,11 @@ size_t bucket_mul_lds_bytes(Format fmt, int W, int E, uint32_t B, uint32_t rowsP
     if (W == w && E == e)                                                                     \
         return fmt == kFp16 ? lds_layout<kFp16, e, w>(B, rowsPerIn, &o1, &o2, &o3, &o4)       \
                             : lds_layout<kQ4, e, w>(B, rowsPerIn, &o1, &o2, &o3, &o4);
-    EFFORT_CASE(16, 1) EFFORT_CASE(16, 2) EFFORT_CASE(8, 1) EFFORT_CASE(8, 2) EFFORT_CASE(8, 4)
-    EFFORT_CASE(4, 1) EFFORT_CASE(4, 2) EFFORT_CASE(4, 4)
+    EFFORT_GEOMS(EFFORT_CASE)
 #undef EFFORT_CASE
     return 0;
 }
 
-hipError_t launch_integrate(Format fmt, int E, const float* slabs, const MulGeom& g, float* out,
-                            const OutlierIndex* ol, const float* v, unsigned long long* tstamp, hipStream_t st) {
-    OutlierIndex o = ol ? *ol : OutlierIndex{nullptr, nullptr, nullptr};
-    const int has = ol && ol->rowPtr ? 1 : 0;
-    const uint32_t total = g.tiles * g.tileFloats;
-    const dim3 grid((total + 255) / 256), block(256);
-#define EFFORT_CASE(f, e) if (fmt == f && E == e) { hipLaunchKernelGGL((integrate_kernel<f, e>), grid, block, 0, st, slabs, g, out, o, v, has, tstamp); return hipGetLastError(); }
-    EFFORT_CASE(kFp16, 1) EFFORT_CASE(kFp16, 2) EFFORT_CASE(kFp16, 4)
-    EFFORT_CASE(kQ4, 1) EFFORT_CASE(kQ4, 2) EFFORT_CASE(kQ4, 4)
-#undef EFFORT_CASE
-    return hipErrorInvalidValue;
-}
+uint32_t bucket_mul_max_candidates(int W) { return (uint32_t)kPre * 64u * (uint32_t)W; }
 
 }  // namespace effort

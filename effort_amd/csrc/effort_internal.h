@@ -23,17 +23,29 @@ struct MulGeom {
     uint32_t slices;       // S: row slices actually used (every slice owns sliceRows input rows)
     uint32_t sliceRows;    // B: input rows per slice
     uint32_t tileFloats;   // accumulators per tile = NACC*E*64
+    uint32_t numExperts;   // experts stacked in the buffers (bounds of the buffer descriptor)
+};
+
+struct OutlierIndex {          // by-output CSR of the Q4 outliers, built at registration
+    const uint32_t* rowPtr;    // [outDim+1]  (nullptr: no outliers)
+    const uint32_t* inIdx;     // [n]
+    const float* value;        // [n]
 };
 
 struct MulArgs {
     const uint16_t* buckets;
     const void* stats;         // f16x4 (FP16) or f32x2 (Q4) per bucket row
+    const uint16_t* probes;    // f16 [numExperts][4096]
     const float* v;
     const uint32_t* expNo;     // nullable
-    const float* cutoff;
-    float* slabs;              // [slices][tiles][tileFloats]
-    uint32_t* dispatchCount;
-    unsigned long long* tstamp;   // nullable: [0]=min start, [1]=max end (wall clock ticks), [2]=sum, [3]=launches
+    float* out;                // f32 [outDim]
+    float* slabs;              // [slices][tiles][tileFloats] partial tiles
+    uint32_t* counters;        // [tiles + 1] arrival tickets, zero between calls
+    uint32_t* sliceCounts;     // [slices] kept rows per slice (sum = dispatch.size)
+    float* cutoffOut;          // BucketMul.cutoff
+    unsigned long long* tstamp;   // nullable profiling stamps: [0]=min start, [1]=max end, [2]=sum, [3]=launches, [16..] phases
+    OutlierIndex ol;
+    uint32_t q;                // Int(4095*(1-effort)), bucketMul.swift:39
     MulGeom g;
 };
 
@@ -55,14 +67,7 @@ hipError_t launch_find_cutoff(const float* v, const uint16_t* probes, const uint
 // Returns hipErrorInvalidValue for unsupported (fmt, W, E).
 hipError_t launch_bucket_mul(Format fmt, int wavesPerGroup, int elemsPerLane, const MulArgs& a, hipStream_t st);
 size_t bucket_mul_lds_bytes(Format fmt, int wavesPerGroup, int elemsPerLane, uint32_t sliceRows, uint32_t rowsPerIn);
-
-struct OutlierIndex {          // by-output CSR of the Q4 outliers, built at registration
-    const uint32_t* rowPtr;    // [outDim+1]
-    const uint32_t* inIdx;     // [n]
-    const float* value;        // [n]
-};
-hipError_t launch_integrate(Format fmt, int elemsPerLane, const float* slabs, const MulGeom& g, float* out,
-                            const OutlierIndex* outliers, const float* v, unsigned long long* tstamp, hipStream_t st);
+uint32_t bucket_mul_max_candidates(int wavesPerGroup);   // rowsPerIn*sliceRows must not exceed this
 
 hipError_t launch_calc_dispatch(Format fmt, const void* stats, const float* v, const uint32_t* expNo,
                                 const float* cutoff, const MulGeom& g, float* dispatch, uint32_t* count,

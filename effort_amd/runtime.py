@@ -58,6 +58,11 @@ class Gpu:
         self.check(self._lib.effort_kernel_clock(self.ctx, C.byref(us), C.byref(n)), "kernel_clock")
         return {"mul_us": us.value, "launches": n.value}
 
+    def debug_stamps(self):
+        buf = (C.c_ulonglong * 16)()
+        self.check(self._lib.effort_debug_stamps(self.ctx, buf), "debug_stamps")
+        return list(buf)
+
     def kernel_timing(self):
         mul, cut, integ, n = C.c_double(), C.c_double(), C.c_double(), C.c_int()
         self.check(self._lib.effort_kernel_timing(self.ctx, C.byref(mul), C.byref(cut), C.byref(integ), C.byref(n)), "kernel_timing")

@@ -142,6 +142,8 @@ EFFORT_API int effort_set_tuning(effort_ctx* ctx, int wavesPerGroup, int elemsPe
  * kernel's own average duration (first start -> last end).  Both reset their accumulators. */
 EFFORT_API int effort_enable_kernel_timing(effort_ctx* ctx, int enable);
 EFFORT_API int effort_kernel_clock(effort_ctx* ctx, double* mul_us_avg, int* n_launches);
+/* Profiling aid: 16 raw u64 phase stamps written by the most recent cutoff / multiply kernels in timing mode. */
+EFFORT_API int effort_debug_stamps(effort_ctx* ctx, unsigned long long* host16);
 EFFORT_API int effort_kernel_timing(effort_ctx* ctx, double* mul_us_avg, double* cutoff_us_avg,
                          double* integrate_us_avg, int* n_samples);
 

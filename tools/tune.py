@@ -60,10 +60,19 @@ def main():
                 torch.cuda.synchronize()
                 t = (time.perf_counter() - t0) / 30 / len(ews)
                 clk = g.kernel_clock()
+                st = g.debug_stamps()
+                g.enable_kernel_timing(1)            # event-to-event intervals (include the launch gap before each kernel)
+                torch.cuda._sleep(10_000_000)
+                for _ in range(4):
+                    for ew, o in zip(ews, outs):
+                        ea.bucketMul(v, ew, None, o, effort)
+                ev = g.kernel_timing()
                 kb = mul_kernel_bytes(D, inDim, outDim)
                 row = {"shape": args.shape, "effort": effort, "W": W, "E": E, "S": S, "D": D, "call_us": round(t * 1e6, 2),
                        "mul_us": round(clk["mul_us"], 2), "mul_GBps": round(kb / clk["mul_us"] / 1e3, 0),
-                       "eff_GBps": round(2 * inDim * outDim / t / 1e9, 0)}
+                       "eff_GBps": round(2 * inDim * outDim / t / 1e9, 0),
+                       "ev_mul_us": round(ev["mul_us"], 2),
+                       "wg0_phases_us(issue,cutoff,select,stream,slab)": [round((st[9 + i] - st[8 + i]) / 100.0, 2) for i in range(5)], "wg0_rows": st[14], "cutoff(setup,loop)us": [round((st[1] - st[0]) / 100.0, 2), round((st[2] - st[1]) / 100.0, 2)], "cutoff_loops,counts": [st[5] // 1000, st[5] % 1000]}
             except Exception as ex:
                 row = {"shape": args.shape, "effort": effort, "W": W, "E": E, "S": S, "error": repr(ex)[:100]}
             rows.append(row)
