@@ -1,27 +1,31 @@
 #!/usr/bin/env python
-"""bench.py -- bucketMul throughput on MI355X (driver contract: see README/DESIGN.md "Measurement").
+"""bench.py -- bucketMul throughput on MI355X (driver contract: DESIGN.md "Measurement").
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--streams 4] [--effort 0.25]
 
-Workload (BASELINE.json configs[1]): Mistral-7B-FFN-shaped matrix 4096 x 11008, fp16 buckets, bucketMul
-at 25 % effort (the north-star operating point), plus an effort sweep 10..100 % reported in the same JSON
-line.  One STEP = one pass of the hot path over one batch of synthetic input = 32 bucketMul calls, one per
-DISTINCT converted matrix (rotation i % 32 exactly like benchmarks/benchmark.swift:206,255 -- 2.9 GB of
-buckets, so reads come from HBM, not the 256 MB Infinity Cache), all on the same input vector, outputs
-written to 32 separate vectors.  Inputs are resident in HBM before the timed region.  The 32 calls of a
-step are replayed from one hipGraph (96 kernels), so the host is not in the timed path -- the reference's
-timeIt (helpers/timeit.swift:10-34) likewise enqueues everything and waits once.
+Workload (BASELINE.json configs[1]): Mistral-7B-FFN-shaped matrix 4096 x 11008, fp16 buckets, bucketMul at
+25 % effort (the north-star operating point), plus an effort sweep 10..100 % in the same JSON line.
+One STEP = one pass of the hot path over one batch of synthetic input = 32 bucketMul calls, one per DISTINCT
+converted matrix (rotation i % 32 exactly like benchmarks/benchmark.swift:206,255 -- 2.9 GB of buckets, so
+reads come from HBM, not the 256 MB Infinity Cache), all on the same input vector, each writing its own output
+vector.  Inputs are resident in HBM before the timed region.  The 32 calls of a step are replayed from ONE
+hipGraph, so the host is not in the timed path (the reference's timeIt, helpers/timeit.swift:10-34, likewise
+enqueues everything and waits once).  The calls of a step are independent, so the graph spreads them round-robin
+over `--streams` HIP streams, each with its own effort context (scratch): the prologue of one call (cutoff,
+row selection) overlaps the streaming phase of another.  `serial` in the output is the same step on ONE stream
+(every call waits for the previous one -- the latency a dependent decode chain sees).
 
-value            = effective (dense-equivalent) GB/s = 2*inDim*outDim bytes per call / time per call,
-                   whole job over all ranks.
+value            = effective (dense-equivalent) GB/s = 2*inDim*outDim bytes per call / time per call, whole job
+                   over all ranks.
 tokens_per_s     = the reference's projection 1/(t_call * 4 * 32) (helpers/timeit.swift:26,33-34).
-roofline         = dominant kernel (bucket_mul_kernel): algorithmic bytes per launch / its duration.
+roofline         = dominant kernel (bucket_mul_kernel, the whole call in one launch): algorithmic bytes per
+                   launch / its average duration in THIS run's timed configuration.
 cpu_baseline     = the CPU oracle (a port: the reference ships no CPU path) on the host cores, bounded sample.
 
-N > 1 (one process per GPU, RCCL): independent matrices are partitioned across the ranks (every rank owns
-32 distinct matrices; weak scaling) and the output vectors of a step are exchanged with ONE all-gather
-(north_star: "partition independent weight matrices ... RCCL all-gather of the output vectors").
-`--partition columns` runs the bucket-column sharding of SURVEY 8e instead (strong scaling).
+N > 1 (one process per GPU, RCCL): independent matrices are partitioned across the ranks (every rank owns 32
+distinct matrices; weak scaling) and the output vectors of a step are exchanged with ONE all-gather (north_star:
+"partition independent weight matrices ... RCCL all-gather of the output vectors").  `--partition columns` runs
+the bucket-column sharding of SURVEY 8e instead (strong scaling).
 """
 from __future__ import annotations
 
@@ -47,14 +51,14 @@ def log(*a):
 
 
 def algorithmic_bytes(D: int, inDim: int, outDim: int) -> int:
-    """SURVEY 8d / BASELINE.md: bucket rows + stats + probes + v + out.  (The fused kernel writes no global
-    dispatch list, so the reference formula's 8*D term is dropped.)"""
+    """SURVEY 8d / BASELINE.md per-call bytes: kept bucket rows + stats + probes + v + out.  (The fused kernel
+    writes no global dispatch list, so the reference formula's 8*D term is dropped.)"""
     return D * (outDim // 16) * 2 + 16 * inDim * 8 + 4096 * 2 + 4 * inDim + 4 * outDim
 
 
 def mul_kernel_bytes(D: int, inDim: int, outDim: int) -> int:
-    """What ONE bucket_mul_kernel launch must move: the kept bucket rows, the stats column it tests, v."""
-    return D * (outDim // 16) * 2 + 16 * inDim * 8 + 4 * inDim
+    """What ONE bucket_mul_kernel launch must move (the fused kernel is the whole call)."""
+    return algorithmic_bytes(D, inDim, outDim)
 
 
 def make_weights(ea, n, inDim, outDim, seed0, dev, keep_core=True):
@@ -63,7 +67,7 @@ def make_weights(ea, n, inDim, outDim, seed0, dev, keep_core=True):
     for k in range(n):
         gen.manual_seed(seed0 + k)
         W = (torch.randn((outDim, inDim), generator=gen, device=dev, dtype=torch.float32) * 0.02).to(torch.float16)
-        ew = ea.ExpertWeights.from_core(W)
+        ew = ea.ExpertWeights.from_core(W)          # product converter (GPU bucketize)
         if not keep_core:
             ew.core = None
         ew.handle
@@ -72,27 +76,67 @@ def make_weights(ea, n, inDim, outDim, seed0, dev, keep_core=True):
     return ews
 
 
-def capture_step(ea, v, ews, outs, effort):
-    for ew, o in zip(ews, outs):                      # warm: handles, function attributes
-        ea.bucketMul(v, ew, None, o, effort)
-    ea.gpu().eval()
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
-        for ew, o in zip(ews, outs):
-            ea.bucketMul(v, ew, None, o, effort)
-    ea.gpu()._bind_stream()
-    return g
+class Lanes:
+    """K effort contexts on K HIP streams; captures a step (one call per matrix, round-robin) into one hipGraph."""
+
+    def __init__(self, ea, device, K, tune=None):
+        self.ea, self.K = ea, K
+        self.ctxs = [ea.gpu(device)] if K == 1 else [ea.Gpu(device) for _ in range(K)]
+        self.streams = [None] if K == 1 else [torch.cuda.Stream(device=device) for _ in range(K)]
+        if tune:
+            for c in self.ctxs:
+                c.set_tuning(*tune)
+
+    def _enqueue(self, fn, items):
+        if self.K == 1:
+            for it in items:
+                fn(self.ctxs[0], *it)
+            return
+        s0 = torch.cuda.current_stream()
+        for st in self.streams:
+            st.wait_stream(s0)
+        for i, it in enumerate(items):
+            with torch.cuda.stream(self.streams[i % self.K]):
+                fn(self.ctxs[i % self.K], *it)
+        for st in self.streams:
+            s0.wait_stream(st)
+
+    def capture(self, fn, items):
+        self._enqueue(fn, items)                     # warm: handles, kernel attributes, rocBLAS workspaces
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._enqueue(fn, items)
+        for c in self.ctxs:
+            c._bind_stream()
+        return g
+
+    def timing(self, mode):
+        for c in self.ctxs:
+            c.enable_kernel_timing(mode)
+
+    def kernel_clock(self):
+        tot, n = 0.0, 0
+        for c in self.ctxs:
+            k = c.kernel_clock()
+            tot += k["mul_us"] * k["launches"]
+            n += k["launches"]
+        return (tot / n if n else 0.0), n
 
 
-def time_replays(g, steps, warmup, barrier=None):
+def time_replays(g, steps, warmup, barrier=None, after=None):
     for _ in range(warmup):
         g.replay()
+        if after:
+            after()
     if barrier:
         barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         g.replay()
+        if after:
+            after()
     torch.cuda.synchronize()
     if barrier:
         barrier()
@@ -101,8 +145,9 @@ def time_replays(g, steps, warmup, barrier=None):
 
 def cpu_baseline(ews, v, effort, inDim, outDim, budget_s=12.0):
     """CPU oracle ("port") on the host cores: same converted weights (4 of the matrices), same v, same effort."""
-    from oracle import cpu
     import numpy as np
+
+    from oracle import cpu
     mats = []
     for ew in ews[:4]:
         mats.append((ew.buckets[0].cpu().numpy().view(np.float16), ew.stats[0].cpu().numpy().view(np.float16),
@@ -118,7 +163,7 @@ def cpu_baseline(ews, v, effort, inDim, outDim, budget_s=12.0):
     return {"value": round(2 * inDim * outDim / dt / 1e9, 3), "unit": "GB/s", "cores": os.cpu_count(),
             "kind": "port", "us_per_call": round(dt * 1e6, 1),
             "sample": f"{n} bucketMul calls at effort {effort} over 4 of the {N_MATS} converted {inDim}x{outDim} matrices "
-                      f"(OpenMP over bucket columns, {os.cpu_count()} threads), {budget_s:.0f} s budget"}, out
+                      f"(OpenMP over bucket columns, {os.cpu_count()} threads), {budget_s:.0f} s budget"}, out, (n - 1) % 4
 
 
 def main():
@@ -127,10 +172,11 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--effort", type=float, default=0.25)
+    ap.add_argument("--streams", type=int, default=4, help="concurrent HIP streams / effort contexts per GPU")
     ap.add_argument("--partition", choices=["matrices", "columns"], default="matrices")
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--tune", default="", help="waves,elems,slices override for the multiply kernel")
+    ap.add_argument("--tune", default="8,2,32", help="waves,elems,slices of the multiply kernel in the overlapped run (0,0,0 = heuristic)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -149,9 +195,7 @@ def main():
 
     import effort_amd as ea
     g = ea.gpu(local)
-    if args.tune:
-        w_, e_, s_ = (int(x) for x in args.tune.split(","))
-        g.set_tuning(w_, e_, s_)
+    tune = tuple(int(x) for x in args.tune.split(",")) if args.streams > 1 else None
 
     inDim, outDim = IN_DIM, OUT_DIM
     t_setup = time.perf_counter()
@@ -170,30 +214,24 @@ def main():
     outs_all = torch.zeros((N_MATS, localOut), device=dev)
     outs = [outs_all[k] for k in range(N_MATS)]
     gathered = torch.zeros((world, N_MATS * localOut), device=dev) if world > 1 else None
+    torch.cuda.synchronize()
     log(f"[rank {rank}] setup {time.perf_counter() - t_setup:.1f} s: {N_MATS} matrices {inDim}x{outDim} converted on the GPU")
 
     def barrier():
         if dist:
             dist.barrier()
 
+    def mul(effort):
+        return lambda ctx, ew, o: ea.bucketMul(v, ew, None, o, effort, gpu=ctx)
+
+    items = list(zip(ews, outs))
+    lanes = Lanes(ea, local, args.streams, tune)
+
     # ---------------- the timed job: K steps at the headline effort --------------------------------
-    graph = capture_step(ea, v, ews, outs, args.effort)
-    D = g.last_dispatch_count()
-
-    def run_steps(n):
-        for _ in range(n):
-            graph.replay()
-            if dist:   # the exchange step: one all-gather of this step's output vectors
-                dist.all_gather_into_tensor(gathered.view(-1), outs_all.view(-1))
-
-    run_steps(args.warmup)
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run_steps(args.steps)
-    torch.cuda.synchronize()
-    barrier()
-    dt = (time.perf_counter() - t0) / args.steps
+    graph = lanes.capture(mul(args.effort), items)
+    D = lanes.ctxs[(N_MATS - 1) % lanes.K].last_dispatch_count()
+    exchange = (lambda: dist.all_gather_into_tensor(gathered.view(-1), outs_all.view(-1))) if dist else None
+    dt = time_replays(graph, args.steps, args.warmup, barrier, exchange)
     if dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -209,61 +247,77 @@ def main():
         "ms_per_step": round(dt * 1e3, 5), "higher_is_better": True, "scaling": "strong" if columns else "weak",
         "vs_baseline": None, "dtype": "f16", "data": "synthetic",
         "config": {"workload": f"bucketMul {inDim}x{outDim} fp16 buckets, effort {args.effort}, {N_MATS} distinct matrices rotated "
-                               f"(one call each per step), f32 accumulate", "effort": args.effort, "matrices_per_step": N_MATS,
-                   "inDim": inDim, "outDim": outDim, "partition": ("columns" if columns else "matrices") if world > 1 else "none",
-                   "dispatch_rows": D},
+                               f"(one call each per step), f32 accumulate; one fused kernel launch per call, calls spread over "
+                               f"{args.streams} HIP streams in one hipGraph", "effort": args.effort, "matrices_per_step": N_MATS,
+                   "inDim": inDim, "outDim": outDim, "streams": args.streams, "kernel_geometry(waves,elems,slices)": args.tune if tune else "heuristic",
+                   "partition": ("columns" if columns else "matrices") if world > 1 else "none", "dispatch_rows": D},
         "us_per_call": round(t_call * 1e6, 3),
         "tokens_per_s": round(1.0 / (t_call * 4 * 32), 2),
     }
 
     if rank == 0 and world == 1:
-        # ---------------- roofline of the dominant kernel -------------------------------------------
         kb = mul_kernel_bytes(D, inDim, outDim)
-        g.enable_kernel_timing(2)                        # device wall clock inside the kernel (graph safe)
-        gt = capture_step(ea, v, ews, outs, args.effort)
+        # ---------------- roofline of the dominant kernel, in the timed configuration -----------------
+        lanes.timing(2)                                  # device wall clock inside the kernel (graph safe)
+        gt = lanes.capture(mul(args.effort), items)
         for _ in range(5):
             gt.replay()
-        g.kernel_clock()
+        lanes.kernel_clock()
         for _ in range(20):
             gt.replay()
-        clk = g.kernel_clock()
-        g.enable_kernel_timing(1)                        # HIP events on the launch stream, queue pre-filled
+        kus, nl = lanes.kernel_clock()
+        lanes.timing(0)
+        del gt
+        # ---------------- the same step on ONE stream (dependent-chain latency) -----------------------
+        one = Lanes(ea, local, 1)
+        gs = one.capture(mul(args.effort), items)
+        ts = time_replays(gs, 50, 10) / N_MATS
+        one.timing(2)
+        gs2 = one.capture(mul(args.effort), items)
+        for _ in range(3):
+            gs2.replay()
+        one.kernel_clock()
+        for _ in range(10):
+            gs2.replay()
+        kus1, _ = one.kernel_clock()
+        one.timing(1)                                    # HIP events on the launch stream, queue pre-filled
         torch.cuda._sleep(20_000_000)                    # keep the GPU busy while the host enqueues
         for r in range(4):
-            for ew, o in zip(ews, outs):
+            for ew, o in items:
                 ea.bucketMul(v, ew, None, o, args.effort)
         evt = g.kernel_timing()
-        g.enable_kernel_timing(0)
-        kus = clk["mul_us"]
+        one.timing(0)
+        del gs, gs2
         result["roofline"] = {
             "bound": "hbm", "kernel": "bucket_mul_kernel", "achieved": round(kb / kus / 1e3, 1), "peak": HBM_PEAK_GBPS,
             "unit": "GB/s", "frac": round(kb / kus / 1e3 / HBM_PEAK_GBPS, 4), "traffic": None,
-            "bytes_per_launch": kb, "kernel_us": round(kus, 3), "kernel_us_source": "device wall clock, first workgroup start -> last end",
-            "kernel_us_hip_events": round(evt["mul_us"], 3), "cutoff_us_hip_events": round(evt["cutoff_us"], 3),
-            "integrate_us_hip_events": round(evt["integrate_us"], 3),
-            "call_achieved_GBps": round(algorithmic_bytes(D, inDim, outDim) / t_call / 1e9, 1),
-            "call_frac": round(algorithmic_bytes(D, inDim, outDim) / t_call / 1e9 / HBM_PEAK_GBPS, 4),
+            "bytes_per_launch": kb, "kernel_us": round(kus, 3), "launches_sampled": nl,
+            "kernel_us_source": f"device wall clock, first workgroup start -> last end, averaged over the launches of the {args.streams}-stream graph",
+            "aggregate_achieved_GBps": round(kb / t_call / 1e9, 1), "aggregate_frac": round(kb / t_call / 1e9 / HBM_PEAK_GBPS, 4),
         }
+        result["serial"] = {"us_per_call": round(ts * 1e6, 3), "effective_GBps": round(eff_bytes / ts / 1e9, 1),
+                            "kernel_us": round(kus1, 3), "kernel_us_hip_events": round(evt["mul_us"], 3),
+                            "kernel_achieved_GBps": round(kb / kus1 / 1e3, 1), "kernel_frac": round(kb / kus1 / 1e3 / HBM_PEAK_GBPS, 4)}
         # ---------------- dense rocBLAS baseline (basicMul over the rotating cores) -------------------
-        dense_out = torch.zeros(outDim, device=dev)
-        ea.basicMul(v, ews[0].core, dense_out)
-        gd = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gd):
-            for ew in ews:
-                ea.basicMul(v, ew.core, dense_out)
-        g._bind_stream()
-        td = time_replays(gd, 50, 10) / N_MATS
-        result["dense_rocblas"] = {"us_per_call": round(td * 1e6, 3), "GBps": round(eff_bytes / td / 1e9, 1),
-                                   "speedup_at_effort": round(td / t_call, 3)}
+        dense_out = [torch.zeros(outDim, device=dev) for _ in range(lanes.K)]
+        ditems = [(ew, dense_out[i % lanes.K]) for i, ew in enumerate(ews)]
+
+        def dense(ctx, ew, o):
+            ea.basicMul(v, ew.core, o, gpu=ctx)
+        td1 = time_replays(one.capture(dense, ditems), 30, 5) / N_MATS
+        tdk = time_replays(lanes.capture(dense, ditems), 30, 5) / N_MATS
+        result["dense_rocblas"] = {"us_per_call_serial": round(td1 * 1e6, 3), f"us_per_call_{lanes.K}_streams": round(tdk * 1e6, 3),
+                                   "GBps": round(eff_bytes / min(td1, tdk) / 1e9, 1),
+                                   "speedup_at_effort": round(min(td1, tdk) / t_call, 3), "speedup_serial_vs_serial": round(td1 / ts, 3)}
         # ---------------- effort sweep ----------------------------------------------------------------
         if not args.no_sweep:
             sweep = []
             for e in SWEEP:
-                ge = capture_step(ea, v, ews, outs, e)
-                De = g.last_dispatch_count()
+                ge = lanes.capture(mul(e), items)
+                De = lanes.ctxs[(N_MATS - 1) % lanes.K].last_dispatch_count()
                 te = time_replays(ge, 40, 10) / N_MATS
-                ea.basicMul(v, ews[N_MATS - 1].core, dense_out)
-                cs = ea.cosineSimilarityTo(outs[N_MATS - 1], dense_out)
+                ea.basicMul(v, ews[N_MATS - 1].core, dense_out[0])
+                cs = ea.cosineSimilarityTo(outs[N_MATS - 1], dense_out[0])
                 sweep.append({"effort": e, "dispatch_rows": De, "us_per_call": round(te * 1e6, 3),
                               "effective_GBps": round(eff_bytes / te / 1e9, 1),
                               "achieved_GBps": round(algorithmic_bytes(De, inDim, outDim) / te / 1e9, 1),
@@ -273,11 +327,11 @@ def main():
         # ---------------- CPU baseline -----------------------------------------------------------------
         if not args.no_cpu:
             try:
-                cb, cpu_out = cpu_baseline(ews, v, args.effort, inDim, outDim)
                 import numpy as np
+                cb, cpu_out, k_last = cpu_baseline(ews, v, args.effort, inDim, outDim)
                 graph.replay()
                 torch.cuda.synchronize()
-                hip = outs[(int(cb["sample"].split()[0]) - 1) % 4].cpu().numpy()      # matrix of the last CPU call
+                hip = outs[k_last].cpu().numpy()
                 cb["gpu_vs_cpu_max_rel_err"] = float(np.abs(hip - cpu_out).max() / (np.abs(cpu_out).max() + 1e-30))
                 result["cpu_baseline"] = cb
             except Exception as ex:  # the oracle is optional infrastructure for the bench

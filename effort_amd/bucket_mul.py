@@ -37,21 +37,24 @@ def _check_expno(expNo: torch.Tensor | None):
         raise ValueError("expNo must be a 4-byte device scalar (ScalarFloat reinterpreted as uint)")
 
 
-def bucketMul(v: torch.Tensor, by: ExpertWeights, expNo: torch.Tensor | None, out: torch.Tensor, effort: float = 0.25):
-    BucketMul.shared().fullMul(v, by, expNo, out, effort)
+def bucketMul(v: torch.Tensor, by: ExpertWeights, expNo: torch.Tensor | None, out: torch.Tensor, effort: float = 0.25,
+              gpu=None):
+    """``gpu``: an extra ``effort_amd.Gpu`` context (own scratch) to run independent multiplies concurrently on
+    another stream; default = the device's shared context, i.e. the reference's BucketMul.shared."""
+    (BucketMul.shared() if gpu is None else BucketMul(gpu.device, gpu)).fullMul(v, by, expNo, out, effort)
 
 
 def bucketMulQ4(v: torch.Tensor, by: ExpertWeights, expNo: torch.Tensor | None, out: torch.Tensor, effort: float = 0.25):
     BucketMulQ4.shared().fullMul(v, by, expNo, out, effort)
 
 
-def basicMul(v: torch.Tensor, by: torch.Tensor, out: torch.Tensor):
+def basicMul(v: torch.Tensor, by: torch.Tensor, out: torch.Tensor, gpu=None):
     """Dense f16 GEMV, ``by`` = core matrix [outDim, inDim]; asserts of helpers/mps.swift:15-18."""
     assert by.shape[0] == out.numel() and by.shape[1] == v.numel() and by.shape[1] % 16 == 0
     _check_vec("v", v, by.shape[1])
     _check_vec("out", out, by.shape[0])
     assert by.is_cuda and by.element_size() == 2 and by.is_contiguous()
-    g = _gpu(v.device.index)
+    g = gpu if gpu is not None else _gpu(v.device.index)
     g._bind_stream()
     g.check(_lib.lib().effort_dense_gemv(g.ctx, _p(by), _p(v), _p(out), by.shape[1], by.shape[0]), "basicMul")
 
@@ -84,8 +87,8 @@ class BucketMul:
             cls._shared[key] = cls(d)
         return cls._shared[key]
 
-    def __init__(self, device: int):
-        self.gpu = _gpu(device)
+    def __init__(self, device: int, gpu=None):
+        self.gpu = gpu if gpu is not None else _gpu(device)
         self.dispatch: torch.Tensor | None = None          # float2[] as [n, 2]
         self.dispatch_size: torch.Tensor | None = None      # dispatch.size (device u32)
 

@@ -37,6 +37,7 @@ struct effort_ctx {
     rocblas_handle blas = nullptr;
     // tuning overrides (0 = heuristic)
     int tuneW = 0, tuneE = 0, tuneS = 0;
+    bool splitCutoff = false;     // run findCutoff32 as its own 1-workgroup kernel instead of inside every workgroup
     // optional per-kernel timing
     bool timing = false;          // HIP events around each kernel
     bool clock = false;           // device wall-clock stamps inside the multiply kernel
@@ -214,8 +215,10 @@ static int choose_geom(const effort_ctx* c, const effort_w* w, MulGeom* g, int* 
         g->sliceRows = (w->inDim + S - 1) / S;
         g->slices = (w->inDim + g->sliceRows - 1) / g->sliceRows;
         const size_t lds = bucket_mul_lds_bytes(w->fmt, W, E, g->sliceRows, g->rowsPerIn);
+        g->sliceLog2 = 0; while ((1u << g->sliceLog2) < g->sliceRows) g->sliceLog2++;
+        const uint32_t slots = w->fmt == kFp16 ? (g->rowsPerIn << g->sliceLog2) : g->sliceRows * 8u;
         const bool fits = lds <= ldsMax && g->sliceRows <= (w->fmt == kFp16 ? 4096u : 8192u) &&
-                          g->rowsPerIn * g->sliceRows <= bucket_mul_max_candidates(W);
+                          slots <= bucket_mul_max_candidates(W);
         const size_t slab = (size_t)g->slices * g->tiles * g->tileFloats * 4;
         if (fits && slab <= c->slabBytes) break;
         if (!fits) { S += 8; if (S > w->inDim + 8) return EFFORT_ERR_SHAPE; }
@@ -251,7 +254,12 @@ static int do_bucketmul(effort_ctx* c, const effort_w* w, Format fmt, const floa
     a.tstamp = c->clock ? c->d_tstamp : nullptr;
     a.ol = OutlierIndex{fmt == kQ4 ? w->olRowPtr : nullptr, w->olInIdx, w->olValue};
     a.q = q; a.g = g;
+    a.cutoffIn = nullptr;
     if (tm) HIP_TRY(c, hipEventRecord(ev[0], c->stream));
+    if (c->splitCutoff) {
+        HIP_TRY(c, launch_find_cutoff(v, w->probes, expNo, q, c->d_cutoff, c->d_count, nullptr, c->stream));
+        a.cutoffIn = c->d_cutoff;
+    }
     HIP_TRY(c, launch_bucket_mul(fmt, W, E, a, c->stream));
     if (tm) { HIP_TRY(c, hipEventRecord(ev[1], c->stream)); c->nSamples++; }
     c->lastSlices = g.slices;                      // dispatch.size = sum of the per-slice counts
@@ -362,6 +370,12 @@ extern "C" int effort_set_tuning(effort_ctx* c, int W, int E, int S) {
     return EFFORT_OK;
 }
 
+extern "C" int effort_set_split_cutoff(effort_ctx* c, int split) {
+    if (!c) return EFFORT_ERR_ARG;
+    c->splitCutoff = split != 0;
+    return EFFORT_OK;
+}
+
 extern "C" int effort_enable_kernel_timing(effort_ctx* c, int enable) {
     if (!c) return EFFORT_ERR_ARG;
     if (enable == 1) { int rc = ensure_timing(c); if (rc != EFFORT_OK) return rc; }
@@ -375,7 +389,7 @@ extern "C" int effort_enable_kernel_timing(effort_ctx* c, int enable) {
 
 extern "C" int effort_debug_stamps(effort_ctx* c, unsigned long long* host16) {
     if (!c || !host16) return EFFORT_ERR_ARG;
-    HIP_TRY(c, hipMemcpyAsync(host16, c->d_tstamp + 8, 128, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(host16, c->d_tstamp + 8, 192, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return EFFORT_OK;
 }

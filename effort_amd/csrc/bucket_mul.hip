@@ -85,13 +85,13 @@ template <> struct Piece<8> {
 
 __host__ __device__ inline uint32_t align_up(uint32_t x, uint32_t a) { return (x + a - 1) / a * a; }
 
-// LDS carve (bytes): [W][tileFloats] f32 | vblk[B] f32 | misc 256 B | list[rows*B] u16 | dlist (Q4) f32
+// LDS carve (bytes): [W][tileFloats] f32 | vblk[B] f32 | misc 512 B | list[rows*B] u16 | dlist (Q4) f32
 template <int FMT, int E, int W>
 __host__ __device__ inline uint32_t lds_layout(uint32_t B, uint32_t rowsPerIn, uint32_t* offV, uint32_t* offC,
                                                uint32_t* offL, uint32_t* offD) {
     uint32_t o = (uint32_t)W * Fmt<FMT>::kAcc * E * 64 * 4;
     *offV = o; o += align_up(B * 4, 16);
-    *offC = o; o += 256;                                   // [0..63] cutoff scratch, [64..191] wave counts, [192] flags
+    *offC = o; o += 512;                                   // [0..255] cutoff scratch, [256..383] wave counts, [384] flags
     *offL = o; o += align_up(rowsPerIn * B * 2, 16);
     *offD = o; if (FMT == kQ4) o += align_up(rowsPerIn * B * 4, 16);
     return o;
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(64 * W) void bucket_mul_kernel(const MulArgs a) {
     if (s >= g.slices) return;
 
     const int tid = threadIdx.x, lane = tid & 63;
-    if (a.tstamp && tid == 0) atomicMin(&a.tstamp[0], (unsigned long long)wall_clock64());
+    if (a.tstamp && tid == 0) { const unsigned long long now = wall_clock64(); atomicMin(&a.tstamp[0], now); atomicMax(&a.tstamp[25], now); }
     const bool stamp = a.tstamp && blockIdx.x == 0 && tid == 0;      // phase stamps of workgroup 0 (profiling aid)
     if (stamp) a.tstamp[16] = wall_clock64();
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -121,38 +121,47 @@ __global__ __launch_bounds__(64 * W) void bucket_mul_kernel(const MulArgs a) {
     lds_layout<FMT, E, W>(B, g.rowsPerIn, &offV, &offC, &offL, &offD);
     float* acc = reinterpret_cast<float*>(smem);
     float* vblk = reinterpret_cast<float*>(smem + offV);
-    uint32_t* wcnt = reinterpret_cast<uint32_t*>(smem + offC + 64);          // [2][16]
-    uint32_t* flags = reinterpret_cast<uint32_t*>(smem + offC + 192);
+    uint32_t* wcnt = reinterpret_cast<uint32_t*>(smem + offC + 256);         // [2][16]
+    uint32_t* flags = reinterpret_cast<uint32_t*>(smem + offC + 384);
     uint16_t* list = reinterpret_cast<uint16_t*>(smem + offL);
     float* dlist = reinterpret_cast<float*>(smem + offD);
     float* myacc = acc + wave * TILE_F + lane;
 
     const uint32_t j0 = s * B;
     const uint32_t nb = min(B, g.inDim - j0);
-    const uint32_t NC = g.rowsPerIn * nb;                       // candidate rows of this slice
     const uint32_t e = a.expNo ? a.expNo[0] : 0u;
 
     // ---- A. everything the selection needs, in one round trip --------------------------------
     float vj[VPT]; uint16_t prj[VPT];
     const uint16_t* pr = a.probes + (size_t)e * kProbes;
+    const bool fused = a.cutoffIn == nullptr;                    // uniform
 #pragma unroll
-    for (int i = 0; i < VPT; i++) { vj[i] = a.v[tid + NT * i]; prj[i] = pr[tid + NT * i]; }
-    // candidate c: FP16 -> rank = c / nb, jl = c % nb (rank-major, convert.metal:83-100; v index = row % inDim)
-    //              Q4   -> jl = c / 8,  rank = c % 8  (input-major, bucketMulQ4.metal:46)
+    for (int i = 0; i < VPT; i++) { vj[i] = 0.0f; prj[i] = 0; }
+    if (fused) {
+#pragma unroll
+        for (int i = 0; i < VPT; i++) { vj[i] = a.v[tid + NT * i]; prj[i] = pr[tid + NT * i]; }
+    }
+    // candidate slot c = r*NT + tid, in ascending bucket-row order:
+    //   FP16 -> rank = c >> lg, jl = c & (2^lg - 1), 2^lg >= B  (rank-major rows, convert.metal:83-100; v index = row % inDim)
+    //   Q4   -> jl = c >> 3,  rank = c & 7                      (input-major rows, bucketMulQ4.metal:46)
+    const uint32_t lg = g.sliceLog2;
+    const uint32_t nSlots = FMT == kFp16 ? (g.rowsPerIn << lg) : (nb << 3);
     float mean[kPre];
     uint32_t codes[kPre];
 #pragma unroll
     for (int r = 0; r < kPre; r++) {
         const uint32_t c = r * NT + tid;
-        mean[r] = 0.0f; codes[r] = 0;
-        if (c < NC) {
-            if (FMT == kFp16) {
-                const uint32_t rank = c / nb, jl = c - rank * nb;
+        mean[r] = 0.0f; codes[r] = 0xFFFFFFFFu;                 // 0xFFFFFFFF: no candidate in this slot
+        if (FMT == kFp16) {
+            const uint32_t rank = c >> lg, jl = c & ((1u << lg) - 1u);
+            if (rank < g.rowsPerIn && jl < nb) {
                 const size_t row = (size_t)e * g.expertRows + (size_t)rank * g.inDim + j0 + jl;
                 mean[r] = half_bits_to_float(reinterpret_cast<const uint16_t*>(a.stats)[row * 4 + 3]);
                 codes[r] = (rank << 12) | jl;
-            } else {
-                const uint32_t jl = c >> 3, rank = c & 7u;
+            }
+        } else {
+            const uint32_t jl = c >> 3, rank = c & 7u;
+            if (jl < nb) {
                 const size_t row = (size_t)e * g.expertRows + (size_t)(j0 + jl) * 8u + rank;
                 mean[r] = reinterpret_cast<const float*>(a.stats)[row * 2 + 1];
                 codes[r] = (jl << 3) | rank;
@@ -160,35 +169,56 @@ __global__ __launch_bounds__(64 * W) void bucket_mul_kernel(const MulArgs a) {
         }
     }
     for (uint32_t jl = tid; jl < nb; jl += NT) vblk[jl] = a.v[j0 + jl];
-#pragma unroll
-    for (int i = 0; i < NACC * E; i++) myacc[i * 64] = 0.0f;
     if (stamp) a.tstamp[17] = wall_clock64();
 
-    // ---- B. cutoff (findCutoff32), redundantly per workgroup; its first barrier also publishes vblk ------
-    const float cutoff = block_find_cutoff<NT>(vj, prj, a.q, smem + offC, stamp ? a.tstamp + 8 : nullptr);
-    if (blockIdx.x == 0 && tid == 0) a.cutoffOut[0] = cutoff;        // BucketMul.cutoff (bucketMul.swift:22)
+    // ---- B. cutoff (findCutoff32), redundantly per workgroup; its first barrier also publishes vblk.  Its
+    //         lookup table borrows the tail of the accumulator region, so the tiles are zeroed around it: the
+    //         waves that idle during the serial bisection zero theirs meanwhile, the rest right after. ---------
+    uint32_t* tbl = reinterpret_cast<uint32_t*>(acc + W * TILE_F) - NT * kCutoffBinsPerThread;
+    const bool tileUnderTable = (uint32_t)(wave + 1) * TILE_F > (uint32_t)W * TILE_F - NT * kCutoffBinsPerThread;
+    auto zero_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < NACC * E; i++) myacc[i * 64] = 0.0f;
+    };
+    float cutoff;
+    if (fused) {
+        cutoff = block_find_cutoff<NT>(vj, prj, a.q, smem + offC, tbl,
+                                       [&]() { if (wave != 0 && !tileUnderTable) zero_tile(); },
+                                       stamp ? a.tstamp + 8 : nullptr);
+        if (wave == 0 || tileUnderTable) zero_tile();
+        if (blockIdx.x == 0 && tid == 0) a.cutoffOut[0] = cutoff;    // BucketMul.cutoff (bucketMul.swift:22)
+    } else {
+        // split mode: the standalone cutoff kernel ran first on this stream (cheaper in aggregate when several
+        // calls overlap: one workgroup evaluates it instead of all of them)
+        cutoff = a.cutoffIn[0];
+        zero_tile();
+        __syncthreads();                                             // publishes vblk
+    }
     if (stamp) a.tstamp[18] = wall_clock64();
 
     // ---- C. keep test (bucketMul.metal:69 / bucketMulQ4.metal:47) + ordered compaction -----------
     uint32_t n = 0;
 #pragma unroll
     for (int r = 0; r < kPre; r++) {
-        if ((uint32_t)(r * NT) < NC) {                          // uniform
-            const uint32_t c = r * NT + tid;
+        if ((uint32_t)(r * NT) < nSlots) {                      // uniform
+            const bool cand = codes[r] != 0xFFFFFFFFu;
             const uint32_t jl = FMT == kFp16 ? (codes[r] & 4095u) : (codes[r] >> 3);
-            const float x = (c < NC) ? vblk[jl] : 0.0f;
-            const bool keep = (c < NC) && (cutoff < (kCutoffScale * mean[r]) * fabsf(x));
+            const float x = cand ? vblk[jl] : 0.0f;
+            const bool keep = cand && (cutoff < (kCutoffScale * mean[r]) * fabsf(x));
             const unsigned long long m = __ballot(keep);
             const uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
             if (lane == 0) wcnt[(r & 1) * 16 + wave] = (uint32_t)__popcll(m);
             __syncthreads();
-            uint32_t woff = 0, tot = 0;
+            // exclusive prefix of the W wave counts: lanes 0..W-1 hold one count each, scanned with shuffles
+            uint32_t inc = (lane < W) ? wcnt[(r & 1) * 16 + lane] : 0u;
 #pragma unroll
-            for (int w2 = 0; w2 < W; w2++) {
-                const uint32_t cw = wcnt[(r & 1) * 16 + w2];
-                woff += (w2 < wave) ? cw : 0u;
-                tot += cw;
+            for (int off = 1; off < W; off <<= 1) {
+                const uint32_t o = __shfl_up(inc, off);
+                inc += (lane >= off) ? o : 0u;
             }
+            const uint32_t tot = __shfl(inc, W - 1);
+            const uint32_t mineInc = __shfl(inc, wave);
+            const uint32_t woff = mineInc - (uint32_t)__popcll(m);
             if (keep) {
                 list[n + woff + pre] = (uint16_t)codes[r];
                 if (FMT == kQ4) dlist[n + woff + pre] = x * mean[r];          // entry value = v*mean (:52)
@@ -286,6 +316,7 @@ __global__ __launch_bounds__(64 * W) void bucket_mul_kernel(const MulArgs a) {
     }
     __syncthreads();
     if (stamp) a.tstamp[20] = wall_clock64();
+    if (a.tstamp && tid == 0) atomicMax(&a.tstamp[26], (unsigned long long)wall_clock64());
 
     // ---- E. W private tiles -> one slab (native [slot][j][lane] order), write-through; ticket; last arriver
     //         of the tile reduces the S slabs in slice order and writes out[] -------------------------------
@@ -303,6 +334,7 @@ __global__ __launch_bounds__(64 * W) void bucket_mul_kernel(const MulArgs a) {
     if (a.tstamp && tid == 0) atomicMax(&a.tstamp[1], (unsigned long long)wall_clock64());
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's slab stores have left the CU
     if (stamp) { a.tstamp[21] = wall_clock64(); a.tstamp[22] = n; }
+    if (a.tstamp && tid == 0) atomicMax(&a.tstamp[27], (unsigned long long)wall_clock64());
     __syncthreads();
     if (tid == 0) {
         const uint32_t ticket = __hip_atomic_fetch_add(&a.counters[t], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -312,36 +344,44 @@ __global__ __launch_bounds__(64 * W) void bucket_mul_kernel(const MulArgs a) {
     if (flags[0] == 0u) return;
 
     // last arriver of tile t: every slab of the tile was stored write-through (sc1) and drained before its ticket;
-    // read them past L1 (sc1), sum in slice order, un-permute, add the Q4 outliers, write out[]
+    // read them past L1 (sc1), sum in slice order, un-permute, add the Q4 outliers, write out[].  Each thread owns
+    // two adjacent tile slots and keeps up to kRed 8-byte loads in flight (each is a fabric round trip); the four
+    // running sums per slot are combined in a fixed order.
+    const bool rstamp = a.tstamp && t == 0 && tid == 0;
+    if (rstamp) a.tstamp[23] = wall_clock64();
+    constexpr int kRed = 48;
+    typedef uint32_t u2v __attribute__((ext_vector_type(2)));
     const uint32_t sliceStride = g.tiles * (uint32_t)(TILE_F * 4);
-    for (int o = tid; o < TILE_F; o += NT) {
-        const uint32_t lane2 = o & 63u, sj = (uint32_t)o >> 6, j = sj % E, slot = sj / E;
-        const uint32_t c2 = t * (64u * E) + lane2 * E + j;
+    for (int o = tid * 2; o < TILE_F; o += NT * 2) {
         const uint32_t vo = t * (uint32_t)(TILE_F * 4) + (uint32_t)o * 4u;
-        // 16 loads in flight per lane (each is a fabric round trip); partial sums combined in a fixed order
-        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-        for (uint32_t sl = 0; sl < g.slices; sl += 16) {
-            uint32_t r[16];
+        float sa[4] = {0.0f, 0.0f, 0.0f, 0.0f}, sb[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (uint32_t sl = 0; sl < g.slices; sl += kRed) {
+            u2v r[kRed];
 #pragma unroll
-            for (int i = 0; i < 16; i++)
-                r[i] = __builtin_amdgcn_raw_buffer_load_b32(srs, vo, min(sl + i, g.slices - 1u) * sliceStride, kSc1);
+            for (int i = 0; i < kRed; i++)
+                r[i] = __builtin_amdgcn_raw_buffer_load_b64(srs, vo, min(sl + i, g.slices - 1u) * sliceStride, kSc1);
 #pragma unroll
-            for (int i = 0; i < 16; i += 4) {
-                if (sl + i + 0 < g.slices) s0 += __uint_as_float(r[i + 0]);
-                if (sl + i + 1 < g.slices) s1 += __uint_as_float(r[i + 1]);
-                if (sl + i + 2 < g.slices) s2 += __uint_as_float(r[i + 2]);
-                if (sl + i + 3 < g.slices) s3 += __uint_as_float(r[i + 3]);
+            for (int i = 0; i < kRed; i++) {
+                if (sl + i < g.slices) { sa[i & 3] += __uint_as_float(r[i][0]); sb[i & 3] += __uint_as_float(r[i][1]); }
             }
         }
-        float sum = (s0 + s1) + (s2 + s3);
-        if (c2 < g.cols) {
-            const uint32_t oi = c2 * NACC + slot;
-            if (FMT == kQ4 && a.ol.rowPtr) {                                   // calcOutliers, bucketMulQ4.metal:13-21
-                for (uint32_t q = a.ol.rowPtr[oi]; q < a.ol.rowPtr[oi + 1]; q++) sum += a.v[a.ol.inIdx[q]] * a.ol.value[q];
+        float sum2[2] = {(sa[0] + sa[1]) + (sa[2] + sa[3]), (sb[0] + sb[1]) + (sb[2] + sb[3])};
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const uint32_t oo = (uint32_t)o + h;
+            const uint32_t lane2 = oo & 63u, sj = oo >> 6, j = sj % E, slot = sj / E;
+            const uint32_t c2 = t * (64u * E) + lane2 * E + j;
+            float sum = sum2[h];
+            if (c2 < g.cols) {
+                const uint32_t oi = c2 * NACC + slot;
+                if (FMT == kQ4 && a.ol.rowPtr) {                               // calcOutliers, bucketMulQ4.metal:13-21
+                    for (uint32_t q = a.ol.rowPtr[oi]; q < a.ol.rowPtr[oi + 1]; q++) sum += a.v[a.ol.inIdx[q]] * a.ol.value[q];
+                }
+                a.out[oi] = sum;
             }
-            a.out[oi] = sum;
         }
     }
+    if (rstamp) a.tstamp[24] = wall_clock64();
     if (tid == 0) {
         __hip_atomic_store(&a.counters[t], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next call
         if (a.tstamp) {
@@ -371,7 +411,7 @@ static hipError_t launch_mul_t(const MulArgs& a, hipStream_t st) {
         if (err != hipSuccess) return err;
         maxSet = lds;
     }
-    if (a.g.rowsPerIn * a.g.sliceRows > (uint32_t)kPre * 64 * W) return hipErrorInvalidValue;   // candidates must fit the preload
+    if ((FMT == kFp16 ? (a.g.rowsPerIn << a.g.sliceLog2) : a.g.sliceRows * 8u) > (uint32_t)kPre * 64 * W) return hipErrorInvalidValue;   // candidate slots must fit the preload
     const uint32_t grid = a.g.tiles * align_up(a.g.slices, 8);
     hipLaunchKernelGGL((bucket_mul_kernel<FMT, E, W>), dim3(grid), dim3(64 * W), lds, st, a);
     return hipGetLastError();

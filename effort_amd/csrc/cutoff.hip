@@ -15,7 +15,8 @@ __global__ __launch_bounds__(1024) void find_cutoff_kernel(const float* __restri
     float vj[4]; uint16_t prj[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) { vj[i] = v[threadIdx.x + 1024 * i]; prj[i] = pr[threadIdx.x + 1024 * i]; }
-    const float c = block_find_cutoff<1024>(vj, prj, q, smem, tstamp ? tstamp + 8 : nullptr);
+    const float c = block_find_cutoff<1024>(vj, prj, q, smem, reinterpret_cast<uint32_t*>(smem + kCutoffLdsBytes), []() {},
+                                            tstamp ? tstamp + 8 : nullptr);
     if (threadIdx.x == 0) {
         cutoff[0] = c;
         dispatchCount[0] = 0;      // dispatch.size.zero(), bucketMul.swift:38
@@ -27,11 +28,11 @@ hipError_t launch_find_cutoff(const float* v, const uint16_t* probes, const uint
     static bool attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&find_cutoff_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCutoffLdsBytes);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kCutoffLdsBytes + cutoff_table_bytes(1024)));
         if (e != hipSuccess) return e;
         attr = true;
     }
-    hipLaunchKernelGGL(find_cutoff_kernel, dim3(1), dim3(1024), kCutoffLdsBytes, st, v, probes, expNo, q, cutoff, dispatchCount, tstamp);
+    hipLaunchKernelGGL(find_cutoff_kernel, dim3(1), dim3(1024), kCutoffLdsBytes + cutoff_table_bytes(1024), st, v, probes, expNo, q, cutoff, dispatchCount, tstamp);
     return hipGetLastError();
 }
 

@@ -5,37 +5,53 @@
 // The reference's loop is a bisection on an f32 threshold: every round counts how many of the 4096
 // bf16-rounded probe products exceed the threshold, until the count hits 4096-q, or the bounds/counters
 // converge, or 100 rounds pass.  With quantised (bf16) values the count usually steps OVER the requested
-// rank; the bracket then shrinks float by float and the loop runs ~25-100 rounds (measured: the literal port
-// took 30 us on MI355X).  Three observations make it cheap without changing a single result bit:
+// rank; the bracket then shrinks float by float and the loop runs ~25-100 rounds (a literal port: 30 us on
+// MI355X, two barriers per round).  This version returns the same bits in ~2 us:
 //   * the values are non-negative bf16 numbers, so  value > threshold  <=>  pattern(value) > bits(threshold)>>16
-//     as integers: a count depends only on the threshold's top 16 bits;
-//   * therefore the counts already obtained at the two current bounds answer every later threshold that
-//     falls into one of their two bf16 cells -- which is every round once the bracket is narrower than two
-//     cells, i.e. all of the long tail; only the first ~10 rounds need a real (workgroup-wide) count;
-//   * once the midpoint stops moving the loop body has reached a fixed point, so the value the reference
-//     would write after grinding on to round 101 is already known.
-// A real count is 4096/NT integer compares per lane, wave ballots, one LDS atomic per wave and one barrier.
+//     as integers: a count depends only on the bf16 cell the threshold falls into;
+//   * so ONE pass builds a table over the cells between the smallest and the largest value -- an LDS histogram
+//     (integer LDS atomics run at full rate) turned into suffix counts by a workgroup scan -- after which
+//     count(threshold) is a single LDS lookup;
+//   * the bisection itself is serial and identical in every lane, so one wave runs it (the others would only
+//     compete for issue slots), with the reference's arithmetic and exit tests in the reference's order;
+//   * once the two bounds sit in adjacent cells with known counts every later threshold falls into one of the
+//     two cells: the long tail of the loop needs no lookups, just a few f32 operations per round;
+//   * once the midpoint stops moving the loop body has reached a fixed point, so the value the reference would
+//     write after grinding on to round 101 is already known.
+// If the values span more cells than the table holds (only when some products are ~0: > 64 octaves of range)
+// the first rounds are counted with wave ballots until the bracket fits.
 #pragma once
 #include "effort_internal.h"
 
 namespace effort {
 
-constexpr uint32_t kCutoffLdsBytes = 64;      // 4 rotating count slots + min/max words
+constexpr uint32_t kCutoffBinsPerThread = 8;
+constexpr uint32_t kCutoffLdsBytes = 256;     // small scratch: count slots, min/max, scan totals, result
+__host__ __device__ constexpr uint32_t cutoff_table_bytes(int NT) { return (uint32_t)NT * kCutoffBinsPerThread * 4u; }
 
-// NT threads (multiple of 64, <= 1024, dividing 4096); lds = kCutoffLdsBytes of scratch (4-byte aligned).
-// v / pr are the loaded inputs of THIS thread: v[j], probes[j] for j = tid + NT*k.  Returns the cutoff in
-// every lane.  Contains barriers: call from uniform control flow.
-template <int NT>
+// NT threads (multiple of 64, <= 1024, dividing 4096); lds = kCutoffLdsBytes of scratch; tbl =
+// cutoff_table_bytes(NT) of scratch, 16-byte aligned (may alias memory the caller initialises afterwards).
+// vj / prj are THIS thread's inputs: v[j], probes[j] for j = tid + NT*k.  Returns the cutoff in every lane.
+// Contains barriers: call from uniform control flow.  `idle` is invoked by the waves that do not run the
+// serial part, with the table still live (it may not touch tbl).
+template <int NT, typename Idle>
 __device__ __forceinline__ float block_find_cutoff(const float (&vj)[4096 / NT], const uint16_t (&prj)[4096 / NT],
-                                                   uint32_t q, char* lds, unsigned long long* dbg = nullptr) {
+                                                   uint32_t q, char* lds, uint32_t* tbl, Idle idle,
+                                                   unsigned long long* dbg = nullptr) {
     static_assert(4096 % NT == 0 && NT % 64 == 0 && NT <= 1024, "block_find_cutoff: bad workgroup size");
     constexpr int VPT = 4096 / NT;                      // probe products per thread
-    uint32_t* s_cnt = reinterpret_cast<uint32_t*>(lds);            // [4] rotating count slots
+    constexpr int NW = NT / 64;
+    constexpr uint32_t BPT = kCutoffBinsPerThread, CAP = (uint32_t)NT * BPT;
+    uint32_t* s_cnt = reinterpret_cast<uint32_t*>(lds);            // [4] rotating count slots (ballot passes)
     uint32_t* s_mm = reinterpret_cast<uint32_t*>(lds) + 4;         // [0] min pattern, [1] max pattern
+    uint32_t* s_tot = reinterpret_cast<uint32_t*>(lds) + 8;        // [16] wave totals of the scan
+    float* s_res = reinterpret_cast<float*>(lds) + 24;             // [0] result
     const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (dbg && tid == 0) { dbg[0] = wall_clock64(); dbg[6] = clock64(); }
 
-    if (tid == 0) { s_cnt[0] = 0; s_cnt[1] = 0; s_cnt[2] = 0; s_cnt[3] = 0; s_mm[0] = 0xFFFFFFFFu; s_mm[1] = 0; }
+    if (tid < 4) s_cnt[tid] = 0;
+    if (tid == 0) { s_mm[0] = 0xFFFFFFFFu; s_mm[1] = 0; }
     __syncthreads();
     // the 4096 values bf16(|(1e5*v[j]) * bf16(probe[j])|), products evaluated left to right (:160), kept as
     // their 16-bit patterns
@@ -56,47 +72,129 @@ __device__ __forceinline__ float block_find_cutoff(const float (&vj)[4096 / NT],
     }
     if (lane == 0) { atomicMin(&s_mm[0], pmin); atomicMax(&s_mm[1], pmax); }
     __syncthreads();
-    if (dbg && tid == 0) dbg[1] = wall_clock64();
+    const uint32_t pminAll = s_mm[0], pmaxAll = s_mm[1];
     // The reference starts each thread's min at 999 / max at -999, clamps per simdgroup and stores the
     // simdgroup results as bfloat (999 -> 1000) before the cross-simdgroup reduction (:155-190).  All values
     // are non-negative bf16 numbers, so the net effect is minBound = min(globalMin, 1000), maxBound = globalMax.
-    float minBound = fminf(__uint_as_float(s_mm[0] << 16), 1000.0f);
-    float maxBound = __uint_as_float(s_mm[1] << 16);
-
-    int nCounts = 0;
-    auto count_above = [&](uint32_t p) -> uint32_t {    // #{value > threshold}; workgroup-wide, uniform call
-        uint32_t wc = 0;
-#pragma unroll
-        for (int k = 0; k < VPT; k++) wc += (uint32_t)__popcll(__ballot(vp[k] > p));
-        const int slot = nCounts & 3;
-        if (tid == 0) s_cnt[(nCounts + 1) & 3] = 0;     // slot of the NEXT count: idle since three counts ago
-        if (lane == 0) atomicAdd(&s_cnt[slot], wc);
-        __syncthreads();
-        nCounts++;
-        return s_cnt[slot];
-    };
+    float minBound = fminf(__uint_as_float(pminAll << 16), 1000.0f);
+    float maxBound = __uint_as_float(pmaxAll << 16);
 
     float newBound = (minBound + maxBound) / 2;          // :195
     const uint32_t effort = 4096u - q;                   // :154
     int loops = 0, minCount = 4096, maxCount = 0;        // :175-176,198
-    uint32_t patLo = 0xFFFFFFFFu, patHi = 0xFFFFFFFFu, cLo = 0, cHi = 0;   // counts known at the current bounds
-    for (;;) {
+    constexpr uint32_t kNoLo = 0xFFFF0000u, kNoHi = 0xFFF00000u;
+    uint32_t patLo = kNoLo, patHi = kNoHi;               // bf16 cells of the bounds whose counts are known
+    int nPasses = 0;
+    bool done = false;
+
+    // one round of the reference's loop body (:199-246) given the count at newBound; returns true on exit
+    auto round = [&](uint32_t countAbove) -> bool {
         loops += 1;
         const uint32_t p = __float_as_uint(newBound) >> 16;
-        uint32_t countAbove;
-        if (p == patHi) countAbove = cHi;
-        else if (p == patLo) countAbove = cLo;
-        else countAbove = count_above(p);
-        if (countAbove < effort) { maxBound = newBound; maxCount = (int)countAbove; patHi = p; cHi = countAbove; }   // :214-220
-        else { minBound = newBound; minCount = (int)countAbove; patLo = p; cLo = countAbove; }
+        if (countAbove < effort) { maxBound = newBound; maxCount = (int)countAbove; patHi = p; }     // :214-220
+        else { minBound = newBound; minCount = (int)countAbove; patLo = p; }
         const float prev = newBound;
         newBound = (maxBound + minBound) / 2;                                               // :222
         int d = maxCount - minCount; if (d < 0) d = -d;
-        if (countAbove == effort || (maxBound - minBound < 0.00001f) || d < 3) break;      // :227-229
-        if (loops > 100) break;                                                            // :236
-        if (newBound == prev) break;                     // fixed point of the loop body: rounds ..101 change nothing
+        if (countAbove == effort || (maxBound - minBound < 0.00001f) || d < 3) return true;  // :227-229
+        if (loops > 100) return true;                                                      // :236
+        return newBound == prev;                         // fixed point: rounds ..101 would change nothing
+    };
+
+    // ---- rare: the value range exceeds the table; count with ballots until the bracket fits ----------------
+    auto lowCell = [&]() { return patLo != kNoLo ? patLo : pminAll; };
+    auto topCell = [&]() { return patHi != kNoHi ? patHi : pmaxAll; };
+    while (!done && patHi != patLo + 1u && topCell() - lowCell() + 1u > CAP) {
+        const uint32_t p = __float_as_uint(newBound) >> 16;
+        uint32_t wc = 0;
+#pragma unroll
+        for (int k = 0; k < VPT; k++) wc += (uint32_t)__popcll(__ballot(vp[k] > p));
+        const int slot = nPasses & 3;
+        if (tid == 0) s_cnt[(nPasses + 1) & 3] = 0;     // slot of the NEXT pass: idle since three passes ago
+        if (lane == 0) atomicAdd(&s_cnt[slot], wc);
+        __syncthreads();
+        nPasses++;
+        done = round(s_cnt[slot]);
     }
-    if (dbg && tid == 0) { dbg[2] = wall_clock64(); dbg[3] = dbg[2]; dbg[4] = dbg[2]; dbg[5] = (unsigned long long)loops * 1000ull + nCounts; dbg[7] = clock64(); }
+    if (dbg && tid == 0) dbg[1] = wall_clock64();
+
+    if (!done && patHi != patLo + 1u) {                  // uniform
+        // ---- table over the cells [base, top]: suffix[i] = #{values with pattern > base + i} ---------------
+        const uint32_t base = lowCell(), top = topCell();
+        const uint32_t above = (patHi != kNoHi) ? (uint32_t)maxCount : 0u;     // values beyond the top cell
+        uint4* t4 = reinterpret_cast<uint4*>(tbl + tid * BPT);
+        t4[0] = make_uint4(0, 0, 0, 0); t4[1] = make_uint4(0, 0, 0, 0);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < VPT; k++) if (vp[k] >= base && vp[k] <= top) atomicAdd(&tbl[vp[k] - base], 1u);
+        __syncthreads();
+        uint4 a4 = t4[0], b4 = t4[1];
+        uint32_t h[BPT] = {a4.x, a4.y, a4.z, a4.w, b4.x, b4.y, b4.z, b4.w};
+        uint32_t mine = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < BPT; i++) mine += h[i];
+        uint32_t suf = mine;                             // inclusive suffix sum over the lanes of this wave
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_down(suf, off);
+            suf += (lane + off < 64) ? o : 0u;
+        }
+        if (lane == 0) s_tot[wave] = suf;                // wave total
+        __syncthreads();
+        uint32_t running = above + suf - mine;           // values in cells owned by later lanes / waves, or beyond top
+#pragma unroll
+        for (int w2 = 0; w2 < NW; w2++) running += (w2 > wave) ? s_tot[w2] : 0u;
+#pragma unroll
+        for (int i = (int)BPT - 1; i >= 0; i--) { const uint32_t c = running; running += h[i]; h[i] = c; }
+        t4[0] = make_uint4(h[0], h[1], h[2], h[3]); t4[1] = make_uint4(h[4], h[5], h[6], h[7]);
+        __syncthreads();
+        if (dbg && tid == 0) dbg[2] = wall_clock64();
+
+        if (wave == 0) {
+            // ---- the bisection proper, one wave, one LDS lookup per round ------------------------------------
+            auto count_above = [&](uint32_t p) -> uint32_t {
+                if (p < base) return 4096u;              // cannot happen (thresholds stay inside the bracket); safe anyway
+                if (p > top) return above;
+                return tbl[p - base];
+            };
+            while (!done && patHi != patLo + 1u) done = round(count_above(__float_as_uint(newBound) >> 16));
+            if (!done) {
+                // tail: bounds in adjacent cells with known counts (below the target at and above X, not below it
+                // under X); those counts differ by >= 3 and neither equals the target, or the loop had exited.
+                const float X = __uint_as_float(patHi << 16);    // first float of the upper cell
+                for (;;) {
+                    loops += 1;
+                    if (newBound >= X) maxBound = newBound; else minBound = newBound;
+                    const float prev = newBound;
+                    newBound = (maxBound + minBound) / 2;
+                    if (maxBound - minBound < 0.00001f) break;
+                    if (loops > 100) break;
+                    if (newBound == prev) break;
+                }
+            }
+            if (lane == 0) s_res[0] = newBound;
+        } else {
+            idle();
+        }
+        __syncthreads();
+        newBound = s_res[0];
+    } else if (!done) {
+        // adjacent cells already (possible only after ballot passes): tail needs no table
+        const float X = __uint_as_float(patHi << 16);
+        for (;;) {
+            loops += 1;
+            if (newBound >= X) maxBound = newBound; else minBound = newBound;
+            const float prev = newBound;
+            newBound = (maxBound + minBound) / 2;
+            if (maxBound - minBound < 0.00001f) break;
+            if (loops > 100) break;
+            if (newBound == prev) break;
+        }
+        idle();
+    } else {
+        idle();
+    }
+    if (dbg && tid == 0) { dbg[3] = wall_clock64(); dbg[4] = dbg[3]; dbg[5] = (unsigned long long)loops * 1000ull + nPasses; dbg[7] = clock64(); }
     return newBound;
 }
 

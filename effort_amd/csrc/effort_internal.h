@@ -22,6 +22,7 @@ struct MulGeom {
     uint32_t tiles;        // T: column tiles of 64*E u16 columns
     uint32_t slices;       // S: row slices actually used (every slice owns sliceRows input rows)
     uint32_t sliceRows;    // B: input rows per slice
+    uint32_t sliceLog2;    // ceil(log2(B)): FP16 candidate slots are laid out [rank][2^sliceLog2]
     uint32_t tileFloats;   // accumulators per tile = NACC*E*64
     uint32_t numExperts;   // experts stacked in the buffers (bounds of the buffer descriptor)
 };
@@ -43,6 +44,7 @@ struct MulArgs {
     uint32_t* counters;        // [tiles + 1] arrival tickets, zero between calls
     uint32_t* sliceCounts;     // [slices] kept rows per slice (sum = dispatch.size)
     float* cutoffOut;          // BucketMul.cutoff
+    const float* cutoffIn;     // nullable: cutoff precomputed by the standalone kernel (split mode); null = evaluate in-kernel
     unsigned long long* tstamp;   // nullable profiling stamps: [0]=min start, [1]=max end, [2]=sum, [3]=launches, [16..] phases
     OutlierIndex ol;
     uint32_t q;                // Int(4095*(1-effort)), bucketMul.swift:39

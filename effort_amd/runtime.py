@@ -48,6 +48,9 @@ class Gpu:
     def set_tuning(self, waves: int = 0, elems: int = 0, slices: int = 0):
         self.check(self._lib.effort_set_tuning(self.ctx, waves, elems, slices), "set_tuning")
 
+    def set_split_cutoff(self, split: bool = True):
+        self.check(self._lib.effort_set_split_cutoff(self.ctx, int(split)), "set_split_cutoff")
+
     def enable_kernel_timing(self, mode: int = 1):
         """1: HIP events + device clock, 2: device clock only (graph safe), 0: off."""
         self._bind_stream()
@@ -59,7 +62,7 @@ class Gpu:
         return {"mul_us": us.value, "launches": n.value}
 
     def debug_stamps(self):
-        buf = (C.c_ulonglong * 16)()
+        buf = (C.c_ulonglong * 24)()
         self.check(self._lib.effort_debug_stamps(self.ctx, buf), "debug_stamps")
         return list(buf)
 

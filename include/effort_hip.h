@@ -134,6 +134,12 @@ EFFORT_API int effort_cosine(effort_ctx* ctx, const float* a_dev, const float* b
  * elements per lane (1, 2 or 4) and number of row slices (0 = heuristic).  Returns EFFORT_ERR_ARG
  * for unsupported combinations. */
 EFFORT_API int effort_set_tuning(effort_ctx* ctx, int wavesPerGroup, int elemsPerLane, int rowSlices);
+/* split = 1: evaluate findCutoff32 in its own one-workgroup launch ahead of the multiply kernel instead of
+ * redundantly inside every workgroup of it.  Costs a kernel boundary per call (worse latency) but frees the
+ * multiply's workgroups sooner -- better aggregate throughput when independent calls overlap on several
+ * streams/contexts.  Results are bit-identical.  Default 0 (fused). */
+EFFORT_API int effort_set_split_cutoff(effort_ctx* ctx, int split);
+
 /* Timing hooks.  enable = 1: HIP events are recorded on the context's stream around each of the three
  * kernels of a call (not capturable into a graph) AND the multiply kernel stamps the device wall clock
  * at its first workgroup's start / last workgroup's end; enable = 2: device clock only (works inside
@@ -142,8 +148,8 @@ EFFORT_API int effort_set_tuning(effort_ctx* ctx, int wavesPerGroup, int elemsPe
  * kernel's own average duration (first start -> last end).  Both reset their accumulators. */
 EFFORT_API int effort_enable_kernel_timing(effort_ctx* ctx, int enable);
 EFFORT_API int effort_kernel_clock(effort_ctx* ctx, double* mul_us_avg, int* n_launches);
-/* Profiling aid: 16 raw u64 phase stamps written by the most recent cutoff / multiply kernels in timing mode. */
-EFFORT_API int effort_debug_stamps(effort_ctx* ctx, unsigned long long* host16);
+/* Profiling aid: 24 raw u64 phase stamps written by the most recent cutoff / multiply kernels in timing mode. */
+EFFORT_API int effort_debug_stamps(effort_ctx* ctx, unsigned long long* host24);
 EFFORT_API int effort_kernel_timing(effort_ctx* ctx, double* mul_us_avg, double* cutoff_us_avg,
                          double* integrate_us_avg, int* n_samples);
 

@@ -22,6 +22,8 @@ def main():
     ap.add_argument("--shape", default="4096x11008")
     ap.add_argument("--efforts", default="0.25,1.0")
     ap.add_argument("--mats", type=int, default=16)
+    ap.add_argument("--split", type=int, default=0)
+    ap.add_argument("--streams", default="1", help="comma list: numbers of concurrent streams/contexts to try")
     ap.add_argument("--configs", default="16,1,0;16,1,24;16,1,32;16,1,64;16,2,0;16,2,32;8,1,0;8,1,48;8,1,96;8,2,0;8,2,48;8,4,0;8,4,32;4,1,0;4,2,0;4,4,0")
     args = ap.parse_args()
     inDim, outDim = (int(x) for x in args.shape.split("x"))
@@ -40,11 +42,40 @@ def main():
             W, E, S = (int(x) for x in cfg.split(","))
             try:
                 g.set_tuning(W, E, S)
+                g.set_split_cutoff(bool(args.split))
                 g.enable_kernel_timing(2)
                 for ew, o in zip(ews, outs):
                     ea.bucketMul(v, ew, None, o, effort)
                 g.eval()
                 D = g.last_dispatch_count()
+                over = {}
+                for K in [int(x) for x in args.streams.split(",") if int(x) > 1]:
+                    ctxs = [ea.Gpu(0) for _ in range(K)]
+                    sts = [torch.cuda.Stream() for _ in range(K)]
+                    for c in ctxs:
+                        c.set_tuning(W, E, S)
+                        c.set_split_cutoff(bool(args.split))
+                    go = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(go):
+                        s0 = torch.cuda.current_stream()
+                        for st in sts:
+                            st.wait_stream(s0)
+                        for i, (ew, o) in enumerate(zip(ews, outs)):
+                            with torch.cuda.stream(sts[i % K]):
+                                ea.bucketMul(v, ew, None, o, effort, gpu=ctxs[i % K])
+                        for st in sts:
+                            s0.wait_stream(st)
+                    for _ in range(5):
+                        go.replay()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(30):
+                        go.replay()
+                    torch.cuda.synchronize()
+                    over[K] = round((time.perf_counter() - t0) / 30 / len(ews) * 1e6, 2)
+                    del go
+                    for c in ctxs:
+                        c.close()
                 gr = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(gr):
                     for ew, o in zip(ews, outs):
@@ -70,9 +101,9 @@ def main():
                 kb = mul_kernel_bytes(D, inDim, outDim)
                 row = {"shape": args.shape, "effort": effort, "W": W, "E": E, "S": S, "D": D, "call_us": round(t * 1e6, 2),
                        "mul_us": round(clk["mul_us"], 2), "mul_GBps": round(kb / clk["mul_us"] / 1e3, 0),
-                       "eff_GBps": round(2 * inDim * outDim / t / 1e9, 0),
+                       "eff_GBps": round(2 * inDim * outDim / t / 1e9, 0), "call_us_by_streams": over,
                        "ev_mul_us": round(ev["mul_us"], 2),
-                       "wg0_phases_us(issue,cutoff,select,stream,slab)": [round((st[9 + i] - st[8 + i]) / 100.0, 2) for i in range(5)], "wg0_rows": st[14], "cutoff(setup,loop)us": [round((st[1] - st[0]) / 100.0, 2), round((st[2] - st[1]) / 100.0, 2)], "cutoff_loops,counts": [st[5] // 1000, st[5] % 1000]}
+                       "wg0_phases_us(issue,cutoff,select,stream,slab)": [round((st[9 + i] - st[8 + i]) / 100.0, 2) for i in range(5)], "wg0_rows": st[14], "reduce_us(tile0)": round((st[16] - st[15]) / 100.0, 2), "rel_wg0_start_us(max_start,max_stream_end,max_slab_drain,tile0_reduce_end)": [round((st[i] - st[8]) / 100.0, 2) for i in (17, 18, 19, 16)], "cutoff(setup,loop)us": [round((st[1] - st[0]) / 100.0, 2), round((st[2] - st[1]) / 100.0, 2)], "cutoff_loops,counts": [st[5] // 1000, st[5] % 1000]}
             except Exception as ex:
                 row = {"shape": args.shape, "effort": effort, "W": W, "E": E, "S": S, "error": repr(ex)[:100]}
             rows.append(row)
