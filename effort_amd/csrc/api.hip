@@ -205,9 +205,12 @@ static int choose_geom(const effort_ctx* c, const effort_w* w, MulGeom* g, int* 
     uint32_t S;
     if (c->tuneS) S = (c->tuneS + 7) / 8 * 8;
     else {
-        // fill the chip: as many workgroups per CU as the private accumulator tiles leave room for (<= 2)
+        // Measured on MI355X (tools/tune.py, 4096x4096 .. 4096x11008, 10-100 % effort): the call is dominated by
+        // per-workgroup fixed work (cutoff, selection, tile reduction, slab hand-off), so FEWER, fatter workgroups
+        // win even when they leave CUs idle; 32 row slices is the sweet spot, capped by one round of workgroups.
         const uint32_t perCU = accBytes * 2 + 16384 <= ldsMax ? 2u : 1u;
-        S = (c->numCU * perCU) / g->tiles / 8 * 8;        // one round of workgroups: tiles*S <= resident capacity
+        const uint32_t cap = (c->numCU * perCU) / g->tiles / 8 * 8;
+        S = cap < 32u ? cap : 32u;
     }
     if (S > w->inDim) S = w->inDim / 8 * 8;
     if (S < 8) S = 8;
@@ -255,8 +258,11 @@ static int do_bucketmul(effort_ctx* c, const effort_w* w, Format fmt, const floa
     a.ol = OutlierIndex{fmt == kQ4 ? w->olRowPtr : nullptr, w->olInIdx, w->olValue};
     a.q = q; a.g = g;
     a.cutoffIn = nullptr;
+    static const uint32_t ablate = getenv("EFFORT_ABLATE") ? (uint32_t)atoi(getenv("EFFORT_ABLATE")) : 0u;   // profiling only
+    a.ablate = ablate;
     if (tm) HIP_TRY(c, hipEventRecord(ev[0], c->stream));
     if (c->splitCutoff) {
+        if (!(ablate & 1u))
         HIP_TRY(c, launch_find_cutoff(v, w->probes, expNo, q, c->d_cutoff, c->d_count, nullptr, c->stream));
         a.cutoffIn = c->d_cutoff;
     }

@@ -62,11 +62,13 @@ template <> struct Piece<1> {
     uint32_t w;
     __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) { w = __builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, 0); }
     __device__ __forceinline__ uint32_t word(int) const { return w & 0xFFFFu; }
+    __device__ __forceinline__ uint32_t dword(int) const { return w; }
 };
 template <> struct Piece<2> {
     uint32_t w;
     __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) { w = __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0); }
     __device__ __forceinline__ uint32_t word(int j) const { return (w >> (16 * j)) & 0xFFFFu; }
+    __device__ __forceinline__ uint32_t dword(int) const { return w; }
 };
 template <> struct Piece<4> {
     uint32_t w[2];
@@ -74,6 +76,7 @@ template <> struct Piece<4> {
         auto t = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0); w[0] = t[0]; w[1] = t[1];
     }
     __device__ __forceinline__ uint32_t word(int j) const { return (w[j >> 1] >> (16 * (j & 1))) & 0xFFFFu; }
+    __device__ __forceinline__ uint32_t dword(int j) const { return w[j >> 1]; }
 };
 template <> struct Piece<8> {
     uint32_t w[4];
@@ -81,17 +84,18 @@ template <> struct Piece<8> {
         auto t = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0); w[0] = t[0]; w[1] = t[1]; w[2] = t[2]; w[3] = t[3];
     }
     __device__ __forceinline__ uint32_t word(int j) const { return (w[j >> 1] >> (16 * (j & 1))) & 0xFFFFu; }
+    __device__ __forceinline__ uint32_t dword(int j) const { return w[j >> 1]; }
 };
 
 __host__ __device__ inline uint32_t align_up(uint32_t x, uint32_t a) { return (x + a - 1) / a * a; }
 
-// LDS carve (bytes): [W][tileFloats] f32 | vblk[B] f32 | misc 512 B | list[rows*B] u16 | dlist (Q4) f32
+// LDS carve (bytes): [W][tileFloats] f32 | vblk[B] f32 | misc 768 B | list[rows*B] u16 | dlist (Q4) f32
 template <int FMT, int E, int W>
 __host__ __device__ inline uint32_t lds_layout(uint32_t B, uint32_t rowsPerIn, uint32_t* offV, uint32_t* offC,
                                                uint32_t* offL, uint32_t* offD) {
     uint32_t o = (uint32_t)W * Fmt<FMT>::kAcc * E * 64 * 4;
     *offV = o; o += align_up(B * 4, 16);
-    *offC = o; o += 512;                                   // [0..255] cutoff scratch, [256..383] wave counts, [384] flags
+    *offC = o; o += 768;                                   // [0..255] cutoff scratch, [256..511] wave counts [kPre][16], [512] flags
     *offL = o; o += align_up(rowsPerIn * B * 2, 16);
     *offD = o; if (FMT == kQ4) o += align_up(rowsPerIn * B * 4, 16);
     return o;
@@ -121,8 +125,8 @@ __global__ __launch_bounds__(64 * W) void bucket_mul_kernel(const MulArgs a) {
     lds_layout<FMT, E, W>(B, g.rowsPerIn, &offV, &offC, &offL, &offD);
     float* acc = reinterpret_cast<float*>(smem);
     float* vblk = reinterpret_cast<float*>(smem + offV);
-    uint32_t* wcnt = reinterpret_cast<uint32_t*>(smem + offC + 256);         // [2][16]
-    uint32_t* flags = reinterpret_cast<uint32_t*>(smem + offC + 384);
+    uint32_t* wcnt = reinterpret_cast<uint32_t*>(smem + offC + 256);         // [kPre][16]
+    uint32_t* flags = reinterpret_cast<uint32_t*>(smem + offC + 512);
     uint16_t* list = reinterpret_cast<uint16_t*>(smem + offL);
     float* dlist = reinterpret_cast<float*>(smem + offD);
     float* myacc = acc + wave * TILE_F + lane;
@@ -152,6 +156,7 @@ __global__ __launch_bounds__(64 * W) void bucket_mul_kernel(const MulArgs a) {
     for (int r = 0; r < kPre; r++) {
         const uint32_t c = r * NT + tid;
         mean[r] = 0.0f; codes[r] = 0xFFFFFFFFu;                 // 0xFFFFFFFF: no candidate in this slot
+        if ((uint32_t)(r * NT) >= nSlots) continue;             // uniform: this round holds no slots at all
         if (FMT == kFp16) {
             const uint32_t rank = c >> lg, jl = c & ((1u << lg) - 1u);
             if (rank < g.rowsPerIn && jl < nb) {
@@ -197,33 +202,42 @@ __global__ __launch_bounds__(64 * W) void bucket_mul_kernel(const MulArgs a) {
     if (stamp) a.tstamp[18] = wall_clock64();
 
     // ---- C. keep test (bucketMul.metal:69 / bucketMulQ4.metal:47) + ordered compaction -----------
-    uint32_t n = 0;
+    // All rounds are balloted first; the kPre*W per-wave counts meet in LDS at ONE barrier; list position of a
+    // kept slot = (kept slots of earlier rounds) + (earlier waves of its round) + (earlier lanes of its wave).
+    bool keep[kPre]; uint32_t pre[kPre]; float xs[kPre];
 #pragma unroll
     for (int r = 0; r < kPre; r++) {
-        if ((uint32_t)(r * NT) < nSlots) {                      // uniform
+        keep[r] = false; pre[r] = 0; xs[r] = 0.0f;
+        if ((uint32_t)(r * NT) < nSlots && !(a.ablate & 8u)) {  // uniform
             const bool cand = codes[r] != 0xFFFFFFFFu;
             const uint32_t jl = FMT == kFp16 ? (codes[r] & 4095u) : (codes[r] >> 3);
-            const float x = cand ? vblk[jl] : 0.0f;
-            const bool keep = cand && (cutoff < (kCutoffScale * mean[r]) * fabsf(x));
-            const unsigned long long m = __ballot(keep);
-            const uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            if (lane == 0) wcnt[(r & 1) * 16 + wave] = (uint32_t)__popcll(m);
-            __syncthreads();
-            // exclusive prefix of the W wave counts: lanes 0..W-1 hold one count each, scanned with shuffles
-            uint32_t inc = (lane < W) ? wcnt[(r & 1) * 16 + lane] : 0u;
+            xs[r] = cand ? vblk[jl] : 0.0f;
+            keep[r] = cand && (cutoff < (kCutoffScale * mean[r]) * fabsf(xs[r]));
+            const unsigned long long m = __ballot(keep[r]);
+            pre[r] = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (lane == 0) wcnt[r * 16 + wave] = (uint32_t)__popcll(m);
+        } else if (lane == 0) {
+            wcnt[r * 16 + wave] = 0u;
+        }
+    }
+    __syncthreads();
+    // lanes 0..kPre*W-1 hold one (round, wave) count each, in list order; inclusive scan with shuffles
+    static_assert(kPre * W <= 64, "selection scan: kPre*W must fit one wave");
+    uint32_t inc = (lane < kPre * W) ? wcnt[(lane / W) * 16 + (lane % W)] : 0u;
+    const uint32_t own = inc;
 #pragma unroll
-            for (int off = 1; off < W; off <<= 1) {
-                const uint32_t o = __shfl_up(inc, off);
-                inc += (lane >= off) ? o : 0u;
-            }
-            const uint32_t tot = __shfl(inc, W - 1);
-            const uint32_t mineInc = __shfl(inc, wave);
-            const uint32_t woff = mineInc - (uint32_t)__popcll(m);
-            if (keep) {
-                list[n + woff + pre] = (uint16_t)codes[r];
-                if (FMT == kQ4) dlist[n + woff + pre] = x * mean[r];          // entry value = v*mean (:52)
-            }
-            n += tot;
+    for (int off = 1; off < kPre * W; off <<= 1) {
+        const uint32_t o = __shfl_up(inc, off);
+        inc += (lane >= off) ? o : 0u;
+    }
+    const uint32_t exc = inc - own;
+    uint32_t n = __shfl(inc, kPre * W - 1);
+#pragma unroll
+    for (int r = 0; r < kPre; r++) {
+        const uint32_t base = __shfl(exc, r * W + wave);
+        if (keep[r]) {
+            list[base + pre[r]] = (uint16_t)codes[r];
+            if (FMT == kQ4) dlist[base + pre[r]] = xs[r] * mean[r];          // entry value = v*mean (:52)
         }
     }
     __syncthreads();
@@ -236,7 +250,8 @@ __global__ __launch_bounds__(64 * W) void bucket_mul_kernel(const MulArgs a) {
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint16_t*>(a.buckets), 0, (int)min((size_t)0xFFFFFFFFu, (size_t)g.numExperts * g.expertRows * g.cols * 2u), 0x00020000);
     const uint32_t voff = (colOK ? col : 0u) * 2u;                 // lanes past the last column re-read column 0
-    const uint32_t myRows = (n > (uint32_t)wave) ? (n - wave + W - 1) / W : 0u;   // entries wave, wave+W, ...
+    const uint32_t nU = (a.ablate & 4u) ? 0u : __builtin_amdgcn_readfirstlane(n);   // n is workgroup-uniform; keep it in an SGPR
+    const uint32_t myRows = (nU > (uint32_t)wave) ? (nU - wave + W - 1) / W : 0u;   // entries wave, wave+W, ...
 
     // Software pipeline: the loads of batch k+1 are issued before batch k is accumulated, so a wave keeps
     // up to 2*kBatch row pieces in flight.  Loads are never predicated: a batch that runs past the wave's
@@ -258,45 +273,62 @@ __global__ __launch_bounds__(64 * W) void bucket_mul_kernel(const MulArgs a) {
 #pragma unroll
         for (int u = 0; u < kBatch; u++) piece[u].load(rsrc, voff, EFFORT_ABLATE_NOLOAD ? 0u : __builtin_amdgcn_readlane(boff, u));
     };
-    auto accumulate = [&](const Piece<E> (&piece)[kBatch], float dv, uint32_t nv) {
+    // One row piece -> E (Q4: 4E) read-add-writes on this lane's private accumulator column.  The LDS byte
+    // address is built with v_bfe_u32 + v_lshl_add_u32 (hipcc otherwise spends three VALU ops per element on it)
+    // and the product is accumulated with one v_fma_f32 (a single rounding, where the reference's
+    // `v = d.x*float(w); acc += v` rounds twice: well inside the parity tolerance and never less accurate).
+    using lds_f = __attribute__((address_space(3))) float;
+    const uint32_t accB = (uint32_t)(size_t)(lds_f*)myacc;
+    constexpr int kShift = (E == 1 ? 8 : E == 2 ? 9 : E == 4 ? 10 : 11);      // log2(E * 64 lanes * 4 bytes)
+    auto row = [&](const Piece<E>& pc, float dd) {
+        if (FMT == kFp16) {
+            // bucketMul.metal:100-106: v = d.x*float(w) with the position bits left in w; acc[pos] += v
+            float w[E], old[E]; lds_f* p[E];
 #pragma unroll
-        for (int u = 0; u < kBatch; u++) {
-            const float dd = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(dv), u));
-            if (EFFORT_ABLATE_NOSCATTER) {   // ablation build: keep the loads live, skip the LDS scatter
-                asm volatile("" ::"v"(piece[u].word(E - 1)), "v"(dd));
-            } else if ((uint32_t)u < nv && colOK) {
-                if (FMT == kFp16) {
-                    // bucketMul.metal:100-106: v = d.x*float(w) with the position bits left in w; acc[pos] += v
-                    float val[E], old[E]; float* p[E];
+            for (int j = 0; j < E; j++) {
+                const uint32_t dw = pc.dword(j);                       // the dword holding element j (bits 16*(j&1)..)
+                w[j] = half_bits_to_float((uint16_t)(dw >> (16 * (j & 1))));
+                uint32_t a2;
+                asm("v_bfe_u32 %0, %1, %2, 4\n\tv_lshl_add_u32 %0, %0, %3, %4" : "=&v"(a2) : "v"(dw), "n"(16 * (j & 1)), "n"(kShift), "v"(accB));
+                p[j] = (lds_f*)(size_t)a2 + j * 64;
+            }
 #pragma unroll
-                    for (int j = 0; j < E; j++) {
-                        const uint32_t x = piece[u].word(j);
-                        val[j] = dd * half_bits_to_float((uint16_t)x);
-                        p[j] = myacc + ((x & 15u) * E + j) * 64;
-                    }
+            for (int j = 0; j < E; j++) old[j] = *p[j];
 #pragma unroll
-                    for (int j = 0; j < E; j++) old[j] = *p[j];
+            for (int j = 0; j < E; j++) *p[j] = __builtin_fmaf(dd, w[j], old[j]);
+        } else {
+            // bucketMulQ4.metal:76-81: low nibble first <-> sub-bucket 3,2,1,0; acc += (n&8) ? -d : d
+            float val[4 * E], old[4 * E]; lds_f* p[4 * E];
 #pragma unroll
-                    for (int j = 0; j < E; j++) *p[j] = old[j] + val[j];
-                } else {
-                    // bucketMulQ4.metal:76-81: low nibble first <-> sub-bucket 3,2,1,0; acc += (n&8) ? -d : d
-                    float val[4 * E], old[4 * E]; float* p[4 * E];
+            for (int j = 0; j < E; j++) {
+                const uint32_t x = pc.word(j);
 #pragma unroll
-                    for (int j = 0; j < E; j++) {
-                        const uint32_t x = piece[u].word(j);
-#pragma unroll
-                        for (int q = 0; q < 4; q++) {
-                            const uint32_t nib = (x >> (4 * q)) & 15u;
-                            val[4 * j + q] = (nib & 8u) ? -dd : dd;
-                            p[4 * j + q] = myacc + (((3 - q) * 8 + (nib & 7u)) * E + j) * 64;
-                        }
-                    }
-#pragma unroll
-                    for (int i = 0; i < 4 * E; i++) old[i] = *p[i];
-#pragma unroll
-                    for (int i = 0; i < 4 * E; i++) *p[i] = old[i] + val[i];
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t nib = (x >> (4 * q)) & 15u;
+                    val[4 * j + q] = (nib & 8u) ? -dd : dd;
+                    p[4 * j + q] = (lds_f*)myacc + (((3 - q) * 8 + (nib & 7u)) * E + j) * 64;
                 }
             }
+#pragma unroll
+            for (int i = 0; i < 4 * E; i++) old[i] = *p[i];
+#pragma unroll
+            for (int i = 0; i < 4 * E; i++) *p[i] = old[i] + val[i];
+        }
+    };
+    auto accumulate = [&](const Piece<E> (&piece)[kBatch], float dv, uint32_t nv) {
+        if (EFFORT_ABLATE_NOSCATTER) {       // ablation build: keep the loads live, skip the LDS scatter
+#pragma unroll
+            for (int u = 0; u < kBatch; u++) asm volatile("" ::"v"(piece[u].word(E - 1)), "v"(dv));
+            return;
+        }
+        if (!colOK) return;                  // lanes past the last column sit the batch out (one exec change)
+        if (nv == (uint32_t)kBatch) {        // uniform: full batch, no per-row test
+#pragma unroll
+            for (int u = 0; u < kBatch; u++) row(piece[u], __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(dv), u)));
+        } else {
+#pragma unroll
+            for (int u = 0; u < kBatch; u++)
+                if ((uint32_t)u < nv) row(piece[u], __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(dv), u)));
         }
     };
 
@@ -308,10 +340,10 @@ __global__ __launch_bounds__(64 * W) void bucket_mul_kernel(const MulArgs a) {
         for (uint32_t i0 = 0; i0 < myRows; i0 += 2 * kBatch) {
             decode(i0 + kBatch, boffB, dvB);
             issue(pb, boffB);
-            accumulate(pa, dvA, min((uint32_t)kBatch, myRows - i0));
+            accumulate(pa, dvA, __builtin_amdgcn_readfirstlane(min((uint32_t)kBatch, myRows - i0)));
             decode(i0 + 2 * kBatch, boffA, dvA);
             issue(pa, boffA);
-            accumulate(pb, dvB, i0 + kBatch < myRows ? min((uint32_t)kBatch, myRows - i0 - kBatch) : 0u);
+            accumulate(pb, dvB, __builtin_amdgcn_readfirstlane(i0 + kBatch < myRows ? min((uint32_t)kBatch, myRows - i0 - kBatch) : 0u));
         }
     }
     __syncthreads();
@@ -342,6 +374,7 @@ __global__ __launch_bounds__(64 * W) void bucket_mul_kernel(const MulArgs a) {
     }
     __syncthreads();
     if (flags[0] == 0u) return;
+    if (a.ablate & 2u) { if (tid == 0) __hip_atomic_store(&a.counters[t], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
 
     // last arriver of tile t: every slab of the tile was stored write-through (sc1) and drained before its ticket;
     // read them past L1 (sc1), sum in slice order, un-permute, add the Q4 outliers, write out[].  Each thread owns
@@ -349,7 +382,7 @@ __global__ __launch_bounds__(64 * W) void bucket_mul_kernel(const MulArgs a) {
     // running sums per slot are combined in a fixed order.
     const bool rstamp = a.tstamp && t == 0 && tid == 0;
     if (rstamp) a.tstamp[23] = wall_clock64();
-    constexpr int kRed = 48;
+    constexpr int kRed = 32;
     typedef uint32_t u2v __attribute__((ext_vector_type(2)));
     const uint32_t sliceStride = g.tiles * (uint32_t)(TILE_F * 4);
     for (int o = tid * 2; o < TILE_F; o += NT * 2) {

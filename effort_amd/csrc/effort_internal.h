@@ -48,6 +48,7 @@ struct MulArgs {
     unsigned long long* tstamp;   // nullable profiling stamps: [0]=min start, [1]=max end, [2]=sum, [3]=launches, [16..] phases
     OutlierIndex ol;
     uint32_t q;                // Int(4095*(1-effort)), bucketMul.swift:39
+    uint32_t ablate;           // profiling only (env EFFORT_ABLATE): 2 = no last-arriver reduce, 4 = no row streaming, 8 = no selection
     MulGeom g;
 };
 

@@ -73,6 +73,24 @@ def main():
                         go.replay()
                     torch.cuda.synchronize()
                     over[K] = round((time.perf_counter() - t0) / 30 / len(ews) * 1e6, 2)
+                    if not args.split:
+                        ctxs[0].enable_kernel_timing(2)
+                        go2 = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(go2):
+                            s0 = torch.cuda.current_stream()
+                            for st in sts:
+                                st.wait_stream(s0)
+                            for i, (ew, o) in enumerate(zip(ews, outs)):
+                                with torch.cuda.stream(sts[i % K]):
+                                    ea.bucketMul(v, ew, None, o, effort, gpu=ctxs[i % K])
+                            for st in sts:
+                                s0.wait_stream(st)
+                        for _ in range(5):
+                            go2.replay()
+                        torch.cuda.synchronize()
+                        stx = ctxs[0].debug_stamps()
+                        over[f"{K}_wg0_phases"] = [round((stx[9 + i] - stx[8 + i]) / 100.0, 2) for i in range(5)] + [round((stx[i] - stx[8]) / 100.0, 2) for i in (17, 18, 19, 16)]
+                        del go2
                     del go
                     for c in ctxs:
                         c.close()
