@@ -61,13 +61,18 @@ def mul_kernel_bytes(D: int, inDim: int, outDim: int) -> int:
     return algorithmic_bytes(D, inDim, outDim)
 
 
-def make_weights(ea, n, inDim, outDim, seed0, dev, keep_core=True):
+def make_weights(ea, n, inDim, outDim, seed0, dev, keep_core=True, q4=False):
     ews = []
     gen = torch.Generator(device=dev)
     for k in range(n):
         gen.manual_seed(seed0 + k)
         W = (torch.randn((outDim, inDim), generator=gen, device=dev, dtype=torch.float32) * 0.02).to(torch.float16)
-        ew = ea.ExpertWeights.from_core(W)          # product converter (GPU bucketize)
+        if q4:                                       # product converter (effort_amd/q4.py, = q4_draft.convert)
+            t = ea.q4_convert(W.t().contiguous())
+            ew = ea.ExpertWeights(t["buckets"], t["bucket.stats"], t["probes"], inSize=inDim, outSize=outDim,
+                                  outliers=t["outliers"], core=W, q4=True)
+        else:
+            ew = ea.ExpertWeights.from_core(W)      # product converter (GPU bucketize)
         if not keep_core:
             ew.core = None
         ew.handle

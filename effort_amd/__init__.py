@@ -23,6 +23,9 @@ def __getattr__(name):
     if name == "bucketize":
         from . import convert as _c
         return _c.bucketize
+    if name == "q4_convert":
+        from . import q4 as _q
+        return _q.convert
     if name in ("ShardedExpertWeights", "shardedExpertMul"):
         from . import sharded as _s
         return getattr(_s, name)

@@ -44,8 +44,9 @@ def bucketMul(v: torch.Tensor, by: ExpertWeights, expNo: torch.Tensor | None, ou
     (BucketMul.shared() if gpu is None else BucketMul(gpu.device, gpu)).fullMul(v, by, expNo, out, effort)
 
 
-def bucketMulQ4(v: torch.Tensor, by: ExpertWeights, expNo: torch.Tensor | None, out: torch.Tensor, effort: float = 0.25):
-    BucketMulQ4.shared().fullMul(v, by, expNo, out, effort)
+def bucketMulQ4(v: torch.Tensor, by: ExpertWeights, expNo: torch.Tensor | None, out: torch.Tensor, effort: float = 0.25,
+                gpu=None):
+    (BucketMulQ4.shared() if gpu is None else BucketMulQ4(gpu.device, gpu)).fullMul(v, by, expNo, out, effort)
 
 
 def basicMul(v: torch.Tensor, by: torch.Tensor, out: torch.Tensor, gpu=None):

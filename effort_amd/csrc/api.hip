@@ -189,9 +189,9 @@ static bool supported(int W, int E) {
 }
 
 static int choose_geom(const effort_ctx* c, const effort_w* w, MulGeom* g, int* Wout, int* Eout) {
-    // defaults: 16 waves per workgroup with 128 KiB of private accumulator tiles (FP16: 2 columns per lane,
-    // Q4: 1 word = 4 sub-buckets per lane)
-    const int W = c->tuneW ? c->tuneW : 16;
+    // defaults: FP16 16 waves per workgroup x 2 columns per lane (128 KiB of private accumulator tiles);
+    // Q4 8 waves x 1 word (= 4 sub-buckets) per lane (64 KiB, two workgroups per CU)
+    const int W = c->tuneW ? c->tuneW : (w->fmt == kFp16 ? 16 : 8);
     const int E = c->tuneE ? c->tuneE : (w->fmt == kFp16 ? 2 : 1);
     if (!supported(W, E)) return EFFORT_ERR_ARG;
     const uint32_t nacc = w->fmt == kFp16 ? 16 : 32;
@@ -267,6 +267,7 @@ static int do_bucketmul(effort_ctx* c, const effort_w* w, Format fmt, const floa
         a.cutoffIn = c->d_cutoff;
     }
     HIP_TRY(c, launch_bucket_mul(fmt, W, E, a, c->stream));
+    if (fmt == kQ4 && w->olRowPtr) HIP_TRY(c, launch_q4_outliers(a.ol, v, out, w->outDim, c->stream));
     if (tm) { HIP_TRY(c, hipEventRecord(ev[1], c->stream)); c->nSamples++; }
     c->lastSlices = g.slices;                      // dispatch.size = sum of the per-slice counts
     return EFFORT_OK;

@@ -34,7 +34,7 @@
 //   E. the W private tiles are summed in wave order into one partial "slab", stored write-through; the workgroup
 //      takes a ticket on its tile's arrival counter, and the LAST workgroup of each tile sums the S slabs in
 //      slice order (and, for Q4, adds that output's outliers in table order) and writes out[].  The result does
-//      not depend on arrival order: deterministic end to end.
+//      not depend on arrival order: deterministic end to end.  (Q4 outliers: q4_outliers_kernel, launched next.)
 #include "cutoff_device.h"
 
 namespace effort {
@@ -407,9 +407,6 @@ __global__ __launch_bounds__(64 * W) void bucket_mul_kernel(const MulArgs a) {
             float sum = sum2[h];
             if (c2 < g.cols) {
                 const uint32_t oi = c2 * NACC + slot;
-                if (FMT == kQ4 && a.ol.rowPtr) {                               // calcOutliers, bucketMulQ4.metal:13-21
-                    for (uint32_t q = a.ol.rowPtr[oi]; q < a.ol.rowPtr[oi + 1]; q++) sum += a.v[a.ol.inIdx[q]] * a.ol.value[q];
-                }
                 a.out[oi] = sum;
             }
         }
@@ -430,6 +427,29 @@ __global__ __launch_bounds__(64 * W) void bucket_mul_kernel(const MulArgs a) {
             }
         }
     }
+}
+
+// calcOutliers (bucketMulQ4.metal:13-21): out[o] += sum over the outliers of output o of v[in]*value.  The reference
+// fires one atomic per outlier in table order; here one wave owns one output (its outliers are contiguous in the
+// by-output index built at registration), lanes stride its segment with coalesced loads, and a fixed xor-butterfly
+// adds the 64 partial sums -- no atomics, deterministic.  Launched right after the multiply kernel on the same stream.
+__global__ __launch_bounds__(256) void q4_outliers_kernel(const OutlierIndex ol, const float* __restrict__ v,
+                                                          float* __restrict__ out, uint32_t outDim) {
+    const uint32_t o = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (o >= outDim) return;
+    const int lane = threadIdx.x & 63;
+    const uint32_t lo = ol.rowPtr[o], hi = ol.rowPtr[o + 1];
+    if (lo == hi) return;
+    float part = 0.0f;
+    for (uint32_t k = lo + lane; k < hi; k += 64) part += v[ol.inIdx[k]] * ol.value[k];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off);
+    if (lane == 0) out[o] += part;
+}
+
+hipError_t launch_q4_outliers(const OutlierIndex& ol, const float* v, float* out, uint32_t outDim, hipStream_t st) {
+    hipLaunchKernelGGL(q4_outliers_kernel, dim3((outDim + 3) / 4), dim3(256), 0, st, ol, v, out, outDim);
+    return hipGetLastError();
 }
 
 // ---- host side ------------------------------------------------------------------------------

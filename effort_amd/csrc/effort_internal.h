@@ -70,7 +70,8 @@ hipError_t launch_find_cutoff(const float* v, const uint16_t* probes, const uint
 // Returns hipErrorInvalidValue for unsupported (fmt, W, E).
 hipError_t launch_bucket_mul(Format fmt, int wavesPerGroup, int elemsPerLane, const MulArgs& a, hipStream_t st);
 size_t bucket_mul_lds_bytes(Format fmt, int wavesPerGroup, int elemsPerLane, uint32_t sliceRows, uint32_t rowsPerIn);
-uint32_t bucket_mul_max_candidates(int wavesPerGroup);   // rowsPerIn*sliceRows must not exceed this
+uint32_t bucket_mul_max_candidates(int wavesPerGroup);
+hipError_t launch_q4_outliers(const OutlierIndex& ol, const float* v, float* out, uint32_t outDim, hipStream_t st);   // rowsPerIn*sliceRows must not exceed this
 
 hipError_t launch_calc_dispatch(Format fmt, const void* stats, const float* v, const uint32_t* expNo,
                                 const float* cutoff, const MulGeom& g, float* dispatch, uint32_t* count,

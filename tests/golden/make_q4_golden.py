@@ -64,3 +64,5 @@ if __name__ == "__main__":
     make("64x256", 64, 256, 11)
     make("96x160", 96, 160, 12, heavy=True)
     make("32x512", 32, 512, 13, scale=0.5)
+    make("16x2048", 16, 2048, 14)            # rank rows of 256 elements: numpy's pairwise sum recurses once
+    make("8x11008", 8, 11008, 15)            # the FFN width: rank rows of 1376 elements (uneven recursion)

@@ -227,6 +227,17 @@ def test_bucketmul_q4_matches_oracle(ea, oracle_cpu, q4_case, with_outliers):
     assert int(bm.dispatch_size.item()) == n and bm.dispatch[:n].cpu().numpy().tobytes() == disp[:n].tobytes()
 
 
+def test_gpu_q4_converter_matches_oracle(ea, q4_case):
+    """effort_amd.q4.convert on the GPU vs the numpy restatement of q4_draft.convert (itself pinned by the
+    reference's fixtures): identical buckets, stats, probes and outlier table."""
+    W, L, inDim, outDim = q4_case
+    out = ea.q4_convert(dev16(np.ascontiguousarray(W.T)).view(torch.float16))
+    assert out["buckets"].cpu().numpy().view(np.uint16).tobytes() == L["buckets"].view(np.uint16).tobytes()
+    assert out["bucket.stats"].cpu().numpy().tobytes() == L["bucket.stats"].tobytes()
+    assert out["probes"].cpu().numpy().view(np.uint16).tobytes() == L["probes"].view(np.uint16).tobytes()
+    assert out["outliers"].cpu().numpy().tobytes() == L["outliers"].tobytes()       # same stable order
+
+
 def test_q4_quality_vs_dense(ea, oracle_cpu, q4_case):
     """playground.swift:16-41: bucketMulQ4 vs basicMul cos-sim (the reference prints a tick above 0.99 on real
     weights at its default effort; on i.i.d. Gaussian weights sign+mean quantisation is coarser)."""

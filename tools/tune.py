@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--efforts", default="0.25,1.0")
     ap.add_argument("--mats", type=int, default=16)
     ap.add_argument("--split", type=int, default=0)
+    ap.add_argument("--q4", type=int, default=0)
     ap.add_argument("--streams", default="1", help="comma list: numbers of concurrent streams/contexts to try")
     ap.add_argument("--configs", default="16,1,0;16,1,24;16,1,32;16,1,64;16,2,0;16,2,32;8,1,0;8,1,48;8,1,96;8,2,0;8,2,48;8,4,0;8,4,32;4,1,0;4,2,0;4,4,0")
     args = ap.parse_args()
@@ -31,7 +32,8 @@ def main():
     from bench import make_weights, mul_kernel_bytes
     dev = torch.device("cuda", 0)
     g = ea.gpu(0)
-    ews = make_weights(ea, args.mats, inDim, outDim, 1234, dev, keep_core=False)
+    ews = make_weights(ea, args.mats, inDim, outDim, 1234, dev, keep_core=False, q4=bool(args.q4))
+    mulfn = ea.bucketMulQ4 if args.q4 else ea.bucketMul
     gen = torch.Generator(device=dev)
     gen.manual_seed(42)
     v = torch.randn(inDim, generator=gen, device=dev)
@@ -45,7 +47,7 @@ def main():
                 g.set_split_cutoff(bool(args.split))
                 g.enable_kernel_timing(2)
                 for ew, o in zip(ews, outs):
-                    ea.bucketMul(v, ew, None, o, effort)
+                    mulfn(v, ew, None, o, effort)
                 g.eval()
                 D = g.last_dispatch_count()
                 over = {}
@@ -62,7 +64,7 @@ def main():
                             st.wait_stream(s0)
                         for i, (ew, o) in enumerate(zip(ews, outs)):
                             with torch.cuda.stream(sts[i % K]):
-                                ea.bucketMul(v, ew, None, o, effort, gpu=ctxs[i % K])
+                                mulfn(v, ew, None, o, effort, gpu=ctxs[i % K])
                         for st in sts:
                             s0.wait_stream(st)
                     for _ in range(5):
@@ -82,7 +84,7 @@ def main():
                                 st.wait_stream(s0)
                             for i, (ew, o) in enumerate(zip(ews, outs)):
                                 with torch.cuda.stream(sts[i % K]):
-                                    ea.bucketMul(v, ew, None, o, effort, gpu=ctxs[i % K])
+                                    mulfn(v, ew, None, o, effort, gpu=ctxs[i % K])
                             for st in sts:
                                 s0.wait_stream(st)
                         for _ in range(5):
@@ -97,7 +99,7 @@ def main():
                 gr = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(gr):
                     for ew, o in zip(ews, outs):
-                        ea.bucketMul(v, ew, None, o, effort)
+                        mulfn(v, ew, None, o, effort)
                 g._bind_stream()
                 for _ in range(5):
                     gr.replay()
@@ -114,7 +116,7 @@ def main():
                 torch.cuda._sleep(10_000_000)
                 for _ in range(4):
                     for ew, o in zip(ews, outs):
-                        ea.bucketMul(v, ew, None, o, effort)
+                        mulfn(v, ew, None, o, effort)
                 ev = g.kernel_timing()
                 kb = mul_kernel_bytes(D, inDim, outDim)
                 row = {"shape": args.shape, "effort": effort, "W": W, "E": E, "S": S, "D": D, "call_us": round(t * 1e6, 2),
