@@ -45,6 +45,12 @@ _SIGS = {
     "effort_weights_free": (None, [_P]),
     "effort_bucketmul": (C.c_int, [_P, _P, _P, _P, _P, C.c_double]),
     "effort_bucketmul_q4": (C.c_int, [_P, _P, _P, _P, _P, C.c_double]),
+    "effort_bucketmul_group": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P]),
+    "effort_bucketmul_q4_group": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P]),
+    "effort_group_dispatch_count": (C.c_int, [_P, C.c_int, C.POINTER(C.c_uint32)]),
+    "effort_group_cutoff": (C.c_int, [_P, C.c_int, C.POINTER(C.c_float)]),
+    "effort_debug_occupancy": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "effort_set_persistent": (C.c_int, [_P, C.c_int]),
     "effort_dense_gemv": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int]),
     "effort_last_dispatch_count": (C.c_int, [_P, C.POINTER(C.c_uint32)]),
     "effort_last_cutoff": (C.c_int, [_P, C.POINTER(C.c_float)]),

@@ -49,6 +49,32 @@ def bucketMulQ4(v: torch.Tensor, by: ExpertWeights, expNo: torch.Tensor | None, 
     (BucketMulQ4.shared() if gpu is None else BucketMulQ4(gpu.device, gpu)).fullMul(v, by, expNo, out, effort)
 
 
+def bucketMulGroup(calls, gpu=None):
+    """One launch for up to 8 independent multiplies: ``calls`` = [(v, by, expNo, out, effort), ...], all FP16 or all
+    Q4 bundles.  Same results as calling bucketMul / bucketMulQ4 on each; the group is how independent projections of
+    the decode loop (Wq|Wk|Wv, W1|W3 -- runNetwork.swift:132-134,178-182) keep the whole chip busy."""
+    calls = list(calls)
+    if not 1 <= len(calls) <= 8:
+        raise ValueError("a group holds 1..8 calls")
+    q4 = calls[0][1].q4
+    cls = BucketMulQ4 if q4 else BucketMul
+    bm = cls.shared() if gpu is None else cls(gpu.device, gpu)
+    for v, ew, expNo, out, _ in calls:
+        bm._validate(v, ew, expNo, out)
+    n = len(calls)
+    P = C.c_void_p * n
+    addr = lambda x: None if x is None else (x.data_ptr() if isinstance(x, torch.Tensor) else (x.value if hasattr(x, "value") else int(x)))
+    ws = P(*[addr(c[1].handle) for c in calls])
+    vs = P(*[addr(c[0]) for c in calls])
+    es = P(*[addr(c[2]) for c in calls])
+    outs = P(*[addr(c[3]) for c in calls])
+    eff = (C.c_double * n)(*[float(c[4]) for c in calls])
+    g = bm.gpu
+    g._bind_stream()
+    fn = _lib.lib().effort_bucketmul_q4_group if q4 else _lib.lib().effort_bucketmul_group
+    g.check(fn(g.ctx, n, ws, vs, es, outs, eff), "bucketMulGroup")
+
+
 def basicMul(v: torch.Tensor, by: torch.Tensor, out: torch.Tensor, gpu=None):
     """Dense f16 GEMV, ``by`` = core matrix [outDim, inDim]; asserts of helpers/mps.swift:15-18."""
     assert by.shape[0] == out.numel() and by.shape[1] == v.numel() and by.shape[1] % 16 == 0

@@ -30,7 +30,10 @@ struct effort_ctx {
     int* d_status = nullptr;
     uint32_t* d_counters = nullptr;   // per-tile arrival tickets (zero between calls)
     uint32_t* d_sliceCounts = nullptr;
-    uint32_t lastSlices = 0;
+    uint32_t* d_queue = nullptr;      // item queues of persistent launches
+    int persistent = -1;              // workgroups per CU of group launches: -1 heuristic, 0 plain grid, R > 0 persistent
+    // where each call of the last (group) launch keeps its per-slice counts; slices == 0: dispatch.size is d_count
+    uint32_t lastCalls = 1, lastSliceOff[effort::kMaxGroup] = {0}, lastSlices[effort::kMaxGroup] = {0};
     static constexpr uint32_t kMaxTiles = 1024, kMaxSlices = 4096;
     unsigned long long* d_tstamp = nullptr;   // device-clock stamps of the multiply kernel (timing mode)
     double wallClockKHz = 100000.0;
@@ -54,6 +57,7 @@ struct effort_w {
     const void* stats = nullptr;
     const uint16_t* probes = nullptr;
     uint32_t inDim = 0, outDim = 0, rowsPerIn = 0, numExperts = 1, cols = 0;
+    float* rankBound = nullptr;       // [numExperts] fixed-point bound of the multiply (see launch_rank_bound)
     // Q4 outliers
     uint64_t nOutliers = 0;
     uint32_t* olRowPtr = nullptr;
@@ -86,19 +90,20 @@ extern "C" effort_ctx* effort_create(int device, void* stream) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->numCU = prop.multiProcessorCount;
     c->slabBytes = (size_t)64 << 20;
-    bool ok = hipMalloc(&c->d_cutoff, 16) == hipSuccess && hipMalloc(&c->d_count, 16) == hipSuccess &&
+    bool ok = hipMalloc(&c->d_cutoff, 64) == hipSuccess && hipMalloc(&c->d_count, 16) == hipSuccess &&
               hipMalloc(&c->d_slabs, c->slabBytes) == hipSuccess && hipMalloc(&c->d_blockScratch, 4096 * 4) == hipSuccess &&
               hipMalloc(&c->d_cos, 16) == hipSuccess && hipMalloc(&c->d_status, 16) == hipSuccess &&
-              hipMalloc(&c->d_tstamp, 256) == hipSuccess && hipMalloc(&c->d_counters, effort_ctx::kMaxTiles * 4) == hipSuccess &&
-              hipMalloc(&c->d_sliceCounts, effort_ctx::kMaxSlices * 4) == hipSuccess;
+              hipMalloc(&c->d_tstamp, 4096) == hipSuccess && hipMalloc(&c->d_counters, effort_ctx::kMaxTiles * 4) == hipSuccess &&
+              hipMalloc(&c->d_sliceCounts, effort_ctx::kMaxSlices * 4) == hipSuccess && hipMalloc(&c->d_queue, 9 * 16 * 4) == hipSuccess;
     if (!ok) { effort_destroy(c); return nullptr; }
     int khz = 0;
     if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0) c->wallClockKHz = khz;
-    hipMemset(c->d_tstamp, 0, 256);
+    hipMemset(c->d_tstamp, 0, 4096);
     hipMemset(c->d_counters, 0, effort_ctx::kMaxTiles * 4);
     hipMemset(c->d_sliceCounts, 0, effort_ctx::kMaxSlices * 4);
+    hipMemset(c->d_queue, 0, 9 * 16 * 4);
     { unsigned long long init[2] = {~0ull, 0ull}; hipMemcpy(c->d_tstamp, init, 16, hipMemcpyHostToDevice); }
-    hipMemset(c->d_cutoff, 0, 16);
+    hipMemset(c->d_cutoff, 0, 64);
     hipMemset(c->d_count, 0, 16);
     hipMemset(c->d_status, 0, 16);
     return c;
@@ -111,7 +116,7 @@ extern "C" void effort_destroy(effort_ctx* c) {
     if (c->blas) rocblas_destroy_handle(c->blas);
     if (c->ev) { for (int i = 0; i < effort_ctx::kMaxSamples * 4; i++) hipEventDestroy(c->ev[i]); delete[] c->ev; }
     hipFree(c->d_cutoff); hipFree(c->d_count); hipFree(c->d_slabs); hipFree(c->d_blockScratch);
-    hipFree(c->d_vhalf); hipFree(c->d_cos); hipFree(c->d_convVals); hipFree(c->d_status); hipFree(c->d_tstamp); hipFree(c->d_counters); hipFree(c->d_sliceCounts);
+    hipFree(c->d_vhalf); hipFree(c->d_cos); hipFree(c->d_convVals); hipFree(c->d_status); hipFree(c->d_tstamp); hipFree(c->d_counters); hipFree(c->d_sliceCounts); hipFree(c->d_queue);
     delete c;
 }
 
@@ -135,6 +140,19 @@ static int check_shape(uint32_t inDim, uint32_t outDim) {
     return EFFORT_OK;
 }
 
+// The multiply accumulates in fixed point; its scale needs a bound on the weights: per expert, the sum over ranks
+// of the largest |w| of that rank (Q4: of the largest row mean).  One pass over the buckets at registration.
+static int register_bound(effort_ctx* c, effort_w* w) {
+    hipSetDevice(c->device);
+    const size_t rows = (size_t)w->numExperts * w->rowsPerIn * w->inDim;
+    float* scratch = nullptr;
+    bool ok = hipMalloc(&w->rankBound, (size_t)w->numExperts * 4) == hipSuccess && hipMalloc(&scratch, rows * 4) == hipSuccess;
+    if (ok) ok = launch_rank_bound(w->fmt, w->buckets, w->stats, w->numExperts, w->rowsPerIn, w->inDim, w->cols, scratch, w->rankBound, c->stream) == hipSuccess;
+    if (ok) ok = hipStreamSynchronize(c->stream) == hipSuccess;
+    hipFree(scratch);
+    return ok ? EFFORT_OK : fail(c, EFFORT_ERR_HIP, "weight registration: rank bound");
+}
+
 extern "C" effort_w* effort_weights_fp16(effort_ctx* c, const void* buckets, const void* stats, const void* probes,
                                          int inDim, int outDim, int percentLoad, int numExperts) {
     if (!c || !buckets || !stats || !probes) { fail(c, EFFORT_ERR_ARG, "effort_weights_fp16: null argument"); return nullptr; }
@@ -146,6 +164,7 @@ extern "C" effort_w* effort_weights_fp16(effort_ctx* c, const void* buckets, con
     w->ctx = c; w->fmt = kFp16;
     w->buckets = static_cast<const uint16_t*>(buckets); w->stats = stats; w->probes = static_cast<const uint16_t*>(probes);
     w->inDim = inDim; w->outDim = outDim; w->rowsPerIn = percentLoad; w->numExperts = numExperts; w->cols = outDim / 16;
+    if (register_bound(c, w) != EFFORT_OK) { effort_weights_free(w); return nullptr; }
     return w;
 }
 
@@ -160,6 +179,7 @@ extern "C" effort_w* effort_weights_q4(effort_ctx* c, const void* buckets, const
     w->ctx = c; w->fmt = kQ4;
     w->buckets = static_cast<const uint16_t*>(buckets); w->stats = stats; w->probes = static_cast<const uint16_t*>(probes);
     w->inDim = inDim; w->outDim = outDim; w->rowsPerIn = 8; w->numExperts = numExperts; w->cols = outDim / 32;
+    if (register_bound(c, w) != EFFORT_OK) { effort_weights_free(w); return nullptr; }
     if (outliers && nOutliers > 0) {
         hipSetDevice(c->device);
         uint32_t* cursor = nullptr;
@@ -177,7 +197,7 @@ extern "C" effort_w* effort_weights_q4(effort_ctx* c, const void* buckets, const
 
 extern "C" void effort_weights_free(effort_w* w) {
     if (!w) return;
-    hipFree(w->olRowPtr); hipFree(w->olInIdx); hipFree(w->olValue);
+    hipFree(w->olRowPtr); hipFree(w->olInIdx); hipFree(w->olValue); hipFree(w->rankBound);
     delete w;
 }
 
@@ -200,28 +220,25 @@ static int choose_geom(const effort_ctx* c, const effort_w* w, MulGeom* g, int* 
     g->tiles = (w->cols + 64 * E - 1) / (64 * E);
     g->tileFloats = nacc * E * 64;
     const size_t ldsMax = 160 * 1024;
-    const size_t accBytes = (size_t)W * g->tileFloats * 4;
-    if (accBytes + 4096 > ldsMax) return EFFORT_ERR_ARG;
     uint32_t S;
     if (c->tuneS) S = (c->tuneS + 7) / 8 * 8;
     else {
         // Measured on MI355X (tools/tune.py, 4096x4096 .. 4096x11008, 10-100 % effort): the call is dominated by
         // per-workgroup fixed work (cutoff, selection, tile reduction, slab hand-off), so FEWER, fatter workgroups
         // win even when they leave CUs idle; 32 row slices is the sweet spot, capped by one round of workgroups.
-        const uint32_t perCU = accBytes * 2 + 16384 <= ldsMax ? 2u : 1u;
-        const uint32_t cap = (c->numCU * perCU) / g->tiles / 8 * 8;
+        const uint32_t cap = (c->numCU * 2u) / g->tiles / 8 * 8;
         S = cap < 32u ? cap : 32u;
     }
     if (S > w->inDim) S = w->inDim / 8 * 8;
     if (S < 8) S = 8;
+    const uint32_t maxCand = bucket_mul_max_candidates(W);
     for (;;) {
         g->sliceRows = (w->inDim + S - 1) / S;
         g->slices = (w->inDim + g->sliceRows - 1) / g->sliceRows;
-        const size_t lds = bucket_mul_lds_bytes(w->fmt, W, E, g->sliceRows, g->rowsPerIn);
         g->sliceLog2 = 0; while ((1u << g->sliceLog2) < g->sliceRows) g->sliceLog2++;
-        const uint32_t slots = w->fmt == kFp16 ? (g->rowsPerIn << g->sliceLog2) : g->sliceRows * 8u;
-        const bool fits = lds <= ldsMax && g->sliceRows <= (w->fmt == kFp16 ? 4096u : 8192u) &&
-                          slots <= bucket_mul_max_candidates(W);
+        g->slots = w->fmt == kFp16 ? (g->rowsPerIn << g->sliceLog2) : g->sliceRows * 8u;
+        const size_t lds = bucket_mul_lds_bytes(w->fmt, W, E, g->sliceRows, g->slots);
+        const bool fits = lds <= ldsMax && g->sliceRows <= (w->fmt == kFp16 ? 4096u : 8192u) && g->slots <= maxCand;
         const size_t slab = (size_t)g->slices * g->tiles * g->tileFloats * 4;
         if (fits && slab <= c->slabBytes) break;
         if (!fits) { S += 8; if (S > w->inDim + 8) return EFFORT_ERR_SHAPE; }
@@ -239,45 +256,74 @@ static int ensure_timing(effort_ctx* c) {
     return EFFORT_OK;
 }
 
-static int do_bucketmul(effort_ctx* c, const effort_w* w, Format fmt, const float* v, const uint32_t* expNo, float* out, double effort) {
-    if (!c || !w || !v || !out) return fail(c, EFFORT_ERR_ARG, "bucketmul: null argument");
-    if (w->fmt != fmt) return fail(c, EFFORT_ERR_KIND, "bucketmul: weight handle of the wrong kind");
-    if (!(effort >= 0.0 && effort <= 1.0)) return fail(c, EFFORT_ERR_EFFORT, "bucketmul: effort outside [0,1]");
-    MulGeom g; int W, E;
-    int rc = choose_geom(c, w, &g, &W, &E);
-    if (rc != EFFORT_OK) return fail(c, rc, "bucketmul: no launch geometry for this shape/tuning");
-    const uint32_t q = (uint32_t)(int)((double)(kProbes - 1) * (1.0 - effort));      // bucketMul.swift:39
+// One launch for a group of independent calls (a lone call is a group of one).
+static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws, const float* const* vs,
+                    const uint32_t* const* expNos, float* const* outs, const double* efforts) {
+    if (!c || !ws || !vs || !outs || !efforts) return fail(c, EFFORT_ERR_ARG, "bucketmul: null argument");
+    if (n < 1 || n > kMaxGroup) return fail(c, EFFORT_ERR_ARG, "bucketmul: group size outside 1..8");
+    static const uint32_t ablate = getenv("EFFORT_ABLATE") ? (uint32_t)atoi(getenv("EFFORT_ABLATE")) : 0u;   // profiling only
+    GroupArgs ga;
+    memset(&ga, 0, sizeof(ga));
+    ga.count = (uint32_t)n;
+    ga.groupDone = c->d_counters + effort_ctx::kMaxTiles - 1;
+    int W = 0, E = 0;
+    size_t slabOff = 0; uint32_t tileOff = 0, sliceOff = 0, wg = 0;
+    for (int i = 0; i < n; i++) {
+        const effort_w* w = ws[i];
+        if (!w || !vs[i] || !outs[i]) return fail(c, EFFORT_ERR_ARG, "bucketmul: null argument");
+        if (w->fmt != fmt) return fail(c, EFFORT_ERR_KIND, "bucketmul: weight handle of the wrong kind");
+        if (!(efforts[i] >= 0.0 && efforts[i] <= 1.0)) return fail(c, EFFORT_ERR_EFFORT, "bucketmul: effort outside [0,1]");
+        MulArgs& a = ga.call[i];
+        int Wi, Ei;
+        int rc = choose_geom(c, w, &a.g, &Wi, &Ei);
+        if (rc != EFFORT_OK) return fail(c, rc, "bucketmul: no launch geometry for this shape/tuning");
+        if (i == 0) { W = Wi; E = Ei; }
+        const MulGeom& g = a.g;
+        const size_t slab = (size_t)g.slices * g.tiles * g.tileFloats * 4;
+        if (tileOff + g.tiles + 1 > effort_ctx::kMaxTiles || sliceOff + g.slices > effort_ctx::kMaxSlices || slabOff + slab > c->slabBytes)
+            return fail(c, EFFORT_ERR_SHAPE, "bucketmul: group exceeds the context scratch");
+        a.buckets = w->buckets; a.stats = w->stats; a.rankBound = w->rankBound; a.probes = w->probes; a.v = vs[i]; a.expNo = expNos ? expNos[i] : nullptr; a.out = outs[i];
+        a.slabs = reinterpret_cast<float*>(reinterpret_cast<char*>(c->d_slabs) + slabOff);
+        a.counters = c->d_counters + tileOff; a.sliceCounts = c->d_sliceCounts + sliceOff; a.cutoffOut = c->d_cutoff + i;
+        a.cutoffIn = c->splitCutoff ? c->d_cutoff + i : nullptr;
+        a.tstamp = c->clock ? c->d_tstamp : nullptr;
+        a.ol = OutlierIndex{fmt == kQ4 ? w->olRowPtr : nullptr, w->olInIdx, w->olValue};
+        a.q = (uint32_t)(int)((double)(kProbes - 1) * (1.0 - efforts[i]));            // bucketMul.swift:39
+        a.ablate = ablate;
+        wg += g.tiles * ((g.slices + 7) / 8 * 8);
+        ga.wgEnd[i] = wg;
+        ga.totalTiles += g.tiles;
+        c->lastSliceOff[i] = sliceOff; c->lastSlices[i] = g.slices;                   // dispatch.size = sum of the per-slice counts
+        slabOff += (slab + 255) / 256 * 256; tileOff += g.tiles; sliceOff += g.slices;
+    }
+    c->lastCalls = (uint32_t)n;
+    // grid: persistent workgroups once the items outnumber what the chip holds at R per CU
+    ga.numCU = (uint32_t)c->numCU; ga.queue = c->d_queue;
+    const uint32_t R = c->persistent < 0 ? 2u : (uint32_t)c->persistent;
+    ga.persistent = (R && wg > ga.numCU * R) ? R : 0u;
     const bool tm = c->timing && c->nSamples < effort_ctx::kMaxSamples;
     hipEvent_t* ev = tm ? c->ev + 4 * c->nSamples : nullptr;
-    if (g.tiles + 1 > effort_ctx::kMaxTiles || g.slices > effort_ctx::kMaxSlices) return fail(c, EFFORT_ERR_SHAPE, "bucketmul: geometry exceeds scratch");
-
-    MulArgs a;
-    a.buckets = w->buckets; a.stats = w->stats; a.probes = w->probes; a.v = v; a.expNo = expNo; a.out = out;
-    a.slabs = c->d_slabs; a.counters = c->d_counters; a.sliceCounts = c->d_sliceCounts; a.cutoffOut = c->d_cutoff;
-    a.tstamp = c->clock ? c->d_tstamp : nullptr;
-    a.ol = OutlierIndex{fmt == kQ4 ? w->olRowPtr : nullptr, w->olInIdx, w->olValue};
-    a.q = q; a.g = g;
-    a.cutoffIn = nullptr;
-    static const uint32_t ablate = getenv("EFFORT_ABLATE") ? (uint32_t)atoi(getenv("EFFORT_ABLATE")) : 0u;   // profiling only
-    a.ablate = ablate;
     if (tm) HIP_TRY(c, hipEventRecord(ev[0], c->stream));
-    if (c->splitCutoff) {
-        if (!(ablate & 1u))
-        HIP_TRY(c, launch_find_cutoff(v, w->probes, expNo, q, c->d_cutoff, c->d_count, nullptr, c->stream));
-        a.cutoffIn = c->d_cutoff;
-    }
-    HIP_TRY(c, launch_bucket_mul(fmt, W, E, a, c->stream));
-    if (fmt == kQ4 && w->olRowPtr) HIP_TRY(c, launch_q4_outliers(a.ol, v, out, w->outDim, c->stream));
+    if (c->splitCutoff && !(ablate & 1u)) HIP_TRY(c, launch_find_cutoff_group(ga, c->stream));
+    HIP_TRY(c, launch_bucket_mul(fmt, W, E, ga, c->stream));
+    if (fmt == kQ4) HIP_TRY(c, launch_q4_outliers(ga, c->stream));
     if (tm) { HIP_TRY(c, hipEventRecord(ev[1], c->stream)); c->nSamples++; }
-    c->lastSlices = g.slices;                      // dispatch.size = sum of the per-slice counts
     return EFFORT_OK;
 }
 
 extern "C" int effort_bucketmul(effort_ctx* c, const effort_w* w, const float* v, const uint32_t* expNo, float* out, double effort) {
-    return do_bucketmul(c, w, kFp16, v, expNo, out, effort);
+    return do_group(c, kFp16, 1, &w, &v, &expNo, &out, &effort);
 }
 extern "C" int effort_bucketmul_q4(effort_ctx* c, const effort_w* w, const float* v, const uint32_t* expNo, float* out, double effort) {
-    return do_bucketmul(c, w, kQ4, v, expNo, out, effort);
+    return do_group(c, kQ4, 1, &w, &v, &expNo, &out, &effort);
+}
+extern "C" int effort_bucketmul_group(effort_ctx* c, int n, const effort_w* const* ws, const float* const* vs,
+                                      const uint32_t* const* expNos, float* const* outs, const double* efforts) {
+    return do_group(c, kFp16, n, ws, vs, expNos, outs, efforts);
+}
+extern "C" int effort_bucketmul_q4_group(effort_ctx* c, int n, const effort_w* const* ws, const float* const* vs,
+                                         const uint32_t* const* expNos, float* const* outs, const double* efforts) {
+    return do_group(c, kQ4, n, ws, vs, expNos, outs, efforts);
 }
 
 extern "C" int effort_calc_dispatch(effort_ctx* c, const effort_w* w, const float* v, const uint32_t* expNo, double effort,
@@ -290,31 +336,33 @@ extern "C" int effort_calc_dispatch(effort_ctx* c, const effort_w* w, const floa
     const uint32_t q = (uint32_t)(int)((double)(kProbes - 1) * (1.0 - effort));
     HIP_TRY(c, launch_find_cutoff(v, w->probes, expNo, q, c->d_cutoff, c->d_count, nullptr, c->stream));
     HIP_TRY(c, launch_calc_dispatch(w->fmt, w->stats, v, expNo, c->d_cutoff, g, dispatch, count, c->d_count, c->d_blockScratch, c->stream));
-    c->lastSlices = 0;                             // dispatch.size is the scalar written by the scan kernel
+    c->lastCalls = 1; c->lastSlices[0] = 0;        // dispatch.size is the scalar written by the scan kernel
     return EFFORT_OK;
 }
 
-extern "C" int effort_last_dispatch_count(effort_ctx* c, uint32_t* host_out) {
-    if (!c || !host_out) return EFFORT_ERR_ARG;
-    if (c->lastSlices == 0) {
+extern "C" int effort_group_dispatch_count(effort_ctx* c, int idx, uint32_t* host_out) {
+    if (!c || !host_out || idx < 0 || (uint32_t)idx >= c->lastCalls) return EFFORT_ERR_ARG;
+    if (c->lastSlices[idx] == 0) {
         HIP_TRY(c, hipMemcpyAsync(host_out, c->d_count, 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         return EFFORT_OK;
     }
     static thread_local uint32_t h[effort_ctx::kMaxSlices];
-    HIP_TRY(c, hipMemcpyAsync(h, c->d_sliceCounts, (size_t)c->lastSlices * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(h, c->d_sliceCounts + c->lastSliceOff[idx], (size_t)c->lastSlices[idx] * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     uint32_t n = 0;
-    for (uint32_t i = 0; i < c->lastSlices; i++) n += h[i];
+    for (uint32_t i = 0; i < c->lastSlices[idx]; i++) n += h[i];
     *host_out = n;
     return EFFORT_OK;
 }
-extern "C" int effort_last_cutoff(effort_ctx* c, float* host_out) {
-    if (!c || !host_out) return EFFORT_ERR_ARG;
-    HIP_TRY(c, hipMemcpyAsync(host_out, c->d_cutoff, 4, hipMemcpyDeviceToHost, c->stream));
+extern "C" int effort_group_cutoff(effort_ctx* c, int idx, float* host_out) {
+    if (!c || !host_out || idx < 0 || (uint32_t)idx >= c->lastCalls) return EFFORT_ERR_ARG;
+    HIP_TRY(c, hipMemcpyAsync(host_out, c->d_cutoff + idx, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return EFFORT_OK;
 }
+extern "C" int effort_last_dispatch_count(effort_ctx* c, uint32_t* host_out) { return effort_group_dispatch_count(c, 0, host_out); }
+extern "C" int effort_last_cutoff(effort_ctx* c, float* host_out) { return effort_group_cutoff(c, 0, host_out); }
 
 // ---- dense baseline ------------------------------------------------------------------------------
 extern "C" int effort_dense_gemv(effort_ctx* c, const void* W, const float* v, float* out, int inDim, int outDim) {
@@ -377,6 +425,17 @@ extern "C" int effort_set_tuning(effort_ctx* c, int W, int E, int S) {
     return EFFORT_OK;
 }
 
+extern "C" int effort_debug_occupancy(effort_ctx* c, int q4, int W, int E, int ldsBytes) {
+    if (!c || !supported(W, E)) return EFFORT_ERR_ARG;
+    return bucket_mul_occupancy(q4 ? kQ4 : kFp16, W, E, (size_t)ldsBytes);
+}
+
+extern "C" int effort_set_persistent(effort_ctx* c, int wgPerCU) {
+    if (!c || wgPerCU < -1 || wgPerCU > 8) return EFFORT_ERR_ARG;
+    c->persistent = wgPerCU;
+    return EFFORT_OK;
+}
+
 extern "C" int effort_set_split_cutoff(effort_ctx* c, int split) {
     if (!c) return EFFORT_ERR_ARG;
     c->splitCutoff = split != 0;
@@ -389,15 +448,18 @@ extern "C" int effort_enable_kernel_timing(effort_ctx* c, int enable) {
     c->timing = enable == 1;      // 1: events + device clock, 2: device clock only (graph-capture safe)
     c->clock = enable != 0;
     c->nSamples = 0;
-    HIP_TRY(c, hipMemsetAsync(c->d_tstamp, 0, 256, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_tstamp, 0, 4096, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_tstamp, 0xFF, 8, c->stream));
     return EFFORT_OK;
 }
 
-extern "C" int effort_debug_stamps(effort_ctx* c, unsigned long long* host16) {
-    if (!c || !host16) return EFFORT_ERR_ARG;
-    HIP_TRY(c, hipMemcpyAsync(host16, c->d_tstamp + 8, 192, hipMemcpyDeviceToHost, c->stream));
+extern "C" int effort_debug_stamps(effort_ctx* c, unsigned long long* host32) {
+    if (!c || !host32) return EFFORT_ERR_ARG;
+    HIP_TRY(c, hipMemcpyAsync(host32, c->d_tstamp + 8, 192, hipMemcpyDeviceToHost, c->stream));
+    unsigned long long lines[32 * 8];
+    HIP_TRY(c, hipMemcpyAsync(lines, c->d_tstamp + 64, sizeof(lines), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 8; i++) { host32[24 + i] = 0; for (int l = 0; l < 32; l++) host32[24 + i] += lines[l * 8 + i]; }   // all-workgroup phase sums
     return EFFORT_OK;
 }
 

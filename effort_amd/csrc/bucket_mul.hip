@@ -35,12 +35,14 @@
 //      takes a ticket on its tile's arrival counter, and the LAST workgroup of each tile sums the S slabs in
 //      slice order (and, for Q4, adds that output's outliers in table order) and writes out[].  The result does
 //      not depend on arrival order: deterministic end to end.  (Q4 outliers: q4_outliers_kernel, launched next.)
+#include <type_traits>
+
 #include "cutoff_device.h"
 
 namespace effort {
 
 constexpr int kBatch = 16;   // bucket rows per batch; two batches in flight per wave
-constexpr int kPre = 4;      // candidate rows per thread whose stats are preloaded into registers
+constexpr int kRounds = 16;  // selection rounds of NT candidate slots a workgroup can run: slots per slice <= kRounds * NT
 
 // Ablation builds for profiling (-DEFFORT_ABLATE_NOSCATTER=1 / -DEFFORT_ABLATE_NOLOAD=1); never shipped.
 #ifndef EFFORT_ABLATE_NOSCATTER
@@ -55,6 +57,10 @@ constexpr int kSc1 = 16;     // buffer aux bit: sc1 = write-through store / L1-b
 template <int FMT> struct Fmt;
 template <> struct Fmt<kFp16> { static constexpr int kAcc = 16; };
 template <> struct Fmt<kQ4> { static constexpr int kAcc = 32; };
+
+template <int FMT> struct MeanT;                       // what the staged row means are kept as in LDS
+template <> struct MeanT<kFp16> { typedef uint16_t type; };    // f16 bits (stats lane .w)
+template <> struct MeanT<kQ4> { typedef float type; };        // f32 (stats lane .y)
 
 // One lane's piece of a bucket row: E u16 words.
 template <int E> struct Piece;
@@ -89,162 +95,206 @@ template <> struct Piece<8> {
 
 __host__ __device__ inline uint32_t align_up(uint32_t x, uint32_t a) { return (x + a - 1) / a * a; }
 
-// LDS carve (bytes): [W][tileFloats] f32 | vblk[B] f32 | misc 768 B | list[rows*B] u16 | dlist (Q4) f32
+// LDS carve (bytes): { acc[tileFloats] i32 | list[slots] u16 }  (the cutoff's lookup table borrows this first region:
+// it is dead before the tile is zeroed and the list written)  | means[slots] f16 / f32 | vblk[B] f32 | misc 2 KB
 template <int FMT, int E, int W>
-__host__ __device__ inline uint32_t lds_layout(uint32_t B, uint32_t rowsPerIn, uint32_t* offV, uint32_t* offC,
-                                               uint32_t* offL, uint32_t* offD) {
-    uint32_t o = (uint32_t)W * Fmt<FMT>::kAcc * E * 64 * 4;
+__host__ __device__ inline uint32_t lds_layout(uint32_t B, uint32_t slots, uint32_t* offV, uint32_t* offC,
+                                               uint32_t* offL, uint32_t* offM) {
+    uint32_t o = (uint32_t)Fmt<FMT>::kAcc * E * 64 * 4;
+    *offL = o; o += align_up(slots * 2, 16);
+    const uint32_t tbl = cutoff_table_bytes(64 * W);
+    if (o < tbl) o = tbl;
+    *offM = o; o += align_up(slots * (uint32_t)sizeof(typename MeanT<FMT>::type), 16);
     *offV = o; o += align_up(B * 4, 16);
-    *offC = o; o += 768;                                   // [0..255] cutoff scratch, [256..511] wave counts [kPre][16], [512] flags
-    *offL = o; o += align_up(rowsPerIn * B * 2, 16);
-    *offD = o; if (FMT == kQ4) o += align_up(rowsPerIn * B * 4, 16);
+    *offC = o; o += 2048;           // [0..255] cutoff scratch, [256..1279] ballot counts [kRounds][W], [1280] flags, [1344..1407] wave bounds
     return o;
 }
 
+// One work item = one (call, tile, slice) of the group: stage, select, stream, hand the partial tile over.
+// `item` numbers the items the way a plain grid would number its blocks (item % 8 = the XCD it should run on).
 template <int FMT, int E, int W>
-__global__ __launch_bounds__(64 * W) void bucket_mul_kernel(const MulArgs a) {
+__device__ __forceinline__ void mul_item(const GroupArgs& ga, const uint32_t item, char* smem, uint32_t& cachedCall, float& cachedCutoff) {
     constexpr int NACC = Fmt<FMT>::kAcc;
     constexpr int TILE_F = NACC * E * 64;
     constexpr int NT = 64 * W;
     constexpr int VPT = 4096 / NT;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
 
+    // which call of the group this item belongs to (item ranges are multiples of 8, so item%8 is still the XCD)
+    uint32_t ci = 0;
+#pragma unroll
+    for (int i = 0; i < kMaxGroup - 1; i++) if ((uint32_t)(i + 1) < ga.count && item >= ga.wgEnd[i]) ci = i + 1;
+    ci = __builtin_amdgcn_readfirstlane(ci);
+    const MulArgs& a = ga.call[ci];
     const MulGeom& g = a.g;
-    // XCD-aware id -> (tile, slice): the dispatcher places block b on XCD b%8 (speed only).
-    const uint32_t b = blockIdx.x, xcd = b & 7u, k = b >> 3;
+    // XCD-aware id -> (tile, slice): all tiles of a slice run on one XCD (speed only).
+    const uint32_t b = item - (ci ? ga.wgEnd[ci - 1] : 0u), xcd = b & 7u, k = b >> 3;
     const uint32_t s = (k / g.tiles) * 8u + xcd, t = k % g.tiles;
     if (s >= g.slices) return;
 
-    const int tid = threadIdx.x, lane = tid & 63;
-    if (a.tstamp && tid == 0) { const unsigned long long now = wall_clock64(); atomicMin(&a.tstamp[0], now); atomicMax(&a.tstamp[25], now); }
-    const bool stamp = a.tstamp && blockIdx.x == 0 && tid == 0;      // phase stamps of workgroup 0 (profiling aid)
+    int tid0 = threadIdx.x;
+    asm volatile("" : "+v"(tid0));      // opaque per item: keeps the compiler from hoisting every tid-derived value out of the item loop (+50 VGPRs)
+    const int tid = tid0, lane = tid & 63;
+    const bool wstamp = a.tstamp && tid == 0;                        // every workgroup: phase durations summed into tstamp[32..]
+    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};
+    if (wstamp) ph[0] = wall_clock64();
+    const bool stamp = a.tstamp && item == 0 && tid == 0;            // phase stamps of item 0 (profiling aid)
     if (stamp) a.tstamp[16] = wall_clock64();
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t B = g.sliceRows;
-    uint32_t offV, offC, offL, offD;
-    lds_layout<FMT, E, W>(B, g.rowsPerIn, &offV, &offC, &offL, &offD);
-    float* acc = reinterpret_cast<float*>(smem);
+    uint32_t offV, offC, offL, offM;
+    lds_layout<FMT, E, W>(B, g.slots, &offV, &offC, &offL, &offM);
+    int* acc = reinterpret_cast<int*>(smem);                                 // ONE fixed-point tile shared by the W waves
     float* vblk = reinterpret_cast<float*>(smem + offV);
-    uint32_t* wcnt = reinterpret_cast<uint32_t*>(smem + offC + 256);         // [kPre][16]
-    uint32_t* flags = reinterpret_cast<uint32_t*>(smem + offC + 512);
+    uint32_t* wcnt = reinterpret_cast<uint32_t*>(smem + offC + 256);         // [kRounds][W]
+    uint32_t* flags = reinterpret_cast<uint32_t*>(smem + offC + 1280);
+    float* wbound = reinterpret_cast<float*>(smem + offC + 1344);            // [16] per-wave sums of |v_j| over the slice
     uint16_t* list = reinterpret_cast<uint16_t*>(smem + offL);
-    float* dlist = reinterpret_cast<float*>(smem + offD);
-    float* myacc = acc + wave * TILE_F + lane;
+    typename MeanT<FMT>::type* means = reinterpret_cast<typename MeanT<FMT>::type*>(smem + offM);
 
     const uint32_t j0 = s * B;
     const uint32_t nb = min(B, g.inDim - j0);
     const uint32_t e = a.expNo ? a.expNo[0] : 0u;
 
-    // ---- A. everything the selection needs, in one round trip --------------------------------
+    // ---- A. stage everything the selection needs in LDS, in one round trip ------------------------
+    // Candidate slot c of the slice, in ascending bucket-row order:
+    //   FP16 -> rank = c >> lg, jl = c & (2^lg - 1), 2^lg >= B   (rank-major rows, convert.metal:83-100; v index = row % inDim)
+    //   Q4   -> jl = c >> 3,  rank = c & 7                        (input-major rows, bucketMulQ4.metal:46)
+    // means[c] = the row mean the keep test reads (f16 bits for FP16, f32 for Q4); slots past the slice hold 0.
     float vj[VPT]; uint16_t prj[VPT];
     const uint16_t* pr = a.probes + (size_t)e * kProbes;
     const bool fused = a.cutoffIn == nullptr;                    // uniform
 #pragma unroll
     for (int i = 0; i < VPT; i++) { vj[i] = 0.0f; prj[i] = 0; }
-    if (fused) {
+    const bool needCut = fused && cachedCall != ci;              // uniform: a persistent workgroup evaluates a call's cutoff once
+    if (needCut) {
 #pragma unroll
         for (int i = 0; i < VPT; i++) { vj[i] = a.v[tid + NT * i]; prj[i] = pr[tid + NT * i]; }
     }
-    // candidate slot c = r*NT + tid, in ascending bucket-row order:
-    //   FP16 -> rank = c >> lg, jl = c & (2^lg - 1), 2^lg >= B  (rank-major rows, convert.metal:83-100; v index = row % inDim)
-    //   Q4   -> jl = c >> 3,  rank = c & 7                      (input-major rows, bucketMulQ4.metal:46)
     const uint32_t lg = g.sliceLog2;
     const uint32_t nSlots = FMT == kFp16 ? (g.rowsPerIn << lg) : (nb << 3);
-    float mean[kPre];
-    uint32_t codes[kPre];
+    const uint32_t rounds = (nSlots + NT - 1) / NT;              // <= kRounds (checked at launch)
+    {
+        // branch-free: every load is issued (slots past the slice read the slice's first row and are zeroed after),
+        // so the loads go out back to back and the whole staging costs one round trip
+        typename MeanT<FMT>::type tmp[kRounds];
+        const size_t rowBase = (size_t)e * g.expertRows;
+        const uint32_t rowsPerIn = g.rowsPerIn, inDim = g.inDim, mask = (1u << lg) - 1u;
+        const uint16_t* st16 = reinterpret_cast<const uint16_t*>(a.stats);
+        const float* st32 = reinterpret_cast<const float*>(a.stats);
 #pragma unroll
-    for (int r = 0; r < kPre; r++) {
-        const uint32_t c = r * NT + tid;
-        mean[r] = 0.0f; codes[r] = 0xFFFFFFFFu;                 // 0xFFFFFFFF: no candidate in this slot
-        if ((uint32_t)(r * NT) >= nSlots) continue;             // uniform: this round holds no slots at all
-        if (FMT == kFp16) {
-            const uint32_t rank = c >> lg, jl = c & ((1u << lg) - 1u);
-            if (rank < g.rowsPerIn && jl < nb) {
-                const size_t row = (size_t)e * g.expertRows + (size_t)rank * g.inDim + j0 + jl;
-                mean[r] = half_bits_to_float(reinterpret_cast<const uint16_t*>(a.stats)[row * 4 + 3]);
-                codes[r] = (rank << 12) | jl;
-            }
-        } else {
-            const uint32_t jl = c >> 3, rank = c & 7u;
-            if (jl < nb) {
-                const size_t row = (size_t)e * g.expertRows + (size_t)(j0 + jl) * 8u + rank;
-                mean[r] = reinterpret_cast<const float*>(a.stats)[row * 2 + 1];
-                codes[r] = (jl << 3) | rank;
+        for (int r = 0; r < kRounds; r++) {
+            const uint32_t c = r * NT + tid;
+            if (FMT == kFp16) {
+                const uint32_t rank = c >> lg, jl = c & mask;
+                const bool ok = rank < rowsPerIn && jl < nb;
+                const size_t row = rowBase + (ok ? (size_t)rank * inDim + j0 + jl : (size_t)j0);
+                tmp[r] = st16[row * 4 + 3];
+                tmp[r] = ok ? tmp[r] : (uint16_t)0;
+            } else {
+                const bool ok = c < nSlots;
+                tmp[r] = st32[(rowBase + (size_t)j0 * 8u + (ok ? c : 0u)) * 2 + 1];
+                tmp[r] = ok ? tmp[r] : 0.0f;
             }
         }
-    }
-    for (uint32_t jl = tid; jl < nb; jl += NT) vblk[jl] = a.v[j0 + jl];
-    if (stamp) a.tstamp[17] = wall_clock64();
-
-    // ---- B. cutoff (findCutoff32), redundantly per workgroup; its first barrier also publishes vblk.  Its
-    //         lookup table borrows the tail of the accumulator region, so the tiles are zeroed around it: the
-    //         waves that idle during the serial bisection zero theirs meanwhile, the rest right after. ---------
-    uint32_t* tbl = reinterpret_cast<uint32_t*>(acc + W * TILE_F) - NT * kCutoffBinsPerThread;
-    const bool tileUnderTable = (uint32_t)(wave + 1) * TILE_F > (uint32_t)W * TILE_F - NT * kCutoffBinsPerThread;
-    auto zero_tile = [&]() {
 #pragma unroll
-        for (int i = 0; i < NACC * E; i++) myacc[i * 64] = 0.0f;
-    };
+        for (int r = 0; r < kRounds; r++)
+            if ((uint32_t)(r * NT) + tid < nSlots) means[r * NT + tid] = tmp[r];
+    }
+    // stage the slice of v; its absolute sum bounds every partial sum of this workgroup (see the scale below)
+    float bound = 0.0f;
+    for (uint32_t jl = tid; jl < nb; jl += NT) { const float x = a.v[j0 + jl]; vblk[jl] = x; bound += fabsf(x); }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) bound += __shfl_xor(bound, off);
+    if (lane == 0) wbound[wave] = bound;
+    const float rankBound = a.rankBound[e];
+    if (stamp) a.tstamp[17] = wall_clock64();
+    if (wstamp) ph[1] = wall_clock64();
+
+    // ---- B. cutoff (findCutoff32), redundantly per workgroup; its first barrier also publishes means / vblk /
+    //         wbound.  Its lookup table borrows the accumulator + list region, which is initialised afterwards. ------
+    uint32_t* tbl = reinterpret_cast<uint32_t*>(smem);
     float cutoff;
-    if (fused) {
-        cutoff = block_find_cutoff<NT>(vj, prj, a.q, smem + offC, tbl,
-                                       [&]() { if (wave != 0 && !tileUnderTable) zero_tile(); },
-                                       stamp ? a.tstamp + 8 : nullptr);
-        if (wave == 0 || tileUnderTable) zero_tile();
-        if (blockIdx.x == 0 && tid == 0) a.cutoffOut[0] = cutoff;    // BucketMul.cutoff (bucketMul.swift:22)
+    if (needCut) {
+        cutoff = block_find_cutoff<NT>(vj, prj, a.q, smem + offC, tbl, []() {}, stamp ? a.tstamp + 8 : nullptr);
+        cachedCall = ci; cachedCutoff = cutoff;
+        if (b == 0 && tid == 0) a.cutoffOut[0] = cutoff;             // BucketMul.cutoff (bucketMul.swift:22)
+    } else if (fused) {
+        cutoff = cachedCutoff;
+        if (b == 0 && tid == 0) a.cutoffOut[0] = cutoff;
+        __syncthreads();                                             // publishes means / vblk / wbound
     } else {
         // split mode: the standalone cutoff kernel ran first on this stream (cheaper in aggregate when several
         // calls overlap: one workgroup evaluates it instead of all of them)
         cutoff = a.cutoffIn[0];
-        zero_tile();
-        __syncthreads();                                             // publishes vblk
+        __syncthreads();                                             // publishes means / vblk / wbound
     }
+    for (int i = tid; i < TILE_F; i += NT) acc[i] = 0;               // the table is dead: zero the tile (barrier in C)
+    // Fixed-point scale of this workgroup's tile.  Every product is |v_j| * |w| with |w| <= (max |w| of its rank), so
+    // every partial sum is bounded by L = (sum over the slice of |v_j|) * (sum over ranks of that rank's max |w|)
+    // (Q4: of that rank's max row mean); rankBound comes from registration.  With 2^k * L < 2^30 no accumulator can
+    // leave int32 (intermediate wrap-around would be harmless anyway: integer addition is modular), and 2^k being a
+    // power of two, scaling and un-scaling are exact.
+    float L = 0.0f;
+#pragma unroll
+    for (int w2 = 0; w2 < W; w2++) L += wbound[w2];
+    L *= rankBound;
+    int kexp = 30 - (int)((__float_as_uint(L) >> 23) & 0xFFu) + 126;     // L < 2^(e-126)  =>  2^kexp * L < 2^30
+    kexp = L > 0.0f ? max(-100, min(100, kexp)) : 0;
+    const float scale = __uint_as_float((uint32_t)(127 + kexp) << 23), unscale = __uint_as_float((uint32_t)(127 - kexp) << 23);
     if (stamp) a.tstamp[18] = wall_clock64();
+    if (wstamp) ph[2] = wall_clock64();
 
     // ---- C. keep test (bucketMul.metal:69 / bucketMulQ4.metal:47) + ordered compaction -----------
-    // All rounds are balloted first; the kPre*W per-wave counts meet in LDS at ONE barrier; list position of a
-    // kept slot = (kept slots of earlier rounds) + (earlier waves of its round) + (earlier lanes of its wave).
-    bool keep[kPre]; uint32_t pre[kPre]; float xs[kPre];
-#pragma unroll
-    for (int r = 0; r < kPre; r++) {
-        keep[r] = false; pre[r] = 0; xs[r] = 0.0f;
-        if ((uint32_t)(r * NT) < nSlots && !(a.ablate & 8u)) {  // uniform
-            const bool cand = codes[r] != 0xFFFFFFFFu;
-            const uint32_t jl = FMT == kFp16 ? (codes[r] & 4095u) : (codes[r] >> 3);
-            xs[r] = cand ? vblk[jl] : 0.0f;
-            keep[r] = cand && (cutoff < (kCutoffScale * mean[r]) * fabsf(xs[r]));
-            const unsigned long long m = __ballot(keep[r]);
-            pre[r] = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            if (lane == 0) wcnt[r * 16 + wave] = (uint32_t)__popcll(m);
-        } else if (lane == 0) {
-            wcnt[r * 16 + wave] = 0u;
+    // `rounds` rounds of NT slots each.  Pass 1 tests and ballots every round (keeping the verdicts in a bit mask) and
+    // leaves the per-(round, wave) counts in LDS; after ONE barrier each wave derives the list offset of each of its
+    // ballots (kept slots of earlier rounds + earlier waves of the round); pass 2 writes the survivors: list position
+    // = that offset + earlier lanes of the wave.  No atomics, ascending bucket-row order.
+    auto keep_test = [&](uint32_t c) -> bool {
+        if (c >= nSlots || (a.ablate & 8u)) return false;
+        if (FMT == kFp16) {
+            const uint32_t jl = c & ((1u << lg) - 1u);
+            const float x = jl < nb ? vblk[jl] : 0.0f;
+            return cutoff < (kCutoffScale * half_bits_to_float((uint16_t)means[c])) * fabsf(x);
+        } else {
+            return cutoff < (kCutoffScale * (float)means[c]) * fabsf(vblk[c >> 3]);
         }
+    };
+    uint32_t keepMask = 0;                                  // bit r: this thread's slot of round r is kept
+#pragma unroll
+    for (int r = 0; r < kRounds; r++) {
+        if ((uint32_t)(r * NT) >= nSlots) break;            // uniform
+        const bool k = keep_test(r * NT + tid);
+        keepMask |= k ? (1u << r) : 0u;
+        const unsigned long long m = __ballot(k);
+        if (lane == 0) wcnt[r * W + wave] = (uint32_t)__popcll(m);
     }
     __syncthreads();
-    // lanes 0..kPre*W-1 hold one (round, wave) count each, in list order; inclusive scan with shuffles
-    static_assert(kPre * W <= 64, "selection scan: kPre*W must fit one wave");
-    uint32_t inc = (lane < kPre * W) ? wcnt[(lane / W) * 16 + (lane % W)] : 0u;
-    const uint32_t own = inc;
+    uint32_t rowsum = 0, part = 0;                        // lane r < rounds: kept in round r (all waves / the earlier waves)
+    if ((uint32_t)lane < rounds) {
 #pragma unroll
-    for (int off = 1; off < kPre * W; off <<= 1) {
+        for (int w2 = 0; w2 < W; w2++) { const uint32_t x = wcnt[lane * W + w2]; rowsum += x; part += (w2 < wave) ? x : 0u; }
+    }
+    uint32_t inc = rowsum;
+#pragma unroll
+    for (int off = 1; off < kRounds; off <<= 1) {
         const uint32_t o = __shfl_up(inc, off);
         inc += (lane >= off) ? o : 0u;
     }
-    const uint32_t exc = inc - own;
-    uint32_t n = __shfl(inc, kPre * W - 1);
-#pragma unroll
-    for (int r = 0; r < kPre; r++) {
-        const uint32_t base = __shfl(exc, r * W + wave);
-        if (keep[r]) {
-            list[base + pre[r]] = (uint16_t)codes[r];
-            if (FMT == kQ4) dlist[base + pre[r]] = xs[r] * mean[r];          // entry value = v*mean (:52)
-        }
+    const uint32_t basev = inc - rowsum + part;
+    const uint32_t n = __shfl(inc, kRounds - 1);          // lanes >= rounds add nothing: the total
+    for (uint32_t r = 0; r < rounds; r++) {
+        const uint32_t c = r * NT + tid;
+        const bool k = (keepMask >> r) & 1u;
+        const unsigned long long m = __ballot(k);
+        const uint32_t pos = __builtin_amdgcn_readlane(basev, r) + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if (k) list[pos] = (uint16_t)(FMT == kFp16 ? (((c >> lg) << 12) | (c & ((1u << lg) - 1u))) : c);
     }
     __syncthreads();
     if (t == 0 && tid == 0) a.sliceCounts[s] = n;                  // dispatch.size = sum over slices (test hook)
     if (stamp) a.tstamp[19] = wall_clock64();
+    if (wstamp) ph[3] = wall_clock64();
 
-    // ---- D. stream the kept rows, scatter-accumulate into the private LDS tile ----------------
+    // ---- D. stream the kept rows, scatter-accumulate into the LDS tile ----------------
     const uint32_t col = t * (64u * E) + (uint32_t)lane * E;
     const bool colOK = col < g.cols;                               // a piece past the last column is skipped whole
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -264,8 +314,11 @@ __global__ __launch_bounds__(64 * W) void bucket_mul_kernel(const MulArgs a) {
             const uint32_t kk = wave + W * min(i0 + (uint32_t)lane, myRows - 1u);
             const uint32_t code = list[kk];
             uint32_t rowIdx;
-            if (FMT == kFp16) { const uint32_t rank = code >> 12, jl = code & 4095u; rowIdx = rank * g.inDim + j0 + jl; dv = vblk[jl]; }
-            else { const uint32_t jl = code >> 3, rank = code & 7u; rowIdx = (j0 + jl) * 8u + rank; dv = dlist[kk]; }
+            if (FMT == kFp16) { const uint32_t rank = code >> 12, jl = code & 4095u; rowIdx = rank * g.inDim + j0 + jl; dv = vblk[jl] * scale; }
+            else {   // entry value = v*mean (bucketMulQ4.metal:52), the one magnitude of the row; carried in fixed point
+                rowIdx = j0 * 8u + code;
+                dv = __int_as_float(__float2int_rn((vblk[code >> 3] * (float)means[code]) * scale));
+            }
             boff = (e * g.expertRows + rowIdx) * g.cols * 2u;       // byte offset of the bucket row (< 4 GiB, checked at registration)
         }
     };
@@ -273,46 +326,44 @@ __global__ __launch_bounds__(64 * W) void bucket_mul_kernel(const MulArgs a) {
 #pragma unroll
         for (int u = 0; u < kBatch; u++) piece[u].load(rsrc, voff, EFFORT_ABLATE_NOLOAD ? 0u : __builtin_amdgcn_readlane(boff, u));
     };
-    // One row piece -> E (Q4: 4E) read-add-writes on this lane's private accumulator column.  The LDS byte
-    // address is built with v_bfe_u32 + v_lshl_add_u32 (hipcc otherwise spends three VALU ops per element on it)
-    // and the product is accumulated with one v_fma_f32 (a single rounding, where the reference's
-    // `v = d.x*float(w); acc += v` rounds twice: well inside the parity tolerance and never less accurate).
-    using lds_f = __attribute__((address_space(3))) float;
-    const uint32_t accB = (uint32_t)(size_t)(lds_f*)myacc;
+    // One row piece -> E (Q4: 4E) integer LDS atomics on the workgroup's tile.  Why fixed point: a float
+    // read-add-write needs a PRIVATE tile per wave (W x the LDS, so two workgroups per CU at best) and two LDS
+    // instructions per element; ds_add_f32 runs at 0.5 elements/clk/CU; ds_add_u32 runs at 13 (tools/microbench.hip),
+    // lets all waves share one tile, and -- integer addition being associative -- makes the sum independent of the
+    // order in which waves and workgroups happen to run.  Each product is rounded once to the grid 2^-k (k above: at
+    // least 30 bits below the bound L), finer than the f32 rounding of a running sum; the reference's own summation
+    // order is unspecified (atomics / simd_sum), see DESIGN.md.
+    // The LDS byte address is built with v_bfe_u32 + v_lshl_add_u32 (hipcc otherwise spends three VALU ops on it).
+    using lds_i = __attribute__((address_space(3))) int;
+    const uint32_t accB = (uint32_t)(size_t)(lds_i*)(acc + lane);
     constexpr int kShift = (E == 1 ? 8 : E == 2 ? 9 : E == 4 ? 10 : 11);      // log2(E * 64 lanes * 4 bytes)
     auto row = [&](const Piece<E>& pc, float dd) {
         if (FMT == kFp16) {
             // bucketMul.metal:100-106: v = d.x*float(w) with the position bits left in w; acc[pos] += v
-            float w[E], old[E]; lds_f* p[E];
 #pragma unroll
             for (int j = 0; j < E; j++) {
                 const uint32_t dw = pc.dword(j);                       // the dword holding element j (bits 16*(j&1)..)
-                w[j] = half_bits_to_float((uint16_t)(dw >> (16 * (j & 1))));
-                uint32_t a2;
+                uint32_t a2; int qv;
                 asm("v_bfe_u32 %0, %1, %2, 4\n\tv_lshl_add_u32 %0, %0, %3, %4" : "=&v"(a2) : "v"(dw), "n"(16 * (j & 1)), "n"(kShift), "v"(accB));
-                p[j] = (lds_f*)(size_t)a2 + j * 64;
+                // product = d * float(w): one v_fma_mix_f32 reads the f16 half in place (exact, as the f32 multiply of
+                // the converted half is); then floor(x + 0.5) to the fixed-point grid
+                if (j & 1) asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[0,1,0] op_sel_hi:[0,1,0]\n\tv_cvt_rpi_i32_f32 %0, %0" : "=v"(qv) : "v"(dd), "v"(dw));
+                else asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[0,1,0]\n\tv_cvt_rpi_i32_f32 %0, %0" : "=v"(qv) : "v"(dd), "v"(dw));
+                __hip_atomic_fetch_add((lds_i*)(size_t)a2 + j * 64, qv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
-#pragma unroll
-            for (int j = 0; j < E; j++) old[j] = *p[j];
-#pragma unroll
-            for (int j = 0; j < E; j++) *p[j] = __builtin_fmaf(dd, w[j], old[j]);
         } else {
             // bucketMulQ4.metal:76-81: low nibble first <-> sub-bucket 3,2,1,0; acc += (n&8) ? -d : d
-            float val[4 * E], old[4 * E]; lds_f* p[4 * E];
+            const int di = __float_as_int(dd);
 #pragma unroll
             for (int j = 0; j < E; j++) {
                 const uint32_t x = pc.word(j);
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     const uint32_t nib = (x >> (4 * q)) & 15u;
-                    val[4 * j + q] = (nib & 8u) ? -dd : dd;
-                    p[4 * j + q] = (lds_f*)myacc + (((3 - q) * 8 + (nib & 7u)) * E + j) * 64;
+                    __hip_atomic_fetch_add((lds_i*)(acc + lane) + (((3 - q) * 8 + (nib & 7u)) * E + j) * 64, (nib & 8u) ? -di : di,
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
-#pragma unroll
-            for (int i = 0; i < 4 * E; i++) old[i] = *p[i];
-#pragma unroll
-            for (int i = 0; i < 4 * E; i++) *p[i] = old[i] + val[i];
         }
     };
     auto accumulate = [&](const Piece<E> (&piece)[kBatch], float dv, uint32_t nv) {
@@ -346,85 +397,132 @@ __global__ __launch_bounds__(64 * W) void bucket_mul_kernel(const MulArgs a) {
             accumulate(pb, dvB, __builtin_amdgcn_readfirstlane(i0 + kBatch < myRows ? min((uint32_t)kBatch, myRows - i0 - kBatch) : 0u));
         }
     }
-    __syncthreads();
+    __syncthreads();                           // every wave's atomics have landed in the tile
     if (stamp) a.tstamp[20] = wall_clock64();
-    if (a.tstamp && tid == 0) atomicMax(&a.tstamp[26], (unsigned long long)wall_clock64());
+    if (wstamp) ph[4] = wall_clock64();
 
-    // ---- E. W private tiles -> one slab (native [slot][j][lane] order), write-through; ticket; last arriver
+    // ---- E. the tile, back in f32 -> one slab (native [slot][j][lane] order), write-through; ticket; last arriver
     //         of the tile reduces the S slabs in slice order and writes out[] -------------------------------
     const size_t slabBytes = (size_t)g.slices * g.tiles * TILE_F * 4;
     const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(a.slabs, 0, (int)slabBytes, 0x00020000);
     const uint32_t slabOff = (s * g.tiles + t) * (uint32_t)(TILE_F * 4);
     for (int o = tid * 2; o < TILE_F; o += NT * 2) {
-        float s0 = acc[o], s1 = acc[o + 1];
-#pragma unroll
-        for (int w2 = 1; w2 < W; w2++) { s0 += acc[w2 * TILE_F + o]; s1 += acc[w2 * TILE_F + o + 1]; }
+        const float s0 = (float)acc[o] * unscale, s1 = (float)acc[o + 1] * unscale;
         typedef uint32_t u2 __attribute__((ext_vector_type(2)));
         u2 pk; pk[0] = __float_as_uint(s0); pk[1] = __float_as_uint(s1);
         __builtin_amdgcn_raw_buffer_store_b64(pk, srs, (uint32_t)o * 4u, slabOff, kSc1);
     }
-    if (a.tstamp && tid == 0) atomicMax(&a.tstamp[1], (unsigned long long)wall_clock64());
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's slab stores have left the CU
     if (stamp) { a.tstamp[21] = wall_clock64(); a.tstamp[22] = n; }
-    if (a.tstamp && tid == 0) atomicMax(&a.tstamp[27], (unsigned long long)wall_clock64());
+    if (wstamp) ph[5] = wall_clock64();
+    // the stamps are flushed off the critical path (after the ticket), spread over 32 cache lines
+    auto flush_stamps = [&]() {
+        if (!wstamp) return;
+        unsigned long long* line = a.tstamp + 64 + (item & 31u) * 8u;
+#pragma unroll
+        for (int i = 0; i < 5; i++) atomicAdd(&line[i], ph[i + 1] - ph[i]);
+        atomicAdd(&line[5], 1ull);
+        atomicMin(&a.tstamp[0], ph[0]);
+        atomicMax(&a.tstamp[26], ph[0]);                                       // latest workgroup start
+        atomicMax(&a.tstamp[28], ph[5] - ph[0]);                               // longest workgroup (start .. slab drained)
+        atomicMax(&a.tstamp[29], ph[4] - ph[3]);                               // longest streaming phase
+        atomicMax(&a.tstamp[1], (unsigned long long)wall_clock64());
+    };
     __syncthreads();
     if (tid == 0) {
         const uint32_t ticket = __hip_atomic_fetch_add(&a.counters[t], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         flags[0] = (ticket == g.slices - 1u) ? 1u : 0u;
     }
     __syncthreads();
-    if (flags[0] == 0u) return;
+    if (flags[0] == 0u) { flush_stamps(); return; }
     if (a.ablate & 2u) { if (tid == 0) __hip_atomic_store(&a.counters[t], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
 
     // last arriver of tile t: every slab of the tile was stored write-through (sc1) and drained before its ticket;
     // read them past L1 (sc1), sum in slice order, un-permute, add the Q4 outliers, write out[].  Each thread owns
     // two adjacent tile slots and keeps up to kRed 8-byte loads in flight (each is a fabric round trip); the four
     // running sums per slot are combined in a fixed order.
-    const bool rstamp = a.tstamp && t == 0 && tid == 0;
+    const bool rstamp = a.tstamp && ci == 0 && t == 0 && tid == 0;
     if (rstamp) a.tstamp[23] = wall_clock64();
-    constexpr int kRed = 32;
     typedef uint32_t u2v __attribute__((ext_vector_type(2)));
     const uint32_t sliceStride = g.tiles * (uint32_t)(TILE_F * 4);
-    for (int o = tid * 2; o < TILE_F; o += NT * 2) {
-        const uint32_t vo = t * (uint32_t)(TILE_F * 4) + (uint32_t)o * 4u;
-        float sa[4] = {0.0f, 0.0f, 0.0f, 0.0f}, sb[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        for (uint32_t sl = 0; sl < g.slices; sl += kRed) {
-            u2v r[kRed];
+    auto reduce_tile = [&](auto kc) {
+        constexpr int kRed = decltype(kc)::value;          // slab loads in flight per thread
+        for (int o = tid * 2; o < TILE_F; o += NT * 2) {
+            const uint32_t vo = t * (uint32_t)(TILE_F * 4) + (uint32_t)o * 4u;
+            float sa[4] = {0.0f, 0.0f, 0.0f, 0.0f}, sb[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            for (uint32_t sl = 0; sl < g.slices; sl += kRed) {
+                u2v r[kRed];
 #pragma unroll
-            for (int i = 0; i < kRed; i++)
-                r[i] = __builtin_amdgcn_raw_buffer_load_b64(srs, vo, min(sl + i, g.slices - 1u) * sliceStride, kSc1);
+                for (int i = 0; i < kRed; i++)
+                    r[i] = __builtin_amdgcn_raw_buffer_load_b64(srs, vo, min(sl + i, g.slices - 1u) * sliceStride, kSc1);
 #pragma unroll
-            for (int i = 0; i < kRed; i++) {
-                if (sl + i < g.slices) { sa[i & 3] += __uint_as_float(r[i][0]); sb[i & 3] += __uint_as_float(r[i][1]); }
+                for (int i = 0; i < kRed; i++) {
+                    if (sl + i < g.slices) { sa[i & 3] += __uint_as_float(r[i][0]); sb[i & 3] += __uint_as_float(r[i][1]); }
+                }
+            }
+            float sum2[2] = {(sa[0] + sa[1]) + (sa[2] + sa[3]), (sb[0] + sb[1]) + (sb[2] + sb[3])};
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const uint32_t oo = (uint32_t)o + h;
+                const uint32_t lane2 = oo & 63u, sj = oo >> 6, j = sj % E, slot = sj / E;
+                const uint32_t c2 = t * (64u * E) + lane2 * E + j;
+                if (c2 < g.cols) a.out[c2 * NACC + slot] = sum2[h];
             }
         }
-        float sum2[2] = {(sa[0] + sa[1]) + (sa[2] + sa[3]), (sb[0] + sb[1]) + (sb[2] + sb[3])};
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const uint32_t oo = (uint32_t)o + h;
-            const uint32_t lane2 = oo & 63u, sj = oo >> 6, j = sj % E, slot = sj / E;
-            const uint32_t c2 = t * (64u * E) + lane2 * E + j;
-            float sum = sum2[h];
-            if (c2 < g.cols) {
-                const uint32_t oi = c2 * NACC + slot;
-                a.out[oi] = sum;
-            }
-        }
-    }
+    };
+    // (the four running sums take slices i%4; chunk sizes are multiples of 4, so the order does not depend on the chunk)
+    if (g.slices <= 8u) reduce_tile(std::integral_constant<int, 8>{});
+    else if (g.slices <= 16u) reduce_tile(std::integral_constant<int, 16>{});
+    else reduce_tile(std::integral_constant<int, 32>{});
     if (rstamp) a.tstamp[24] = wall_clock64();
     if (tid == 0) {
         __hip_atomic_store(&a.counters[t], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next call
         if (a.tstamp) {
-            atomicMax(&a.tstamp[1], (unsigned long long)wall_clock64());
-            const uint32_t done = __hip_atomic_fetch_add(&a.counters[g.tiles], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (done == g.tiles - 1u) {                                        // whole kernel finished: fold the stamps
+            flush_stamps();
+            const uint32_t done = __hip_atomic_fetch_add(ga.groupDone, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (done == ga.totalTiles - 1u) {                                  // whole kernel finished: fold the stamps
                 const unsigned long long t0 = __hip_atomic_load(&a.tstamp[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const unsigned long long t1 = __hip_atomic_load(&a.tstamp[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 a.tstamp[2] += t1 - t0; a.tstamp[3] += 1;
+                a.tstamp[27] += __hip_atomic_load(&a.tstamp[26], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - t0;   // dispatch ramp
+                __hip_atomic_store(&a.tstamp[26], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&a.tstamp[0], ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&a.tstamp[1], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&a.counters[g.tiles], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(ga.groupDone, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+        }
+    }
+}
+
+// The kernel: every workgroup pulls items until the queue of its XCD is dry.  Launched with one item per workgroup it
+// is a plain grid; launched with fewer workgroups than items (ga.persistent) the workgroups are PERSISTENT: the
+// dispatcher only places ~40 workgroups/us chip-wide and spreads a large grid unevenly over the CUs (measured with
+// tools/microbench.hip: residency probe), so a group launch sizes its grid to the chip -- R workgroups per CU,
+// R fixed by the LDS each one asks for -- and balances the work itself.
+template <int FMT, int E, int W>
+__global__ __launch_bounds__(64 * W) void bucket_mul_kernel(const GroupArgs ga) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ uint32_t s_item;
+    const uint32_t total = ga.wgEnd[ga.count - 1];
+    uint32_t cachedCall = 0xFFFFFFFFu; float cachedCutoff = 0.0f;
+    const uint32_t x = blockIdx.x & 7u;                    // block b sits on XCD b%8; item i wants XCD i%8
+    for (uint32_t it = 0;; it++) {
+        uint32_t item = blockIdx.x;
+        if (ga.persistent) {                               // uniform
+            if (threadIdx.x == 0) s_item = __hip_atomic_fetch_add(&ga.queue[x * 16u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * 8u + x;
+            __syncthreads();
+            item = __builtin_amdgcn_readfirstlane(s_item);   // uniform by construction: keep everything derived from it scalar
+            __syncthreads();
+            if (item >= total) break;
+        } else if (it) {
+            return;
+        }
+        mul_item<FMT, E, W>(ga, item, smem, cachedCall, cachedCutoff);
+    }
+    if (threadIdx.x == 0) {                                // the last workgroup out rewinds the queues for the next launch
+        const uint32_t gone = __hip_atomic_fetch_add(&ga.queue[8 * 16], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (gone == gridDim.x - 1u) {
+            for (int i = 0; i <= 8; i++) __hip_atomic_store(&ga.queue[i * 16], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -433,10 +531,13 @@ __global__ __launch_bounds__(64 * W) void bucket_mul_kernel(const MulArgs a) {
 // fires one atomic per outlier in table order; here one wave owns one output (its outliers are contiguous in the
 // by-output index built at registration), lanes stride its segment with coalesced loads, and a fixed xor-butterfly
 // adds the 64 partial sums -- no atomics, deterministic.  Launched right after the multiply kernel on the same stream.
-__global__ __launch_bounds__(256) void q4_outliers_kernel(const OutlierIndex ol, const float* __restrict__ v,
-                                                          float* __restrict__ out, uint32_t outDim) {
+__global__ __launch_bounds__(256) void q4_outliers_kernel(const GroupArgs ga) {
+    const MulArgs& a = ga.call[blockIdx.y];
+    const OutlierIndex& ol = a.ol;
+    const float* __restrict__ v = a.v;
+    float* __restrict__ out = a.out;
     const uint32_t o = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (o >= outDim) return;
+    if (o >= a.g.outDim || !ol.rowPtr) return;
     const int lane = threadIdx.x & 63;
     const uint32_t lo = ol.rowPtr[o], hi = ol.rowPtr[o + 1];
     if (lo == hi) return;
@@ -447,54 +548,84 @@ __global__ __launch_bounds__(256) void q4_outliers_kernel(const OutlierIndex ol,
     if (lane == 0) out[o] += part;
 }
 
-hipError_t launch_q4_outliers(const OutlierIndex& ol, const float* v, float* out, uint32_t outDim, hipStream_t st) {
-    hipLaunchKernelGGL(q4_outliers_kernel, dim3((outDim + 3) / 4), dim3(256), 0, st, ol, v, out, outDim);
+hipError_t launch_q4_outliers(const GroupArgs& ga, hipStream_t st) {
+    uint32_t maxOut = 0; bool any = false;
+    for (uint32_t i = 0; i < ga.count; i++) { maxOut = max(maxOut, ga.call[i].g.outDim); any = any || ga.call[i].ol.rowPtr; }
+    if (!any) return hipSuccess;
+    hipLaunchKernelGGL(q4_outliers_kernel, dim3((maxOut + 3) / 4, ga.count), dim3(256), 0, st, ga);
     return hipGetLastError();
 }
 
 // ---- host side ------------------------------------------------------------------------------
 template <int FMT, int E, int W>
-static hipError_t launch_mul_t(const MulArgs& a, hipStream_t st) {
+static hipError_t launch_mul_t(const GroupArgs& ga, hipStream_t st) {
     uint32_t o1, o2, o3, o4;
-    const uint32_t lds = lds_layout<FMT, E, W>(a.g.sliceRows, a.g.rowsPerIn, &o1, &o2, &o3, &o4);
+    uint32_t lds = 0;
+    for (uint32_t i = 0; i < ga.count; i++) {
+        const MulGeom& g = ga.call[i].g;
+        lds = max(lds, lds_layout<FMT, E, W>(g.sliceRows, g.slots, &o1, &o2, &o3, &o4));
+        if (g.slots > (uint32_t)kRounds * 64 * W || g.slots != (FMT == kFp16 ? (g.rowsPerIn << g.sliceLog2) : g.sliceRows * 8u)) return hipErrorInvalidValue;
+        if (ga.wgEnd[i] - (i ? ga.wgEnd[i - 1] : 0u) != g.tiles * align_up(g.slices, 8)) return hipErrorInvalidValue;
+    }
     static uint32_t maxSet = 0;   // per instantiation
+    uint32_t grid = ga.wgEnd[ga.count - 1];
+    if (ga.persistent) {
+        // R workgroups per CU, exactly: ask for enough LDS that R+1 cannot share a CU
+        const uint32_t R = ga.persistent;
+        grid = ga.numCU * R;
+        const uint32_t force = (160u * 1024u) / (R + 1u) + 512u;
+        if (lds < force && force <= (160u * 1024u) / R) lds = force;
+    }
     if (lds > maxSet) {
         hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&bucket_mul_kernel<FMT, E, W>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (err != hipSuccess) return err;
         maxSet = lds;
     }
-    if ((FMT == kFp16 ? (a.g.rowsPerIn << a.g.sliceLog2) : a.g.sliceRows * 8u) > (uint32_t)kPre * 64 * W) return hipErrorInvalidValue;   // candidate slots must fit the preload
-    const uint32_t grid = a.g.tiles * align_up(a.g.slices, 8);
-    hipLaunchKernelGGL((bucket_mul_kernel<FMT, E, W>), dim3(grid), dim3(64 * W), lds, st, a);
+    hipLaunchKernelGGL((bucket_mul_kernel<FMT, E, W>), dim3(grid), dim3(64 * W), lds, st, ga);
     return hipGetLastError();
 }
 
 #define EFFORT_GEOMS(X) X(16, 1) X(16, 2) X(8, 1) X(8, 2) X(8, 4) X(4, 1) X(4, 2) X(4, 4) X(4, 8) X(2, 4) X(2, 8)
 
 template <int FMT>
-static hipError_t launch_mul_fmt(int W, int E, const MulArgs& a, hipStream_t st) {
+static hipError_t launch_mul_fmt(int W, int E, const GroupArgs& a, hipStream_t st) {
 #define EFFORT_CASE(w, e) if (W == w && E == e) return launch_mul_t<FMT, e, w>(a, st);
     EFFORT_GEOMS(EFFORT_CASE)
 #undef EFFORT_CASE
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_bucket_mul(Format fmt, int W, int E, const MulArgs& a, hipStream_t st) {
+hipError_t launch_bucket_mul(Format fmt, int W, int E, const GroupArgs& a, hipStream_t st) {
     return fmt == kFp16 ? launch_mul_fmt<kFp16>(W, E, a, st) : launch_mul_fmt<kQ4>(W, E, a, st);
 }
 
-size_t bucket_mul_lds_bytes(Format fmt, int W, int E, uint32_t B, uint32_t rowsPerIn) {
+size_t bucket_mul_lds_bytes(Format fmt, int W, int E, uint32_t B, uint32_t slots) {
     uint32_t o1, o2, o3, o4;
 #define EFFORT_CASE(w, e)                                                                     \
     if (W == w && E == e)                                                                     \
-        return fmt == kFp16 ? lds_layout<kFp16, e, w>(B, rowsPerIn, &o1, &o2, &o3, &o4)       \
-                            : lds_layout<kQ4, e, w>(B, rowsPerIn, &o1, &o2, &o3, &o4);
+        return fmt == kFp16 ? lds_layout<kFp16, e, w>(B, slots, &o1, &o2, &o3, &o4)           \
+                            : lds_layout<kQ4, e, w>(B, slots, &o1, &o2, &o3, &o4);
     EFFORT_GEOMS(EFFORT_CASE)
 #undef EFFORT_CASE
     return 0;
 }
 
-uint32_t bucket_mul_max_candidates(int W) { return (uint32_t)kPre * 64u * (uint32_t)W; }
+// Resident workgroups per CU the runtime grants an instantiation at a given dynamic LDS size (0: unsupported).
+int bucket_mul_occupancy(Format fmt, int W, int E, size_t ldsBytes) {
+    int n = 0;
+#define EFFORT_CASE(w, e)                                                                                              \
+    if (W == w && E == e) {                                                                                            \
+        const void* f = fmt == kFp16 ? reinterpret_cast<const void*>(&bucket_mul_kernel<kFp16, e, w>)                  \
+                                     : reinterpret_cast<const void*>(&bucket_mul_kernel<kQ4, e, w>);                   \
+        hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);                             \
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, f, 64 * w, ldsBytes) != hipSuccess) n = 0;                \
+    }
+    EFFORT_GEOMS(EFFORT_CASE)
+#undef EFFORT_CASE
+    return n;
+}
+
+uint32_t bucket_mul_max_candidates(int W) { return (uint32_t)kRounds * 64u * (uint32_t)W; }
 
 }  // namespace effort

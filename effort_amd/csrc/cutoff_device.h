@@ -46,7 +46,9 @@ __device__ __forceinline__ float block_find_cutoff(const float (&vj)[4096 / NT],
     uint32_t* s_mm = reinterpret_cast<uint32_t*>(lds) + 4;         // [0] min pattern, [1] max pattern
     uint32_t* s_tot = reinterpret_cast<uint32_t*>(lds) + 8;        // [16] wave totals of the scan
     float* s_res = reinterpret_cast<float*>(lds) + 24;             // [0] result
-    const int tid = threadIdx.x, lane = tid & 63;
+    int tid0 = threadIdx.x;
+    asm volatile("" : "+v"(tid0));      // opaque: a caller looping over work items must not hoist tid-derived state
+    const int tid = tid0, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (dbg && tid == 0) { dbg[0] = wall_clock64(); dbg[6] = clock64(); }
 

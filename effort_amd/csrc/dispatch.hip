@@ -91,6 +91,54 @@ __global__ void f32_to_f16_kernel(const float* in, uint16_t* out, uint32_t n) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i < n) out[i] = __half_as_ushort(__float2half_rn(in[i]));
 }
+// max |w| of every bucket row (position bits included, exactly the value the multiply uses): one wave per row.
+// Run once when a weight handle is registered (first half of launch_rank_bound).
+__global__ __launch_bounds__(256) void row_max_kernel(const uint16_t* __restrict__ buckets, uint32_t rows, uint32_t cols,
+                                                      float* __restrict__ rowMax) {
+    const uint32_t row = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const uint16_t* p = buckets + (size_t)row * cols;
+    float m = 0.0f;
+    for (uint32_t c = lane; c < cols; c += 64) m = fmaxf(m, fabsf(half_bits_to_float(p[c])));
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if (lane == 0) rowMax[row] = m;
+}
+
+// rankBound[e] = sum over ranks r of  max over input rows j of  rowValue(e, r, j), where rowValue is the row's max |w|
+// (FP16, from row_max_kernel) or its |mean| (Q4, the magnitude every weight of the row decodes to).
+__global__ __launch_bounds__(1024) void rank_bound_kernel(const float* __restrict__ rowMax, const float* __restrict__ statsQ4,
+                                                          uint32_t rowsPerIn, uint32_t inDim, float* __restrict__ rankBound) {
+    __shared__ float red[16];
+    const uint32_t e = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t base = (size_t)e * rowsPerIn * inDim;
+    float total = 0.0f;
+    for (uint32_t r = 0; r < rowsPerIn; r++) {
+        float m = 0.0f;
+        for (uint32_t j = tid; j < inDim; j += 1024)
+            m = fmaxf(m, statsQ4 ? fabsf(statsQ4[(base + (size_t)j * rowsPerIn + r) * 2 + 1]) : rowMax[base + (size_t)r * inDim + j]);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        if (lane == 0) red[wave] = m;
+        __syncthreads();
+        float mm = 0.0f;
+        for (int w2 = 0; w2 < 16; w2++) mm = fmaxf(mm, red[w2]);
+        total += mm;
+        __syncthreads();
+    }
+    if (tid == 0) rankBound[e] = total;
+}
+
+hipError_t launch_rank_bound(Format fmt, const uint16_t* buckets, const void* stats, uint32_t numExperts, uint32_t rowsPerIn,
+                             uint32_t inDim, uint32_t cols, float* rowScratch, float* rankBound, hipStream_t st) {
+    const uint32_t rows = numExperts * rowsPerIn * inDim;
+    if (fmt == kFp16) hipLaunchKernelGGL(row_max_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, buckets, rows, cols, rowScratch);
+    hipLaunchKernelGGL(rank_bound_kernel, dim3(numExperts), dim3(1024), 0, st, rowScratch,
+                       fmt == kQ4 ? static_cast<const float*>(stats) : nullptr, rowsPerIn, inDim, rankBound);
+    return hipGetLastError();
+}
+
 hipError_t launch_f32_to_f16(const float* in, uint16_t* out, uint32_t n, hipStream_t st) {
     hipLaunchKernelGGL(f32_to_f16_kernel, dim3((n + 255) / 256), dim3(256), 0, st, in, out, n);
     return hipGetLastError();

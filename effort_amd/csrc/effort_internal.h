@@ -23,6 +23,7 @@ struct MulGeom {
     uint32_t slices;       // S: row slices actually used (every slice owns sliceRows input rows)
     uint32_t sliceRows;    // B: input rows per slice
     uint32_t sliceLog2;    // ceil(log2(B)): FP16 candidate slots are laid out [rank][2^sliceLog2]
+    uint32_t slots;        // candidate slots per slice: rowsPerIn << sliceLog2 (FP16) or 8*B (Q4)
     uint32_t tileFloats;   // accumulators per tile = NACC*E*64
     uint32_t numExperts;   // experts stacked in the buffers (bounds of the buffer descriptor)
 };
@@ -36,6 +37,7 @@ struct OutlierIndex {          // by-output CSR of the Q4 outliers, built at reg
 struct MulArgs {
     const uint16_t* buckets;
     const void* stats;         // f16x4 (FP16) or f32x2 (Q4) per bucket row
+    const float* rankBound;    // [numExperts] sum over ranks of the rank's max |w| (Q4: max row mean): fixed-point bound, from registration
     const uint16_t* probes;    // f16 [numExperts][4096]
     const float* v;
     const uint32_t* expNo;     // nullable
@@ -50,6 +52,22 @@ struct MulArgs {
     uint32_t q;                // Int(4095*(1-effort)), bucketMul.swift:39
     uint32_t ablate;           // profiling only (env EFFORT_ABLATE): 2 = no last-arriver reduce, 4 = no row streaming, 8 = no selection
     MulGeom g;
+};
+
+// One launch = a GROUP of up to kMaxGroup independent bucketMul calls (own weights, v, out, effort, scratch):
+// the decode loop's Wq|Wk|Wv and W1|W3 (runNetwork.swift:132-134,178-182) are such groups.  A lone call's
+// workgroups spend most of their life in dependent fixed-latency steps, so one call cannot load the chip; in a
+// group the workgroups of different calls overlap on the CUs inside ONE kernel, no stream juggling involved.
+constexpr int kMaxGroup = 8;
+struct GroupArgs {
+    MulArgs call[kMaxGroup];
+    uint32_t wgEnd[kMaxGroup];     // exclusive end of each call's block range (multiples of 8)
+    uint32_t count;
+    uint32_t totalTiles;           // sum of tiles: the workgroup that finishes the last tile folds the timing stamps
+    uint32_t* groupDone;           // its counter (zero between launches)
+    uint32_t persistent;           // 0: one workgroup per item; R > 0: numCU*R persistent workgroups pull items from the queues
+    uint32_t numCU;
+    uint32_t* queue;               // [9][16]: per-XCD item cursors (one cache line each) + exit counter; zero between launches
 };
 
 // ---- device helpers -------------------------------------------------------------------------
@@ -68,10 +86,13 @@ hipError_t launch_find_cutoff(const float* v, const uint16_t* probes, const uint
                               float* cutoff, uint32_t* dispatchCount, unsigned long long* tstamp, hipStream_t st);
 
 // Returns hipErrorInvalidValue for unsupported (fmt, W, E).
-hipError_t launch_bucket_mul(Format fmt, int wavesPerGroup, int elemsPerLane, const MulArgs& a, hipStream_t st);
-size_t bucket_mul_lds_bytes(Format fmt, int wavesPerGroup, int elemsPerLane, uint32_t sliceRows, uint32_t rowsPerIn);
+hipError_t launch_bucket_mul(Format fmt, int wavesPerGroup, int elemsPerLane, const GroupArgs& ga, hipStream_t st);
+hipError_t launch_find_cutoff_group(const GroupArgs& ga, hipStream_t st);     // cutoffOut[0] of every call
+size_t bucket_mul_lds_bytes(Format fmt, int wavesPerGroup, int elemsPerLane, uint32_t sliceRows, uint32_t slots);
 uint32_t bucket_mul_max_candidates(int wavesPerGroup);
-hipError_t launch_q4_outliers(const OutlierIndex& ol, const float* v, float* out, uint32_t outDim, hipStream_t st);   // rowsPerIn*sliceRows must not exceed this
+int bucket_mul_occupancy(Format fmt, int wavesPerGroup, int elemsPerLane, size_t ldsBytes);
+  // rowsPerIn*sliceRows must not exceed this
+hipError_t launch_q4_outliers(const GroupArgs& ga, hipStream_t st);
 
 hipError_t launch_calc_dispatch(Format fmt, const void* stats, const float* v, const uint32_t* expNo,
                                 const float* cutoff, const MulGeom& g, float* dispatch, uint32_t* count,
@@ -80,6 +101,8 @@ hipError_t launch_calc_dispatch(Format fmt, const void* stats, const float* v, c
 hipError_t launch_convert_fp16(const uint16_t* W, uint32_t outDim, uint32_t inDim, uint16_t* buckets,
                                uint16_t* stats, uint16_t* probes, uint16_t* scratchVals, int* status, hipStream_t st);
 
+hipError_t launch_rank_bound(Format fmt, const uint16_t* buckets, const void* stats, uint32_t numExperts, uint32_t rowsPerIn,
+                             uint32_t inDim, uint32_t cols, float* rowScratch, float* rankBound, hipStream_t st);
 hipError_t launch_f32_to_f16(const float* in, uint16_t* out, uint32_t n, hipStream_t st);
 hipError_t launch_cosine(const float* a, const float* b, uint32_t n, float* out3, hipStream_t st);
 hipError_t launch_build_outlier_index(const float* outliers, uint64_t n, uint32_t outDim, uint32_t* rowPtr,

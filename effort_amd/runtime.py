@@ -61,8 +61,11 @@ class Gpu:
         self.check(self._lib.effort_kernel_clock(self.ctx, C.byref(us), C.byref(n)), "kernel_clock")
         return {"mul_us": us.value, "launches": n.value}
 
+    def set_persistent(self, wg_per_cu: int = -1):
+        self.check(self._lib.effort_set_persistent(self.ctx, int(wg_per_cu)), "set_persistent")
+
     def debug_stamps(self):
-        buf = (C.c_ulonglong * 24)()
+        buf = (C.c_ulonglong * 32)()
         self.check(self._lib.effort_debug_stamps(self.ctx, buf), "debug_stamps")
         return list(buf)
 
@@ -71,14 +74,15 @@ class Gpu:
         self.check(self._lib.effort_kernel_timing(self.ctx, C.byref(mul), C.byref(cut), C.byref(integ), C.byref(n)), "kernel_timing")
         return {"mul_us": mul.value, "cutoff_us": cut.value, "integrate_us": integ.value, "samples": n.value}
 
-    def last_dispatch_count(self) -> int:
+    def last_dispatch_count(self, idx: int = 0) -> int:
+        """dispatch.size of call ``idx`` of the most recent (group) launch."""
         n = C.c_uint32()
-        self.check(self._lib.effort_last_dispatch_count(self.ctx, C.byref(n)), "last_dispatch_count")
+        self.check(self._lib.effort_group_dispatch_count(self.ctx, int(idx), C.byref(n)), "last_dispatch_count")
         return int(n.value)
 
-    def last_cutoff(self) -> float:
+    def last_cutoff(self, idx: int = 0) -> float:
         x = C.c_float()
-        self.check(self._lib.effort_last_cutoff(self.ctx, C.byref(x)), "last_cutoff")
+        self.check(self._lib.effort_group_cutoff(self.ctx, int(idx), C.byref(x)), "last_cutoff")
         return float(x.value)
 
     def close(self):

@@ -65,7 +65,9 @@ EFFORT_API const char* effort_version(void);
  *   stats   f16 [numExperts][inDim*percentLoad][4]           mean|row| in all four lanes (.w is read)
  *   probes  f16 [numExperts][4096]
  * percentLoad (1..16) = rank slices present per expert (loader.swift:50, expertSize = percentLoad*inDim).
- * Pointers are BORROWED: the caller keeps the buffers alive while the handle is in use. */
+ * Pointers are BORROWED: the caller keeps the buffers alive while the handle is in use.  Registration reads the
+ * buckets once (max |w| of every bucket row, which bounds the multiply's fixed-point accumulators): fill the
+ * buffers BEFORE registering, and register again if their contents change. */
 EFFORT_API effort_w* effort_weights_fp16(effort_ctx* ctx, const void* buckets_dev, const void* stats_dev,
                               const void* probes_dev, int inDim, int outDim, int percentLoad,
                               int numExperts);
@@ -103,6 +105,19 @@ EFFORT_API int effort_dense_gemv(effort_ctx* ctx, const void* W_f16_dev, const f
 
 /* ---- reference-visible state / test hooks ------------------------------------------------------ */
 
+/* A GROUP of n (1..8) independent bucketMul calls in ONE kernel launch: call i multiplies vs[i] by ws[i] at
+ * efforts[i] into outs[i] (expNos may be NULL, or hold NULL entries = expert 0).  Same results, bit for bit, as n
+ * effort_bucketmul calls; the point is throughput: the decode loop issues such groups back to back on unchanged
+ * input -- Wq|Wk|Wv (runNetwork.swift:132-134) and W1|W3 (runNetwork.swift:178-182) -- and the reference's command
+ * buffer lets them overlap; here their workgroups share the CUs inside one launch.  All handles of a group are of
+ * the same kind; shapes may differ.  effort_group_dispatch_count / effort_group_cutoff read call idx's hooks. */
+EFFORT_API int effort_bucketmul_group(effort_ctx* ctx, int n, const effort_w* const* ws, const float* const* vs_dev,
+                           const uint32_t* const* expNos_dev, float* const* outs_dev, const double* efforts);
+EFFORT_API int effort_bucketmul_q4_group(effort_ctx* ctx, int n, const effort_w* const* ws, const float* const* vs_dev,
+                              const uint32_t* const* expNos_dev, float* const* outs_dev, const double* efforts);
+EFFORT_API int effort_group_dispatch_count(effort_ctx* ctx, int idx, uint32_t* host_out);
+EFFORT_API int effort_group_cutoff(effort_ctx* ctx, int idx, float* host_out);
+
 /* dispatch.size after calcDispatch (bucketMul.swift:46-47): number of bucket rows selected by the most
  * recent effort_bucketmul / _q4 / effort_calc_dispatch, before padding.  Synchronises the stream. */
 EFFORT_API int effort_last_dispatch_count(effort_ctx* ctx, uint32_t* host_out);
@@ -138,6 +153,9 @@ EFFORT_API int effort_set_tuning(effort_ctx* ctx, int wavesPerGroup, int elemsPe
  * redundantly inside every workgroup of it.  Costs a kernel boundary per call (worse latency) but frees the
  * multiply's workgroups sooner -- better aggregate throughput when independent calls overlap on several
  * streams/contexts.  Results are bit-identical.  Default 0 (fused). */
+/* Group launches with more work items than wgPerCU workgroups per CU run as that many PERSISTENT workgroups pulling
+ * items from per-XCD queues.  -1 = heuristic (default), 0 = always one workgroup per item. */
+EFFORT_API int effort_set_persistent(effort_ctx* ctx, int wgPerCU);
 EFFORT_API int effort_set_split_cutoff(effort_ctx* ctx, int split);
 
 /* Timing hooks.  enable = 1: HIP events are recorded on the context's stream around each of the three
@@ -149,7 +167,9 @@ EFFORT_API int effort_set_split_cutoff(effort_ctx* ctx, int split);
 EFFORT_API int effort_enable_kernel_timing(effort_ctx* ctx, int enable);
 EFFORT_API int effort_kernel_clock(effort_ctx* ctx, double* mul_us_avg, int* n_launches);
 /* Profiling aid: 24 raw u64 phase stamps written by the most recent cutoff / multiply kernels in timing mode. */
-EFFORT_API int effort_debug_stamps(effort_ctx* ctx, unsigned long long* host24);
+/* resident workgroups per CU the runtime grants the (q4, waves, elems) multiply kernel at ldsBytes of LDS */
+EFFORT_API int effort_debug_occupancy(effort_ctx* ctx, int q4, int waves, int elems, int ldsBytes);
+EFFORT_API int effort_debug_stamps(effort_ctx* ctx, unsigned long long* host32);
 EFFORT_API int effort_kernel_timing(effort_ctx* ctx, double* mul_us_avg, double* cutoff_us_avg,
                          double* integrate_us_avg, int* n_samples);
 

@@ -330,3 +330,92 @@ def test_column_shards_reproduce_the_full_product(ea, oracle_cpu):
     shardedExpertMulGroup(vd, [one], [o], 0.5)
     ea.gpu().eval()
     assert close(o.cpu().numpy(), want)
+
+
+# ---------------------------------------------------------------- grouped launches
+@pytest.mark.parametrize("split", [False, True])
+def test_group_launch_equals_single_calls(ea, oracle_cpu, split):
+    """effort_bucketmul_group: n independent calls (different shapes, inputs, efforts) in one launch give, bit for
+    bit, what n effort_bucketmul launches give, and expose every call's cutoff / dispatch.size."""
+    shapes = [(4096, 4096), (1024, 4096), (256, 4096), (1024, 4096), (4096, 4096)]
+    efforts = [0.25, 0.5, 1.0, 0.08, 0.0]
+    calls, singles, wants = [], [], []
+    for i, ((outDim, inDim), effort) in enumerate(zip(shapes, efforts)):
+        W, b, s, p = converted(oracle_cpu, outDim, inDim)
+        ew = gpu_weights(ea, W, b, s, p)
+        v = make_v(inDim, seed=40 + i, heavy=bool(i & 1))
+        vd = devf(v)
+        single = torch.zeros(outDim, device=DEV)
+        ea.bucketMul(vd, ew, None, single, effort)
+        ea.gpu().eval()
+        singles.append((single.cpu().numpy(), ea.gpu().last_dispatch_count(), ea.gpu().last_cutoff()))
+        wants.append(oracle_cpu.bucket_mul(v, b, s, p, inDim, outDim, effort))
+        calls.append((vd, ew, None, torch.full((outDim,), float("nan"), device=DEV), effort))
+    g = ea.gpu()
+    g.set_split_cutoff(split)
+    try:
+        for _ in range(2):
+            ea.bucketMulGroup(calls)
+            g.eval()
+            for i, (call, (single, n, cutoff), (want, n_or, cutoff_or)) in enumerate(zip(calls, singles, wants)):
+                got = call[3].cpu().numpy()
+                assert got.tobytes() == single.tobytes(), i
+                assert g.last_dispatch_count(i) == n == n_or and g.last_cutoff(i) == cutoff == cutoff_or
+                assert close(got, want), i
+    finally:
+        g.set_split_cutoff(False)
+    with pytest.raises(ValueError):
+        ea.bucketMulGroup(calls + calls)                      # more than 8
+
+
+@pytest.mark.parametrize("per_cu", [1, 2])
+def test_group_launch_persistent_workgroups(ea, oracle_cpu, per_cu):
+    """A group with more work items than the chip holds runs as persistent workgroups pulling items from per-XCD queues
+    (one workgroup evaluates several items, possibly of different calls): same bits as single launches, launch after
+    launch (the queues rewind)."""
+    outDim, inDim = 4096, 4096
+    W, b, s, p = converted(oracle_cpu, outDim, inDim)
+    ew = gpu_weights(ea, W, b, s, p)
+    g = ea.gpu()
+    calls, singles = [], []
+    for i in range(8):
+        vd = devf(make_v(inDim, seed=60 + i, heavy=bool(i & 1)))
+        effort = (0.1, 0.25, 0.5, 1.0)[i % 4]
+        single = torch.zeros(outDim, device=DEV)
+        ea.bucketMul(vd, ew, None, single, effort)
+        g.eval()
+        singles.append((single.cpu().numpy(), g.last_dispatch_count(), g.last_cutoff()))
+        calls.append((vd, ew, None, torch.full((outDim,), float("nan"), device=DEV), effort))
+    try:
+        g.set_persistent(per_cu)
+        g.set_tuning(8, 1, 64)                      # 4 tiles x 64 slices x 8 calls = 2048 items
+        for _ in range(3):
+            for c in calls:
+                c[3].fill_(float("nan"))
+            ea.bucketMulGroup(calls)
+            g.eval()
+            for i, (call, (single, n, cutoff)) in enumerate(zip(calls, singles)):
+                assert g.last_dispatch_count(i) == n and g.last_cutoff(i) == cutoff
+                assert close(call[3].cpu().numpy(), single), i
+    finally:
+        g.set_persistent(-1)
+        g.set_tuning(0, 0, 0)
+
+
+def test_group_launch_q4(ea, oracle_cpu, q4_case):
+    W, L, inDim, outDim = q4_case
+    ews = [ea.ExpertWeights(dev16(L["buckets"]), devf(L["bucket.stats"]), dev16(L["probes"]), inSize=inDim, outSize=outDim,
+                            outliers=devf(L["outliers"]) if k != 1 else None, q4=True) for k in range(3)]
+    calls, wants = [], []
+    for k, effort in enumerate((0.25, 0.5, 1.0)):
+        v = make_v(inDim, seed=50 + k, heavy=k == 2)
+        wants.append(oracle_cpu.bucket_mul_q4(v, L["buckets"], L["bucket.stats"], L["probes"], L["outliers"] if k != 1 else None,
+                                              inDim, outDim, effort))
+        calls.append((devf(v), ews[k], None, torch.full((outDim,), float("nan"), device=DEV), effort))
+    ea.bucketMulGroup(calls)
+    ea.gpu().eval()
+    for k, (call, (want, n, cutoff)) in enumerate(zip(calls, wants)):
+        assert ea.gpu().last_dispatch_count(k) == n and ea.gpu().last_cutoff(k) == cutoff
+        assert close(call[3].cpu().numpy(), want), k
+    with pytest.raises(ValueError):
+        ea.bucketMulGroup([calls[0], (calls[0][0],) + (gpu_weights(ea, *converted(oracle_cpu, 256, 4096)),) + calls[0][2:]])   # mixed kinds

@@ -71,6 +71,44 @@ __global__ __launch_bounds__(1024) void k_scatter(unsigned* out, int iters, unsi
     if (tid == 0) { atomicMin(&clk[0], t0); atomicMax(&clk[1], t1); }
 }
 
+// Residency probe: every workgroup spins for a fixed wall-clock time; total time / spin time = rounds, hence how
+// many workgroups the chip really keeps resident for a given (threads, LDS, VGPR) footprint.
+template <int VG>
+__global__ void k_spin(unsigned* out, unsigned long long ticks, unsigned long long* clk) {
+    extern __shared__ char sm[];
+    float r[VG];
+#pragma unroll
+    for (int i = 0; i < VG; i++) r[i] = threadIdx.x * 0.5f + i;
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) {
+#pragma unroll
+        for (int i = 0; i < VG; i++) r[i] = r[i] * 1.0001f + 0.5f;
+        __builtin_amdgcn_s_sleep(8);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VG; i++) s += r[i];
+    if (s == 1234.5f) { out[0] = 1; sm[threadIdx.x] = 1; }
+    if (threadIdx.x == 0) { atomicMin(&clk[0], t0); atomicMax(&clk[1], (unsigned long long)wall_clock64()); }
+}
+
+template <int VG>
+static void run_spin(int threads, int lds, int blocks, double spinUs, double wallKHz, unsigned* dOut, unsigned long long* dClk) {
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spin<VG>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    int occ = 0;
+    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(&k_spin<VG>), threads, lds));
+    for (int rep = 0; rep < 2; rep++) {
+        unsigned long long h[2] = {~0ull, 0};
+        CK(hipMemcpy(dClk, h, 16, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_spin<VG>, dim3(blocks), dim3(threads), lds, 0, dOut, (unsigned long long)(spinUs * wallKHz / 1000.0), dClk);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(h, dClk, 16, hipMemcpyDeviceToHost));
+        const double us = (double)(h[1] - h[0]) * 1000.0 / wallKHz;
+        if (rep) printf("spin vgpr~%3d threads %4d lds %6d blocks %5d spin %5.1f us: total %7.1f us  => %.2f rounds, ~%.0f resident (runtime occupancy %d/CU)\n",
+                        VG, threads, lds, blocks, spinUs, us, us / spinUs, blocks / (us / spinUs), occ);
+    }
+}
+
 template <int MODE>
 static void run_scatter(const char* name, int nCU, double wallKHz, unsigned* dOut, unsigned long long* dClk) {
     const int iters = 2000, blocks = nCU * 2;
@@ -118,6 +156,17 @@ int main() {
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
             if (rep) printf("stream 2B/lane 128-B pieces, pitch %6zu elems: %7.1f GB/s (useful bytes)\n", pitch, nPieces * 128.0 / ms / 1e6);
         }
+    }
+    if (getenv("MB_SPIN")) {
+        for (int threads : {256, 512, 1024})
+            for (int lds : {8192, 36000, 70000}) {
+                run_spin<16>(threads, lds, 1536, 20.0, wallKHz, dOut, dClk);
+                run_spin<16>(threads, lds, 6144, 20.0, wallKHz, dOut, dClk);
+            }
+        run_spin<16>(512, 20000, 1536, 5.0, wallKHz, dOut, dClk);
+        run_spin<16>(512, 20000, 6144, 5.0, wallKHz, dOut, dClk);
+        run_spin<64>(512, 20000, 1536, 20.0, wallKHz, dOut, dClk);
+        return 0;
     }
     run_scatter<0>("ds_add_f32 (private slots)", nCU, wallKHz, dOut, dClk);
     run_scatter<1>("ds_add_u32 (private slots)", nCU, wallKHz, dOut, dClk);

@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--mats", type=int, default=16)
     ap.add_argument("--split", type=int, default=0)
     ap.add_argument("--q4", type=int, default=0)
+    ap.add_argument("--persistent", type=int, default=-1, help="workgroups per CU of persistent group launches (0 = plain grid)")
+    ap.add_argument("--groups", default="", help="comma list: group sizes (calls per launch, effort_bucketmul_group) to try")
     ap.add_argument("--streams", default="1", help="comma list: numbers of concurrent streams/contexts to try")
     ap.add_argument("--configs", default="16,1,0;16,1,24;16,1,32;16,1,64;16,2,0;16,2,32;8,1,0;8,1,48;8,1,96;8,2,0;8,2,48;8,4,0;8,4,32;4,1,0;4,2,0;4,4,0")
     args = ap.parse_args()
@@ -45,6 +47,7 @@ def main():
             try:
                 g.set_tuning(W, E, S)
                 g.set_split_cutoff(bool(args.split))
+                g.set_persistent(args.persistent)
                 g.enable_kernel_timing(2)
                 for ew, o in zip(ews, outs):
                     mulfn(v, ew, None, o, effort)
@@ -96,6 +99,43 @@ def main():
                     del go
                     for c in ctxs:
                         c.close()
+                for G in [int(x) for x in args.groups.split(",") if x]:
+                    g.enable_kernel_timing(0)            # the stamps cost contended atomics: throughput is measured without
+                    gg = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gg):
+                        for i in range(0, len(ews), G):
+                            ea.bucketMulGroup([(v, ew, None, o, effort) for ew, o in zip(ews[i:i + G], outs[i:i + G])])
+                    for _ in range(5):
+                        gg.replay()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(30):
+                        gg.replay()
+                    torch.cuda.synchronize()
+                    over[f"g{G}_nostamp"] = round((time.perf_counter() - t0) / 30 / len(ews) * 1e6, 2)
+                    del gg
+                    g.enable_kernel_timing(2)
+                    gg = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gg):
+                        for i in range(0, len(ews), G):
+                            ea.bucketMulGroup([(v, ew, None, o, effort) for ew, o in zip(ews[i:i + G], outs[i:i + G])])
+                    g._bind_stream()
+                    for _ in range(5):
+                        gg.replay()
+                    g.kernel_clock()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(30):
+                        gg.replay()
+                    torch.cuda.synchronize()
+                    over[f"g{G}"] = round((time.perf_counter() - t0) / 30 / len(ews) * 1e6, 2)
+                    over[f"g{G}_kernel_us"] = round(g.kernel_clock()["mul_us"], 2)
+                    stg = g.debug_stamps()
+                    over[f"g{G}_wg0"] = [round((stg[9 + i] - stg[8 + i]) / 100.0, 2) for i in range(5)]
+                    over[f"g{G}_ramp_us"] = round(stg[19] / (35 * ((len(ews) + G - 1) // G)) / 100.0, 2)   # 5 + 30 replays since the stamps were reset
+                    over[f"g{G}_wgmax,streammax,reduce_us"] = [round(stg[20] / 100.0, 2), round(stg[21] / 100.0, 2), round((stg[16] - stg[15]) / 100.0, 2)]
+                    over[f"g{G}_wgmean"] = [round(stg[24 + i] / max(1, stg[29]) / 100.0, 2) for i in range(5)]
+                    del gg
                 gr = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(gr):
                     for ew, o in zip(ews, outs):
