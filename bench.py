@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- bucketMul throughput on MI355X (driver contract: DESIGN.md "Measurement").
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--streams 4] [--effort 0.25]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--group 8] [--effort 0.25]
 
 Workload (BASELINE.json configs[1]): Mistral-7B-FFN-shaped matrix 4096 x 11008, fp16 buckets, bucketMul at
 25 % effort (the north-star operating point), plus an effort sweep 10..100 % in the same JSON line.
@@ -9,17 +9,18 @@ One STEP = one pass of the hot path over one batch of synthetic input = 32 bucke
 converted matrix (rotation i % 32 exactly like benchmarks/benchmark.swift:206,255 -- 2.9 GB of buckets, so
 reads come from HBM, not the 256 MB Infinity Cache), all on the same input vector, each writing its own output
 vector.  Inputs are resident in HBM before the timed region.  The 32 calls of a step are replayed from ONE
-hipGraph, so the host is not in the timed path (the reference's timeIt, helpers/timeit.swift:10-34, likewise
-enqueues everything and waits once).  The calls of a step are independent, so the graph spreads them round-robin
-over `--streams` HIP streams, each with its own effort context (scratch): the prologue of one call (cutoff,
-row selection) overlaps the streaming phase of another.  `serial` in the output is the same step on ONE stream
-(every call waits for the previous one -- the latency a dependent decode chain sees).
+hipGraph on ONE stream, so the host is not in the timed path (the reference's timeIt, helpers/timeit.swift:10-34,
+likewise enqueues everything and waits once).  The calls of a step are independent (as Wq|Wk|Wv or W1|W3 are in the
+decode loop), so they are issued `--group` at a time through effort_bucketmul_group: ONE kernel launch per group.
+`by_group_size` in the output gives the same step at 1, 2, 3, 4 and 8 calls per launch; group size 1 is the
+dependent-chain latency (every call waits for the previous one).
 
 value            = effective (dense-equivalent) GB/s = 2*inDim*outDim bytes per call / time per call, whole job
                    over all ranks.
 tokens_per_s     = the reference's projection 1/(t_call * 4 * 32) (helpers/timeit.swift:26,33-34).
-roofline         = dominant kernel (bucket_mul_kernel, the whole call in one launch): algorithmic bytes per
-                   launch / its average duration in THIS run's timed configuration.
+roofline         = dominant kernel (bucket_mul_kernel: a whole group of calls in one launch): algorithmic bytes per
+                   launch / its average duration in THIS run's timed configuration.  Kernels of one stream do not
+                   overlap, so this is also what `rocprofv3 --kernel-trace --stats` reports for the same command.
 cpu_baseline     = the CPU oracle (a port: the reference ships no CPU path) on the host cores, bounded sample.
 
 N > 1 (one process per GPU, RCCL): independent matrices are partitioned across the ranks (every rank owns 32
@@ -44,6 +45,7 @@ IN_DIM, OUT_DIM = 4096, 11008
 N_MATS = 32
 SWEEP = [0.10, 0.15, 0.20, 0.25, 0.30, 0.40, 0.50, 0.60, 0.70, 0.80, 0.90, 1.00]
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PMC_FILE = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")   # written from a rocprofv3 --pmc pass (tools/pmc_traffic.py)
 
 
 def log(*a):
@@ -57,7 +59,7 @@ def algorithmic_bytes(D: int, inDim: int, outDim: int) -> int:
 
 
 def mul_kernel_bytes(D: int, inDim: int, outDim: int) -> int:
-    """What ONE bucket_mul_kernel launch must move (the fused kernel is the whole call)."""
+    """What bucket_mul_kernel must move per CALL it serves (a launch serves `group` calls)."""
     return algorithmic_bytes(D, inDim, outDim)
 
 
@@ -81,52 +83,43 @@ def make_weights(ea, n, inDim, outDim, seed0, dev, keep_core=True, q4=False):
     return ews
 
 
-class Lanes:
-    """K effort contexts on K HIP streams; captures a step (one call per matrix, round-robin) into one hipGraph."""
+class Step:
+    """One step = one call per (matrix, output) item.  `group` calls per launch on the context's stream; with K > 1
+    the launches are additionally spread round-robin over K HIP streams / contexts (used for the dense baseline,
+    which has no grouped form).  capture() returns the step as one hipGraph."""
 
-    def __init__(self, ea, device, K, tune=None):
+    def __init__(self, ea, device, K=1):
         self.ea, self.K = ea, K
         self.ctxs = [ea.gpu(device)] if K == 1 else [ea.Gpu(device) for _ in range(K)]
         self.streams = [None] if K == 1 else [torch.cuda.Stream(device=device) for _ in range(K)]
-        if tune:
-            for c in self.ctxs:
-                c.set_tuning(*tune)
 
-    def _enqueue(self, fn, items):
+    def _enqueue(self, fn, chunks):
         if self.K == 1:
-            for it in items:
-                fn(self.ctxs[0], *it)
+            for ch in chunks:
+                fn(self.ctxs[0], ch)
             return
         s0 = torch.cuda.current_stream()
         for st in self.streams:
             st.wait_stream(s0)
-        for i, it in enumerate(items):
+        for i, ch in enumerate(chunks):
             with torch.cuda.stream(self.streams[i % self.K]):
-                fn(self.ctxs[i % self.K], *it)
+                fn(self.ctxs[i % self.K], ch)
         for st in self.streams:
             s0.wait_stream(st)
 
-    def capture(self, fn, items):
-        self._enqueue(fn, items)                     # warm: handles, kernel attributes, rocBLAS workspaces
+    def capture(self, fn, chunks):
+        self._enqueue(fn, chunks)                    # warm: handles, kernel attributes, rocBLAS workspaces
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            self._enqueue(fn, items)
+            self._enqueue(fn, chunks)
         for c in self.ctxs:
             c._bind_stream()
         return g
 
-    def timing(self, mode):
-        for c in self.ctxs:
-            c.enable_kernel_timing(mode)
 
-    def kernel_clock(self):
-        tot, n = 0.0, 0
-        for c in self.ctxs:
-            k = c.kernel_clock()
-            tot += k["mul_us"] * k["launches"]
-            n += k["launches"]
-        return (tot / n if n else 0.0), n
+def chunked(items, n):
+    return [items[i:i + n] for i in range(0, len(items), n)]
 
 
 def time_replays(g, steps, warmup, barrier=None, after=None):
@@ -177,12 +170,14 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--effort", type=float, default=0.25)
-    ap.add_argument("--streams", type=int, default=4, help="concurrent HIP streams / effort contexts per GPU")
+    ap.add_argument("--group", type=int, default=8, help="independent calls per kernel launch (1..8)")
     ap.add_argument("--partition", choices=["matrices", "columns"], default="matrices")
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--tune", default="8,2,32", help="waves,elems,slices of the multiply kernel in the overlapped run (0,0,0 = heuristic)")
+    ap.add_argument("--headline-only", action="store_true", help="only the timed job (for rocprofv3 passes: every bucket_mul_kernel dispatch is then the timed configuration)")
+    ap.add_argument("--tune", default="0,0,0", help="waves,elems,slices of the multiply kernel (0,0,0 = heuristic)")
     args = ap.parse_args()
+    G = max(1, min(8, args.group))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -200,7 +195,7 @@ def main():
 
     import effort_amd as ea
     g = ea.gpu(local)
-    tune = tuple(int(x) for x in args.tune.split(",")) if args.streams > 1 else None
+    g.set_tuning(*(int(x) for x in args.tune.split(",")))
 
     inDim, outDim = IN_DIM, OUT_DIM
     t_setup = time.perf_counter()
@@ -227,14 +222,14 @@ def main():
             dist.barrier()
 
     def mul(effort):
-        return lambda ctx, ew, o: ea.bucketMul(v, ew, None, o, effort, gpu=ctx)
+        return lambda ctx, chunk: ea.bucketMulGroup([(v, ew, None, o, effort) for ew, o in chunk], gpu=ctx)
 
     items = list(zip(ews, outs))
-    lanes = Lanes(ea, local, args.streams, tune)
+    one = Step(ea, local)
 
     # ---------------- the timed job: K steps at the headline effort --------------------------------
-    graph = lanes.capture(mul(args.effort), items)
-    D = lanes.ctxs[(N_MATS - 1) % lanes.K].last_dispatch_count()
+    graph = one.capture(mul(args.effort), chunked(items, G))
+    D = g.last_dispatch_count((N_MATS - 1) % G)
     exchange = (lambda: dist.all_gather_into_tensor(gathered.view(-1), outs_all.view(-1))) if dist else None
     dt = time_replays(graph, args.steps, args.warmup, barrier, exchange)
     if dist:
@@ -252,80 +247,91 @@ def main():
         "ms_per_step": round(dt * 1e3, 5), "higher_is_better": True, "scaling": "strong" if columns else "weak",
         "vs_baseline": None, "dtype": "f16", "data": "synthetic",
         "config": {"workload": f"bucketMul {inDim}x{outDim} fp16 buckets, effort {args.effort}, {N_MATS} distinct matrices rotated "
-                               f"(one call each per step), f32 accumulate; one fused kernel launch per call, calls spread over "
-                               f"{args.streams} HIP streams in one hipGraph", "effort": args.effort, "matrices_per_step": N_MATS,
-                   "inDim": inDim, "outDim": outDim, "streams": args.streams, "kernel_geometry(waves,elems,slices)": args.tune if tune else "heuristic",
+                               f"(one call each per step), fixed-point accumulate (f32 out); {G} independent calls per fused "
+                               f"kernel launch, one stream, one hipGraph", "effort": args.effort, "matrices_per_step": N_MATS,
+                   "inDim": inDim, "outDim": outDim, "calls_per_launch": G, "kernel_geometry(waves,elems,slices)": args.tune if args.tune != "0,0,0" else "heuristic",
                    "partition": ("columns" if columns else "matrices") if world > 1 else "none", "dispatch_rows": D},
         "us_per_call": round(t_call * 1e6, 3),
         "tokens_per_s": round(1.0 / (t_call * 4 * 32), 2),
     }
 
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.headline_only:
         kb = mul_kernel_bytes(D, inDim, outDim)
+        launches = (N_MATS + G - 1) // G
         # ---------------- roofline of the dominant kernel, in the timed configuration -----------------
-        lanes.timing(2)                                  # device wall clock inside the kernel (graph safe)
-        gt = lanes.capture(mul(args.effort), items)
+        g.enable_kernel_timing(2)                        # device wall clock inside the kernel (graph safe)
+        gt = one.capture(mul(args.effort), chunked(items, G))
         for _ in range(5):
             gt.replay()
-        lanes.kernel_clock()
+        g.kernel_clock()
         for _ in range(20):
             gt.replay()
-        kus, nl = lanes.kernel_clock()
-        lanes.timing(0)
+        kc = g.kernel_clock()
+        kus, nl = kc["mul_us"], kc["launches"]
         del gt
-        # ---------------- the same step on ONE stream (dependent-chain latency) -----------------------
-        one = Lanes(ea, local, 1)
-        gs = one.capture(mul(args.effort), items)
-        ts = time_replays(gs, 50, 10) / N_MATS
-        one.timing(2)
-        gs2 = one.capture(mul(args.effort), items)
-        for _ in range(3):
-            gs2.replay()
-        one.kernel_clock()
-        for _ in range(10):
-            gs2.replay()
-        kus1, _ = one.kernel_clock()
-        one.timing(1)                                    # HIP events on the launch stream, queue pre-filled
+        g.enable_kernel_timing(1)                        # HIP events on the launch stream, queue pre-filled
         torch.cuda._sleep(20_000_000)                    # keep the GPU busy while the host enqueues
         for r in range(4):
-            for ew, o in items:
-                ea.bucketMul(v, ew, None, o, args.effort)
+            for ch in chunked(items, G):
+                ea.bucketMulGroup([(v, ew, None, o, args.effort) for ew, o in ch])
         evt = g.kernel_timing()
-        one.timing(0)
-        del gs, gs2
+        g.enable_kernel_timing(0)
+        traffic = None
+        try:
+            with open(PMC_FILE) as f:
+                pmc = json.load(f)
+            if pmc.get("calls_per_launch") == G and abs(pmc.get("effort", -1) - args.effort) < 1e-9:
+                traffic = pmc["hbm_bytes_per_launch"]
+        except Exception:
+            pmc = None
+        t_launch = dt / launches                         # launch-to-launch in the timed graph (includes the gap between kernels)
         result["roofline"] = {
-            "bound": "hbm", "kernel": "bucket_mul_kernel", "achieved": round(kb / kus / 1e3, 1), "peak": HBM_PEAK_GBPS,
-            "unit": "GB/s", "frac": round(kb / kus / 1e3 / HBM_PEAK_GBPS, 4), "traffic": None,
-            "bytes_per_launch": kb, "kernel_us": round(kus, 3), "launches_sampled": nl,
-            "kernel_us_source": f"device wall clock, first workgroup start -> last end, averaged over the launches of the {args.streams}-stream graph",
-            "aggregate_achieved_GBps": round(kb / t_call / 1e9, 1), "aggregate_frac": round(kb / t_call / 1e9 / HBM_PEAK_GBPS, 4),
+            "bound": "hbm", "kernel": "bucket_mul_kernel", "achieved": round(G * kb / kus / 1e3, 1), "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s", "frac": round(G * kb / kus / 1e3 / HBM_PEAK_GBPS, 4), "traffic": traffic,
+            "traffic_source": (f"rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE pass of this command ({os.path.relpath(PMC_FILE, ROOT)}), "
+                               "corrected as MI355X_MICROARCH.md prescribes") if traffic else None,
+            "calls_per_launch": G, "bytes_per_launch": G * kb, "bytes_per_call": kb, "kernel_us": round(kus, 3), "launches_sampled": nl,
+            "kernel_us_source": "device wall clock, first workgroup start -> last workgroup end, averaged over the launches of the timed graph",
+            "kernel_us_hip_events": round(evt["mul_us"], 3),
+            "launch_to_launch_us": round(t_launch * 1e6, 3),
+            "achieved_incl_launch_gaps": round(G * kb / t_launch / 1e9, 1), "frac_incl_launch_gaps": round(G * kb / t_launch / 1e9 / HBM_PEAK_GBPS, 4),
         }
-        result["serial"] = {"us_per_call": round(ts * 1e6, 3), "effective_GBps": round(eff_bytes / ts / 1e9, 1),
-                            "kernel_us": round(kus1, 3), "kernel_us_hip_events": round(evt["mul_us"], 3),
-                            "kernel_achieved_GBps": round(kb / kus1 / 1e3, 1), "kernel_frac": round(kb / kus1 / 1e3 / HBM_PEAK_GBPS, 4)}
+        # ---------------- the same step at other group sizes (1 = dependent-chain latency) ------------
+        by = {}
+        for n in (1, 2, 3, 4, 8):
+            gn = one.capture(mul(args.effort), chunked(items, n))
+            tn = time_replays(gn, 40, 10) / N_MATS
+            by[str(n)] = {"us_per_call": round(tn * 1e6, 3), "effective_GBps": round(eff_bytes / tn / 1e9, 1),
+                          "achieved_GBps": round(kb / tn / 1e9, 1), "tokens_per_s": round(1.0 / (tn * 4 * 32), 1)}
+            del gn
+        result["by_group_size"] = by
+        ts = by["1"]["us_per_call"] * 1e-6
         # ---------------- dense rocBLAS baseline (basicMul over the rotating cores) -------------------
-        dense_out = [torch.zeros(outDim, device=dev) for _ in range(lanes.K)]
-        ditems = [(ew, dense_out[i % lanes.K]) for i, ew in enumerate(ews)]
+        four = Step(ea, local, 4)
+        dense_out = [torch.zeros(outDim, device=dev) for _ in range(4)]
+        ditems = [[(ew, dense_out[i % 4])] for i, ew in enumerate(ews)]
 
-        def dense(ctx, ew, o):
-            ea.basicMul(v, ew.core, o, gpu=ctx)
+        def dense(ctx, chunk):
+            for ew, o in chunk:
+                ea.basicMul(v, ew.core, o, gpu=ctx)
         td1 = time_replays(one.capture(dense, ditems), 30, 5) / N_MATS
-        tdk = time_replays(lanes.capture(dense, ditems), 30, 5) / N_MATS
-        result["dense_rocblas"] = {"us_per_call_serial": round(td1 * 1e6, 3), f"us_per_call_{lanes.K}_streams": round(tdk * 1e6, 3),
+        tdk = time_replays(four.capture(dense, ditems), 30, 5) / N_MATS
+        result["dense_rocblas"] = {"us_per_call_serial": round(td1 * 1e6, 3), "us_per_call_4_streams": round(tdk * 1e6, 3),
                                    "GBps": round(eff_bytes / min(td1, tdk) / 1e9, 1),
                                    "speedup_at_effort": round(min(td1, tdk) / t_call, 3), "speedup_serial_vs_serial": round(td1 / ts, 3)}
         # ---------------- effort sweep ----------------------------------------------------------------
         if not args.no_sweep:
             sweep = []
             for e in SWEEP:
-                ge = lanes.capture(mul(e), items)
-                De = lanes.ctxs[(N_MATS - 1) % lanes.K].last_dispatch_count()
+                ge = one.capture(mul(e), chunked(items, G))
+                De = g.last_dispatch_count((N_MATS - 1) % G)
                 te = time_replays(ge, 40, 10) / N_MATS
                 ea.basicMul(v, ews[N_MATS - 1].core, dense_out[0])
                 cs = ea.cosineSimilarityTo(outs[N_MATS - 1], dense_out[0])
                 sweep.append({"effort": e, "dispatch_rows": De, "us_per_call": round(te * 1e6, 3),
                               "effective_GBps": round(eff_bytes / te / 1e9, 1),
                               "achieved_GBps": round(algorithmic_bytes(De, inDim, outDim) / te / 1e9, 1),
+                              "frac_of_hbm_peak": round(algorithmic_bytes(De, inDim, outDim) / te / 1e9 / HBM_PEAK_GBPS, 4),
                               "tokens_per_s": round(1.0 / (te * 4 * 32), 1), "cos_vs_dense": round(cs, 5)})
                 del ge
             result["sweep"] = sweep

@@ -208,10 +208,9 @@ static bool supported(int W, int E) {
            (W == 4 && (E == 1 || E == 2 || E == 4 || E == 8)) || (W == 2 && (E == 4 || E == 8));
 }
 
-static int choose_geom(const effort_ctx* c, const effort_w* w, MulGeom* g, int* Wout, int* Eout) {
-    // defaults: FP16 16 waves per workgroup x 2 columns per lane (128 KiB of private accumulator tiles);
-    // Q4 8 waves x 1 word (= 4 sub-buckets) per lane (64 KiB, two workgroups per CU)
-    const int W = c->tuneW ? c->tuneW : (w->fmt == kFp16 ? 16 : 8);
+static int choose_geom(const effort_ctx* c, const effort_w* w, int groupSize, MulGeom* g, int* Wout, int* Eout) {
+    // defaults: 8 waves per workgroup; a lane owns 2 columns of a tile (FP16) or 1 word = 4 sub-buckets (Q4)
+    const int W = c->tuneW ? c->tuneW : 8;
     const int E = c->tuneE ? c->tuneE : (w->fmt == kFp16 ? 2 : 1);
     if (!supported(W, E)) return EFFORT_ERR_ARG;
     const uint32_t nacc = w->fmt == kFp16 ? 16 : 32;
@@ -223,11 +222,14 @@ static int choose_geom(const effort_ctx* c, const effort_w* w, MulGeom* g, int* 
     uint32_t S;
     if (c->tuneS) S = (c->tuneS + 7) / 8 * 8;
     else {
-        // Measured on MI355X (tools/tune.py, 4096x4096 .. 4096x11008, 10-100 % effort): the call is dominated by
-        // per-workgroup fixed work (cutoff, selection, tile reduction, slab hand-off), so FEWER, fatter workgroups
-        // win even when they leave CUs idle; 32 row slices is the sweet spot, capped by one round of workgroups.
-        const uint32_t cap = (c->numCU * 2u) / g->tiles / 8 * 8;
-        S = cap < 32u ? cap : 32u;
+        // Measured on MI355X (tools/tune.py, 4096x4096 .. 4096x11008, 10-100 % effort).  A workgroup's life is mostly
+        // fixed-latency steps (staging, cutoff, selection, hand-off), so FEWER, fatter workgroups win even when they
+        // leave CUs idle: slices of 128 input rows for a lone call; and the more calls share a launch, the fatter the
+        // slices (256 rows from 2 calls, 512 from 8), because the other calls' workgroups fill the chip.
+        const uint32_t rows = groupSize >= 8 ? 512u : groupSize >= 2 ? 256u : 128u;
+        const uint32_t want = ((w->inDim + rows - 1) / rows + 7) / 8 * 8;
+        const uint32_t cap = (c->numCU * 2u) / g->tiles / 8 * 8;              // one round of workgroups
+        S = cap < want ? cap : want;
     }
     if (S > w->inDim) S = w->inDim / 8 * 8;
     if (S < 8) S = 8;
@@ -275,7 +277,7 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
         if (!(efforts[i] >= 0.0 && efforts[i] <= 1.0)) return fail(c, EFFORT_ERR_EFFORT, "bucketmul: effort outside [0,1]");
         MulArgs& a = ga.call[i];
         int Wi, Ei;
-        int rc = choose_geom(c, w, &a.g, &Wi, &Ei);
+        int rc = choose_geom(c, w, n, &a.g, &Wi, &Ei);
         if (rc != EFFORT_OK) return fail(c, rc, "bucketmul: no launch geometry for this shape/tuning");
         if (i == 0) { W = Wi; E = Ei; }
         const MulGeom& g = a.g;
@@ -331,7 +333,7 @@ extern "C" int effort_calc_dispatch(effort_ctx* c, const effort_w* w, const floa
     if (!c || !w || !v || !dispatch) return fail(c, EFFORT_ERR_ARG, "calc_dispatch: null argument");
     if (!(effort >= 0.0 && effort <= 1.0)) return fail(c, EFFORT_ERR_EFFORT, "calc_dispatch: effort outside [0,1]");
     MulGeom g; int W, E;
-    int rc = choose_geom(c, w, &g, &W, &E);
+    int rc = choose_geom(c, w, 1, &g, &W, &E);
     if (rc != EFFORT_OK) return fail(c, rc, "calc_dispatch: geometry");
     const uint32_t q = (uint32_t)(int)((double)(kProbes - 1) * (1.0 - effort));
     HIP_TRY(c, launch_find_cutoff(v, w->probes, expNo, q, c->d_cutoff, c->d_count, nullptr, c->stream));

@@ -1,40 +1,40 @@
-// bucket_mul -- the hot path as ONE kernel launch per bucketMul call.
+// bucket_mul -- the hot path as ONE kernel launch per bucketMul call, or per GROUP of independent calls.
 // Replaces the reference's six launches: findCutoff32, prepareDispatch, roundUp, zeroRange32, bucketMul,
 // bucketIntegrate (bucketMul.metal:11-247) and, for Q4, prepareDispatchQ4, bucketMulQ4, calcOutliers
-// (bucketMulQ4.metal:13-92).  On MI355X a dependent kernel boundary costs 1.5-5 us and the whole call moves
-// ~23 MB (2.8 us of HBM time), so the call is a latency chain first and a bandwidth problem second: the design
-// goal is one launch, one memory round trip per dependent step, and no host involvement.
+// (bucketMulQ4.metal:13-92).  On MI355X a dependent kernel boundary costs 1.5-5 us and a whole call moves
+// ~23 MB (2.9 us of HBM time), so a call is a latency chain first and a bandwidth problem second: one launch, one
+// memory round trip per dependent step, no host involvement -- and, for throughput, several independent calls
+// (the decode loop's Wq|Wk|Wv, W1|W3) sharing one launch so that their workgroups overlap on the CUs.
 //
 // Work decomposition (MI355X-first, not the reference's [cols x 32] grid of 32-thread groups):
-//   grid   = T column tiles x S row slices, one workgroup of W wave64 each; tiles*S <= resident capacity so
-//            the grid is one round of workgroups; block id -> (tile, slice) remapped so all tiles of a slice sit
-//            on one XCD (same L2: they share the stats lines and the 128-B lines that straddle two tiles).
+//   item   = one (call, column tile, row slice); one workgroup of W wave64 works an item.  Item id -> (tile, slice)
+//            is remapped so all tiles of a slice sit on one XCD (same L2: they share the stats lines and the 128-B
+//            lines that straddle two tiles).
 //   slice  = a contiguous block of B input rows (all ranks of them) -> its kept bucket rows are neighbours in
-//            HBM within each rank plane.
+//            HBM within each rank plane.  B = 128 for a lone call, up to 512 when 8 calls share the launch.
 //   tile   = 64*E u16 columns; lane l of every wave owns columns l*E .. l*E+E-1 of the tile, so one wave load
 //            instruction reads one contiguous 128*E-byte piece of one bucket row.
-// Per workgroup:
-//   A. every thread issues ALL the loads the selection needs up front -- its share of v and the probes, its
-//      slice of v, the stats of the candidate rows it will test -- one memory round trip; the private
-//      accumulator tiles are zeroed while those loads fly.
+// Per item:
+//   A. stage in LDS, in one memory round trip, the slice of v and the row means of all candidate rows of the slice
+//      (16*B, Q4 8*B); sum |v| (the fixed-point bound, D).
 //   B. the cutoff is evaluated redundantly by every workgroup (cutoff_device.h: bit-exact findCutoff32), which
 //      is cheaper than a kernel boundary or a cross-workgroup flag.
-//   C. the 16*B (Q4: 8*B) candidate rows are tested exactly as prepareDispatch does (cutoff < (1e5*mean)*|v|)
-//      and the survivors compacted, in ascending bucket-row order, into an LDS list (wave ballots + mbcnt
-//      prefix; no global atomics, deterministic).
+//   C. the candidate rows are tested exactly as prepareDispatch does (cutoff < (1e5*mean)*|v|) and the survivors
+//      compacted, in ascending bucket-row order, into an LDS list (wave ballots + mbcnt, ONE barrier; no global
+//      atomics, deterministic).
 //   D. waves take list entries round-robin and stream those rows from HBM: two batches of 16 buffer loads in
 //      flight per lane, the row offset in an SGPR (v_readlane of the decoded entry -> buffer soffset, no per-row
-//      address VALU).  Each product is added into a PRIVATE per-wave LDS accumulator tile acc[slot][j][lane]
-//      (slot = the 4 position bits of the f16 weight; Q4: sub-bucket*8 + the 3 position bits of the nibble) by a
-//      plain ds_read / v_add / ds_write: the LDS float atomic (ds_add_f32) measured 0.5 elements/clk/CU on
-//      MI355X against 6.8 for read-add-write and 2.1 for a 16-way register select chain (tools/microbench.hip).
-//      The layout puts lane l on LDS bank l%32 whatever the slot, so the scatter is bank-conflict free; the E
-//      (Q4: 4E) slots one lane touches for one row are distinct by construction, so their read-add-writes are
-//      issued together; rows are processed in order, which fixes the f32 summation order.
-//   E. the W private tiles are summed in wave order into one partial "slab", stored write-through; the workgroup
-//      takes a ticket on its tile's arrival counter, and the LAST workgroup of each tile sums the S slabs in
-//      slice order (and, for Q4, adds that output's outliers in table order) and writes out[].  The result does
-//      not depend on arrival order: deterministic end to end.  (Q4 outliers: q4_outliers_kernel, launched next.)
+//      address VALU).  Each product is added into ONE LDS accumulator tile acc[slot][j][lane] shared by the
+//      workgroup (slot = the 4 position bits of the f16 weight; Q4: sub-bucket*8 + the 3 position bits of the
+//      nibble) with an INTEGER LDS atomic: products are converted to fixed point on a per-workgroup power-of-two
+//      grid.  Measured on MI355X (tools/microbench.hip, elements/clk/CU): ds_add_f32 0.5, read-add-write on
+//      private per-wave tiles 6.8, 16-way register select 2.1, ds_add_u32 13.  Integer addition is associative:
+//      the result does not depend on the order waves run in.  The layout puts lane l on LDS bank l%32 whatever
+//      the slot, so a wave's scatter is bank-conflict free.
+//   E. the tile is converted back to f32 into one partial "slab", stored write-through; the workgroup takes a ticket
+//      on its tile's arrival counter, and the LAST workgroup of each tile sums the S slabs in slice order and writes
+//      out[].  The result does not depend on arrival order: deterministic end to end.  (Q4 outliers:
+//      q4_outliers_kernel, launched next.)
 #include <type_traits>
 
 #include "cutoff_device.h"
@@ -50,6 +50,12 @@ constexpr int kRounds = 16;  // selection rounds of NT candidate slots a workgro
 #endif
 #ifndef EFFORT_ABLATE_NOLOAD
 #define EFFORT_ABLATE_NOLOAD 0
+#endif
+
+// Register budget of the 8-wave (and smaller) instantiations, as waves per SIMD the kernel must fit.  4 = 128 VGPRs
+// (two 8-wave workgroups per CU).  Measured: forcing 6 (80 VGPRs, three per CU; hipcc spills 64 B) is 5-15 % SLOWER.
+#ifndef EFFORT_MIN_WAVES_PER_EU
+#define EFFORT_MIN_WAVES_PER_EU 4
 #endif
 
 constexpr int kSc1 = 16;     // buffer aux bit: sc1 = write-through store / L1-bypassing load (cross-XCD visible)
@@ -500,7 +506,7 @@ __device__ __forceinline__ void mul_item(const GroupArgs& ga, const uint32_t ite
 // tools/microbench.hip: residency probe), so a group launch sizes its grid to the chip -- R workgroups per CU,
 // R fixed by the LDS each one asks for -- and balances the work itself.
 template <int FMT, int E, int W>
-__global__ __launch_bounds__(64 * W) void bucket_mul_kernel(const GroupArgs ga) {
+__global__ __launch_bounds__(64 * W, (W <= 8 ? EFFORT_MIN_WAVES_PER_EU : 4)) void bucket_mul_kernel(const GroupArgs ga) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ uint32_t s_item;
     const uint32_t total = ga.wgEnd[ga.count - 1];

@@ -335,35 +335,42 @@ def test_column_shards_reproduce_the_full_product(ea, oracle_cpu):
 # ---------------------------------------------------------------- grouped launches
 @pytest.mark.parametrize("split", [False, True])
 def test_group_launch_equals_single_calls(ea, oracle_cpu, split):
-    """effort_bucketmul_group: n independent calls (different shapes, inputs, efforts) in one launch give, bit for
-    bit, what n effort_bucketmul launches give, and expose every call's cutoff / dispatch.size."""
+    """effort_bucketmul_group: n independent calls (different shapes, inputs, efforts) in one launch.  Selection is
+    exact whatever the launch geometry: every call's cutoff / dispatch.size equal the single launch's and the
+    oracle's.  With the geometry pinned the outputs are the single launches' bit for bit; with the default geometry
+    (fatter row slices the more calls share the launch) they agree to the f32 rounding of the slice sums."""
     shapes = [(4096, 4096), (1024, 4096), (256, 4096), (1024, 4096), (4096, 4096)]
     efforts = [0.25, 0.5, 1.0, 0.08, 0.0]
-    calls, singles, wants = [], [], []
-    for i, ((outDim, inDim), effort) in enumerate(zip(shapes, efforts)):
-        W, b, s, p = converted(oracle_cpu, outDim, inDim)
-        ew = gpu_weights(ea, W, b, s, p)
-        v = make_v(inDim, seed=40 + i, heavy=bool(i & 1))
-        vd = devf(v)
-        single = torch.zeros(outDim, device=DEV)
-        ea.bucketMul(vd, ew, None, single, effort)
-        ea.gpu().eval()
-        singles.append((single.cpu().numpy(), ea.gpu().last_dispatch_count(), ea.gpu().last_cutoff()))
-        wants.append(oracle_cpu.bucket_mul(v, b, s, p, inDim, outDim, effort))
-        calls.append((vd, ew, None, torch.full((outDim,), float("nan"), device=DEV), effort))
     g = ea.gpu()
-    g.set_split_cutoff(split)
-    try:
-        for _ in range(2):
-            ea.bucketMulGroup(calls)
+    for pinned in (True, False):
+        if pinned:
+            g.set_tuning(8, 2, 32)
+        calls, singles, wants = [], [], []
+        for i, ((outDim, inDim), effort) in enumerate(zip(shapes, efforts)):
+            W, b, s, p = converted(oracle_cpu, outDim, inDim)
+            ew = gpu_weights(ea, W, b, s, p)
+            v = make_v(inDim, seed=40 + i, heavy=bool(i & 1))
+            vd = devf(v)
+            single = torch.zeros(outDim, device=DEV)
+            ea.bucketMul(vd, ew, None, single, effort)
             g.eval()
-            for i, (call, (single, n, cutoff), (want, n_or, cutoff_or)) in enumerate(zip(calls, singles, wants)):
-                got = call[3].cpu().numpy()
-                assert got.tobytes() == single.tobytes(), i
-                assert g.last_dispatch_count(i) == n == n_or and g.last_cutoff(i) == cutoff == cutoff_or
-                assert close(got, want), i
-    finally:
-        g.set_split_cutoff(False)
+            singles.append((single.cpu().numpy(), g.last_dispatch_count(), g.last_cutoff()))
+            wants.append(oracle_cpu.bucket_mul(v, b, s, p, inDim, outDim, effort))
+            calls.append((vd, ew, None, torch.full((outDim,), float("nan"), device=DEV), effort))
+        g.set_split_cutoff(split)
+        try:
+            for _ in range(2):
+                ea.bucketMulGroup(calls)
+                g.eval()
+                for i, (call, (single, n, cutoff), (want, n_or, cutoff_or)) in enumerate(zip(calls, singles, wants)):
+                    got = call[3].cpu().numpy()
+                    if pinned:
+                        assert got.tobytes() == single.tobytes(), i
+                    assert g.last_dispatch_count(i) == n == n_or and g.last_cutoff(i) == cutoff == cutoff_or
+                    assert close(got, want) and close(got, single), i
+        finally:
+            g.set_split_cutoff(False)
+            g.set_tuning(0, 0, 0)
     with pytest.raises(ValueError):
         ea.bucketMulGroup(calls + calls)                      # more than 8
 
