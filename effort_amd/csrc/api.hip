@@ -90,7 +90,7 @@ extern "C" effort_ctx* effort_create(int device, void* stream) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->numCU = prop.multiProcessorCount;
     c->slabBytes = (size_t)64 << 20;
-    bool ok = hipMalloc(&c->d_cutoff, 64) == hipSuccess && hipMalloc(&c->d_count, 16) == hipSuccess &&
+    bool ok = hipMalloc(&c->d_cutoff, 256) == hipSuccess && hipMalloc(&c->d_count, 16) == hipSuccess &&
               hipMalloc(&c->d_slabs, c->slabBytes) == hipSuccess && hipMalloc(&c->d_blockScratch, 4096 * 4) == hipSuccess &&
               hipMalloc(&c->d_cos, 16) == hipSuccess && hipMalloc(&c->d_status, 16) == hipSuccess &&
               hipMalloc(&c->d_tstamp, 4096) == hipSuccess && hipMalloc(&c->d_counters, effort_ctx::kMaxTiles * 4) == hipSuccess &&
@@ -103,7 +103,7 @@ extern "C" effort_ctx* effort_create(int device, void* stream) {
     hipMemset(c->d_sliceCounts, 0, effort_ctx::kMaxSlices * 4);
     hipMemset(c->d_queue, 0, 9 * 16 * 4);
     { unsigned long long init[2] = {~0ull, 0ull}; hipMemcpy(c->d_tstamp, init, 16, hipMemcpyHostToDevice); }
-    hipMemset(c->d_cutoff, 0, 64);
+    hipMemset(c->d_cutoff, 0, 256);
     hipMemset(c->d_count, 0, 16);
     hipMemset(c->d_status, 0, 16);
     return c;
@@ -220,7 +220,7 @@ static int choose_geom(const effort_ctx* c, const effort_w* w, int groupSize, Mu
     g->tileFloats = nacc * E * 64;
     const size_t ldsMax = 160 * 1024;
     uint32_t S;
-    if (c->tuneS) S = (c->tuneS + 7) / 8 * 8;
+    if (c->tuneS) S = c->tuneS;                            // any count: the item grid is padded to a multiple of 8 slices
     else {
         // Measured on MI355X (tools/tune.py, 4096x4096 .. 4096x11008, 10-100 % effort).  A workgroup's life is mostly
         // fixed-latency steps (staging, cutoff, selection, hand-off), so FEWER, fatter workgroups win even when they
@@ -232,7 +232,7 @@ static int choose_geom(const effort_ctx* c, const effort_w* w, int groupSize, Mu
         S = cap < want ? cap : want;
     }
     if (S > w->inDim) S = w->inDim / 8 * 8;
-    if (S < 8) S = 8;
+    if (S < 1) S = 1;
     const uint32_t maxCand = bucket_mul_max_candidates(W);
     for (;;) {
         g->sliceRows = (w->inDim + S - 1) / S;
@@ -243,7 +243,7 @@ static int choose_geom(const effort_ctx* c, const effort_w* w, int groupSize, Mu
         const bool fits = lds <= ldsMax && g->sliceRows <= (w->fmt == kFp16 ? 4096u : 8192u) && g->slots <= maxCand;
         const size_t slab = (size_t)g->slices * g->tiles * g->tileFloats * 4;
         if (fits && slab <= c->slabBytes) break;
-        if (!fits) { S += 8; if (S > w->inDim + 8) return EFFORT_ERR_SHAPE; }
+        if (!fits) { S += 1; if (S > w->inDim + 8) return EFFORT_ERR_SHAPE; }
         else return EFFORT_ERR_SHAPE;
     }
     *Wout = W; *Eout = E;
@@ -262,7 +262,7 @@ static int ensure_timing(effort_ctx* c) {
 static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws, const float* const* vs,
                     const uint32_t* const* expNos, float* const* outs, const double* efforts) {
     if (!c || !ws || !vs || !outs || !efforts) return fail(c, EFFORT_ERR_ARG, "bucketmul: null argument");
-    if (n < 1 || n > kMaxGroup) return fail(c, EFFORT_ERR_ARG, "bucketmul: group size outside 1..8");
+    if (n < 1 || n > kMaxGroup) return fail(c, EFFORT_ERR_ARG, "bucketmul: group size outside 1..16");
     static const uint32_t ablate = getenv("EFFORT_ABLATE") ? (uint32_t)atoi(getenv("EFFORT_ABLATE")) : 0u;   // profiling only
     GroupArgs ga;
     memset(&ga, 0, sizeof(ga));

@@ -58,7 +58,7 @@ struct MulArgs {
 // the decode loop's Wq|Wk|Wv and W1|W3 (runNetwork.swift:132-134,178-182) are such groups.  A lone call's
 // workgroups spend most of their life in dependent fixed-latency steps, so one call cannot load the chip; in a
 // group the workgroups of different calls overlap on the CUs inside ONE kernel, no stream juggling involved.
-constexpr int kMaxGroup = 8;
+constexpr int kMaxGroup = 16;   // 16 descriptors = 3 KB of kernel arguments (limit 4 KB)
 struct GroupArgs {
     MulArgs call[kMaxGroup];
     uint32_t wgEnd[kMaxGroup];     // exclusive end of each call's block range (multiples of 8)

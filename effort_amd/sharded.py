@@ -62,6 +62,18 @@ def _default_mul(v, by, out, effort, expNo):
     expertMul(v, by, out, effort, expNo)
 
 
+def _default_mul_group(v, bys, outs, effort, expNo):
+    """The shards of matrices sharing ``v`` are independent calls: one grouped kernel launch (effort_bucketmul_group)
+    when they are all bucketed bundles of one kind, expertMul one by one otherwise (dense fallback of expertMul.swift:29)."""
+    from .bucket_mul import bucketMulGroup, expertMul
+    same = all(b.q4 == bys[0].q4 for b in bys) and all((not b.q4) or b.bucketsLoaded for b in bys)
+    if same and 1 < len(bys) <= 16:
+        bucketMulGroup([(v, b, expNo, o, effort) for b, o in zip(bys, outs)])
+    else:
+        for b, o in zip(bys, outs):
+            expertMul(v, b, o, effort, expNo)
+
+
 def shardedExpertMulGroup(v: torch.Tensor, bys: Sequence[ShardedExpertWeights], outs: Sequence[torch.Tensor], effort: float = 0.25,
                           expNo: torch.Tensor | None = None, group=None,
                           mul: Callable = _default_mul, scratch: dict | None = None):
@@ -77,10 +89,15 @@ def shardedExpertMulGroup(v: torch.Tensor, bys: Sequence[ShardedExpertWeights], 
         sc[key] = (torch.empty(total, dtype=torch.float32, device=v.device),
                    torch.empty((world, total), dtype=torch.float32, device=v.device))
     send, recv = sc[key]
-    off = 0
+    off, pieces = 0, []
     for b in bys:
-        mul(v, b.local, send[off:off + b.localOut], effort, expNo)
+        pieces.append(send[off:off + b.localOut])
         off += b.localOut
+    if mul is _default_mul:
+        _default_mul_group(v, [b.local for b in bys], pieces, effort, expNo)
+    else:
+        for b, piece in zip(bys, pieces):
+            mul(v, b.local, piece, effort, expNo)
     if world == 1:
         recv[0].copy_(send)
     else:

@@ -372,7 +372,7 @@ def test_group_launch_equals_single_calls(ea, oracle_cpu, split):
             g.set_split_cutoff(False)
             g.set_tuning(0, 0, 0)
     with pytest.raises(ValueError):
-        ea.bucketMulGroup(calls + calls)                      # more than 8
+        ea.bucketMulGroup(calls * 4)                          # more than 16
 
 
 @pytest.mark.parametrize("per_cu", [1, 2])
