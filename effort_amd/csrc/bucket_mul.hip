@@ -445,41 +445,45 @@ __device__ __forceinline__ void mul_item(const GroupArgs& ga, const uint32_t ite
 
     // last arriver of tile t: every slab of the tile was stored write-through (sc1) and drained before its ticket;
     // read them past L1 (sc1), sum in slice order, un-permute, add the Q4 outliers, write out[].  Each thread owns
-    // two adjacent tile slots and keeps up to kRed 8-byte loads in flight (each is a fabric round trip); the four
+    // four adjacent tile slots and keeps up to kRed 16-byte loads in flight (each is a fabric round trip); the four
     // running sums per slot are combined in a fixed order.
     const bool rstamp = a.tstamp && ci == 0 && t == 0 && tid == 0;
     if (rstamp) a.tstamp[23] = wall_clock64();
-    typedef uint32_t u2v __attribute__((ext_vector_type(2)));
+    typedef uint32_t u4v __attribute__((ext_vector_type(4)));
     const uint32_t sliceStride = g.tiles * (uint32_t)(TILE_F * 4);
     auto reduce_tile = [&](auto kc) {
-        constexpr int kRed = decltype(kc)::value;          // slab loads in flight per thread
-        for (int o = tid * 2; o < TILE_F; o += NT * 2) {
+        constexpr int kRed = decltype(kc)::value;          // 16-byte slab loads in flight per thread
+        for (int o = tid * 4; o < TILE_F; o += NT * 4) {
             const uint32_t vo = t * (uint32_t)(TILE_F * 4) + (uint32_t)o * 4u;
-            float sa[4] = {0.0f, 0.0f, 0.0f, 0.0f}, sb[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            float sm[4][4];                                // [tile slot of this thread][slice % 4]: fixed summation order
+#pragma unroll
+            for (int h = 0; h < 4; h++) { sm[h][0] = 0.0f; sm[h][1] = 0.0f; sm[h][2] = 0.0f; sm[h][3] = 0.0f; }
             for (uint32_t sl = 0; sl < g.slices; sl += kRed) {
-                u2v r[kRed];
+                u4v r[kRed];
 #pragma unroll
                 for (int i = 0; i < kRed; i++)
-                    r[i] = __builtin_amdgcn_raw_buffer_load_b64(srs, vo, min(sl + i, g.slices - 1u) * sliceStride, kSc1);
+                    r[i] = __builtin_amdgcn_raw_buffer_load_b128(srs, vo, min(sl + i, g.slices - 1u) * sliceStride, kSc1);
 #pragma unroll
                 for (int i = 0; i < kRed; i++) {
-                    if (sl + i < g.slices) { sa[i & 3] += __uint_as_float(r[i][0]); sb[i & 3] += __uint_as_float(r[i][1]); }
+                    if (sl + i < g.slices) {
+#pragma unroll
+                        for (int h = 0; h < 4; h++) sm[h][i & 3] += __uint_as_float(r[i][h]);
+                    }
                 }
             }
-            float sum2[2] = {(sa[0] + sa[1]) + (sa[2] + sa[3]), (sb[0] + sb[1]) + (sb[2] + sb[3])};
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
+            for (int h = 0; h < 4; h++) {
                 const uint32_t oo = (uint32_t)o + h;
                 const uint32_t lane2 = oo & 63u, sj = oo >> 6, j = sj % E, slot = sj / E;
                 const uint32_t c2 = t * (64u * E) + lane2 * E + j;
-                if (c2 < g.cols) a.out[c2 * NACC + slot] = sum2[h];
+                if (c2 < g.cols) a.out[c2 * NACC + slot] = (sm[h][0] + sm[h][1]) + (sm[h][2] + sm[h][3]);
             }
         }
     };
-    // (the four running sums take slices i%4; chunk sizes are multiples of 4, so the order does not depend on the chunk)
+    // (the four running sums take slices i%4; chunk sizes are multiples of 4, so the order does not depend on the chunk.
+    //  Up to 16 slices the whole reduction is ONE memory round trip per thread.)
     if (g.slices <= 8u) reduce_tile(std::integral_constant<int, 8>{});
-    else if (g.slices <= 16u) reduce_tile(std::integral_constant<int, 16>{});
-    else reduce_tile(std::integral_constant<int, 32>{});
+    else reduce_tile(std::integral_constant<int, 16>{});
     if (rstamp) a.tstamp[24] = wall_clock64();
     if (tid == 0) {
         __hip_atomic_store(&a.counters[t], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next call

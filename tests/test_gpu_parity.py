@@ -385,7 +385,7 @@ def test_group_launch_persistent_workgroups(ea, oracle_cpu, per_cu):
     ew = gpu_weights(ea, W, b, s, p)
     g = ea.gpu()
     calls, singles = [], []
-    for i in range(8):
+    for i in range(16):                              # the largest group one launch takes
         vd = devf(make_v(inDim, seed=60 + i, heavy=bool(i & 1)))
         effort = (0.1, 0.25, 0.5, 1.0)[i % 4]
         single = torch.zeros(outDim, device=DEV)
@@ -395,7 +395,7 @@ def test_group_launch_persistent_workgroups(ea, oracle_cpu, per_cu):
         calls.append((vd, ew, None, torch.full((outDim,), float("nan"), device=DEV), effort))
     try:
         g.set_persistent(per_cu)
-        g.set_tuning(8, 1, 64)                      # 4 tiles x 64 slices x 8 calls = 2048 items
+        g.set_tuning(8, 1, 64)                      # 4 tiles x 64 slices x 16 calls = 4096 items
         for _ in range(3):
             for c in calls:
                 c[3].fill_(float("nan"))
