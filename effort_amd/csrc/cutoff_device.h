@@ -43,9 +43,10 @@ __device__ __forceinline__ float block_find_cutoff(const float (&vj)[4096 / NT],
     constexpr int NW = NT / 64;
     constexpr uint32_t BPT = kCutoffBinsPerThread, CAP = (uint32_t)NT * BPT;
     uint32_t* s_cnt = reinterpret_cast<uint32_t*>(lds);            // [4] rotating count slots (ballot passes)
-    uint32_t* s_mm = reinterpret_cast<uint32_t*>(lds) + 4;         // [0] min pattern, [1] max pattern
+    uint32_t* s_mm = reinterpret_cast<uint32_t*>(lds) + 4;         // [0] min pattern, [1] max pattern, [2] min NONZERO pattern
     uint32_t* s_tot = reinterpret_cast<uint32_t*>(lds) + 8;        // [16] wave totals of the scan
     float* s_res = reinterpret_cast<float*>(lds) + 24;             // [0] result
+    uint32_t* s_all = reinterpret_cast<uint32_t*>(lds) + 25;       // [0] values at or above the table's first cell
     int tid0 = threadIdx.x;
     asm volatile("" : "+v"(tid0));      // opaque: a caller looping over work items must not hoist tid-derived state
     const int tid = tid0, lane = tid & 63;
@@ -53,12 +54,12 @@ __device__ __forceinline__ float block_find_cutoff(const float (&vj)[4096 / NT],
     if (dbg && tid == 0) { dbg[0] = wall_clock64(); dbg[6] = clock64(); }
 
     if (tid < 4) s_cnt[tid] = 0;
-    if (tid == 0) { s_mm[0] = 0xFFFFFFFFu; s_mm[1] = 0; }
+    if (tid == 0) { s_mm[0] = 0xFFFFFFFFu; s_mm[1] = 0; s_mm[2] = 0xFFFFFFFFu; }
     __syncthreads();
     // the 4096 values bf16(|(1e5*v[j]) * bf16(probe[j])|), products evaluated left to right (:160), kept as
     // their 16-bit patterns
     uint32_t vp[VPT];
-    uint32_t pmin = 0xFFFFu, pmax = 0u;
+    uint32_t pmin = 0xFFFFu, pmax = 0u, pminnz = 0xFFFFu;
 #pragma unroll
     for (int k = 0; k < VPT; k++) {
         const float t = kCutoffScale * vj[k];
@@ -66,15 +67,21 @@ __device__ __forceinline__ float block_find_cutoff(const float (&vj)[4096 / NT],
         vp[k] = __float_as_uint(bf16_round(fabsf(u))) >> 16;
         pmin = min(pmin, vp[k]);
         pmax = max(pmax, vp[k]);
+        pminnz = min(pminnz, vp[k] ? vp[k] : 0xFFFFu);
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
         pmin = min(pmin, (uint32_t)__shfl_xor((int)pmin, off));
         pmax = max(pmax, (uint32_t)__shfl_xor((int)pmax, off));
+        pminnz = min(pminnz, (uint32_t)__shfl_xor((int)pminnz, off));
     }
-    if (lane == 0) { atomicMin(&s_mm[0], pmin); atomicMax(&s_mm[1], pmax); }
+    if (lane == 0) { atomicMin(&s_mm[0], pmin); atomicMax(&s_mm[1], pmax); atomicMin(&s_mm[2], pminnz); }
     __syncthreads();
     const uint32_t pminAll = s_mm[0], pmaxAll = s_mm[1];
+    // Exact zeros (a zero input, or a probe zeroed as a Q4 outlier) exceed no threshold, so the count table only has
+    // to start at the smallest NONZERO value: below it every count is the same.  (Without this, zeros make the value
+    // range span every bf16 cell down to 0 and the bracket never fits the table: ~100 ballot rounds at effort 1.)
+    const uint32_t pminNZ = min(s_mm[2], pmaxAll);
     // The reference starts each thread's min at 999 / max at -999, clamps per simdgroup and stores the
     // simdgroup results as bfloat (999 -> 1000) before the cross-simdgroup reduction (:155-190).  All values
     // are non-negative bf16 numbers, so the net effect is minBound = min(globalMin, 1000), maxBound = globalMax.
@@ -104,7 +111,7 @@ __device__ __forceinline__ float block_find_cutoff(const float (&vj)[4096 / NT],
     };
 
     // ---- rare: the value range exceeds the table; count with ballots until the bracket fits ----------------
-    auto lowCell = [&]() { return patLo != kNoLo ? patLo : pminAll; };
+    auto lowCell = [&]() { return patLo != kNoLo ? max(patLo, pminNZ) : pminNZ; };
     auto topCell = [&]() { return patHi != kNoHi ? patHi : pmaxAll; };
     while (!done && patHi != patLo + 1u && topCell() - lowCell() + 1u > CAP) {
         const uint32_t p = __float_as_uint(newBound) >> 16;
@@ -148,6 +155,7 @@ __device__ __forceinline__ float block_find_cutoff(const float (&vj)[4096 / NT],
         for (int w2 = 0; w2 < NW; w2++) running += (w2 > wave) ? s_tot[w2] : 0u;
 #pragma unroll
         for (int i = (int)BPT - 1; i >= 0; i--) { const uint32_t c = running; running += h[i]; h[i] = c; }
+        if (tid == 0) s_all[0] = running;                // values with pattern >= base
         t4[0] = make_uint4(h[0], h[1], h[2], h[3]); t4[1] = make_uint4(h[4], h[5], h[6], h[7]);
         __syncthreads();
         if (dbg && tid == 0) dbg[2] = wall_clock64();
@@ -155,7 +163,7 @@ __device__ __forceinline__ float block_find_cutoff(const float (&vj)[4096 / NT],
         if (wave == 0) {
             // ---- the bisection proper, one wave, one LDS lookup per round ------------------------------------
             auto count_above = [&](uint32_t p) -> uint32_t {
-                if (p < base) return 4096u;              // cannot happen (thresholds stay inside the bracket); safe anyway
+                if (p < base) return s_all[0];           // below the first cell: everything at or above it (zeros never count)
                 if (p > top) return above;
                 return tbl[p - base];
             };

@@ -82,6 +82,32 @@ def test_cutoff_and_dispatch_bit_exact(ea, oracle_cpu, outDim, inDim, heavy):
         assert got.tobytes() == disp[:n].tobytes()
 
 
+def test_cutoff_with_exact_zero_inputs(ea, oracle_cpu):
+    """Exact zeros among the probe products (zero inputs; Q4 probes zeroed as outliers) stretch the value range down to
+    0: the cutoff stays bit-exact at every effort, including effort 1 where the reference bisects towards 0 for its
+    full 100 rounds."""
+    outDim, inDim = 1024, 4096
+    W, b, s, p = converted(oracle_cpu, outDim, inDim)
+    ew = gpu_weights(ea, W, b, s, p)
+    bm = ea.BucketMul.shared()
+    for heavy in (False, True):
+        v = make_v(inDim, seed=9, heavy=heavy)
+        v[::7] = 0.0
+        v[5] = -0.0
+        vd = devf(v)
+        for effort in (0.0, 0.05, 0.5, 0.97, 1.0):
+            cutoff, _ = oracle_cpu.find_cutoff(v, p, 0, effort)
+            disp, n = oracle_cpu.prepare_dispatch(v, s, 0, cutoff, inDim, outDim // 16)
+            bm.calcDispatch(vd, ew, None, effort)
+            ea.gpu().eval()
+            assert np.float32(bm.cutoff).tobytes() == np.float32(cutoff).tobytes(), (heavy, effort, bm.cutoff, cutoff)
+            assert int(bm.dispatch_size.item()) == n
+            out = torch.zeros(outDim, device=DEV)
+            ea.bucketMul(vd, ew, None, out, effort)
+            ea.gpu().eval()
+            assert ea.gpu().last_cutoff() == cutoff and ea.gpu().last_dispatch_count() == n
+
+
 # ---------------------------------------------------------------- FP16 multiply
 SHAPES = [(256, 4096), (64, 4096), (1024, 4096), (4096, 4096), (11008, 4096), (4096, 14336)]
 
