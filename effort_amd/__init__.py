@@ -2,7 +2,8 @@
 
 Hand-written HIP kernels behind a C ABI (include/effort_hip.h, built as effort_amd/libeffort_hip.so) and
 this thin host mirror of the reference's Swift interface for the path: ``bucketMul``, ``bucketMulQ4``,
-``expertMul``, ``basicMul``, ``ExpertWeights``, ``BucketMul``, ``bucketize``, ``gpu().eval()``.
+``expertMul``, ``basicMul``, ``ExpertWeights``, ``BucketMul``, ``bucketize``, ``gpu().eval()``; plus the on-disk bucket
+format and the model converter driver (``TensorSaver``, ``TensorLoader``, ``convertMistral``, ``loadExpertWeights``).
 PyTorch is used for device memory, streams and torch.distributed only.  There is no CPU fallback.
 """
 from ._lib import EffortError, build, lib  # noqa: F401
@@ -26,6 +27,9 @@ def __getattr__(name):
     if name == "q4_convert":
         from . import q4 as _q
         return _q.convert
+    if name in ("TensorSaver", "TensorLoader", "convertMistral", "loadExpertWeights"):
+        from . import bucketfile as _f
+        return getattr(_f, name)
     if name in ("ShardedExpertWeights", "shardedExpertMul"):
         from . import sharded as _s
         return getattr(_s, name)

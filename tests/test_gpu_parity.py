@@ -452,3 +452,50 @@ def test_group_launch_q4(ea, oracle_cpu, q4_case):
         assert close(call[3].cpu().numpy(), want), k
     with pytest.raises(ValueError):
         ea.bucketMulGroup([calls[0], (calls[0][0],) + (gpu_weights(ea, *converted(oracle_cpu, 256, 4096)),) + calls[0][2:]])   # mixed kinds
+
+
+# ---------------------------------------------------------------- on-disk bucket format + model converter driver
+def test_model_file_roundtrip(ea, oracle_cpu, tmp_path):
+    """convertMistral on the GPU (one synthetic layer: hidden 4096, kv 256, ffn 1024) -> safetensors shards + index ->
+    ExpertWeights loaded back by name (loader.swift:60-167) -> bucketMul equals the oracle on the same matrix; loading
+    with percentLoad < 16 reads only the first rank planes; the FFN name pattern stacks experts."""
+    from effort_amd import bucketfile as bf
+    hidden, kv, ffn = 4096, 256, 1024
+    shapes = {"self_attn.q_proj": (hidden, hidden), "self_attn.k_proj": (kv, hidden), "self_attn.v_proj": (kv, hidden),
+              "self_attn.o_proj": (hidden, hidden), "mlp.gate_proj": (ffn, hidden), "mlp.up_proj": (ffn, hidden),
+              "mlp.down_proj": (hidden, 4096)}          # (down_proj kept square: inDim >= 4096 is a bucketize precondition)
+    src = {"model.norm.weight": torch.ones(hidden).half(), "lm_head.weight": torch.zeros(8, hidden).half(),
+           "model.embed_tokens.weight": torch.zeros(8, hidden).half(),
+           "model.layers.0.input_layernorm.weight": torch.ones(hidden).half(),
+           "model.layers.0.post_attention_layernorm.weight": torch.ones(hidden).half()}
+    mats = {}
+    for k, (o, i) in shapes.items():
+        mats[k] = make_w(o, i, seed=70 + len(mats))
+        src[f"model.layers.0.{k}.weight"] = torch.from_numpy(mats[k])
+    saver = bf.convertMistral(src, bf.TensorSaver(str(tmp_path), "buckets-FP16"), numLayers=1)
+    saver.save()
+    L = bf.TensorLoader(str(tmp_path), "buckets-FP16")
+    v = make_v(hidden, seed=3)
+    vd = devf(v)
+    # attention matrix by element name; layout identical to the oracle's conversion
+    ew = bf.loadExpertWeights(L, "layers.0.attention.wk")
+    b, s, p, _ = oracle_cpu.convert_fp16(mats["self_attn.k_proj"])
+    assert ew.buckets.cpu().numpy().view(np.uint16).tobytes() == b.view(np.uint16).tobytes()
+    assert (ew.inSize, ew.outSize, ew.percentLoad) == (hidden, kv, 16) and ew.core is not None
+    out = torch.zeros(kv, device=DEV)
+    ea.expertMul(vd, ew, out, 0.3)
+    ea.gpu().eval()
+    want, n, _ = oracle_cpu.bucket_mul(v, b, s, p, hidden, kv, 0.3)
+    assert ea.gpu().last_dispatch_count() == n and close(out.cpu().numpy(), want)
+    # FFN matrix by (prefix, wId), percentLoad 16 and 4
+    b, s, p, _ = oracle_cpu.convert_fp16(mats["mlp.gate_proj"])
+    for pl in (16, 4):
+        ew = bf.loadExpertWeights(L, "layers.0.feed_forward.experts.", "w1", inDim=hidden, outDim=ffn, numExperts=1, percentLoad=pl)
+        assert ew.buckets.shape == (1, hidden * pl, ffn // 16)
+        out = torch.zeros(ffn, device=DEV)
+        ea.bucketMul(vd, ew, None, out, 0.5)
+        ea.gpu().eval()
+        want, n, _ = oracle_cpu.bucket_mul(v, b[:hidden * pl], s[:hidden * pl], p, hidden, ffn, 0.5, percentLoad=pl)
+        assert ea.gpu().last_dispatch_count() == n and close(out.cpu().numpy(), want), pl
+    with pytest.raises(KeyError):
+        bf.loadExpertWeights(L, "layers.0.attention.nope", inDim=hidden, outDim=kv)
