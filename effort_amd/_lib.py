@@ -51,6 +51,12 @@ _SIGS = {
     "effort_group_cutoff": (C.c_int, [_P, C.c_int, C.POINTER(C.c_float)]),
     "effort_debug_occupancy": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int]),
     "effort_set_persistent": (C.c_int, [_P, C.c_int]),
+    "effort_add_rmsnorm_mul": (C.c_int, [_P, _P, _P, _P, _P, C.c_int]),
+    "effort_rope_kv": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float]),
+    "effort_attention": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int]),
+    "effort_silu_mul": (C.c_int, [_P, _P, _P, _P, C.c_int]),
+    "effort_fetch_row": (C.c_int, [_P, _P, _P, _P, C.c_int]),
+    "effort_argmax": (C.c_int, [_P, _P, C.c_int, _P, _P, _P]),
     "effort_dense_gemv": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int]),
     "effort_last_dispatch_count": (C.c_int, [_P, C.POINTER(C.c_uint32)]),
     "effort_last_cutoff": (C.c_int, [_P, C.POINTER(C.c_float)]),

@@ -418,6 +418,44 @@ extern "C" int effort_cosine(effort_ctx* c, const float* a, const float* b, int 
     return EFFORT_OK;
 }
 
+// ---- decode-loop glue (runNetwork.swift:68-316; kernels in decode.hip) ---------------------------------------
+extern "C" int effort_add_rmsnorm_mul(effort_ctx* c, float* h, const float* delta, const void* w, float* out, int n) {
+    if (!c || !h || !w || !out || n <= 0) return fail(c, EFFORT_ERR_ARG, "add_rmsnorm_mul: bad argument");
+    HIP_TRY(c, launch_add_rmsnorm_mul(h, delta, static_cast<const uint16_t*>(w), out, (uint32_t)n, c->stream));
+    return EFFORT_OK;
+}
+extern "C" int effort_rope_kv(effort_ctx* c, const float* xq, const float* xk, const float* xv, float* qOut, float* kCache,
+                              float* vCache, const uint32_t* pos, int numHeads, int numHeadsKV, int headDim, float ropeBase) {
+    if (!c || !xq || !xk || !xv || !qOut || !kCache || !vCache || !pos) return fail(c, EFFORT_ERR_ARG, "rope_kv: null argument");
+    if (numHeads <= 0 || numHeadsKV <= 0 || numHeads % numHeadsKV || headDim < 2 || headDim > 1024 || headDim % 2 || !(ropeBase > 1.0f))
+        return fail(c, EFFORT_ERR_SHAPE, "rope_kv: bad head geometry");
+    HIP_TRY(c, launch_rope_kv(xq, xk, xv, qOut, kCache, vCache, pos, numHeads, numHeadsKV, headDim, ropeBase, c->stream));
+    return EFFORT_OK;
+}
+extern "C" int effort_attention(effort_ctx* c, const float* q, const float* kCache, const float* vCache, const uint32_t* pos,
+                                float* out, int numHeads, int headDim, int maxTokens) {
+    if (!c || !q || !kCache || !vCache || !pos || !out) return fail(c, EFFORT_ERR_ARG, "attention: null argument");
+    if (numHeads <= 0 || maxTokens <= 0 || maxTokens > 8192 || (headDim != 64 && headDim != 128 && headDim != 256))
+        return fail(c, EFFORT_ERR_SHAPE, "attention: headDim 64/128/256, maxTokens <= 8192");
+    HIP_TRY(c, launch_attention(q, kCache, vCache, pos, out, numHeads, headDim, maxTokens, c->stream));
+    return EFFORT_OK;
+}
+extern "C" int effort_silu_mul(effort_ctx* c, const float* x1, const float* x3, float* out, int n) {
+    if (!c || !x1 || !x3 || !out || n <= 0) return fail(c, EFFORT_ERR_ARG, "silu_mul: bad argument");
+    HIP_TRY(c, launch_silu_mul(x1, x3, out, (uint32_t)n, c->stream));
+    return EFFORT_OK;
+}
+extern "C" int effort_fetch_row(effort_ctx* c, const void* emb, const uint32_t* id, float* out, int n) {
+    if (!c || !emb || !id || !out || n <= 0) return fail(c, EFFORT_ERR_ARG, "fetch_row: bad argument");
+    HIP_TRY(c, launch_fetch_row(static_cast<const uint16_t*>(emb), id, out, (uint32_t)n, c->stream));
+    return EFFORT_OK;
+}
+extern "C" int effort_argmax(effort_ctx* c, const float* logits, int n, uint32_t* idOut, uint32_t* pos, uint32_t* history) {
+    if (!c || !logits || !idOut || !pos || n <= 0) return fail(c, EFFORT_ERR_ARG, "argmax: bad argument");
+    HIP_TRY(c, launch_argmax(logits, (uint32_t)n, idOut, pos, history, c->stream));
+    return EFFORT_OK;
+}
+
 // ---- tuning / timing -----------------------------------------------------------------------------
 extern "C" int effort_set_tuning(effort_ctx* c, int W, int E, int S) {
     if (!c) return EFFORT_ERR_ARG;

@@ -1,0 +1,178 @@
+// Glue kernels of the decode loop around bucketMul (runNetwork.swift:68-316) -- the callers either side of the hot
+// path, SURVEY section 8f row 1.  Everything a token needs between two multiplies, with the token position and the
+// token id kept in DEVICE memory so that a whole token step can be replayed from one hipGraph (the reference's loop
+// spends ~15 ms/token in gaps between its ~25 dispatches per layer, runNetwork.swift:91-103).
+//   add_rmsnorm_mul  h += delta; out = h / sqrt(mean(h^2) + 1e-5) * w     rmsNorm32fast + mulVec32by16 + add (aux.metal:113-152,268-274)
+//   rope_kv          rope_mx on q and on the 4x repeated k, repeat4x32 of k and v, written at cache[pos]   (aux.metal:218-261)
+//   attention        dotSetScore2 (/sqrt(headDim)) + softmax + sumScores32 over tokens 0..pos, one workgroup per head (aux.metal:185-198,379-447)
+//   silu_mul         x3 * x1 / (1 + exp(-x1))                              silu32b (matrix.metal:25-35)
+//   fetch_row        tok_embeddings row (f16) -> f32                       fetchRow16to32 (aux.metal:355)
+//   argmax           greedy pick of the next token (the reference takes mpsTopK[0], helpers/mps.swift:52-84), pos += 1
+#include "effort_internal.h"
+
+namespace effort {
+
+__device__ __forceinline__ float block_sum(float x, float* red /* [17] */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off);
+    __syncthreads();                                  // red may still be read from a previous call
+    if (lane == 0) red[wave] = x;
+    __syncthreads();
+    float s = 0.0f;
+    for (int w = 0; w < nw; w++) s += red[w];         // same order in every thread: identical result everywhere
+    return s;
+}
+
+__device__ __forceinline__ float block_max(float x, float* red) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) x = fmaxf(x, __shfl_xor(x, off));
+    __syncthreads();
+    if (lane == 0) red[wave] = x;
+    __syncthreads();
+    float s = red[0];
+    for (int w = 1; w < nw; w++) s = fmaxf(s, red[w]);
+    return s;
+}
+
+__global__ __launch_bounds__(1024) void add_rmsnorm_mul_kernel(float* __restrict__ h, const float* __restrict__ delta,
+                                                               const uint16_t* __restrict__ w, float* __restrict__ out, uint32_t n) {
+    __shared__ float red[17];
+    float ss = 0.0f;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        float x = h[i];
+        if (delta) { x += delta[i]; h[i] = x; }
+        ss += x * x;
+    }
+    const float inv = 1.0f / sqrtf(block_sum(ss, red) / (float)n + 1e-5f);                // aux.metal:150
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) out[i] = (h[i] * inv) * half_bits_to_float(w[i]);
+}
+
+// grid = numHeads, block = headDim.  freq_j = base^(-2j/headDim) (createFreqsCis2, model.swift:693-717: logspace with
+// base 1e-6 <=> theta 1e6), rotate_half convention of rope_mx.
+__global__ void rope_kv_kernel(const float* __restrict__ xq, const float* __restrict__ xk, const float* __restrict__ xv,
+                               float* __restrict__ qOut, float* __restrict__ kCache, float* __restrict__ vCache,
+                               const uint32_t* __restrict__ posPtr, uint32_t numHeads, uint32_t kvRepeats, float logBase) {
+    const uint32_t head = blockIdx.x, d = threadIdx.x, headDim = blockDim.x, half = headDim / 2, pos = posPtr[0];
+    const uint32_t j = d % half;
+    const float freq = (float)exp((double)logBase * (-(double)j / (double)half));          // Float(freq), model.swift:707
+    const float angle = (float)pos * freq;
+    const float c = cosf(angle), s = sinf(angle);
+    const float* q = xq + head * headDim;
+    const float* k = xk + (head / kvRepeats) * headDim;                                    // repeat4x32: kv head y feeds heads 4y..4y+3
+    const float qr = d < half ? q[d] * c - q[d + half] * s : q[d] * c + q[d - half] * s;
+    const float kr = d < half ? k[d] * c - k[d + half] * s : k[d] * c + k[d - half] * s;
+    const size_t slot = ((size_t)pos * numHeads + head) * headDim + d;
+    qOut[head * headDim + d] = qr;
+    kCache[slot] = kr;
+    vCache[slot] = xv[(head / kvRepeats) * headDim + d];
+}
+
+// grid = numHeads, block = 256.  Tokens 0..pos.  exp(x - max) / sum exp(x - max) == the reference's exp(x) / sum exp(x).
+__global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ q, const float* __restrict__ kCache,
+                                                        const float* __restrict__ vCache, const uint32_t* __restrict__ posPtr,
+                                                        float* __restrict__ out, uint32_t numHeads, uint32_t headDim, uint32_t maxTokens) {
+    extern __shared__ float sc[];                      // [maxTokens] scores, then probabilities
+    __shared__ float red[17];
+    const uint32_t head = blockIdx.x, tid = threadIdx.x, nTok = min(posPtr[0] + 1u, maxTokens);
+    const float* qh = q + head * headDim;
+    const float scale = 1.0f / sqrtf((float)headDim);
+    const int lane = tid & 63, wave = tid >> 6;
+    // one wave per token: lanes stride the head dimension
+    for (uint32_t t = wave; t < nTok; t += 4) {
+        const float* kh = kCache + ((size_t)t * numHeads + head) * headDim;
+        float dot = 0.0f;
+        for (uint32_t d = lane; d < headDim; d += 64) dot += qh[d] * kh[d];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) dot += __shfl_xor(dot, off);
+        if (lane == 0) sc[t] = dot * scale;
+    }
+    __syncthreads();
+    float m = -INFINITY;
+    for (uint32_t t = tid; t < nTok; t += 256) m = fmaxf(m, sc[t]);
+    m = block_max(m, red);
+    float sum = 0.0f;
+    for (uint32_t t = tid; t < nTok; t += 256) { const float e = expf(sc[t] - m); sc[t] = e; sum += e; }
+    sum = block_sum(sum, red);
+    const float inv = 1.0f / sum;
+    // sumScores32: out[head][d] = sum_t p_t * v[t][head][d]; threads = (token phase, d)
+    __shared__ float part[256];
+    const uint32_t d = tid % headDim, ph = tid / headDim, nph = 256 / headDim;
+    float acc = 0.0f;
+    if (ph < nph)
+        for (uint32_t t = ph; t < nTok; t += nph) acc += sc[t] * vCache[((size_t)t * numHeads + head) * headDim + d];
+    part[tid] = acc;
+    __syncthreads();
+    if (tid < headDim) {
+        float s2 = 0.0f;
+        for (uint32_t p = 0; p < nph; p++) s2 += part[p * headDim + tid];
+        out[head * headDim + tid] = s2 * inv;
+    }
+}
+
+__global__ void silu_mul_kernel(const float* __restrict__ x1, const float* __restrict__ x3, float* __restrict__ out, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = x3[i] * x1[i] / (1.0f + expf(-x1[i]));
+}
+
+__global__ void fetch_row_kernel(const uint16_t* __restrict__ emb, const uint32_t* __restrict__ idPtr, float* __restrict__ out, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = half_bits_to_float(emb[(size_t)idPtr[0] * n + i]);
+}
+
+// one workgroup: greedy next token = index of the largest logit (lowest index on ties); advances the position
+__global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ logits, uint32_t n, uint32_t* __restrict__ idOut,
+                                                      uint32_t* __restrict__ posPtr, uint32_t* __restrict__ history) {
+    __shared__ float bv[16];
+    __shared__ uint32_t bi[16];
+    float best = -INFINITY; uint32_t idx = 0xFFFFFFFFu;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const float x = logits[i];
+        if (x > best || (x == best && i < idx)) { best = x; idx = i; }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float ob = __shfl_xor(best, off); const uint32_t oi = (uint32_t)__shfl_xor((int)idx, off);
+        if (ob > best || (ob == best && oi < idx)) { best = ob; idx = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { bv[threadIdx.x >> 6] = best; bi[threadIdx.x >> 6] = idx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (uint32_t w = 1; w < (blockDim.x >> 6); w++)
+            if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
+        idOut[0] = idx;
+        if (history) history[posPtr[0]] = idx;
+        posPtr[0] += 1u;
+    }
+}
+
+hipError_t launch_add_rmsnorm_mul(float* h, const float* delta, const uint16_t* w, float* out, uint32_t n, hipStream_t st) {
+    hipLaunchKernelGGL(add_rmsnorm_mul_kernel, dim3(1), dim3(1024), 0, st, h, delta, w, out, n);
+    return hipGetLastError();
+}
+hipError_t launch_rope_kv(const float* xq, const float* xk, const float* xv, float* qOut, float* kCache, float* vCache,
+                          const uint32_t* pos, uint32_t numHeads, uint32_t numHeadsKV, uint32_t headDim, float ropeBase, hipStream_t st) {
+    hipLaunchKernelGGL(rope_kv_kernel, dim3(numHeads), dim3(headDim), 0, st, xq, xk, xv, qOut, kCache, vCache, pos, numHeads,
+                       numHeads / numHeadsKV, logf(ropeBase));
+    return hipGetLastError();
+}
+hipError_t launch_attention(const float* q, const float* kCache, const float* vCache, const uint32_t* pos, float* out,
+                            uint32_t numHeads, uint32_t headDim, uint32_t maxTokens, hipStream_t st) {
+    hipLaunchKernelGGL(attention_kernel, dim3(numHeads), dim3(256), maxTokens * sizeof(float), st, q, kCache, vCache, pos, out, numHeads, headDim, maxTokens);
+    return hipGetLastError();
+}
+hipError_t launch_silu_mul(const float* x1, const float* x3, float* out, uint32_t n, hipStream_t st) {
+    hipLaunchKernelGGL(silu_mul_kernel, dim3((n + 255) / 256), dim3(256), 0, st, x1, x3, out, n);
+    return hipGetLastError();
+}
+hipError_t launch_fetch_row(const uint16_t* emb, const uint32_t* id, float* out, uint32_t n, hipStream_t st) {
+    hipLaunchKernelGGL(fetch_row_kernel, dim3((n + 255) / 256), dim3(256), 0, st, emb, id, out, n);
+    return hipGetLastError();
+}
+hipError_t launch_argmax(const float* logits, uint32_t n, uint32_t* idOut, uint32_t* pos, uint32_t* history, hipStream_t st) {
+    hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, st, logits, n, idOut, pos, history);
+    return hipGetLastError();
+}
+
+}  // namespace effort

@@ -1,0 +1,218 @@
+"""The decode loop around bucketMul -- host mirror of ``runNetwork`` (runNetwork.swift:68-316) for Mistral-7B-shaped
+models (the caller of the hot path).
+
+One token step = per layer: rmsNorm * attnNorm -> wq | wk | wv (ONE grouped bucketMul launch: three independent calls on
+the same input) -> rope + 4x kv repeat + cache -> scores / softmax / weighted sum -> wo -> residual + rmsNorm * ffnNorm
+-> w1 | w3 (one grouped launch) -> silu -> w2 -> residual; then the output norm, the dense LM head (``basicMul``,
+runNetwork.swift:222) and a greedy pick.  The glue runs in the HIP kernels of effort_amd/csrc/decode.hip through the C
+ABI; the token position and the current token id live in device memory, so a whole step is captured once into a hipGraph
+and replayed per token -- no host work, no per-kernel launch gaps (the reference spends ~15 ms/token in such gaps,
+runNetwork.swift:91-103).  torch is used for buffers and graph capture only.
+
+``dense=True`` routes every projection through ``basicMul`` (rocBLAS GEMV on the f16 cores): the baseline the
+reference compares against (``effort`` 100 % vs dense, KL divergence of the logits).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import time
+from dataclasses import dataclass
+
+import torch
+
+from . import _lib
+from .bucket_mul import basicMul, bucketMul, bucketMulGroup
+from .runtime import gpu as _gpu
+from .weights import ExpertWeights
+
+
+@dataclass
+class MistralConfig:                      # main.swift:45-77
+    stateDim: int = 4096
+    hiddenDim: int = 14336
+    numLayers: int = 32
+    numHeads: int = 32
+    numHeadsKV: int = 8
+    headDim: int = 128
+    vocab: int = 32000
+    ropeBase: float = 1e6                 # createFreqsCis2: logspace base 1e-6 (model.swift:700)
+
+
+class Layer:                              # loader.swift Layer: norms + seven ExpertWeights
+    __slots__ = ("attnNorm", "ffnNorm", "wq", "wk", "wv", "wo", "w1", "w2", "w3")
+
+
+class Model:
+    def __init__(self, cfg: MistralConfig):
+        self.cfg = cfg
+        self.layers: list[Layer] = []
+        self.norm = None                  # f16 [stateDim]
+        self.output = None                # f16 [vocab, stateDim]  (output.core)
+        self.tokEmbeddings = None         # f16 [vocab, stateDim]  (tok_embeddings.core)
+
+    @classmethod
+    def random(cls, cfg: MistralConfig, seed: int = 0, device="cuda", scale: float = 0.02, keep_cores: bool = True) -> "Model":
+        """Random-init weights of the architecture (no checkpoints here), converted by the GPU bucketizer."""
+        m = cls(cfg)
+        gen = torch.Generator(device=device)
+        gen.manual_seed(seed)
+
+        def mat(o, i):
+            return (torch.randn((o, i), generator=gen, device=device, dtype=torch.float32) * scale).to(torch.float16)
+
+        def vec(n):
+            return (1.0 + 0.1 * torch.randn(n, generator=gen, device=device, dtype=torch.float32)).to(torch.float16)
+
+        kv = cfg.numHeadsKV * cfg.headDim
+        for _ in range(cfg.numLayers):
+            L = Layer()
+            L.attnNorm, L.ffnNorm = vec(cfg.stateDim), vec(cfg.stateDim)
+            for name, (o, i) in (("wq", (cfg.stateDim, cfg.stateDim)), ("wk", (kv, cfg.stateDim)), ("wv", (kv, cfg.stateDim)),
+                                 ("wo", (cfg.stateDim, cfg.stateDim)), ("w1", (cfg.hiddenDim, cfg.stateDim)),
+                                 ("w3", (cfg.hiddenDim, cfg.stateDim)), ("w2", (cfg.stateDim, cfg.hiddenDim))):
+                ew = ExpertWeights.from_core(mat(o, i))
+                if not keep_cores:
+                    ew.core = None
+                ew.handle
+                setattr(L, name, ew)
+            m.layers.append(L)
+        m.norm = vec(cfg.stateDim)
+        m.output = mat(cfg.vocab, cfg.stateDim)
+        m.tokEmbeddings = (torch.randn((cfg.vocab, cfg.stateDim), generator=gen, device=device, dtype=torch.float32)).to(torch.float16)
+        return m
+
+    @classmethod
+    def load(cls, loader, cfg: MistralConfig, percentLoad: int = 16, device="cuda") -> "Model":
+        """From a bucketed model on disk (effort_amd.bucketfile, names of convert.swift:70-105)."""
+        from .bucketfile import loadExpertWeights
+        m = cls(cfg)
+        for n in range(cfg.numLayers):
+            L = Layer()
+            L.attnNorm = loader[f"layers.{n}.attention_norm"].to(device=device, dtype=torch.float16)
+            L.ffnNorm = loader[f"layers.{n}.ffn_norm"].to(device=device, dtype=torch.float16)
+            for s in "qkvo":
+                setattr(L, "w" + s, loadExpertWeights(loader, f"layers.{n}.attention.w{s}", device=device))
+            for w, (o, i) in (("w1", (cfg.hiddenDim, cfg.stateDim)), ("w3", (cfg.hiddenDim, cfg.stateDim)), ("w2", (cfg.stateDim, cfg.hiddenDim))):
+                setattr(L, w, loadExpertWeights(loader, f"layers.{n}.feed_forward.experts.", w, inDim=i, outDim=o, numExperts=1,
+                                                percentLoad=percentLoad, device=device))
+            m.layers.append(L)
+        m.norm = loader["model.norm"].to(device=device, dtype=torch.float16)
+        m.output = loader["output.core"].to(device=device, dtype=torch.float16)
+        m.tokEmbeddings = loader["tok_embeddings.core"].to(device=device, dtype=torch.float16)
+        return m
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class Decoder:
+    """State of one sequence (the globals of main.swift:78-140: h, xq, KV caches, scores ...) + the token step."""
+
+    def __init__(self, model: Model, maxTokens: int = 256):
+        cfg = self.cfg = model.cfg
+        self.model, self.maxTokens = model, int(maxTokens)
+        dev = model.norm.device
+        self.g = _gpu(dev.index)
+        f = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)      # noqa: E731
+        q, kv = cfg.numHeads * cfg.headDim, cfg.numHeadsKV * cfg.headDim
+        self.h, self.h_norm, self.fxn, self.outNormed = f(cfg.stateDim), f(cfg.stateDim), f(cfg.stateDim), f(cfg.stateDim)
+        self.xq_temp, self.xk_temp, self.xv_temp, self.xq = f(q), f(kv), f(kv), f(q)
+        self.attnOutput, self.attnFfnOut, self.ffnOut = f(q), f(cfg.stateDim), f(cfg.stateDim)
+        self.x1, self.x3, self.x2 = f(cfg.hiddenDim), f(cfg.hiddenDim), f(cfg.hiddenDim)
+        self.logits = f(cfg.vocab)
+        self.kCache = [f(self.maxTokens, cfg.numHeads, cfg.headDim) for _ in range(cfg.numLayers)]     # xkLayerTokenHead
+        self.vCache = [f(self.maxTokens, cfg.numHeads, cfg.headDim) for _ in range(cfg.numLayers)]     # xvLayerToken
+        self.pos = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.tokId = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.history = torch.zeros(self.maxTokens, dtype=torch.int32, device=dev)
+        self._graphs: dict = {}
+
+    # -- one token: everything between fetching the embedding and picking the next token ----------------------------
+    def token_step(self, effort: float = 0.25, dense: bool = False):
+        cfg, g, lib, m = self.cfg, self.g, _lib.lib(), self.model
+        g._bind_stream()
+        ck = lambda rc, what: g.check(rc, what)                                     # noqa: E731
+
+        def muls(v, pairs):
+            if dense:
+                for ew, out in pairs:
+                    basicMul(v, ew.core, out)
+            elif len(pairs) == 1:
+                bucketMul(v, pairs[0][0], None, pairs[0][1], effort)
+            else:
+                bucketMulGroup([(v, ew, None, out, effort) for ew, out in pairs])
+
+        ck(lib.effort_fetch_row(g.ctx, _p(m.tokEmbeddings), _p(self.tokId), _p(self.h), cfg.stateDim), "fetch_row")
+        delta = None
+        for n, L in enumerate(m.layers):
+            ck(lib.effort_add_rmsnorm_mul(g.ctx, _p(self.h), _p(delta), _p(L.attnNorm), _p(self.h_norm), cfg.stateDim), "rmsnorm")
+            muls(self.h_norm, [(L.wq, self.xq_temp), (L.wk, self.xk_temp), (L.wv, self.xv_temp)])      # runNetwork.swift:132-134
+            ck(lib.effort_rope_kv(g.ctx, _p(self.xq_temp), _p(self.xk_temp), _p(self.xv_temp), _p(self.xq), _p(self.kCache[n]),
+                                  _p(self.vCache[n]), _p(self.pos), cfg.numHeads, cfg.numHeadsKV, cfg.headDim, C.c_float(cfg.ropeBase)), "rope_kv")
+            ck(lib.effort_attention(g.ctx, _p(self.xq), _p(self.kCache[n]), _p(self.vCache[n]), _p(self.pos), _p(self.attnOutput),
+                                    cfg.numHeads, cfg.headDim, self.maxTokens), "attention")
+            muls(self.attnOutput, [(L.wo, self.attnFfnOut)])                                          # :170
+            ck(lib.effort_add_rmsnorm_mul(g.ctx, _p(self.h), _p(self.attnFfnOut), _p(L.ffnNorm), _p(self.fxn), cfg.stateDim), "rmsnorm")
+            muls(self.fxn, [(L.w1, self.x1), (L.w3, self.x3)])                                        # :178-179
+            ck(lib.effort_silu_mul(g.ctx, _p(self.x1), _p(self.x3), _p(self.x2), cfg.hiddenDim), "silu")
+            muls(self.x2, [(L.w2, self.ffnOut)])                                                      # :182
+            delta = self.ffnOut
+        ck(lib.effort_add_rmsnorm_mul(g.ctx, _p(self.h), _p(delta), _p(m.norm), _p(self.outNormed), cfg.stateDim), "rmsnorm")
+        basicMul(self.outNormed, m.output, self.logits)                                               # :222
+        ck(lib.effort_argmax(g.ctx, _p(self.logits), cfg.vocab, _p(self.tokId), _p(self.pos), _p(self.history)), "argmax")
+
+    def _graph(self, effort: float, dense: bool):
+        key = ("dense",) if dense else (float(effort),)
+        if key not in self._graphs:
+            self.reset()
+            self.token_step(effort, dense)                       # warm (handles, kernel attributes, rocBLAS)
+            torch.cuda.synchronize()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                self.token_step(effort, dense)
+            self.g._bind_stream()
+            self._graphs[key] = gr
+        return self._graphs[key]
+
+    def reset(self):
+        self.pos.zero_()
+        self.tokId.zero_()
+        self.history.zero_()
+
+    def run(self, tokenIds: list[int], numTokens: int, effort: float = 0.25, dense: bool = False, forced: bool = False,
+            collect_logits: bool = False):
+        """runNetwork(tokens:effort:): feed the prompt one token per step, then continue greedily until ``numTokens``
+        steps have run.  ``forced``: every step's input comes from ``tokenIds`` (teacher forcing, for the KL measurement).
+        Returns (token ids picked at every step, seconds per step measured from the 3rd step on like the reference,
+        logits per step if asked)."""
+        assert 1 <= len(tokenIds) and numTokens <= self.maxTokens
+        gr = self._graph(effort, dense)
+        self.reset()
+        logits = []
+        t0, timed = None, 0
+        for step in range(numTokens):
+            if step < len(tokenIds):
+                self.tokId.fill_(int(tokenIds[step]))            # prompt (or forced) token; otherwise the previous pick stays
+            elif forced:
+                break
+            if step == 2:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            gr.replay()
+            if collect_logits:
+                logits.append(self.logits.clone())
+            if step >= 2:
+                timed += 1
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / timed if t0 is not None and timed else float("nan")
+        steps = min(numTokens, len(tokenIds)) if forced else numTokens
+        picked = self.history[:steps].cpu().tolist()
+        return picked, dt, (torch.stack(logits) if collect_logits else None)
+
+
+def kl_divergence(logits_ref: torch.Tensor, logits_test: torch.Tensor) -> float:
+    """mean over positions of KL(softmax(ref) || softmax(test))."""
+    a = torch.log_softmax(logits_ref.double(), -1)
+    b = torch.log_softmax(logits_test.double(), -1)
+    return float((a.exp() * (a - b)).sum(-1).mean())

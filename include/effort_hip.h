@@ -131,6 +131,30 @@ EFFORT_API int effort_last_cutoff(effort_ctx* ctx, float* host_out);
 EFFORT_API int effort_calc_dispatch(effort_ctx* ctx, const effort_w* w, const float* v_dev, const uint32_t* expNo_dev,
                          double effort, float* dispatch_dev, uint32_t* count_dev);
 
+/* ---- decode-loop glue around the multiplies (runNetwork.swift:68-316) -----------------------------
+ * The callers either side of the hot path: what a token step does between two expertMul calls.  The token position
+ * and the token id live in DEVICE memory (pos_dev, id_dev), so a whole token step can be replayed from one hipGraph.
+ * All vectors f32 on the device (VectorFloat), norm weights / embeddings f16. */
+
+/* h += delta (delta may be NULL); out = h / sqrt(mean(h^2) + 1e-5) * w -- rmsNormFast + mul(by:) + add(by:)
+ * (aux.metal:113-152,268-274; runNetwork.swift:121-122,170-173). */
+EFFORT_API int effort_add_rmsnorm_mul(effort_ctx* ctx, float* h_dev, const float* delta_dev, const void* w_f16_dev, float* out_dev, int n);
+/* rope_mx on q and on k, repeat4x32 of k and v over the query heads, stored at cache row *pos_dev
+ * (runNetwork.swift:128-149, aux.metal:218-261, createFreqsCis2 model.swift:693-717; caches f32 [maxTokens][numHeads][headDim]). */
+EFFORT_API int effort_rope_kv(effort_ctx* ctx, const float* xq_dev, const float* xk_dev, const float* xv_dev, float* q_out_dev,
+                   float* k_cache_dev, float* v_cache_dev, const uint32_t* pos_dev, int numHeads, int numHeadsKV, int headDim,
+                   float ropeBase);
+/* calcScores (/sqrt(headDim)) + softmax + sumScores over tokens 0..*pos_dev (runNetwork.swift:151-163, aux.metal:185-198,379-447). */
+EFFORT_API int effort_attention(effort_ctx* ctx, const float* q_dev, const float* k_cache_dev, const float* v_cache_dev,
+                     const uint32_t* pos_dev, float* out_dev, int numHeads, int headDim, int maxTokens);
+/* silu(x1, x3, out:) = x3 * x1 / (1 + exp(-x1)) (matrix.metal:25-35). */
+EFFORT_API int effort_silu_mul(effort_ctx* ctx, const float* x1_dev, const float* x3_dev, float* out_dev, int n);
+/* tokEmbeddings.fetchRow(id, out:) (aux.metal:355): row *id_dev of an f16 [vocab][n] table as f32. */
+EFFORT_API int effort_fetch_row(effort_ctx* ctx, const void* emb_f16_dev, const uint32_t* id_dev, float* out_dev, int n);
+/* greedy pick: *id_out_dev = argmax(logits) (the reference takes mpsTopK[0], helpers/mps.swift:52-84); if history_dev is
+ * given, history_dev[*pos_dev] = the pick; then *pos_dev += 1. */
+EFFORT_API int effort_argmax(effort_ctx* ctx, const float* logits_dev, int n, uint32_t* id_out_dev, uint32_t* pos_dev, uint32_t* history_dev);
+
 /* ---- weight layout converter ------------------------------------------------------------------- */
 
 /* func bucketize(_:outTensorsPref:tensors:goQ8:false) -- convert.swift:209-260 with kernels getProbes,
