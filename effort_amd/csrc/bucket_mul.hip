@@ -628,7 +628,6 @@ int bucket_mul_occupancy(Format fmt, int W, int E, size_t ldsBytes) {
     if (W == w && E == e) {                                                                                            \
         const void* f = fmt == kFp16 ? reinterpret_cast<const void*>(&bucket_mul_kernel<kFp16, e, w>)                  \
                                      : reinterpret_cast<const void*>(&bucket_mul_kernel<kQ4, e, w>);                   \
-        hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);                             \
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, f, 64 * w, ldsBytes) != hipSuccess) n = 0;                \
     }
     EFFORT_GEOMS(EFFORT_CASE)
