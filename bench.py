@@ -378,6 +378,35 @@ def main():
                               "tokens_per_s": round(1.0 / (te * 4 * 32), 1), "cos_vs_dense": round(cs, 5)})
                 del ge
             result["sweep"] = sweep
+        # ---------------- the other shapes / formats BASELINE.json names ------------------------------------
+        if not args.no_sweep:
+            def quick(ews_x, outDim_x, inDim_x, effort, n, q4=False):
+                vx = v if inDim_x == inDim else torch.randn(inDim_x, generator=gen, device=dev, dtype=torch.float32)
+                ox = [torch.zeros(outDim_x, device=dev) for _ in ews_x]
+                fnx = lambda ctx, ch: ea.bucketMulGroup([(vx, ew, None, o, effort) for ew, o in ch], gpu=ctx)    # noqa: E731
+                gx = one.capture(fnx, chunked(list(zip(ews_x, ox)), n))
+                Dx = g.last_dispatch_count((len(ews_x) - 1) % n)
+                tx = time_replays(gx, 40, 10) / len(ews_x)
+                del gx
+                if q4:
+                    nol = ews_x[0].outliers.shape[0]
+                    ab = Dx * (outDim_x // 32) * 2 + 8 * inDim_x * 8 + 4096 * 2 + 4 * inDim_x + 4 * outDim_x + 16 * nol
+                else:
+                    ab = algorithmic_bytes(Dx, inDim_x, outDim_x)
+                return {"us_per_call": round(tx * 1e6, 3), "dispatch_rows": Dx, "effective_GBps": round(2 * inDim_x * outDim_x / tx / 1e9, 1),
+                        "achieved_GBps": round(ab / tx / 1e9, 1), "frac_of_hbm_peak": round(ab / tx / 1e9 / HBM_PEAK_GBPS, 4)}
+            other = {}
+            sq = make_weights(ea, 16, 4096, 4096, 4321, dev, keep_core=False)
+            other["4096x4096 fp16"] = {f"effort {e}, {n} per launch": quick(sq, 4096, 4096, e, n) for e in (0.5, 0.25) for n in (1, 16)}
+            del sq
+            dn = make_weights(ea, 16, 14336, 4096, 5321, dev, keep_core=False)       # W2 of the FFN: 14336 -> 4096
+            other["14336x4096 fp16"] = {f"effort {e}, {n} per launch": quick(dn, 4096, 14336, e, n) for e in (0.25,) for n in (1, 16)}
+            del dn
+            q4w = make_weights(ea, 16, inDim, outDim, 6321, dev, keep_core=False, q4=True)
+            other["4096x11008 q4 (bucketMulQ4, 2 % outliers)"] = {f"effort {e}, {n} per launch": quick(q4w, outDim, inDim, e, n, q4=True)
+                                                                  for e in (0.25,) for n in (1, 16)}
+            del q4w
+            result["other_configs"] = other
         # ---------------- CPU baseline -----------------------------------------------------------------
         if not args.no_cpu:
             try:
