@@ -61,8 +61,12 @@ constexpr int kRounds = 16;  // selection rounds of NT candidate slots a workgro
 constexpr int kSc1 = 16;     // buffer aux bit: sc1 = write-through store / L1-bypassing load (cross-XCD visible)
 
 template <int FMT> struct Fmt;
-template <> struct Fmt<kFp16> { static constexpr int kAcc = 16; };
-template <> struct Fmt<kQ4> { static constexpr int kAcc = 32; };
+// kAcc: outputs per u16 column (16 positions / 4 sub-buckets x 8 positions); kSlots: LDS accumulators per u16 column.
+// Q4 keeps TWO accumulators per output, one for each sign nibble (slot = sub-bucket*16 + the whole 4-bit nibble): every
+// nibble then adds the same +d and the address comes straight out of the nibble -- 3 instructions per nibble instead of
+// 6 (no sign select) -- and the hand-off subtracts the planes.
+template <> struct Fmt<kFp16> { static constexpr int kAcc = 16, kSlots = 16; };
+template <> struct Fmt<kQ4> { static constexpr int kAcc = 32, kSlots = 64; };
 
 template <int FMT> struct MeanT;                       // what the staged row means are kept as in LDS
 template <> struct MeanT<kFp16> { typedef uint16_t type; };    // f16 bits (stats lane .w)
@@ -106,7 +110,7 @@ __host__ __device__ inline uint32_t align_up(uint32_t x, uint32_t a) { return (x
 template <int FMT, int E, int W>
 __host__ __device__ inline uint32_t lds_layout(uint32_t B, uint32_t slots, uint32_t* offV, uint32_t* offC,
                                                uint32_t* offL, uint32_t* offM) {
-    uint32_t o = (uint32_t)Fmt<FMT>::kAcc * E * 64 * 4;
+    uint32_t o = (uint32_t)Fmt<FMT>::kSlots * E * 64 * 4;
     *offL = o; o += align_up(slots * 2, 16);
     const uint32_t tbl = cutoff_table_bytes(64 * W);
     if (o < tbl) o = tbl;
@@ -121,7 +125,8 @@ __host__ __device__ inline uint32_t lds_layout(uint32_t B, uint32_t slots, uint3
 template <int FMT, int E, int W>
 __device__ __forceinline__ void mul_item(const GroupArgs& ga, const uint32_t item, char* smem, uint32_t& cachedCall, float& cachedCutoff) {
     constexpr int NACC = Fmt<FMT>::kAcc;
-    constexpr int TILE_F = NACC * E * 64;
+    constexpr int TILE_F = NACC * E * 64;                    // outputs of a tile (slab / out[] granularity)
+    constexpr int TILE_L = Fmt<FMT>::kSlots * E * 64;        // LDS accumulators of a tile
     constexpr int NT = 64 * W;
     constexpr int VPT = 4096 / NT;
 
@@ -234,7 +239,7 @@ __device__ __forceinline__ void mul_item(const GroupArgs& ga, const uint32_t ite
         cutoff = a.cutoffIn[0];
         __syncthreads();                                             // publishes means / vblk / wbound
     }
-    for (int i = tid; i < TILE_F; i += NT) acc[i] = 0;               // the table is dead: zero the tile (barrier in C)
+    for (int i = tid; i < TILE_L; i += NT) acc[i] = 0;               // the table is dead: zero the tile (barrier in C)
     // Fixed-point scale of this workgroup's tile.  Every product is |v_j| * |w| with |w| <= (max |w| of its rank), so
     // every partial sum is bounded by L = (sum over the slice of |v_j|) * (sum over ranks of that rank's max |w|)
     // (Q4: of that rank's max row mean); rankBound comes from registration.  With 2^k * L < 2^30 no accumulator can
@@ -358,16 +363,17 @@ __device__ __forceinline__ void mul_item(const GroupArgs& ga, const uint32_t ite
                 __hip_atomic_fetch_add((lds_i*)(size_t)a2 + j * 64, qv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         } else {
-            // bucketMulQ4.metal:76-81: low nibble first <-> sub-bucket 3,2,1,0; acc += (n&8) ? -d : d
+            // bucketMulQ4.metal:76-81: low nibble first <-> sub-bucket 3,2,1,0; out += (n&8) ? -d : d.  Here: plane
+            // (n&8) of slot (sub-bucket, n&7) += d; the planes are subtracted at the hand-off.
             const int di = __float_as_int(dd);
 #pragma unroll
             for (int j = 0; j < E; j++) {
                 const uint32_t x = pc.word(j);
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    const uint32_t nib = (x >> (4 * q)) & 15u;
-                    __hip_atomic_fetch_add((lds_i*)(acc + lane) + (((3 - q) * 8 + (nib & 7u)) * E + j) * 64, (nib & 8u) ? -di : di,
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    uint32_t a2;
+                    asm("v_bfe_u32 %0, %1, %2, 4\n\tv_lshl_add_u32 %0, %0, %3, %4" : "=&v"(a2) : "v"(x), "n"(4 * q), "n"(kShift), "v"(accB));
+                    __hip_atomic_fetch_add((lds_i*)(size_t)a2 + ((3 - q) * 16 * E + j) * 64, di, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
         }
@@ -412,8 +418,14 @@ __device__ __forceinline__ void mul_item(const GroupArgs& ga, const uint32_t ite
     const size_t slabBytes = (size_t)g.slices * g.tiles * TILE_F * 4;
     const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(a.slabs, 0, (int)slabBytes, 0x00020000);
     const uint32_t slabOff = (s * g.tiles + t) * (uint32_t)(TILE_F * 4);
+    auto tile_out = [&](int o) -> float {                           // output o of the tile, native [slot][j][lane] order
+        if (FMT == kFp16) return (float)acc[o] * unscale;
+        const int slot = o / (E * 64), rem = o % (E * 64);          // slot = sub-bucket*8 + position
+        const int p = (((slot >> 3) * 16 + (slot & 7)) * E * 64) + rem;
+        return (float)(acc[p] - acc[p + 8 * E * 64]) * unscale;
+    };
     for (int o = tid * 2; o < TILE_F; o += NT * 2) {
-        const float s0 = (float)acc[o] * unscale, s1 = (float)acc[o + 1] * unscale;
+        const float s0 = tile_out(o), s1 = tile_out(o + 1);
         typedef uint32_t u2 __attribute__((ext_vector_type(2)));
         u2 pk; pk[0] = __float_as_uint(s0); pk[1] = __float_as_uint(s1);
         __builtin_amdgcn_raw_buffer_store_b64(pk, srs, (uint32_t)o * 4u, slabOff, kSc1);

@@ -163,7 +163,10 @@ def main():
                        "mul_us": round(clk["mul_us"], 2), "mul_GBps": round(kb / clk["mul_us"] / 1e3, 0),
                        "eff_GBps": round(2 * inDim * outDim / t / 1e9, 0), "call_us_by_streams": over,
                        "ev_mul_us": round(ev["mul_us"], 2),
-                       "wg0_phases_us(issue,cutoff,select,stream,slab)": [round((st[9 + i] - st[8 + i]) / 100.0, 2) for i in range(5)], "wg0_rows": st[14], "reduce_us(tile0)": round((st[16] - st[15]) / 100.0, 2), "rel_wg0_start_us(max_start,max_stream_end,max_slab_drain,tile0_reduce_end)": [round((st[i] - st[8]) / 100.0, 2) for i in (17, 18, 19, 16)], "cutoff(setup,loop)us": [round((st[1] - st[0]) / 100.0, 2), round((st[2] - st[1]) / 100.0, 2)], "cutoff_loops,counts": [st[5] // 1000, st[5] % 1000]}
+                       "item0_phases_us(stage,cutoff,select,stream,handoff)": [round((st[9 + i] - st[8 + i]) / 100.0, 2) for i in range(5)],
+                       "item0_rows": st[14], "reduce_us(tile0)": round((st[16] - st[15]) / 100.0, 2),
+                       "cutoff(setup,table)us": [round((st[1] - st[0]) / 100.0, 2), round((st[2] - st[1]) / 100.0, 2)],
+                       "cutoff_loops,ballot_passes": [st[5] // 1000, st[5] % 1000]}
             except Exception as ex:
                 row = {"shape": args.shape, "effort": effort, "W": W, "E": E, "S": S, "error": repr(ex)[:100]}
             rows.append(row)
