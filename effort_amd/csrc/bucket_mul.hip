@@ -41,7 +41,10 @@
 
 namespace effort {
 
-constexpr int kBatch = 16;   // bucket rows per batch; two batches in flight per wave
+#ifndef EFFORT_KBATCH
+#define EFFORT_KBATCH 16
+#endif
+constexpr int kBatch = EFFORT_KBATCH;   // bucket rows per batch; two batches in flight per wave
 constexpr int kRounds = 16;  // selection rounds of NT candidate slots a workgroup can run: slots per slice <= kRounds * NT
 
 // Ablation builds for profiling (-DEFFORT_ABLATE_NOSCATTER=1 / -DEFFORT_ABLATE_NOLOAD=1); never shipped.
@@ -145,7 +148,11 @@ __device__ __forceinline__ void mul_item(const GroupArgs& ga, const uint32_t ite
     int tid0 = threadIdx.x;
     asm volatile("" : "+v"(tid0));      // opaque per item: keeps the compiler from hoisting every tid-derived value out of the item loop (+50 VGPRs)
     const int tid = tid0, lane = tid & 63;
-    const bool wstamp = a.tstamp && tid == 0;                        // every workgroup: phase durations summed into tstamp[32..]
+#ifdef EFFORT_NO_STAMPS
+    const bool wstamp = false;
+#else
+    const bool wstamp = a.tstamp && tid == 0;
+#endif                        // every workgroup: phase durations summed into tstamp[32..]
     unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};
     if (wstamp) ph[0] = wall_clock64();
     const bool stamp = a.tstamp && item == 0 && tid == 0;            // phase stamps of item 0 (profiling aid)
