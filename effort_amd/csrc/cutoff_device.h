@@ -162,10 +162,11 @@ __device__ __forceinline__ float block_find_cutoff(const float (&vj)[4096 / NT],
 
         if (wave == 0) {
             // ---- the bisection proper, one wave, one LDS lookup per round ------------------------------------
-            auto count_above = [&](uint32_t p) -> uint32_t {
-                if (p < base) return s_all[0];           // below the first cell: everything at or above it (zeros never count)
-                if (p > top) return above;
-                return tbl[p - base];
+            const uint32_t allGE = s_all[0];
+            auto count_above = [&](uint32_t p) -> uint32_t {     // branch-free: the lookup is always issued (clamped)
+                const uint32_t c = tbl[min(max(p, base), top) - base];
+                // below the first cell: everything at or above it (zeros never count); beyond the last: `above`
+                return p < base ? allGE : (p > top ? above : c);
             };
             while (!done && patHi != patLo + 1u) done = round(count_above(__float_as_uint(newBound) >> 16));
             if (!done) {
