@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- bucketMul throughput on MI355X (driver contract: DESIGN.md "Measurement").
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--group 16] [--effort 0.25]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--group 32] [--effort 0.25]
 
 Workload (BASELINE.json configs[1]): Mistral-7B-FFN-shaped matrix 4096 x 11008, fp16 buckets, bucketMul at
 25 % effort (the north-star operating point), plus an effort sweep 10..100 % in the same JSON line.
@@ -12,7 +12,7 @@ vector.  Inputs are resident in HBM before the timed region.  The 32 calls of a 
 hipGraph on ONE stream, so the host is not in the timed path (the reference's timeIt, helpers/timeit.swift:10-34,
 likewise enqueues everything and waits once).  The calls of a step are independent (as Wq|Wk|Wv or W1|W3 are in the
 decode loop), so they are issued `--group` at a time through effort_bucketmul_group: ONE kernel launch per group.
-`by_group_size` in the output gives the same step at 1, 2, 3, 4, 8 and 16 calls per launch; group size 1 is the
+`by_group_size` in the output gives the same step at 1, 2, 3, 4, 8, 16 and 32 calls per launch; group size 1 is the
 dependent-chain latency (every call waits for the previous one).  `two_streams` spreads the launches over two HIP
 streams (the head of one launch then overlaps the tail of another).
 
@@ -171,14 +171,14 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--effort", type=float, default=0.25)
-    ap.add_argument("--group", type=int, default=16, help="independent calls per kernel launch (1..16)")
+    ap.add_argument("--group", type=int, default=32, help="independent calls per kernel launch (1..32)")
     ap.add_argument("--partition", choices=["matrices", "columns"], default="matrices")
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--headline-only", action="store_true", help="only the timed job (for rocprofv3 passes: every bucket_mul_kernel dispatch is then the timed configuration)")
     ap.add_argument("--tune", default="0,0,0", help="waves,elems,slices of the multiply kernel (0,0,0 = heuristic)")
     args = ap.parse_args()
-    G = max(1, min(16, args.group))
+    G = max(1, min(32, args.group))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -330,7 +330,7 @@ def main():
         }
         # ---------------- the same step at other group sizes (1 = dependent-chain latency) ------------
         by = {}
-        for n in (1, 2, 3, 4, 8, 16):
+        for n in (1, 2, 3, 4, 8, 16, 32):
             gn = one.capture(mul(args.effort), chunked(items, n))
             tn = time_replays(gn, 40, 10) / N_MATS
             by[str(n)] = {"us_per_call": round(tn * 1e6, 3), "effective_GBps": round(eff_bytes / tn / 1e9, 1),
@@ -341,7 +341,7 @@ def main():
         for c in two.ctxs:
             c.set_tuning(*(int(x) for x in args.tune.split(",")))
         tw = {}
-        for n in (4, 8, 16):
+        for n in (8, 16, 32):
             gn = two.capture(mul(args.effort), chunked(items, n))
             tn = time_replays(gn, 40, 10) / N_MATS
             tw[str(n)] = {"us_per_call": round(tn * 1e6, 3), "effective_GBps": round(eff_bytes / tn / 1e9, 1),

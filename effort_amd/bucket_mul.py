@@ -50,12 +50,12 @@ def bucketMulQ4(v: torch.Tensor, by: ExpertWeights, expNo: torch.Tensor | None, 
 
 
 def bucketMulGroup(calls, gpu=None):
-    """One launch for up to 16 independent multiplies: ``calls`` = [(v, by, expNo, out, effort), ...], all FP16 or all
+    """One launch for up to 32 independent multiplies: ``calls`` = [(v, by, expNo, out, effort), ...], all FP16 or all
     Q4 bundles.  Same results as calling bucketMul / bucketMulQ4 on each; the group is how independent projections of
     the decode loop (Wq|Wk|Wv, W1|W3 -- runNetwork.swift:132-134,178-182) keep the whole chip busy."""
     calls = list(calls)
-    if not 1 <= len(calls) <= 16:
-        raise ValueError("a group holds 1..16 calls")
+    if not 1 <= len(calls) <= 32:
+        raise ValueError("a group holds 1..32 calls")
     q4 = calls[0][1].q4
     cls = BucketMulQ4 if q4 else BucketMul
     bm = cls.shared() if gpu is None else cls(gpu.device, gpu)

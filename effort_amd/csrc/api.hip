@@ -31,6 +31,8 @@ struct effort_ctx {
     uint32_t* d_counters = nullptr;   // per-tile arrival tickets (zero between calls)
     uint32_t* d_sliceCounts = nullptr;
     uint32_t* d_queue = nullptr;      // item queues of persistent launches
+    MulArgs* d_descCalls = nullptr;   // descriptor table of groups larger than kInlineGroup
+    uint32_t* d_descEnds = nullptr;
     int persistent = -1;              // workgroups per CU of group launches: -1 heuristic, 0 plain grid, R > 0 persistent
     // where each call of the last (group) launch keeps its per-slice counts; slices == 0: dispatch.size is d_count
     uint32_t lastCalls = 1, lastSliceOff[effort::kMaxGroup] = {0}, lastSlices[effort::kMaxGroup] = {0};
@@ -90,11 +92,12 @@ extern "C" effort_ctx* effort_create(int device, void* stream) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->numCU = prop.multiProcessorCount;
     c->slabBytes = (size_t)64 << 20;
-    bool ok = hipMalloc(&c->d_cutoff, 256) == hipSuccess && hipMalloc(&c->d_count, 16) == hipSuccess &&
+    bool ok = hipMalloc(&c->d_cutoff, 512) == hipSuccess && hipMalloc(&c->d_count, 16) == hipSuccess &&
               hipMalloc(&c->d_slabs, c->slabBytes) == hipSuccess && hipMalloc(&c->d_blockScratch, 4096 * 4) == hipSuccess &&
               hipMalloc(&c->d_cos, 16) == hipSuccess && hipMalloc(&c->d_status, 16) == hipSuccess &&
               hipMalloc(&c->d_tstamp, 4096) == hipSuccess && hipMalloc(&c->d_counters, effort_ctx::kMaxTiles * 4) == hipSuccess &&
-              hipMalloc(&c->d_sliceCounts, effort_ctx::kMaxSlices * 4) == hipSuccess && hipMalloc(&c->d_queue, 9 * 16 * 4) == hipSuccess;
+              hipMalloc(&c->d_sliceCounts, effort_ctx::kMaxSlices * 4) == hipSuccess && hipMalloc(&c->d_queue, 9 * 16 * 4) == hipSuccess &&
+              hipMalloc(&c->d_descCalls, sizeof(MulArgs) * kMaxGroup) == hipSuccess && hipMalloc(&c->d_descEnds, 4 * kMaxGroup) == hipSuccess;
     if (!ok) { effort_destroy(c); return nullptr; }
     int khz = 0;
     if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0) c->wallClockKHz = khz;
@@ -103,7 +106,7 @@ extern "C" effort_ctx* effort_create(int device, void* stream) {
     hipMemset(c->d_sliceCounts, 0, effort_ctx::kMaxSlices * 4);
     hipMemset(c->d_queue, 0, 9 * 16 * 4);
     { unsigned long long init[2] = {~0ull, 0ull}; hipMemcpy(c->d_tstamp, init, 16, hipMemcpyHostToDevice); }
-    hipMemset(c->d_cutoff, 0, 256);
+    hipMemset(c->d_cutoff, 0, 512);
     hipMemset(c->d_count, 0, 16);
     hipMemset(c->d_status, 0, 16);
     return c;
@@ -116,7 +119,7 @@ extern "C" void effort_destroy(effort_ctx* c) {
     if (c->blas) rocblas_destroy_handle(c->blas);
     if (c->ev) { for (int i = 0; i < effort_ctx::kMaxSamples * 4; i++) hipEventDestroy(c->ev[i]); delete[] c->ev; }
     hipFree(c->d_cutoff); hipFree(c->d_count); hipFree(c->d_slabs); hipFree(c->d_blockScratch);
-    hipFree(c->d_vhalf); hipFree(c->d_cos); hipFree(c->d_convVals); hipFree(c->d_status); hipFree(c->d_tstamp); hipFree(c->d_counters); hipFree(c->d_sliceCounts); hipFree(c->d_queue);
+    hipFree(c->d_vhalf); hipFree(c->d_cos); hipFree(c->d_convVals); hipFree(c->d_status); hipFree(c->d_tstamp); hipFree(c->d_counters); hipFree(c->d_sliceCounts); hipFree(c->d_queue); hipFree(c->d_descCalls); hipFree(c->d_descEnds);
     delete c;
 }
 
@@ -209,9 +212,17 @@ static bool supported(int W, int E) {
 }
 
 static int choose_geom(const effort_ctx* c, const effort_w* w, int groupSize, MulGeom* g, int* Wout, int* Eout) {
-    // defaults: 8 waves per workgroup; a lane owns 2 columns of a tile (FP16) or 1 word = 4 sub-buckets (Q4)
+    // defaults: 8 waves per workgroup; a lane owns 2 columns of a tile (FP16) or 1 word = 4 sub-buckets (Q4).  Large FP16
+    // groups take 4 columns per lane (fewer, fatter items: less fixed work per byte) -- unless that leaves the launch with
+    // between one and three items per CU, where half the chip runs two workgroups per CU in lockstep with the other half's
+    // one (measured, 4096x11008: 8 calls 7.9 vs 8.4 us/call, 16 calls 7.2 vs 6.6, 32 calls 5.7 vs 6.3).
     const int W = c->tuneW ? c->tuneW : 8;
-    const int E = c->tuneE ? c->tuneE : (w->fmt == kFp16 ? 2 : 1);
+    int E = c->tuneE ? c->tuneE : (w->fmt == kFp16 ? 2 : 1);
+    if (!c->tuneE && !c->tuneS && w->fmt == kFp16 && groupSize >= 8) {
+        const uint32_t tiles4 = (w->cols + 255) / 256, slices = ((w->inDim + 511) / 512 + 7) / 8 * 8;
+        const uint32_t items4 = (uint32_t)groupSize * tiles4 * slices;
+        if (items4 <= (uint32_t)c->numCU || items4 >= 3u * (uint32_t)c->numCU) E = 4;
+    }
     if (!supported(W, E)) return EFFORT_ERR_ARG;
     const uint32_t nacc = w->fmt == kFp16 ? 16 : 32;
     g->inDim = w->inDim; g->outDim = w->outDim; g->cols = w->cols; g->rowsPerIn = w->rowsPerIn;
@@ -262,12 +273,13 @@ static int ensure_timing(effort_ctx* c) {
 static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws, const float* const* vs,
                     const uint32_t* const* expNos, float* const* outs, const double* efforts) {
     if (!c || !ws || !vs || !outs || !efforts) return fail(c, EFFORT_ERR_ARG, "bucketmul: null argument");
-    if (n < 1 || n > kMaxGroup) return fail(c, EFFORT_ERR_ARG, "bucketmul: group size outside 1..16");
+    if (n < 1 || n > kMaxGroup) return fail(c, EFFORT_ERR_ARG, "bucketmul: group size outside 1..32");
     static const uint32_t ablate = getenv("EFFORT_ABLATE") ? (uint32_t)atoi(getenv("EFFORT_ABLATE")) : 0u;   // profiling only
     GroupArgs ga;
     memset(&ga, 0, sizeof(ga));
     ga.count = (uint32_t)n;
     ga.groupDone = c->d_counters + effort_ctx::kMaxTiles - 1;
+    ga.descCalls = c->d_descCalls; ga.descEnds = c->d_descEnds;
     int W = 0, E = 0;
     size_t slabOff = 0; uint32_t tileOff = 0, sliceOff = 0, wg = 0;
     for (int i = 0; i < n; i++) {

@@ -35,6 +35,7 @@
 //      on its tile's arrival counter, and the LAST workgroup of each tile sums the S slabs in slice order and writes
 //      out[].  The result does not depend on arrival order: deterministic end to end.  (Q4 outliers:
 //      q4_outliers_kernel, launched next.)
+#include <cstring>
 #include <type_traits>
 
 #include "cutoff_device.h"
@@ -125,8 +126,8 @@ __host__ __device__ inline uint32_t lds_layout(uint32_t B, uint32_t slots, uint3
 
 // One work item = one (call, tile, slice) of the group: stage, select, stream, hand the partial tile over.
 // `item` numbers the items the way a plain grid would number its blocks (item % 8 = the XCD it should run on).
-template <int FMT, int E, int W>
-__device__ __forceinline__ void mul_item(const GroupArgs& ga, const uint32_t item, char* smem, uint32_t& cachedCall, float& cachedCutoff) {
+template <int FMT, int E, int W, bool EXT>
+__device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t item, char* smem, uint32_t& cachedCall, float& cachedCutoff) {
     constexpr int NACC = Fmt<FMT>::kAcc;
     constexpr int TILE_F = NACC * E * 64;                    // outputs of a tile (slab / out[] granularity)
     constexpr int TILE_L = Fmt<FMT>::kSlots * E * 64;        // LDS accumulators of a tile
@@ -135,13 +136,12 @@ __device__ __forceinline__ void mul_item(const GroupArgs& ga, const uint32_t ite
 
     // which call of the group this item belongs to (item ranges are multiples of 8, so item%8 is still the XCD)
     uint32_t ci = 0;
-#pragma unroll
-    for (int i = 0; i < kMaxGroup - 1; i++) if ((uint32_t)(i + 1) < ga.count && item >= ga.wgEnd[i]) ci = i + 1;
+    for (uint32_t i = 0; i + 1 < ga.count; i++) if (item >= ga.template endAt<EXT>(i)) ci = i + 1;
     ci = __builtin_amdgcn_readfirstlane(ci);
-    const MulArgs& a = ga.call[ci];
-    const MulGeom& g = a.g;
+    const auto& a = ga.template callAt<EXT>(ci);
+    const auto& g = a.g;
     // XCD-aware id -> (tile, slice): all tiles of a slice run on one XCD (speed only).
-    const uint32_t b = item - (ci ? ga.wgEnd[ci - 1] : 0u), xcd = b & 7u, k = b >> 3;
+    const uint32_t b = item - (ci ? ga.template endAt<EXT>(ci - 1) : 0u), xcd = b & 7u, k = b >> 3;
     const uint32_t s = (k / g.tiles) * 8u + xcd, t = k % g.tiles;
     if (s >= g.slices) return;
 
@@ -528,11 +528,11 @@ __device__ __forceinline__ void mul_item(const GroupArgs& ga, const uint32_t ite
 // dispatcher only places ~40 workgroups/us chip-wide and spreads a large grid unevenly over the CUs (measured with
 // tools/microbench.hip: residency probe), so a group launch sizes its grid to the chip -- R workgroups per CU,
 // R fixed by the LDS each one asks for -- and balances the work itself.
-template <int FMT, int E, int W>
-__global__ __launch_bounds__(64 * W, (W <= 8 ? EFFORT_MIN_WAVES_PER_EU : 4)) void bucket_mul_kernel(const GroupArgs ga) {
+template <int FMT, int E, int W, bool EXT>
+__global__ __launch_bounds__(64 * W, (W <= 8 ? EFFORT_MIN_WAVES_PER_EU : 4)) void bucket_mul_kernel(const GroupKArgs ga) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ uint32_t s_item;
-    const uint32_t total = ga.wgEnd[ga.count - 1];
+    const uint32_t total = ga.template endAt<EXT>(ga.count - 1);
     uint32_t cachedCall = 0xFFFFFFFFu; float cachedCutoff = 0.0f;
     const uint32_t x = blockIdx.x & 7u;                    // block b sits on XCD b%8; item i wants XCD i%8
     for (uint32_t it = 0;; it++) {
@@ -546,7 +546,7 @@ __global__ __launch_bounds__(64 * W, (W <= 8 ? EFFORT_MIN_WAVES_PER_EU : 4)) voi
         } else if (it) {
             return;
         }
-        mul_item<FMT, E, W>(ga, item, smem, cachedCall, cachedCutoff);
+        mul_item<FMT, E, W, EXT>(ga, item, smem, cachedCall, cachedCutoff);
     }
     if (threadIdx.x == 0) {                                // the last workgroup out rewinds the queues for the next launch
         const uint32_t gone = __hip_atomic_fetch_add(&ga.queue[8 * 16], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -560,9 +560,10 @@ __global__ __launch_bounds__(64 * W, (W <= 8 ? EFFORT_MIN_WAVES_PER_EU : 4)) voi
 // fires one atomic per outlier in table order; here one wave owns one output (its outliers are contiguous in the
 // by-output index built at registration), lanes stride its segment with coalesced loads, and a fixed xor-butterfly
 // adds the 64 partial sums -- no atomics, deterministic.  Launched right after the multiply kernel on the same stream.
-__global__ __launch_bounds__(256) void q4_outliers_kernel(const GroupArgs ga) {
-    const MulArgs& a = ga.call[blockIdx.y];
-    const OutlierIndex& ol = a.ol;
+template <bool EXT>
+__global__ __launch_bounds__(256) void q4_outliers_kernel(const GroupKArgs ga) {
+    const auto& a = ga.template callAt<EXT>(blockIdx.y);
+    const auto& ol = a.ol;
     const float* __restrict__ v = a.v;
     float* __restrict__ out = a.out;
     const uint32_t o = blockIdx.x * 4u + (threadIdx.x >> 6);
@@ -581,7 +582,41 @@ hipError_t launch_q4_outliers(const GroupArgs& ga, hipStream_t st) {
     uint32_t maxOut = 0; bool any = false;
     for (uint32_t i = 0; i < ga.count; i++) { maxOut = max(maxOut, ga.call[i].g.outDim); any = any || ga.call[i].ol.rowPtr; }
     if (!any) return hipSuccess;
-    hipLaunchKernelGGL(q4_outliers_kernel, dim3((maxOut + 3) / 4, ga.count), dim3(256), 0, st, ga);
+    GroupKArgs k;
+    hipError_t e = make_group_kargs(ga, &k, st);
+    if (e != hipSuccess) return e;
+    if (k.extCalls) hipLaunchKernelGGL(q4_outliers_kernel<true>, dim3((maxOut + 3) / 4, ga.count), dim3(256), 0, st, k);
+    else hipLaunchKernelGGL(q4_outliers_kernel<false>, dim3((maxOut + 3) / 4, ga.count), dim3(256), 0, st, k);
+    return hipGetLastError();
+}
+
+// ---- group descriptors ----------------------------------------------------------------------
+// Up to kInlineGroup descriptors ride in the kernel arguments.  Larger groups: a tiny kernel copies them, 16 per
+// launch, from ITS arguments into the context's device table, and the multiply reads them from there.  (Kernel
+// arguments are copied when a launch is captured into a hipGraph; a host-to-device memcpy node would keep reading a host
+// buffer that the next capture overwrites.)
+struct PublishArgs { MulArgs call[kInlineGroup]; uint32_t wgEnd[kInlineGroup]; uint32_t first, n; };
+__global__ void publish_group_kernel(const PublishArgs p, MulArgs* __restrict__ calls, uint32_t* __restrict__ ends) {
+    const uint32_t i = threadIdx.x;
+    if (i < p.n) { calls[p.first + i] = p.call[i]; ends[p.first + i] = p.wgEnd[i]; }
+}
+
+hipError_t make_group_kargs(const GroupArgs& ga, GroupKArgs* k, hipStream_t st) {
+    memset(k, 0, sizeof(*k));
+    k->count = ga.count; k->totalTiles = ga.totalTiles; k->persistent = ga.persistent; k->numCU = ga.numCU;
+    k->groupDone = ga.groupDone; k->queue = ga.queue;
+    if (ga.count <= (uint32_t)kInlineGroup) {
+        for (uint32_t i = 0; i < ga.count; i++) { k->call[i] = ga.call[i]; k->wgEnd[i] = ga.wgEnd[i]; }
+        return hipSuccess;
+    }
+    if (!ga.descCalls || !ga.descEnds) return hipErrorInvalidValue;
+    for (uint32_t first = 0; first < ga.count; first += kInlineGroup) {
+        PublishArgs p;
+        p.first = first; p.n = min((uint32_t)kInlineGroup, ga.count - first);
+        for (uint32_t i = 0; i < p.n; i++) { p.call[i] = ga.call[first + i]; p.wgEnd[i] = ga.wgEnd[first + i]; }
+        hipLaunchKernelGGL(publish_group_kernel, dim3(1), dim3(64), 0, st, p, ga.descCalls, ga.descEnds);
+    }
+    k->extCalls = ga.descCalls; k->extEnds = ga.descEnds;
     return hipGetLastError();
 }
 
@@ -606,12 +641,18 @@ static hipError_t launch_mul_t(const GroupArgs& ga, hipStream_t st) {
         if (lds < force && force <= (160u * 1024u) / R) lds = force;
     }
     if (lds > maxSet) {
-        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&bucket_mul_kernel<FMT, E, W>),
+        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&bucket_mul_kernel<FMT, E, W, false>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (err == hipSuccess) err = hipFuncSetAttribute(reinterpret_cast<const void*>(&bucket_mul_kernel<FMT, E, W, true>),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (err != hipSuccess) return err;
         maxSet = lds;
     }
-    hipLaunchKernelGGL((bucket_mul_kernel<FMT, E, W>), dim3(grid), dim3(64 * W), lds, st, ga);
+    GroupKArgs k;
+    hipError_t e = make_group_kargs(ga, &k, st);
+    if (e != hipSuccess) return e;
+    if (k.extCalls) hipLaunchKernelGGL((bucket_mul_kernel<FMT, E, W, true>), dim3(grid), dim3(64 * W), lds, st, k);
+    else hipLaunchKernelGGL((bucket_mul_kernel<FMT, E, W, false>), dim3(grid), dim3(64 * W), lds, st, k);
     return hipGetLastError();
 }
 
@@ -645,8 +686,8 @@ int bucket_mul_occupancy(Format fmt, int W, int E, size_t ldsBytes) {
     int n = 0;
 #define EFFORT_CASE(w, e)                                                                                              \
     if (W == w && E == e) {                                                                                            \
-        const void* f = fmt == kFp16 ? reinterpret_cast<const void*>(&bucket_mul_kernel<kFp16, e, w>)                  \
-                                     : reinterpret_cast<const void*>(&bucket_mul_kernel<kQ4, e, w>);                   \
+        const void* f = fmt == kFp16 ? reinterpret_cast<const void*>(&bucket_mul_kernel<kFp16, e, w, false>)                  \
+                                     : reinterpret_cast<const void*>(&bucket_mul_kernel<kQ4, e, w, false>);                   \
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, f, 64 * w, ldsBytes) != hipSuccess) n = 0;                \
     }
     EFFORT_GEOMS(EFFORT_CASE)

@@ -25,9 +25,10 @@ __global__ __launch_bounds__(1024) void find_cutoff_kernel(const float* __restri
 
 // One workgroup per call of a group (split mode of grouped launches): the multiply workgroups then read the
 // cutoff instead of each re-deriving it.
-__global__ __launch_bounds__(1024) void find_cutoff_group_kernel(const GroupArgs ga) {
+template <bool EXT>
+__global__ __launch_bounds__(1024) void find_cutoff_group_kernel(const GroupKArgs ga) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const MulArgs& a = ga.call[blockIdx.x];
+    const auto& a = ga.template callAt<EXT>(blockIdx.x);
     const uint32_t e = a.expNo ? a.expNo[0] : 0u;
     const uint16_t* pr = a.probes + (size_t)e * kProbes;
     float vj[4]; uint16_t prj[4];
@@ -44,11 +45,16 @@ static hipError_t cutoff_attr(const void* fn) {
 hipError_t launch_find_cutoff_group(const GroupArgs& ga, hipStream_t st) {
     static bool attr = false;
     if (!attr) {
-        hipError_t e = cutoff_attr(reinterpret_cast<const void*>(&find_cutoff_group_kernel));
+        hipError_t e = cutoff_attr(reinterpret_cast<const void*>(&find_cutoff_group_kernel<false>));
+        if (e == hipSuccess) e = cutoff_attr(reinterpret_cast<const void*>(&find_cutoff_group_kernel<true>));
         if (e != hipSuccess) return e;
         attr = true;
     }
-    hipLaunchKernelGGL(find_cutoff_group_kernel, dim3(ga.count), dim3(1024), kCutoffLdsBytes + cutoff_table_bytes(1024), st, ga);
+    GroupKArgs k;
+    hipError_t e2 = make_group_kargs(ga, &k, st);
+    if (e2 != hipSuccess) return e2;
+    if (k.extCalls) hipLaunchKernelGGL(find_cutoff_group_kernel<true>, dim3(ga.count), dim3(1024), kCutoffLdsBytes + cutoff_table_bytes(1024), st, k);
+    else hipLaunchKernelGGL(find_cutoff_group_kernel<false>, dim3(ga.count), dim3(1024), kCutoffLdsBytes + cutoff_table_bytes(1024), st, k);
     return hipGetLastError();
 }
 

@@ -6,7 +6,7 @@
 // bf16-rounded probe products exceed the threshold, until the count hits 4096-q, or the bounds/counters
 // converge, or 100 rounds pass.  With quantised (bf16) values the count usually steps OVER the requested
 // rank; the bracket then shrinks float by float and the loop runs ~25-100 rounds (a literal port: 30 us on
-// MI355X, two barriers per round).  This version returns the same bits in ~2 us:
+// MI355X, two barriers per round).  This version returns the same bits in ~5 us (of which ~3 us is the serial bisection: ~26 dependent rounds on one wave):
 //   * the values are non-negative bf16 numbers, so  value > threshold  <=>  pattern(value) > bits(threshold)>>16
 //     as integers: a count depends only on the bf16 cell the threshold falls into;
 //   * so ONE pass builds a table over the cells between the smallest and the largest value -- an LDS histogram

@@ -58,17 +58,45 @@ struct MulArgs {
 // the decode loop's Wq|Wk|Wv and W1|W3 (runNetwork.swift:132-134,178-182) are such groups.  A lone call's
 // workgroups spend most of their life in dependent fixed-latency steps, so one call cannot load the chip; in a
 // group the workgroups of different calls overlap on the CUs inside ONE kernel, no stream juggling involved.
-constexpr int kMaxGroup = 16;   // 16 descriptors = 3 KB of kernel arguments (limit 4 KB)
-struct GroupArgs {
+constexpr int kMaxGroup = 32;        // calls per launch
+constexpr int kInlineGroup = 16;     // ... of which this many descriptors travel as kernel arguments (3 KB; limit 4 KB)
+struct GroupArgs {                   // host side: everything one launch serves
     MulArgs call[kMaxGroup];
-    uint32_t wgEnd[kMaxGroup];     // exclusive end of each call's block range (multiples of 8)
+    uint32_t wgEnd[kMaxGroup];     // exclusive end of each call's item range (multiples of 8)
     uint32_t count;
     uint32_t totalTiles;           // sum of tiles: the workgroup that finishes the last tile folds the timing stamps
     uint32_t* groupDone;           // its counter (zero between launches)
     uint32_t persistent;           // 0: one workgroup per item; R > 0: numCU*R persistent workgroups pull items from the queues
     uint32_t numCU;
     uint32_t* queue;               // [9][16]: per-XCD item cursors (one cache line each) + exit counter; zero between launches
+    MulArgs* descCalls;            // context scratch for groups larger than kInlineGroup: the descriptors are published to
+    uint32_t* descEnds;            // device memory by a tiny kernel (graph-capture safe: no host buffer is referenced)
 };
+struct GroupKArgs {                  // device side: what the kernels receive by value
+    MulArgs call[kInlineGroup];
+    uint32_t wgEnd[kInlineGroup];
+    uint32_t count, totalTiles, persistent, numCU;
+    uint32_t* groupDone;
+    uint32_t* queue;
+    const MulArgs* extCalls;       // non-null: count > kInlineGroup, descriptors and ranges live in device memory
+    const uint32_t* extEnds;
+    // EXT = false: descriptors in the kernel arguments.  EXT = true: in the device table, read through the CONSTANT address
+    // space -- they never change during a launch, so the compiler may re-load a field whenever it likes (as it does for
+    // kernel arguments) instead of assuming every store could have hit it.
+    typedef const MulArgs __attribute__((address_space(4))) ConstMulArgs;
+    typedef const uint32_t __attribute__((address_space(4))) ConstU32;
+    template <bool EXT> struct Sel;
+    template <bool EXT> __device__ __forceinline__ auto& callAt(uint32_t i) const {
+        if constexpr (EXT) return reinterpret_cast<ConstMulArgs*>(reinterpret_cast<uintptr_t>(extCalls))[i];
+        else return call[i];
+    }
+    template <bool EXT> __device__ __forceinline__ uint32_t endAt(uint32_t i) const {
+        if constexpr (EXT) return reinterpret_cast<ConstU32*>(reinterpret_cast<uintptr_t>(extEnds))[i];
+        else return wgEnd[i];
+    }
+};
+// Fills the kernel-side arguments of a launch (publishing the descriptors to device memory first when they do not fit).
+hipError_t make_group_kargs(const GroupArgs& ga, GroupKArgs* k, hipStream_t st);
 
 // ---- device helpers -------------------------------------------------------------------------
 __device__ __forceinline__ float half_bits_to_float(uint16_t h) { return __half2float(__ushort_as_half(h)); }

@@ -67,7 +67,7 @@ def _default_mul_group(v, bys, outs, effort, expNo):
     when they are all bucketed bundles of one kind, expertMul one by one otherwise (dense fallback of expertMul.swift:29)."""
     from .bucket_mul import bucketMulGroup, expertMul
     same = all(b.q4 == bys[0].q4 for b in bys) and all((not b.q4) or b.bucketsLoaded for b in bys)
-    if same and 1 < len(bys) <= 16:
+    if same and 1 < len(bys) <= 32:
         bucketMulGroup([(v, b, expNo, o, effort) for b, o in zip(bys, outs)])
     else:
         for b, o in zip(bys, outs):

@@ -105,7 +105,7 @@ EFFORT_API int effort_dense_gemv(effort_ctx* ctx, const void* W_f16_dev, const f
 
 /* ---- reference-visible state / test hooks ------------------------------------------------------ */
 
-/* A GROUP of n (1..16) independent bucketMul calls in ONE kernel launch: call i multiplies vs[i] by ws[i] at
+/* A GROUP of n (1..32) independent bucketMul calls in ONE kernel launch: call i multiplies vs[i] by ws[i] at
  * efforts[i] into outs[i] (expNos may be NULL, or hold NULL entries = expert 0).  Same results, bit for bit, as n
  * effort_bucketmul calls; the point is throughput: the decode loop issues such groups back to back on unchanged
  * input -- Wq|Wk|Wv (runNetwork.swift:132-134) and W1|W3 (runNetwork.swift:178-182) -- and the reference's command

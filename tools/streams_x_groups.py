@@ -26,8 +26,9 @@ def main():
         st = bench.Step(ea, 0, K)
         for c in st.ctxs:
             c.set_persistent(per)
+            c.set_tuning(*(int(x) for x in os.environ.get("TUNE", "0,0,0").split(",")))
         row = {"streams": K}
-        for G in (1, 2, 4, 8, 16):
+        for G in (1, 2, 4, 8, 16, 32):
             fn = lambda ctx, ch: ea.bucketMulGroup([(v, ew, None, o, effort) for ew, o in ch], gpu=ctx)
             g = st.capture(fn, bench.chunked(items, G))
             row[f"g{G}_us_per_call"] = round(bench.time_replays(g, 40, 10) / 32 * 1e6, 2)
