@@ -215,13 +215,13 @@ static int choose_geom(const effort_ctx* c, const effort_w* w, int groupSize, Mu
     // defaults: 8 waves per workgroup; a lane owns 2 columns of a tile (FP16) or 1 word = 4 sub-buckets (Q4).  Large FP16
     // groups take 4 columns per lane (fewer, fatter items: less fixed work per byte) -- unless that leaves the launch with
     // between one and three items per CU, where half the chip runs two workgroups per CU in lockstep with the other half's
-    // one (measured, 4096x11008: 8 calls 7.9 vs 8.4 us/call, 16 calls 7.2 vs 6.6, 32 calls 5.7 vs 6.3).
+    // one, or with less than half an item per CU (measured, 4096x11008: 8 calls 7.9 vs 8.4 us/call, 16 calls 7.2 vs 6.6, 32 calls 5.7 vs 6.3).
     const int W = c->tuneW ? c->tuneW : 8;
     int E = c->tuneE ? c->tuneE : (w->fmt == kFp16 ? 2 : 1);
     if (!c->tuneE && !c->tuneS && w->fmt == kFp16 && groupSize >= 8) {
         const uint32_t tiles4 = (w->cols + 255) / 256, slices = ((w->inDim + 511) / 512 + 7) / 8 * 8;
         const uint32_t items4 = (uint32_t)groupSize * tiles4 * slices;
-        if (items4 <= (uint32_t)c->numCU || items4 >= 3u * (uint32_t)c->numCU) E = 4;
+        if ((items4 > (uint32_t)c->numCU / 2 && items4 <= (uint32_t)c->numCU) || items4 >= 3u * (uint32_t)c->numCU) E = 4;
     }
     if (!supported(W, E)) return EFFORT_ERR_ARG;
     const uint32_t nacc = w->fmt == kFp16 ? 16 : 32;
