@@ -31,8 +31,6 @@ struct effort_ctx {
     uint32_t* d_counters = nullptr;   // per-tile arrival tickets (zero between calls)
     uint32_t* d_sliceCounts = nullptr;
     uint32_t* d_queue = nullptr;      // item queues of persistent launches
-    MulArgs* d_descCalls = nullptr;   // descriptor table of groups larger than kInlineGroup
-    uint32_t* d_descEnds = nullptr;
     int persistent = -1;              // workgroups per CU of group launches: -1 heuristic, 0 plain grid, R > 0 persistent
     // where each call of the last (group) launch keeps its per-slice counts; slices == 0: dispatch.size is d_count
     uint32_t lastCalls = 1, lastSliceOff[effort::kMaxGroup] = {0}, lastSlices[effort::kMaxGroup] = {0};
@@ -96,8 +94,7 @@ extern "C" effort_ctx* effort_create(int device, void* stream) {
               hipMalloc(&c->d_slabs, c->slabBytes) == hipSuccess && hipMalloc(&c->d_blockScratch, 4096 * 4) == hipSuccess &&
               hipMalloc(&c->d_cos, 16) == hipSuccess && hipMalloc(&c->d_status, 16) == hipSuccess &&
               hipMalloc(&c->d_tstamp, 4096) == hipSuccess && hipMalloc(&c->d_counters, effort_ctx::kMaxTiles * 4) == hipSuccess &&
-              hipMalloc(&c->d_sliceCounts, effort_ctx::kMaxSlices * 4) == hipSuccess && hipMalloc(&c->d_queue, 9 * 16 * 4) == hipSuccess &&
-              hipMalloc(&c->d_descCalls, sizeof(MulArgs) * kMaxGroup) == hipSuccess && hipMalloc(&c->d_descEnds, 4 * kMaxGroup) == hipSuccess;
+              hipMalloc(&c->d_sliceCounts, effort_ctx::kMaxSlices * 4) == hipSuccess && hipMalloc(&c->d_queue, 9 * 16 * 4) == hipSuccess;
     if (!ok) { effort_destroy(c); return nullptr; }
     int khz = 0;
     if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0) c->wallClockKHz = khz;
@@ -119,7 +116,7 @@ extern "C" void effort_destroy(effort_ctx* c) {
     if (c->blas) rocblas_destroy_handle(c->blas);
     if (c->ev) { for (int i = 0; i < effort_ctx::kMaxSamples * 4; i++) hipEventDestroy(c->ev[i]); delete[] c->ev; }
     hipFree(c->d_cutoff); hipFree(c->d_count); hipFree(c->d_slabs); hipFree(c->d_blockScratch);
-    hipFree(c->d_vhalf); hipFree(c->d_cos); hipFree(c->d_convVals); hipFree(c->d_status); hipFree(c->d_tstamp); hipFree(c->d_counters); hipFree(c->d_sliceCounts); hipFree(c->d_queue); hipFree(c->d_descCalls); hipFree(c->d_descEnds);
+    hipFree(c->d_vhalf); hipFree(c->d_cos); hipFree(c->d_convVals); hipFree(c->d_status); hipFree(c->d_tstamp); hipFree(c->d_counters); hipFree(c->d_sliceCounts); hipFree(c->d_queue);
     delete c;
 }
 
@@ -275,35 +272,43 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
     if (!c || !ws || !vs || !outs || !efforts) return fail(c, EFFORT_ERR_ARG, "bucketmul: null argument");
     if (n < 1 || n > kMaxGroup) return fail(c, EFFORT_ERR_ARG, "bucketmul: group size outside 1..32");
     static const uint32_t ablate = getenv("EFFORT_ABLATE") ? (uint32_t)atoi(getenv("EFFORT_ABLATE")) : 0u;   // profiling only
-    GroupArgs ga;
+    GroupKArgs ga;
     memset(&ga, 0, sizeof(ga));
     ga.count = (uint32_t)n;
     ga.groupDone = c->d_counters + effort_ctx::kMaxTiles - 1;
-    ga.descCalls = c->d_descCalls; ga.descEnds = c->d_descEnds;
+    ga.slabs = c->d_slabs; ga.counters = c->d_counters; ga.sliceCounts = c->d_sliceCounts; ga.cutoff = c->d_cutoff;
+    ga.tstamp = c->clock ? c->d_tstamp : nullptr;
+    ga.ablate = ablate; ga.split = c->splitCutoff ? 1u : 0u;
     int W = 0, E = 0;
+    uint32_t nGeoms = 0;
     size_t slabOff = 0; uint32_t tileOff = 0, sliceOff = 0, wg = 0;
     for (int i = 0; i < n; i++) {
         const effort_w* w = ws[i];
         if (!w || !vs[i] || !outs[i]) return fail(c, EFFORT_ERR_ARG, "bucketmul: null argument");
         if (w->fmt != fmt) return fail(c, EFFORT_ERR_KIND, "bucketmul: weight handle of the wrong kind");
         if (!(efforts[i] >= 0.0 && efforts[i] <= 1.0)) return fail(c, EFFORT_ERR_EFFORT, "bucketmul: effort outside [0,1]");
-        MulArgs& a = ga.call[i];
+        CallDesc& a = ga.call[i];
+        MulGeom g;
+        memset(&g, 0, sizeof(g));
         int Wi, Ei;
-        int rc = choose_geom(c, w, n, &a.g, &Wi, &Ei);
+        int rc = choose_geom(c, w, n, &g, &Wi, &Ei);
         if (rc != EFFORT_OK) return fail(c, rc, "bucketmul: no launch geometry for this shape/tuning");
         if (i == 0) { W = Wi; E = Ei; }
-        const MulGeom& g = a.g;
+        else if (Wi != W || Ei != E) return fail(c, EFFORT_ERR_SHAPE, "bucketmul: the calls of a group must agree on the kernel variant");
+        uint32_t gi = 0;
+        while (gi < nGeoms && memcmp(&ga.geom[gi], &g, sizeof(g)) != 0) gi++;
+        if (gi == nGeoms) {
+            if (nGeoms == kMaxGeoms) return fail(c, EFFORT_ERR_SHAPE, "bucketmul: more than 6 distinct shapes in one group");
+            ga.geom[nGeoms++] = g;
+        }
         const size_t slab = (size_t)g.slices * g.tiles * g.tileFloats * 4;
         if (tileOff + g.tiles + 1 > effort_ctx::kMaxTiles || sliceOff + g.slices > effort_ctx::kMaxSlices || slabOff + slab > c->slabBytes)
             return fail(c, EFFORT_ERR_SHAPE, "bucketmul: group exceeds the context scratch");
-        a.buckets = w->buckets; a.stats = w->stats; a.rankBound = w->rankBound; a.probes = w->probes; a.v = vs[i]; a.expNo = expNos ? expNos[i] : nullptr; a.out = outs[i];
-        a.slabs = reinterpret_cast<float*>(reinterpret_cast<char*>(c->d_slabs) + slabOff);
-        a.counters = c->d_counters + tileOff; a.sliceCounts = c->d_sliceCounts + sliceOff; a.cutoffOut = c->d_cutoff + i;
-        a.cutoffIn = c->splitCutoff ? c->d_cutoff + i : nullptr;
-        a.tstamp = c->clock ? c->d_tstamp : nullptr;
+        a.buckets = w->buckets; a.stats = w->stats; a.rankBound = w->rankBound; a.probes = w->probes; a.v = vs[i];
+        a.expNo = expNos ? expNos[i] : nullptr; a.out = outs[i];
         a.ol = OutlierIndex{fmt == kQ4 ? w->olRowPtr : nullptr, w->olInIdx, w->olValue};
         a.q = (uint32_t)(int)((double)(kProbes - 1) * (1.0 - efforts[i]));            // bucketMul.swift:39
-        a.ablate = ablate;
+        a.slabOff = (uint32_t)(slabOff / 256); a.tileOff = (uint16_t)tileOff; a.sliceOff = (uint16_t)sliceOff; a.geom = (uint16_t)gi;
         wg += g.tiles * ((g.slices + 7) / 8 * 8);
         ga.wgEnd[i] = wg;
         ga.totalTiles += g.tiles;

@@ -126,7 +126,7 @@ __host__ __device__ inline uint32_t lds_layout(uint32_t B, uint32_t slots, uint3
 
 // One work item = one (call, tile, slice) of the group: stage, select, stream, hand the partial tile over.
 // `item` numbers the items the way a plain grid would number its blocks (item % 8 = the XCD it should run on).
-template <int FMT, int E, int W, bool EXT>
+template <int FMT, int E, int W>
 __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t item, char* smem, uint32_t& cachedCall, float& cachedCutoff) {
     constexpr int NACC = Fmt<FMT>::kAcc;
     constexpr int TILE_F = NACC * E * 64;                    // outputs of a tile (slab / out[] granularity)
@@ -136,12 +136,16 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
 
     // which call of the group this item belongs to (item ranges are multiples of 8, so item%8 is still the XCD)
     uint32_t ci = 0;
-    for (uint32_t i = 0; i + 1 < ga.count; i++) if (item >= ga.template endAt<EXT>(i)) ci = i + 1;
+    for (uint32_t i = 0; i + 1 < ga.count; i++) if (item >= ga.wgEnd[i]) ci = i + 1;
     ci = __builtin_amdgcn_readfirstlane(ci);
-    const auto& a = ga.template callAt<EXT>(ci);
-    const auto& g = a.g;
+    const CallDesc& a = ga.call[ci];
+    const MulGeom& g = ga.geom[a.geom];
+    float* const a_slabs = ga.slabs + (size_t)a.slabOff * 64u;
+    uint32_t* const a_counters = ga.counters + a.tileOff;
+    uint32_t* const a_sliceCounts = ga.sliceCounts + a.sliceOff;
+    float* const a_cutoff = ga.cutoff + ci;
     // XCD-aware id -> (tile, slice): all tiles of a slice run on one XCD (speed only).
-    const uint32_t b = item - (ci ? ga.template endAt<EXT>(ci - 1) : 0u), xcd = b & 7u, k = b >> 3;
+    const uint32_t b = item - (ci ? ga.wgEnd[ci - 1] : 0u), xcd = b & 7u, k = b >> 3;
     const uint32_t s = (k / g.tiles) * 8u + xcd, t = k % g.tiles;
     if (s >= g.slices) return;
 
@@ -151,12 +155,12 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
 #ifdef EFFORT_NO_STAMPS
     const bool wstamp = false;
 #else
-    const bool wstamp = a.tstamp && tid == 0;
+    const bool wstamp = ga.tstamp && tid == 0;
 #endif                        // every workgroup: phase durations summed into tstamp[32..]
     unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};
     if (wstamp) ph[0] = wall_clock64();
-    const bool stamp = a.tstamp && item == 0 && tid == 0;            // phase stamps of item 0 (profiling aid)
-    if (stamp) a.tstamp[16] = wall_clock64();
+    const bool stamp = ga.tstamp && item == 0 && tid == 0;            // phase stamps of item 0 (profiling aid)
+    if (stamp) ga.tstamp[16] = wall_clock64();
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t B = g.sliceRows;
     uint32_t offV, offC, offL, offM;
@@ -180,7 +184,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     // means[c] = the row mean the keep test reads (f16 bits for FP16, f32 for Q4); slots past the slice hold 0.
     float vj[VPT]; uint16_t prj[VPT];
     const uint16_t* pr = a.probes + (size_t)e * kProbes;
-    const bool fused = a.cutoffIn == nullptr;                    // uniform
+    const bool fused = ga.split == 0u;                           // uniform
 #pragma unroll
     for (int i = 0; i < VPT; i++) { vj[i] = 0.0f; prj[i] = 0; }
     const bool needCut = fused && cachedCall != ci;              // uniform: a persistent workgroup evaluates a call's cutoff once
@@ -225,7 +229,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     for (int off = 32; off >= 1; off >>= 1) bound += __shfl_xor(bound, off);
     if (lane == 0) wbound[wave] = bound;
     const float rankBound = a.rankBound[e];
-    if (stamp) a.tstamp[17] = wall_clock64();
+    if (stamp) ga.tstamp[17] = wall_clock64();
     if (wstamp) ph[1] = wall_clock64();
 
     // ---- B. cutoff (findCutoff32), redundantly per workgroup; its first barrier also publishes means / vblk /
@@ -233,17 +237,17 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     uint32_t* tbl = reinterpret_cast<uint32_t*>(smem);
     float cutoff;
     if (needCut) {
-        cutoff = block_find_cutoff<NT>(vj, prj, a.q, smem + offC, tbl, []() {}, stamp ? a.tstamp + 8 : nullptr);
+        cutoff = block_find_cutoff<NT>(vj, prj, a.q, smem + offC, tbl, []() {}, stamp ? ga.tstamp + 8 : nullptr);
         cachedCall = ci; cachedCutoff = cutoff;
-        if (b == 0 && tid == 0) a.cutoffOut[0] = cutoff;             // BucketMul.cutoff (bucketMul.swift:22)
+        if (b == 0 && tid == 0) a_cutoff[0] = cutoff;             // BucketMul.cutoff (bucketMul.swift:22)
     } else if (fused) {
         cutoff = cachedCutoff;
-        if (b == 0 && tid == 0) a.cutoffOut[0] = cutoff;
+        if (b == 0 && tid == 0) a_cutoff[0] = cutoff;
         __syncthreads();                                             // publishes means / vblk / wbound
     } else {
         // split mode: the standalone cutoff kernel ran first on this stream (cheaper in aggregate when several
         // calls overlap: one workgroup evaluates it instead of all of them)
-        cutoff = a.cutoffIn[0];
+        cutoff = a_cutoff[0];
         __syncthreads();                                             // publishes means / vblk / wbound
     }
     for (int i = tid; i < TILE_L; i += NT) acc[i] = 0;               // the table is dead: zero the tile (barrier in C)
@@ -259,7 +263,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     int kexp = 30 - (int)((__float_as_uint(L) >> 23) & 0xFFu) + 126;     // L < 2^(e-126)  =>  2^kexp * L < 2^30
     kexp = L > 0.0f ? max(-100, min(100, kexp)) : 0;
     const float scale = __uint_as_float((uint32_t)(127 + kexp) << 23), unscale = __uint_as_float((uint32_t)(127 - kexp) << 23);
-    if (stamp) a.tstamp[18] = wall_clock64();
+    if (stamp) ga.tstamp[18] = wall_clock64();
     if (wstamp) ph[2] = wall_clock64();
 
     // ---- C. keep test (bucketMul.metal:69 / bucketMulQ4.metal:47) + ordered compaction -----------
@@ -268,7 +272,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     // ballots (kept slots of earlier rounds + earlier waves of the round); pass 2 writes the survivors: list position
     // = that offset + earlier lanes of the wave.  No atomics, ascending bucket-row order.
     auto keep_test = [&](uint32_t c) -> bool {
-        if (c >= nSlots || (a.ablate & 8u)) return false;
+        if (c >= nSlots || (ga.ablate & 8u)) return false;
         if (FMT == kFp16) {
             const uint32_t jl = c & ((1u << lg) - 1u);
             const float x = jl < nb ? vblk[jl] : 0.0f;
@@ -308,8 +312,8 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
         if (k) list[pos] = (uint16_t)(FMT == kFp16 ? (((c >> lg) << 12) | (c & ((1u << lg) - 1u))) : c);
     }
     __syncthreads();
-    if (t == 0 && tid == 0) a.sliceCounts[s] = n;                  // dispatch.size = sum over slices (test hook)
-    if (stamp) a.tstamp[19] = wall_clock64();
+    if (t == 0 && tid == 0) a_sliceCounts[s] = n;                  // dispatch.size = sum over slices (test hook)
+    if (stamp) ga.tstamp[19] = wall_clock64();
     if (wstamp) ph[3] = wall_clock64();
 
     // ---- D. stream the kept rows, scatter-accumulate into the LDS tile ----------------
@@ -318,7 +322,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint16_t*>(a.buckets), 0, (int)min((size_t)0xFFFFFFFFu, (size_t)g.numExperts * g.expertRows * g.cols * 2u), 0x00020000);
     const uint32_t voff = (colOK ? col : 0u) * 2u;                 // lanes past the last column re-read column 0
-    const uint32_t nU = (a.ablate & 4u) ? 0u : __builtin_amdgcn_readfirstlane(n);   // n is workgroup-uniform; keep it in an SGPR
+    const uint32_t nU = (ga.ablate & 4u) ? 0u : __builtin_amdgcn_readfirstlane(n);   // n is workgroup-uniform; keep it in an SGPR
     const uint32_t myRows = (nU > (uint32_t)wave) ? (nU - wave + W - 1) / W : 0u;   // entries wave, wave+W, ...
 
     // Software pipeline: the loads of batch k+1 are issued before batch k is accumulated, so a wave keeps
@@ -417,13 +421,13 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
         }
     }
     __syncthreads();                           // every wave's atomics have landed in the tile
-    if (stamp) a.tstamp[20] = wall_clock64();
+    if (stamp) ga.tstamp[20] = wall_clock64();
     if (wstamp) ph[4] = wall_clock64();
 
     // ---- E. the tile, back in f32 -> one slab (native [slot][j][lane] order), write-through; ticket; last arriver
     //         of the tile reduces the S slabs in slice order and writes out[] -------------------------------
     const size_t slabBytes = (size_t)g.slices * g.tiles * TILE_F * 4;
-    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(a.slabs, 0, (int)slabBytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(a_slabs, 0, (int)slabBytes, 0x00020000);
     const uint32_t slabOff = (s * g.tiles + t) * (uint32_t)(TILE_F * 4);
     auto tile_out = [&](int o) -> float {                           // output o of the tile, native [slot][j][lane] order
         if (FMT == kFp16) return (float)acc[o] * unscale;
@@ -438,36 +442,36 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
         __builtin_amdgcn_raw_buffer_store_b64(pk, srs, (uint32_t)o * 4u, slabOff, kSc1);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's slab stores have left the CU
-    if (stamp) { a.tstamp[21] = wall_clock64(); a.tstamp[22] = n; }
+    if (stamp) { ga.tstamp[21] = wall_clock64(); ga.tstamp[22] = n; }
     if (wstamp) ph[5] = wall_clock64();
     // the stamps are flushed off the critical path (after the ticket), spread over 32 cache lines
     auto flush_stamps = [&]() {
         if (!wstamp) return;
-        unsigned long long* line = a.tstamp + 64 + (item & 31u) * 8u;
+        unsigned long long* line = ga.tstamp + 64 + (item & 31u) * 8u;
 #pragma unroll
         for (int i = 0; i < 5; i++) atomicAdd(&line[i], ph[i + 1] - ph[i]);
         atomicAdd(&line[5], 1ull);
-        atomicMin(&a.tstamp[0], ph[0]);
-        atomicMax(&a.tstamp[26], ph[0]);                                       // latest workgroup start
-        atomicMax(&a.tstamp[28], ph[5] - ph[0]);                               // longest workgroup (start .. slab drained)
-        atomicMax(&a.tstamp[29], ph[4] - ph[3]);                               // longest streaming phase
-        atomicMax(&a.tstamp[1], (unsigned long long)wall_clock64());
+        atomicMin(&ga.tstamp[0], ph[0]);
+        atomicMax(&ga.tstamp[26], ph[0]);                                       // latest workgroup start
+        atomicMax(&ga.tstamp[28], ph[5] - ph[0]);                               // longest workgroup (start .. slab drained)
+        atomicMax(&ga.tstamp[29], ph[4] - ph[3]);                               // longest streaming phase
+        atomicMax(&ga.tstamp[1], (unsigned long long)wall_clock64());
     };
     __syncthreads();
     if (tid == 0) {
-        const uint32_t ticket = __hip_atomic_fetch_add(&a.counters[t], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t ticket = __hip_atomic_fetch_add(&a_counters[t], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         flags[0] = (ticket == g.slices - 1u) ? 1u : 0u;
     }
     __syncthreads();
     if (flags[0] == 0u) { flush_stamps(); return; }
-    if (a.ablate & 2u) { if (tid == 0) __hip_atomic_store(&a.counters[t], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+    if (ga.ablate & 2u) { if (tid == 0) __hip_atomic_store(&a_counters[t], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
 
     // last arriver of tile t: every slab of the tile was stored write-through (sc1) and drained before its ticket;
     // read them past L1 (sc1), sum in slice order, un-permute, add the Q4 outliers, write out[].  Each thread owns
     // four adjacent tile slots and keeps up to kRed 16-byte loads in flight (each is a fabric round trip); the four
     // running sums per slot are combined in a fixed order.
-    const bool rstamp = a.tstamp && ci == 0 && t == 0 && tid == 0;
-    if (rstamp) a.tstamp[23] = wall_clock64();
+    const bool rstamp = ga.tstamp && ci == 0 && t == 0 && tid == 0;
+    if (rstamp) ga.tstamp[23] = wall_clock64();
     typedef uint32_t u4v __attribute__((ext_vector_type(4)));
     const uint32_t sliceStride = g.tiles * (uint32_t)(TILE_F * 4);
     auto reduce_tile = [&](auto kc) {
@@ -503,20 +507,20 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     //  Up to 16 slices the whole reduction is ONE memory round trip per thread.)
     if (g.slices <= 8u) reduce_tile(std::integral_constant<int, 8>{});
     else reduce_tile(std::integral_constant<int, 16>{});
-    if (rstamp) a.tstamp[24] = wall_clock64();
+    if (rstamp) ga.tstamp[24] = wall_clock64();
     if (tid == 0) {
-        __hip_atomic_store(&a.counters[t], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next call
-        if (a.tstamp) {
+        __hip_atomic_store(&a_counters[t], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next call
+        if (ga.tstamp) {
             flush_stamps();
             const uint32_t done = __hip_atomic_fetch_add(ga.groupDone, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (done == ga.totalTiles - 1u) {                                  // whole kernel finished: fold the stamps
-                const unsigned long long t0 = __hip_atomic_load(&a.tstamp[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned long long t1 = __hip_atomic_load(&a.tstamp[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                a.tstamp[2] += t1 - t0; a.tstamp[3] += 1;
-                a.tstamp[27] += __hip_atomic_load(&a.tstamp[26], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - t0;   // dispatch ramp
-                __hip_atomic_store(&a.tstamp[26], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&a.tstamp[0], ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&a.tstamp[1], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long t0 = __hip_atomic_load(&ga.tstamp[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long t1 = __hip_atomic_load(&ga.tstamp[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ga.tstamp[2] += t1 - t0; ga.tstamp[3] += 1;
+                ga.tstamp[27] += __hip_atomic_load(&ga.tstamp[26], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - t0;   // dispatch ramp
+                __hip_atomic_store(&ga.tstamp[26], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&ga.tstamp[0], ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&ga.tstamp[1], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(ga.groupDone, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
@@ -528,11 +532,11 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
 // dispatcher only places ~40 workgroups/us chip-wide and spreads a large grid unevenly over the CUs (measured with
 // tools/microbench.hip: residency probe), so a group launch sizes its grid to the chip -- R workgroups per CU,
 // R fixed by the LDS each one asks for -- and balances the work itself.
-template <int FMT, int E, int W, bool EXT>
+template <int FMT, int E, int W>
 __global__ __launch_bounds__(64 * W, (W <= 8 ? EFFORT_MIN_WAVES_PER_EU : 4)) void bucket_mul_kernel(const GroupKArgs ga) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ uint32_t s_item;
-    const uint32_t total = ga.template endAt<EXT>(ga.count - 1);
+    const uint32_t total = ga.wgEnd[ga.count - 1];
     uint32_t cachedCall = 0xFFFFFFFFu; float cachedCutoff = 0.0f;
     const uint32_t x = blockIdx.x & 7u;                    // block b sits on XCD b%8; item i wants XCD i%8
     for (uint32_t it = 0;; it++) {
@@ -546,7 +550,7 @@ __global__ __launch_bounds__(64 * W, (W <= 8 ? EFFORT_MIN_WAVES_PER_EU : 4)) voi
         } else if (it) {
             return;
         }
-        mul_item<FMT, E, W, EXT>(ga, item, smem, cachedCall, cachedCutoff);
+        mul_item<FMT, E, W>(ga, item, smem, cachedCall, cachedCutoff);
     }
     if (threadIdx.x == 0) {                                // the last workgroup out rewinds the queues for the next launch
         const uint32_t gone = __hip_atomic_fetch_add(&ga.queue[8 * 16], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -560,14 +564,13 @@ __global__ __launch_bounds__(64 * W, (W <= 8 ? EFFORT_MIN_WAVES_PER_EU : 4)) voi
 // fires one atomic per outlier in table order; here one wave owns one output (its outliers are contiguous in the
 // by-output index built at registration), lanes stride its segment with coalesced loads, and a fixed xor-butterfly
 // adds the 64 partial sums -- no atomics, deterministic.  Launched right after the multiply kernel on the same stream.
-template <bool EXT>
 __global__ __launch_bounds__(256) void q4_outliers_kernel(const GroupKArgs ga) {
-    const auto& a = ga.template callAt<EXT>(blockIdx.y);
-    const auto& ol = a.ol;
+    const CallDesc& a = ga.call[blockIdx.y];
+    const OutlierIndex& ol = a.ol;
     const float* __restrict__ v = a.v;
     float* __restrict__ out = a.out;
     const uint32_t o = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (o >= a.g.outDim || !ol.rowPtr) return;
+    if (o >= ga.geom[a.geom].outDim || !ol.rowPtr) return;
     const int lane = threadIdx.x & 63;
     const uint32_t lo = ol.rowPtr[o], hi = ol.rowPtr[o + 1];
     if (lo == hi) return;
@@ -578,55 +581,21 @@ __global__ __launch_bounds__(256) void q4_outliers_kernel(const GroupKArgs ga) {
     if (lane == 0) out[o] += part;
 }
 
-hipError_t launch_q4_outliers(const GroupArgs& ga, hipStream_t st) {
+hipError_t launch_q4_outliers(const GroupKArgs& ga, hipStream_t st) {
     uint32_t maxOut = 0; bool any = false;
-    for (uint32_t i = 0; i < ga.count; i++) { maxOut = max(maxOut, ga.call[i].g.outDim); any = any || ga.call[i].ol.rowPtr; }
+    for (uint32_t i = 0; i < ga.count; i++) { maxOut = max(maxOut, ga.geom[ga.call[i].geom].outDim); any = any || ga.call[i].ol.rowPtr; }
     if (!any) return hipSuccess;
-    GroupKArgs k;
-    hipError_t e = make_group_kargs(ga, &k, st);
-    if (e != hipSuccess) return e;
-    if (k.extCalls) hipLaunchKernelGGL(q4_outliers_kernel<true>, dim3((maxOut + 3) / 4, ga.count), dim3(256), 0, st, k);
-    else hipLaunchKernelGGL(q4_outliers_kernel<false>, dim3((maxOut + 3) / 4, ga.count), dim3(256), 0, st, k);
-    return hipGetLastError();
-}
-
-// ---- group descriptors ----------------------------------------------------------------------
-// Up to kInlineGroup descriptors ride in the kernel arguments.  Larger groups: a tiny kernel copies them, 16 per
-// launch, from ITS arguments into the context's device table, and the multiply reads them from there.  (Kernel
-// arguments are copied when a launch is captured into a hipGraph; a host-to-device memcpy node would keep reading a host
-// buffer that the next capture overwrites.)
-struct PublishArgs { MulArgs call[kInlineGroup]; uint32_t wgEnd[kInlineGroup]; uint32_t first, n; };
-__global__ void publish_group_kernel(const PublishArgs p, MulArgs* __restrict__ calls, uint32_t* __restrict__ ends) {
-    const uint32_t i = threadIdx.x;
-    if (i < p.n) { calls[p.first + i] = p.call[i]; ends[p.first + i] = p.wgEnd[i]; }
-}
-
-hipError_t make_group_kargs(const GroupArgs& ga, GroupKArgs* k, hipStream_t st) {
-    memset(k, 0, sizeof(*k));
-    k->count = ga.count; k->totalTiles = ga.totalTiles; k->persistent = ga.persistent; k->numCU = ga.numCU;
-    k->groupDone = ga.groupDone; k->queue = ga.queue;
-    if (ga.count <= (uint32_t)kInlineGroup) {
-        for (uint32_t i = 0; i < ga.count; i++) { k->call[i] = ga.call[i]; k->wgEnd[i] = ga.wgEnd[i]; }
-        return hipSuccess;
-    }
-    if (!ga.descCalls || !ga.descEnds) return hipErrorInvalidValue;
-    for (uint32_t first = 0; first < ga.count; first += kInlineGroup) {
-        PublishArgs p;
-        p.first = first; p.n = min((uint32_t)kInlineGroup, ga.count - first);
-        for (uint32_t i = 0; i < p.n; i++) { p.call[i] = ga.call[first + i]; p.wgEnd[i] = ga.wgEnd[first + i]; }
-        hipLaunchKernelGGL(publish_group_kernel, dim3(1), dim3(64), 0, st, p, ga.descCalls, ga.descEnds);
-    }
-    k->extCalls = ga.descCalls; k->extEnds = ga.descEnds;
+    hipLaunchKernelGGL(q4_outliers_kernel, dim3((maxOut + 3) / 4, ga.count), dim3(256), 0, st, ga);
     return hipGetLastError();
 }
 
 // ---- host side ------------------------------------------------------------------------------
 template <int FMT, int E, int W>
-static hipError_t launch_mul_t(const GroupArgs& ga, hipStream_t st) {
+static hipError_t launch_mul_t(const GroupKArgs& ga, hipStream_t st) {
     uint32_t o1, o2, o3, o4;
     uint32_t lds = 0;
     for (uint32_t i = 0; i < ga.count; i++) {
-        const MulGeom& g = ga.call[i].g;
+        const MulGeom& g = ga.geom[ga.call[i].geom];
         lds = max(lds, lds_layout<FMT, E, W>(g.sliceRows, g.slots, &o1, &o2, &o3, &o4));
         if (g.slots > (uint32_t)kRounds * 64 * W || g.slots != (FMT == kFp16 ? (g.rowsPerIn << g.sliceLog2) : g.sliceRows * 8u)) return hipErrorInvalidValue;
         if (ga.wgEnd[i] - (i ? ga.wgEnd[i - 1] : 0u) != g.tiles * align_up(g.slices, 8)) return hipErrorInvalidValue;
@@ -641,32 +610,26 @@ static hipError_t launch_mul_t(const GroupArgs& ga, hipStream_t st) {
         if (lds < force && force <= (160u * 1024u) / R) lds = force;
     }
     if (lds > maxSet) {
-        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&bucket_mul_kernel<FMT, E, W, false>),
+        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&bucket_mul_kernel<FMT, E, W>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (err == hipSuccess) err = hipFuncSetAttribute(reinterpret_cast<const void*>(&bucket_mul_kernel<FMT, E, W, true>),
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (err != hipSuccess) return err;
         maxSet = lds;
     }
-    GroupKArgs k;
-    hipError_t e = make_group_kargs(ga, &k, st);
-    if (e != hipSuccess) return e;
-    if (k.extCalls) hipLaunchKernelGGL((bucket_mul_kernel<FMT, E, W, true>), dim3(grid), dim3(64 * W), lds, st, k);
-    else hipLaunchKernelGGL((bucket_mul_kernel<FMT, E, W, false>), dim3(grid), dim3(64 * W), lds, st, k);
+    hipLaunchKernelGGL((bucket_mul_kernel<FMT, E, W>), dim3(grid), dim3(64 * W), lds, st, ga);
     return hipGetLastError();
 }
 
 #define EFFORT_GEOMS(X) X(16, 1) X(16, 2) X(8, 1) X(8, 2) X(8, 4) X(4, 1) X(4, 2) X(4, 4) X(4, 8) X(2, 4) X(2, 8)
 
 template <int FMT>
-static hipError_t launch_mul_fmt(int W, int E, const GroupArgs& a, hipStream_t st) {
+static hipError_t launch_mul_fmt(int W, int E, const GroupKArgs& a, hipStream_t st) {
 #define EFFORT_CASE(w, e) if (W == w && E == e) return launch_mul_t<FMT, e, w>(a, st);
     EFFORT_GEOMS(EFFORT_CASE)
 #undef EFFORT_CASE
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_bucket_mul(Format fmt, int W, int E, const GroupArgs& a, hipStream_t st) {
+hipError_t launch_bucket_mul(Format fmt, int W, int E, const GroupKArgs& a, hipStream_t st) {
     return fmt == kFp16 ? launch_mul_fmt<kFp16>(W, E, a, st) : launch_mul_fmt<kQ4>(W, E, a, st);
 }
 
@@ -686,8 +649,8 @@ int bucket_mul_occupancy(Format fmt, int W, int E, size_t ldsBytes) {
     int n = 0;
 #define EFFORT_CASE(w, e)                                                                                              \
     if (W == w && E == e) {                                                                                            \
-        const void* f = fmt == kFp16 ? reinterpret_cast<const void*>(&bucket_mul_kernel<kFp16, e, w, false>)                  \
-                                     : reinterpret_cast<const void*>(&bucket_mul_kernel<kQ4, e, w, false>);                   \
+        const void* f = fmt == kFp16 ? reinterpret_cast<const void*>(&bucket_mul_kernel<kFp16, e, w>)                  \
+                                     : reinterpret_cast<const void*>(&bucket_mul_kernel<kQ4, e, w>);                   \
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, f, 64 * w, ldsBytes) != hipSuccess) n = 0;                \
     }
     EFFORT_GEOMS(EFFORT_CASE)

@@ -25,36 +25,30 @@ __global__ __launch_bounds__(1024) void find_cutoff_kernel(const float* __restri
 
 // One workgroup per call of a group (split mode of grouped launches): the multiply workgroups then read the
 // cutoff instead of each re-deriving it.
-template <bool EXT>
 __global__ __launch_bounds__(1024) void find_cutoff_group_kernel(const GroupKArgs ga) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const auto& a = ga.template callAt<EXT>(blockIdx.x);
+    const CallDesc& a = ga.call[blockIdx.x];
     const uint32_t e = a.expNo ? a.expNo[0] : 0u;
     const uint16_t* pr = a.probes + (size_t)e * kProbes;
     float vj[4]; uint16_t prj[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) { vj[i] = a.v[threadIdx.x + 1024 * i]; prj[i] = pr[threadIdx.x + 1024 * i]; }
     const float c = block_find_cutoff<1024>(vj, prj, a.q, smem, reinterpret_cast<uint32_t*>(smem + kCutoffLdsBytes), []() {}, nullptr);
-    if (threadIdx.x == 0) a.cutoffOut[0] = c;
+    if (threadIdx.x == 0) ga.cutoff[blockIdx.x] = c;
 }
 
 static hipError_t cutoff_attr(const void* fn) {
     return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kCutoffLdsBytes + cutoff_table_bytes(1024)));
 }
 
-hipError_t launch_find_cutoff_group(const GroupArgs& ga, hipStream_t st) {
+hipError_t launch_find_cutoff_group(const GroupKArgs& ga, hipStream_t st) {
     static bool attr = false;
     if (!attr) {
-        hipError_t e = cutoff_attr(reinterpret_cast<const void*>(&find_cutoff_group_kernel<false>));
-        if (e == hipSuccess) e = cutoff_attr(reinterpret_cast<const void*>(&find_cutoff_group_kernel<true>));
+        hipError_t e = cutoff_attr(reinterpret_cast<const void*>(&find_cutoff_group_kernel));
         if (e != hipSuccess) return e;
         attr = true;
     }
-    GroupKArgs k;
-    hipError_t e2 = make_group_kargs(ga, &k, st);
-    if (e2 != hipSuccess) return e2;
-    if (k.extCalls) hipLaunchKernelGGL(find_cutoff_group_kernel<true>, dim3(ga.count), dim3(1024), kCutoffLdsBytes + cutoff_table_bytes(1024), st, k);
-    else hipLaunchKernelGGL(find_cutoff_group_kernel<false>, dim3(ga.count), dim3(1024), kCutoffLdsBytes + cutoff_table_bytes(1024), st, k);
+    hipLaunchKernelGGL(find_cutoff_group_kernel, dim3(ga.count), dim3(1024), kCutoffLdsBytes + cutoff_table_bytes(1024), st, ga);
     return hipGetLastError();
 }
 

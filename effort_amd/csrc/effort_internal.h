@@ -34,7 +34,16 @@ struct OutlierIndex {          // by-output CSR of the Q4 outliers, built at reg
     const float* value;        // [n]
 };
 
-struct MulArgs {
+// One launch = a GROUP of up to kMaxGroup independent bucketMul calls (own weights, v, out, effort, scratch):
+// the decode loop's Wq|Wk|Wv and W1|W3 (runNetwork.swift:132-134,178-182) are such groups.  A lone call's
+// workgroups spend most of their life in dependent fixed-latency steps, so one call cannot load the chip; in a
+// group the workgroups of different calls overlap on the CUs inside ONE kernel, no stream juggling involved.
+// Everything a launch needs travels BY VALUE in the kernel arguments (3.6 KB of the 4 KB a kernel may take; arguments
+// are copied when a launch is captured into a hipGraph): a compact descriptor per call, the few distinct launch
+// geometries of the group, and the bases of the context scratch the calls index into.
+constexpr int kMaxGroup = 32;        // calls per launch
+constexpr int kMaxGeoms = 6;         // distinct (shape, slicing) geometries per launch
+struct CallDesc {                    // 96 bytes
     const uint16_t* buckets;
     const void* stats;         // f16x4 (FP16) or f32x2 (Q4) per bucket row
     const float* rankBound;    // [numExperts] sum over ranks of the rank's max |w| (Q4: max row mean): fixed-point bound, from registration
@@ -42,61 +51,33 @@ struct MulArgs {
     const float* v;
     const uint32_t* expNo;     // nullable
     float* out;                // f32 [outDim]
-    float* slabs;              // [slices][tiles][tileFloats] partial tiles
-    uint32_t* counters;        // [tiles + 1] arrival tickets, zero between calls
-    uint32_t* sliceCounts;     // [slices] kept rows per slice (sum = dispatch.size)
-    float* cutoffOut;          // BucketMul.cutoff
-    const float* cutoffIn;     // nullable: cutoff precomputed by the standalone kernel (split mode); null = evaluate in-kernel
-    unsigned long long* tstamp;   // nullable profiling stamps: [0]=min start, [1]=max end, [2]=sum, [3]=launches, [16..] phases
     OutlierIndex ol;
     uint32_t q;                // Int(4095*(1-effort)), bucketMul.swift:39
-    uint32_t ablate;           // profiling only (env EFFORT_ABLATE): 2 = no last-arriver reduce, 4 = no row streaming, 8 = no selection
-    MulGeom g;
+    uint32_t slabOff;          // this call's partial-tile slabs [slices][tiles][tileFloats]: offset into GroupKArgs::slabs, in units of 64 floats
+    uint16_t tileOff;          // ... arrival tickets [tiles]: offset into GroupKArgs::counters
+    uint16_t sliceOff;         // ... kept rows per slice [slices] (sum = dispatch.size): offset into GroupKArgs::sliceCounts
+    uint16_t geom;             // index into GroupKArgs::geom
+    uint16_t pad_;
 };
-
-// One launch = a GROUP of up to kMaxGroup independent bucketMul calls (own weights, v, out, effort, scratch):
-// the decode loop's Wq|Wk|Wv and W1|W3 (runNetwork.swift:132-134,178-182) are such groups.  A lone call's
-// workgroups spend most of their life in dependent fixed-latency steps, so one call cannot load the chip; in a
-// group the workgroups of different calls overlap on the CUs inside ONE kernel, no stream juggling involved.
-constexpr int kMaxGroup = 32;        // calls per launch
-constexpr int kInlineGroup = 16;     // ... of which this many descriptors travel as kernel arguments (3 KB; limit 4 KB)
-struct GroupArgs {                   // host side: everything one launch serves
-    MulArgs call[kMaxGroup];
+struct GroupKArgs {
+    CallDesc call[kMaxGroup];
+    MulGeom geom[kMaxGeoms];
     uint32_t wgEnd[kMaxGroup];     // exclusive end of each call's item range (multiples of 8)
     uint32_t count;
     uint32_t totalTiles;           // sum of tiles: the workgroup that finishes the last tile folds the timing stamps
-    uint32_t* groupDone;           // its counter (zero between launches)
     uint32_t persistent;           // 0: one workgroup per item; R > 0: numCU*R persistent workgroups pull items from the queues
     uint32_t numCU;
+    uint32_t ablate;               // profiling only (env EFFORT_ABLATE): 2 = no last-arriver reduce, 4 = no row streaming, 8 = no selection
+    uint32_t split;                // 1: the cutoffs were evaluated by find_cutoff_group_kernel (split mode); 0: in the multiply kernel
+    uint32_t* groupDone;           // counter of finished tiles (zero between launches)
     uint32_t* queue;               // [9][16]: per-XCD item cursors (one cache line each) + exit counter; zero between launches
-    MulArgs* descCalls;            // context scratch for groups larger than kInlineGroup: the descriptors are published to
-    uint32_t* descEnds;            // device memory by a tiny kernel (graph-capture safe: no host buffer is referenced)
+    float* slabs;                  // context scratch the calls index into
+    uint32_t* counters;
+    uint32_t* sliceCounts;
+    float* cutoff;                 // [count]: BucketMul.cutoff of every call
+    unsigned long long* tstamp;    // nullable profiling stamps: [0]=min start, [1]=max end, [2]=sum, [3]=launches, [16..] phases
 };
-struct GroupKArgs {                  // device side: what the kernels receive by value
-    MulArgs call[kInlineGroup];
-    uint32_t wgEnd[kInlineGroup];
-    uint32_t count, totalTiles, persistent, numCU;
-    uint32_t* groupDone;
-    uint32_t* queue;
-    const MulArgs* extCalls;       // non-null: count > kInlineGroup, descriptors and ranges live in device memory
-    const uint32_t* extEnds;
-    // EXT = false: descriptors in the kernel arguments.  EXT = true: in the device table, read through the CONSTANT address
-    // space -- they never change during a launch, so the compiler may re-load a field whenever it likes (as it does for
-    // kernel arguments) instead of assuming every store could have hit it.
-    typedef const MulArgs __attribute__((address_space(4))) ConstMulArgs;
-    typedef const uint32_t __attribute__((address_space(4))) ConstU32;
-    template <bool EXT> struct Sel;
-    template <bool EXT> __device__ __forceinline__ auto& callAt(uint32_t i) const {
-        if constexpr (EXT) return reinterpret_cast<ConstMulArgs*>(reinterpret_cast<uintptr_t>(extCalls))[i];
-        else return call[i];
-    }
-    template <bool EXT> __device__ __forceinline__ uint32_t endAt(uint32_t i) const {
-        if constexpr (EXT) return reinterpret_cast<ConstU32*>(reinterpret_cast<uintptr_t>(extEnds))[i];
-        else return wgEnd[i];
-    }
-};
-// Fills the kernel-side arguments of a launch (publishing the descriptors to device memory first when they do not fit).
-hipError_t make_group_kargs(const GroupArgs& ga, GroupKArgs* k, hipStream_t st);
+static_assert(sizeof(CallDesc) == 96 && sizeof(GroupKArgs) <= 4000, "the launch descriptor must fit the kernel-argument segment");
 
 // ---- device helpers -------------------------------------------------------------------------
 __device__ __forceinline__ float half_bits_to_float(uint16_t h) { return __half2float(__ushort_as_half(h)); }
@@ -114,13 +95,13 @@ hipError_t launch_find_cutoff(const float* v, const uint16_t* probes, const uint
                               float* cutoff, uint32_t* dispatchCount, unsigned long long* tstamp, hipStream_t st);
 
 // Returns hipErrorInvalidValue for unsupported (fmt, W, E).
-hipError_t launch_bucket_mul(Format fmt, int wavesPerGroup, int elemsPerLane, const GroupArgs& ga, hipStream_t st);
-hipError_t launch_find_cutoff_group(const GroupArgs& ga, hipStream_t st);     // cutoffOut[0] of every call
+hipError_t launch_bucket_mul(Format fmt, int wavesPerGroup, int elemsPerLane, const GroupKArgs& ga, hipStream_t st);
+hipError_t launch_find_cutoff_group(const GroupKArgs& ga, hipStream_t st);    // ga.cutoff[i] of every call
 size_t bucket_mul_lds_bytes(Format fmt, int wavesPerGroup, int elemsPerLane, uint32_t sliceRows, uint32_t slots);
 uint32_t bucket_mul_max_candidates(int wavesPerGroup);
 int bucket_mul_occupancy(Format fmt, int wavesPerGroup, int elemsPerLane, size_t ldsBytes);
   // rowsPerIn*sliceRows must not exceed this
-hipError_t launch_q4_outliers(const GroupArgs& ga, hipStream_t st);
+hipError_t launch_q4_outliers(const GroupKArgs& ga, hipStream_t st);
 
 hipError_t launch_calc_dispatch(Format fmt, const void* stats, const float* v, const uint32_t* expNo,
                                 const float* cutoff, const MulGeom& g, float* dispatch, uint32_t* count,
