@@ -499,3 +499,30 @@ def test_model_file_roundtrip(ea, oracle_cpu, tmp_path):
         assert ea.gpu().last_dispatch_count() == n and close(out.cpu().numpy(), want), pl
     with pytest.raises(KeyError):
         bf.loadExpertWeights(L, "layers.0.attention.nope", inDim=hidden, outDim=kv)
+
+
+def test_ragged_input_dimension(ea, oracle_cpu):
+    """inDim that no slice size divides (4500 = 35 slices of 128 + 20 rows; 8 of 512 + 404): the last slice is partial, in
+    lone launches and in groups (fatter slices), FP16 with and without stacked experts."""
+    outDim, inDim = 256, 4500
+    mats = [converted(oracle_cpu, outDim, inDim, seed=200 + e) for e in range(2)]
+    ews = [gpu_weights(ea, *m) for m in mats]
+    stacked = ea.ExpertWeights.stack(ews)
+    B = np.concatenate([m[1] for m in mats]); S = np.concatenate([m[2] for m in mats]); P = np.concatenate([m[3] for m in mats])
+    g = ea.gpu()
+    calls, wants = [], []
+    for i in range(9):
+        v = make_v(inDim, seed=300 + i, heavy=bool(i & 1))
+        e, effort = i & 1, (0.1, 0.3, 0.7, 1.0)[i % 4]
+        want, n, cutoff = oracle_cpu.bucket_mul(v, B, S, P, inDim, outDim, effort, expNo=e)
+        expNo = torch.tensor([e], dtype=torch.int32, device=DEV)
+        out = torch.full((outDim,), float("nan"), device=DEV)
+        ea.bucketMul(devf(v), stacked, expNo, out, effort)
+        g.eval()
+        assert g.last_dispatch_count() == n and g.last_cutoff() == cutoff and close(out.cpu().numpy(), want), i
+        calls.append((devf(v), stacked, expNo, torch.full((outDim,), float("nan"), device=DEV), effort))
+        wants.append((want, n, cutoff))
+    ea.bucketMulGroup(calls)
+    g.eval()
+    for i, (call, (want, n, cutoff)) in enumerate(zip(calls, wants)):
+        assert g.last_dispatch_count(i) == n and g.last_cutoff(i) == cutoff and close(call[3].cpu().numpy(), want), i
