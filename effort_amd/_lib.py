@@ -57,6 +57,8 @@ _SIGS = {
     "effort_silu_mul": (C.c_int, [_P, _P, _P, _P, C.c_int]),
     "effort_fetch_row": (C.c_int, [_P, _P, _P, _P, C.c_int]),
     "effort_argmax": (C.c_int, [_P, _P, C.c_int, _P, _P, _P]),
+    "effort_top2_softmax": (C.c_int, [_P, _P, C.c_int, _P, _P]),
+    "effort_mix2": (C.c_int, [_P, _P, _P, _P, _P, C.c_int]),
     "effort_dense_gemv": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int]),
     "effort_last_dispatch_count": (C.c_int, [_P, C.POINTER(C.c_uint32)]),
     "effort_last_cutoff": (C.c_int, [_P, C.POINTER(C.c_float)]),

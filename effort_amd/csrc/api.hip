@@ -467,6 +467,16 @@ extern "C" int effort_fetch_row(effort_ctx* c, const void* emb, const uint32_t* 
     HIP_TRY(c, launch_fetch_row(static_cast<const uint16_t*>(emb), id, out, (uint32_t)n, c->stream));
     return EFFORT_OK;
 }
+extern "C" int effort_top2_softmax(effort_ctx* c, const float* gate, int n, uint32_t* idx2, float* val2) {
+    if (!c || !gate || !idx2 || !val2 || n < 1) return fail(c, EFFORT_ERR_ARG, "top2_softmax: bad argument");
+    HIP_TRY(c, launch_top2_softmax(gate, (uint32_t)n, idx2, val2, c->stream));
+    return EFFORT_OK;
+}
+extern "C" int effort_mix2(effort_ctx* c, const float* f0, const float* f1, const float* val2, float* out, int n) {
+    if (!c || !f0 || !f1 || !val2 || !out || n <= 0) return fail(c, EFFORT_ERR_ARG, "mix2: bad argument");
+    HIP_TRY(c, launch_mix2(f0, f1, val2, out, (uint32_t)n, c->stream));
+    return EFFORT_OK;
+}
 extern "C" int effort_argmax(effort_ctx* c, const float* logits, int n, uint32_t* idOut, uint32_t* pos, uint32_t* history) {
     if (!c || !logits || !idOut || !pos || n <= 0) return fail(c, EFFORT_ERR_ARG, "argmax: bad argument");
     HIP_TRY(c, launch_argmax(logits, (uint32_t)n, idOut, pos, history, c->stream));

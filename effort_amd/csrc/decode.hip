@@ -7,6 +7,7 @@
 //   attention        dotSetScore2 (/sqrt(headDim)) + softmax + sumScores32 over tokens 0..pos, one workgroup per head (aux.metal:185-198,379-447)
 //   silu_mul         x3 * x1 / (1 + exp(-x1))                              silu32b (matrix.metal:25-35)
 //   fetch_row        tok_embeddings row (f16) -> f32                       fetchRow16to32 (aux.metal:355)
+//   top2_softmax     Mixtral gate: top-2 experts + softmax of their logits (mpsTopK + softmax, runNetwork.swift:186-189); mix2: weighted sum
 //   argmax           greedy pick of the next token (the reference takes mpsTopK[0], helpers/mps.swift:52-84), pos += 1
 #include "effort_internal.h"
 
@@ -147,6 +148,34 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ 
     }
 }
 
+// Mixtral routing (runNetwork.swift:185-199): mpsTopK(topK: 2) of the gate logits, softmax over the two picked values.
+__global__ void top2_softmax_kernel(const float* __restrict__ gate, uint32_t n, uint32_t* __restrict__ idx, float* __restrict__ val) {
+    if (threadIdx.x != 0) return;
+    uint32_t i0 = 0, i1 = 0xFFFFFFFFu; float v0 = -INFINITY, v1 = -INFINITY;
+    for (uint32_t i = 0; i < n; i++) {
+        const float x = gate[i];
+        if (x > v0) { v1 = v0; i1 = i0; v0 = x; i0 = i; }
+        else if (x > v1) { v1 = x; i1 = i; }
+    }
+    if (i1 == 0xFFFFFFFFu) { i1 = i0; v1 = v0; }
+    const float e1 = expf(v1 - v0), inv = 1.0f / (1.0f + e1);
+    idx[0] = i0; idx[1] = i1; val[0] = inv; val[1] = e1 * inv;
+}
+// out = f0 * val[0] + f1 * val[1]   (ffnOut[i].mul(by: gateVals[i]); h.add(by: ffnOut[i]) -- the add rides in the next norm)
+__global__ void mix2_kernel(const float* __restrict__ f0, const float* __restrict__ f1, const float* __restrict__ val,
+                            float* __restrict__ out, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = f0[i] * val[0] + f1[i] * val[1];
+}
+
+hipError_t launch_top2_softmax(const float* gate, uint32_t n, uint32_t* idx, float* val, hipStream_t st) {
+    hipLaunchKernelGGL(top2_softmax_kernel, dim3(1), dim3(64), 0, st, gate, n, idx, val);
+    return hipGetLastError();
+}
+hipError_t launch_mix2(const float* f0, const float* f1, const float* val, float* out, uint32_t n, hipStream_t st) {
+    hipLaunchKernelGGL(mix2_kernel, dim3((n + 255) / 256), dim3(256), 0, st, f0, f1, val, out, n);
+    return hipGetLastError();
+}
 hipError_t launch_add_rmsnorm_mul(float* h, const float* delta, const uint16_t* w, float* out, uint32_t n, hipStream_t st) {
     hipLaunchKernelGGL(add_rmsnorm_mul_kernel, dim3(1), dim3(1024), 0, st, h, delta, w, out, n);
     return hipGetLastError();

@@ -120,6 +120,8 @@ hipError_t launch_attention(const float* q, const float* kCache, const float* vC
                             uint32_t numHeads, uint32_t headDim, uint32_t maxTokens, hipStream_t st);
 hipError_t launch_silu_mul(const float* x1, const float* x3, float* out, uint32_t n, hipStream_t st);
 hipError_t launch_fetch_row(const uint16_t* emb, const uint32_t* id, float* out, uint32_t n, hipStream_t st);
+hipError_t launch_top2_softmax(const float* gate, uint32_t n, uint32_t* idx, float* val, hipStream_t st);
+hipError_t launch_mix2(const float* f0, const float* f1, const float* val, float* out, uint32_t n, hipStream_t st);
 hipError_t launch_argmax(const float* logits, uint32_t n, uint32_t* idOut, uint32_t* pos, uint32_t* history, hipStream_t st);
 
 hipError_t launch_f32_to_f16(const float* in, uint16_t* out, uint32_t n, hipStream_t st);

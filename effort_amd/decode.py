@@ -36,10 +36,11 @@ class MistralConfig:                      # main.swift:45-77
     headDim: int = 128
     vocab: int = 32000
     ropeBase: float = 1e6                 # createFreqsCis2: logspace base 1e-6 (model.swift:700)
+    numExperts: int = 1                   # > 1: Mixtral -- a dense gate picks 2 experts per token and layer (runNetwork.swift:185-199)
 
 
 class Layer:                              # loader.swift Layer: norms + seven ExpertWeights
-    __slots__ = ("attnNorm", "ffnNorm", "wq", "wk", "wv", "wo", "w1", "w2", "w3")
+    __slots__ = ("attnNorm", "ffnNorm", "wq", "wk", "wv", "wo", "w1", "w2", "w3", "ffnGate")
 
 
 class Model:
@@ -64,17 +65,31 @@ class Model:
             return (1.0 + 0.1 * torch.randn(n, generator=gen, device=device, dtype=torch.float32)).to(torch.float16)
 
         kv = cfg.numHeadsKV * cfg.headDim
+
+        def bundle(o, i, experts=1):
+            ews = []
+            for _ in range(experts):
+                ew = ExpertWeights.from_core(mat(o, i))
+                if not keep_cores:
+                    ew.core = None
+                ews.append(ew)
+            if experts == 1:
+                ew = ews[0]
+            else:                                         # Mixtral: all experts in one buffer, picked by expNo (loader.swift:113-166)
+                ew = ExpertWeights.stack(ews)
+                ew.core = torch.stack([e.core for e in ews]) if keep_cores else None      # [E, out, in] for the dense path
+            ew.handle
+            return ew
+
         for _ in range(cfg.numLayers):
             L = Layer()
             L.attnNorm, L.ffnNorm = vec(cfg.stateDim), vec(cfg.stateDim)
             for name, (o, i) in (("wq", (cfg.stateDim, cfg.stateDim)), ("wk", (kv, cfg.stateDim)), ("wv", (kv, cfg.stateDim)),
-                                 ("wo", (cfg.stateDim, cfg.stateDim)), ("w1", (cfg.hiddenDim, cfg.stateDim)),
-                                 ("w3", (cfg.hiddenDim, cfg.stateDim)), ("w2", (cfg.stateDim, cfg.hiddenDim))):
-                ew = ExpertWeights.from_core(mat(o, i))
-                if not keep_cores:
-                    ew.core = None
-                ew.handle
-                setattr(L, name, ew)
+                                 ("wo", (cfg.stateDim, cfg.stateDim))):
+                setattr(L, name, bundle(o, i))
+            for name, (o, i) in (("w1", (cfg.hiddenDim, cfg.stateDim)), ("w3", (cfg.hiddenDim, cfg.stateDim)), ("w2", (cfg.stateDim, cfg.hiddenDim))):
+                setattr(L, name, bundle(o, i, cfg.numExperts))
+            L.ffnGate = mat(cfg.numExperts, cfg.stateDim) * 10 if cfg.numExperts > 1 else None     # f16 [numExperts, stateDim]
             m.layers.append(L)
         m.norm = vec(cfg.stateDim)
         m.output = mat(cfg.vocab, cfg.stateDim)
@@ -93,8 +108,10 @@ class Model:
             for s in "qkvo":
                 setattr(L, "w" + s, loadExpertWeights(loader, f"layers.{n}.attention.w{s}", device=device))
             for w, (o, i) in (("w1", (cfg.hiddenDim, cfg.stateDim)), ("w3", (cfg.hiddenDim, cfg.stateDim)), ("w2", (cfg.stateDim, cfg.hiddenDim))):
-                setattr(L, w, loadExpertWeights(loader, f"layers.{n}.feed_forward.experts.", w, inDim=i, outDim=o, numExperts=1,
+                setattr(L, w, loadExpertWeights(loader, f"layers.{n}.feed_forward.experts.", w, inDim=i, outDim=o, numExperts=cfg.numExperts,
                                                 percentLoad=percentLoad, device=device))
+            gate = f"layers.{n}.feed_forward.gate"
+            L.ffnGate = loader[gate].to(device=device, dtype=torch.float16) if cfg.numExperts > 1 and loader.hasTensor(gate) else None
             m.layers.append(L)
         m.norm = loader["model.norm"].to(device=device, dtype=torch.float16)
         m.output = loader["output.core"].to(device=device, dtype=torch.float16)
@@ -120,6 +137,11 @@ class Decoder:
         self.xq_temp, self.xk_temp, self.xv_temp, self.xq = f(q), f(kv), f(kv), f(q)
         self.attnOutput, self.attnFfnOut, self.ffnOut = f(q), f(cfg.stateDim), f(cfg.stateDim)
         self.x1, self.x3, self.x2 = f(cfg.hiddenDim), f(cfg.hiddenDim), f(cfg.hiddenDim)
+        if cfg.numExperts > 1:                                                      # second routed expert + the gate (runNetwork.swift:185-199)
+            self.x1b, self.x3b, self.x2b, self.ffnOutB = f(cfg.hiddenDim), f(cfg.hiddenDim), f(cfg.hiddenDim), f(cfg.stateDim)
+            self.ffnMix = f(cfg.stateDim)
+            self.gateOut, self.gateVals = f(cfg.numExperts), f(2)
+            self.gateIdxs = torch.zeros(2, dtype=torch.int32, device=dev)
         self.logits = f(cfg.vocab)
         self.kCache = [f(self.maxTokens, cfg.numHeads, cfg.headDim) for _ in range(cfg.numLayers)]     # xkLayerTokenHead
         self.vCache = [f(self.maxTokens, cfg.numHeads, cfg.headDim) for _ in range(cfg.numLayers)]     # xvLayerToken
@@ -154,13 +176,40 @@ class Decoder:
                                     cfg.numHeads, cfg.headDim, self.maxTokens), "attention")
             muls(self.attnOutput, [(L.wo, self.attnFfnOut)])                                          # :170
             ck(lib.effort_add_rmsnorm_mul(g.ctx, _p(self.h), _p(self.attnFfnOut), _p(L.ffnNorm), _p(self.fxn), cfg.stateDim), "rmsnorm")
-            muls(self.fxn, [(L.w1, self.x1), (L.w3, self.x3)])                                        # :178-179
-            ck(lib.effort_silu_mul(g.ctx, _p(self.x1), _p(self.x3), _p(self.x2), cfg.hiddenDim), "silu")
-            muls(self.x2, [(L.w2, self.ffnOut)])                                                      # :182
-            delta = self.ffnOut
+            if L.ffnGate is None:
+                muls(self.fxn, [(L.w1, self.x1), (L.w3, self.x3)])                                    # :178-179
+                ck(lib.effort_silu_mul(g.ctx, _p(self.x1), _p(self.x3), _p(self.x2), cfg.hiddenDim), "silu")
+                muls(self.x2, [(L.w2, self.ffnOut)])                                                  # :182
+                delta = self.ffnOut
+            else:
+                # Mixtral (:185-199): dense gate -> top-2 experts -> softmax of the two; the expert numbers stay on the
+                # device (expNo).  Both experts' w1|w3 share the input: ONE grouped launch of four calls; their w2 another.
+                basicMul(self.fxn, L.ffnGate, self.gateOut)
+                ck(lib.effort_top2_softmax(g.ctx, _p(self.gateOut), cfg.numExperts, _p(self.gateIdxs), _p(self.gateVals)), "top2")
+                e0, e1 = self.gateIdxs[0:1], self.gateIdxs[1:2]
+                if dense:
+                    self._dense_experts(L, e0, e1)
+                else:
+                    bucketMulGroup([(self.fxn, L.w1, e0, self.x1, effort), (self.fxn, L.w3, e0, self.x3, effort),
+                                    (self.fxn, L.w1, e1, self.x1b, effort), (self.fxn, L.w3, e1, self.x3b, effort)])
+                    ck(lib.effort_silu_mul(g.ctx, _p(self.x1), _p(self.x3), _p(self.x2), cfg.hiddenDim), "silu")
+                    ck(lib.effort_silu_mul(g.ctx, _p(self.x1b), _p(self.x3b), _p(self.x2b), cfg.hiddenDim), "silu")
+                    bucketMulGroup([(self.x2, L.w2, e0, self.ffnOut, effort), (self.x2b, L.w2, e1, self.ffnOutB, effort)])
+                ck(lib.effort_mix2(g.ctx, _p(self.ffnOut), _p(self.ffnOutB), _p(self.gateVals), _p(self.ffnMix), cfg.stateDim), "mix2")
+                delta = self.ffnMix
         ck(lib.effort_add_rmsnorm_mul(g.ctx, _p(self.h), _p(delta), _p(m.norm), _p(self.outNormed), cfg.stateDim), "rmsnorm")
         basicMul(self.outNormed, m.output, self.logits)                                               # :222
         ck(lib.effort_argmax(g.ctx, _p(self.logits), cfg.vocab, _p(self.tokId), _p(self.pos), _p(self.history)), "argmax")
+
+    def _dense_experts(self, L, e0, e1):
+        """Dense baseline of the routed FFN: the picked experts' cores are gathered on the device (index_select keeps the
+        step graph-capturable), then plain basicMul."""
+        cfg, g, lib = self.cfg, self.g, _lib.lib()
+        for e, x1, x3, x2, out in ((e0, self.x1, self.x3, self.x2, self.ffnOut), (e1, self.x1b, self.x3b, self.x2b, self.ffnOutB)):
+            basicMul(self.fxn, torch.index_select(L.w1.core, 0, e)[0], x1)
+            basicMul(self.fxn, torch.index_select(L.w3.core, 0, e)[0], x3)
+            g.check(lib.effort_silu_mul(g.ctx, _p(x1), _p(x3), _p(x2), cfg.hiddenDim), "silu")
+            basicMul(x2, torch.index_select(L.w2.core, 0, e)[0], out)
 
     def _graph(self, effort: float, dense: bool):
         key = ("dense",) if dense else (float(effort),)

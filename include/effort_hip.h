@@ -151,6 +151,10 @@ EFFORT_API int effort_attention(effort_ctx* ctx, const float* q_dev, const float
 EFFORT_API int effort_silu_mul(effort_ctx* ctx, const float* x1_dev, const float* x3_dev, float* out_dev, int n);
 /* tokEmbeddings.fetchRow(id, out:) (aux.metal:355): row *id_dev of an f16 [vocab][n] table as f32. */
 EFFORT_API int effort_fetch_row(effort_ctx* ctx, const void* emb_f16_dev, const uint32_t* id_dev, float* out_dev, int n);
+/* Mixtral routing (runNetwork.swift:185-199): idx2_dev = the two largest gate logits' experts (mpsTopK(topK: 2)),
+ * val2_dev = softmax over those two logits; effort_mix2: out = f0 * val2[0] + f1 * val2[1]. */
+EFFORT_API int effort_top2_softmax(effort_ctx* ctx, const float* gate_dev, int n, uint32_t* idx2_dev, float* val2_dev);
+EFFORT_API int effort_mix2(effort_ctx* ctx, const float* f0_dev, const float* f1_dev, const float* val2_dev, float* out_dev, int n);
 /* greedy pick: *id_out_dev = argmax(logits) (the reference takes mpsTopK[0], helpers/mps.swift:52-84); if history_dev is
  * given, history_dev[*pos_dev] = the pick; then *pos_dev += 1. */
 EFFORT_API int effort_argmax(effort_ctx* ctx, const float* logits_dev, int n, uint32_t* id_out_dev, uint32_t* pos_dev, uint32_t* history_dev);

@@ -50,9 +50,21 @@ def torch_reference(model, tokenIds, numTokens):
             att = torch.einsum("ht,thd->hd", p, V).reshape(-1)
             h = h + f(L.wo.core) @ att.half().float()
             fx = rms(h, L.ffnNorm).half().float()
-            x1, x3 = f(L.w1.core) @ fx, f(L.w3.core) @ fx
-            x2 = x3 * x1 / (1 + torch.exp(-x1))
-            h = h + f(L.w2.core) @ x2.half().float()
+            if L.ffnGate is None:
+                x1, x3 = f(L.w1.core) @ fx, f(L.w3.core) @ fx
+                x2 = x3 * x1 / (1 + torch.exp(-x1))
+                h = h + f(L.w2.core) @ x2.half().float()
+            else:                                                                  # Mixtral routing, runNetwork.swift:185-199
+                gate = f(L.ffnGate) @ fx
+                vals, idxs = torch.topk(gate, 2)
+                w = torch.softmax(vals, 0)
+                mix = 0
+                for k in range(2):
+                    e = int(idxs[k])
+                    x1, x3 = f(L.w1.core[e]) @ fx, f(L.w3.core[e]) @ fx
+                    x2 = x3 * x1 / (1 + torch.exp(-x1))
+                    mix = mix + w[k] * (f(L.w2.core[e]) @ x2.half().float())
+                h = h + mix
         lg = f(model.output) @ rms(h, model.norm).half().float()
         logits_all.append(lg)
         tok = int(torch.argmax(lg))
@@ -97,3 +109,21 @@ def test_effort_one_tracks_dense_and_low_effort_degrades(small_model):
     assert 0.0 <= kl_1 < kl_q, (kl_1, kl_q)                                       # less effort, further from dense
     ids_g, dt_g, _ = dec.run(prompt, steps, effort=1.0)                             # free-running greedy at effort 1
     assert ids_g == ids_d and dt_g > 0
+
+
+def test_mixtral_routing(hip_lib_built):
+    """numExperts > 1: dense gate -> top-2 experts -> softmax weights, experts picked on the device through expNo
+    (runNetwork.swift:185-199).  Dense path vs the torch restatement; effort 1.0 vs dense."""
+    from effort_amd.decode import Decoder, MistralConfig, Model
+    cfg = MistralConfig(stateDim=4096, hiddenDim=4096, numLayers=2, numHeads=32, numHeadsKV=8, headDim=128, vocab=512, numExperts=4)
+    model = Model.random(cfg, seed=9)
+    prompt, steps = [5, 9], 8
+    want_ids, want_logits = torch_reference(model, prompt, steps)
+    dec = Decoder(model, maxTokens=16)
+    ids, _, logits = dec.run(prompt, steps, dense=True, collect_logits=True)
+    assert ids == want_ids
+    assert float((logits - want_logits).abs().max() / want_logits.abs().max()) < 2e-3
+    forced = prompt + ids[len(prompt) - 1:-1]
+    ids_1, _, lg_1 = dec.run(forced, steps, effort=1.0, forced=True, collect_logits=True)
+    assert float(torch.nn.functional.cosine_similarity(lg_1, logits, dim=1).min()) > 0.999
+    assert ids_1 == ids
