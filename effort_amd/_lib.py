@@ -54,6 +54,7 @@ _SIGS = {
     "effort_add_rmsnorm_mul": (C.c_int, [_P, _P, _P, _P, _P, C.c_int]),
     "effort_rope_kv": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float]),
     "effort_attention": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int]),
+    "effort_rope_attention": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float]),
     "effort_silu_mul": (C.c_int, [_P, _P, _P, _P, C.c_int]),
     "effort_fetch_row": (C.c_int, [_P, _P, _P, _P, C.c_int]),
     "effort_argmax": (C.c_int, [_P, _P, C.c_int, _P, _P, _P]),

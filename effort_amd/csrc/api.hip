@@ -457,6 +457,15 @@ extern "C" int effort_attention(effort_ctx* c, const float* q, const float* kCac
     HIP_TRY(c, launch_attention(q, kCache, vCache, pos, out, numHeads, headDim, maxTokens, c->stream));
     return EFFORT_OK;
 }
+extern "C" int effort_rope_attention(effort_ctx* c, const float* xq, const float* xk, const float* xv, float* kCache, float* vCache,
+                                     const uint32_t* pos, float* out, int numHeads, int numHeadsKV, int headDim, int maxTokens, float ropeBase) {
+    if (!c || !xq || !xk || !xv || !kCache || !vCache || !pos || !out) return fail(c, EFFORT_ERR_ARG, "rope_attention: null argument");
+    if (numHeads <= 0 || numHeadsKV <= 0 || numHeads % numHeadsKV || maxTokens <= 0 || maxTokens > 8192 || !(ropeBase > 1.0f) ||
+        (headDim != 64 && headDim != 128 && headDim != 256))
+        return fail(c, EFFORT_ERR_SHAPE, "rope_attention: headDim 64/128/256, maxTokens <= 8192");
+    HIP_TRY(c, launch_rope_attention(xq, xk, xv, kCache, vCache, pos, out, numHeads, numHeadsKV, headDim, maxTokens, ropeBase, c->stream));
+    return EFFORT_OK;
+}
 extern "C" int effort_silu_mul(effort_ctx* c, const float* x1, const float* x3, float* out, int n) {
     if (!c || !x1 || !x3 || !out || n <= 0) return fail(c, EFFORT_ERR_ARG, "silu_mul: bad argument");
     HIP_TRY(c, launch_silu_mul(x1, x3, out, (uint32_t)n, c->stream));

@@ -112,6 +112,65 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
     }
 }
 
+// rope_kv + attention in ONE launch (one workgroup per query head): the head ropes its q and its kv head's k, stores k / v
+// at cache[pos], and attends over tokens 0..pos, the newest token straight from LDS.  Saves a dependent launch per layer.
+__global__ __launch_bounds__(256) void rope_attention_kernel(const float* __restrict__ xq, const float* __restrict__ xk,
+                                                             const float* __restrict__ xv, float* __restrict__ kCache,
+                                                             float* __restrict__ vCache, const uint32_t* __restrict__ posPtr,
+                                                             float* __restrict__ out, uint32_t numHeads, uint32_t kvRepeats,
+                                                             uint32_t headDim, uint32_t maxTokens, float logBase) {
+    extern __shared__ float sc[];                      // [maxTokens] scores, then probabilities
+    __shared__ float red[17];
+    __shared__ float qs[256], ks[256], vs[256];        // this head's roped q, roped k and v of the newest token
+    __shared__ float part[256];
+    const uint32_t head = blockIdx.x, tid = threadIdx.x, half = headDim / 2;
+    const uint32_t pos = min(posPtr[0], maxTokens - 1u), nTok = pos + 1u;
+    if (tid < headDim) {
+        const uint32_t d = tid, j = d % half;
+        const float freq = (float)exp((double)logBase * (-(double)j / (double)half));
+        const float angle = (float)pos * freq;
+        const float c = cosf(angle), s = sinf(angle);
+        const float* q = xq + head * headDim;
+        const float* k = xk + (head / kvRepeats) * headDim;
+        const float qr = d < half ? q[d] * c - q[d + half] * s : q[d] * c + q[d - half] * s;
+        const float kr = d < half ? k[d] * c - k[d + half] * s : k[d] * c + k[d - half] * s;
+        const float vv = xv[(head / kvRepeats) * headDim + d];
+        const size_t slot = ((size_t)pos * numHeads + head) * headDim + d;
+        qs[d] = qr; ks[d] = kr; vs[d] = vv;
+        kCache[slot] = kr; vCache[slot] = vv;
+    }
+    __syncthreads();
+    const float scale = 1.0f / sqrtf((float)headDim);
+    const int lane = tid & 63, wave = tid >> 6;
+    for (uint32_t t = wave; t < nTok; t += 4) {        // one wave per token: lanes stride the head dimension
+        const float* kh = kCache + ((size_t)t * numHeads + head) * headDim;
+        float dot = 0.0f;
+        for (uint32_t d = lane; d < headDim; d += 64) dot += qs[d] * (t == pos ? ks[d] : kh[d]);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) dot += __shfl_xor(dot, off);
+        if (lane == 0) sc[t] = dot * scale;
+    }
+    __syncthreads();
+    float m = -INFINITY;
+    for (uint32_t t = tid; t < nTok; t += 256) m = fmaxf(m, sc[t]);
+    m = block_max(m, red);
+    float sum = 0.0f;
+    for (uint32_t t = tid; t < nTok; t += 256) { const float e = expf(sc[t] - m); sc[t] = e; sum += e; }
+    sum = block_sum(sum, red);
+    const float inv = 1.0f / sum;
+    const uint32_t d = tid % headDim, ph = tid / headDim, nph = 256 / headDim;
+    float acc = 0.0f;
+    if (ph < nph)
+        for (uint32_t t = ph; t < nTok; t += nph) acc += sc[t] * (t == pos ? vs[d] : vCache[((size_t)t * numHeads + head) * headDim + d]);
+    part[tid] = acc;
+    __syncthreads();
+    if (tid < headDim) {
+        float s2 = 0.0f;
+        for (uint32_t p = 0; p < nph; p++) s2 += part[p * headDim + tid];
+        out[head * headDim + tid] = s2 * inv;
+    }
+}
+
 __global__ void silu_mul_kernel(const float* __restrict__ x1, const float* __restrict__ x3, float* __restrict__ out, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = x3[i] * x1[i] / (1.0f + expf(-x1[i]));
@@ -189,6 +248,13 @@ hipError_t launch_rope_kv(const float* xq, const float* xk, const float* xv, flo
 hipError_t launch_attention(const float* q, const float* kCache, const float* vCache, const uint32_t* pos, float* out,
                             uint32_t numHeads, uint32_t headDim, uint32_t maxTokens, hipStream_t st) {
     hipLaunchKernelGGL(attention_kernel, dim3(numHeads), dim3(256), maxTokens * sizeof(float), st, q, kCache, vCache, pos, out, numHeads, headDim, maxTokens);
+    return hipGetLastError();
+}
+hipError_t launch_rope_attention(const float* xq, const float* xk, const float* xv, float* kCache, float* vCache, const uint32_t* pos,
+                                 float* out, uint32_t numHeads, uint32_t numHeadsKV, uint32_t headDim, uint32_t maxTokens, float ropeBase,
+                                 hipStream_t st) {
+    hipLaunchKernelGGL(rope_attention_kernel, dim3(numHeads), dim3(256), maxTokens * sizeof(float), st, xq, xk, xv, kCache, vCache, pos, out,
+                       numHeads, numHeads / numHeadsKV, headDim, maxTokens, logf(ropeBase));
     return hipGetLastError();
 }
 hipError_t launch_silu_mul(const float* x1, const float* x3, float* out, uint32_t n, hipStream_t st) {

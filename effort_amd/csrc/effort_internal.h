@@ -118,6 +118,9 @@ hipError_t launch_rope_kv(const float* xq, const float* xk, const float* xv, flo
                           const uint32_t* pos, uint32_t numHeads, uint32_t numHeadsKV, uint32_t headDim, float ropeBase, hipStream_t st);
 hipError_t launch_attention(const float* q, const float* kCache, const float* vCache, const uint32_t* pos, float* out,
                             uint32_t numHeads, uint32_t headDim, uint32_t maxTokens, hipStream_t st);
+hipError_t launch_rope_attention(const float* xq, const float* xk, const float* xv, float* kCache, float* vCache, const uint32_t* pos,
+                                 float* out, uint32_t numHeads, uint32_t numHeadsKV, uint32_t headDim, uint32_t maxTokens, float ropeBase,
+                                 hipStream_t st);
 hipError_t launch_silu_mul(const float* x1, const float* x3, float* out, uint32_t n, hipStream_t st);
 hipError_t launch_fetch_row(const uint16_t* emb, const uint32_t* id, float* out, uint32_t n, hipStream_t st);
 hipError_t launch_top2_softmax(const float* gate, uint32_t n, uint32_t* idx, float* val, hipStream_t st);

@@ -126,8 +126,9 @@ def _p(t):
 class Decoder:
     """State of one sequence (the globals of main.swift:78-140: h, xq, KV caches, scores ...) + the token step."""
 
-    def __init__(self, model: Model, maxTokens: int = 256):
+    def __init__(self, model: Model, maxTokens: int = 256, fused_attention: bool = True):
         cfg = self.cfg = model.cfg
+        self.fused_attention = bool(fused_attention)      # rope + cache + attention in one launch per layer (else two)
         self.model, self.maxTokens = model, int(maxTokens)
         dev = model.norm.device
         self.g = _gpu(dev.index)
@@ -170,10 +171,15 @@ class Decoder:
         for n, L in enumerate(m.layers):
             ck(lib.effort_add_rmsnorm_mul(g.ctx, _p(self.h), _p(delta), _p(L.attnNorm), _p(self.h_norm), cfg.stateDim), "rmsnorm")
             muls(self.h_norm, [(L.wq, self.xq_temp), (L.wk, self.xk_temp), (L.wv, self.xv_temp)])      # runNetwork.swift:132-134
-            ck(lib.effort_rope_kv(g.ctx, _p(self.xq_temp), _p(self.xk_temp), _p(self.xv_temp), _p(self.xq), _p(self.kCache[n]),
-                                  _p(self.vCache[n]), _p(self.pos), cfg.numHeads, cfg.numHeadsKV, cfg.headDim, C.c_float(cfg.ropeBase)), "rope_kv")
-            ck(lib.effort_attention(g.ctx, _p(self.xq), _p(self.kCache[n]), _p(self.vCache[n]), _p(self.pos), _p(self.attnOutput),
-                                    cfg.numHeads, cfg.headDim, self.maxTokens), "attention")
+            if self.fused_attention:
+                ck(lib.effort_rope_attention(g.ctx, _p(self.xq_temp), _p(self.xk_temp), _p(self.xv_temp), _p(self.kCache[n]), _p(self.vCache[n]),
+                                             _p(self.pos), _p(self.attnOutput), cfg.numHeads, cfg.numHeadsKV, cfg.headDim, self.maxTokens,
+                                             C.c_float(cfg.ropeBase)), "rope_attention")
+            else:
+                ck(lib.effort_rope_kv(g.ctx, _p(self.xq_temp), _p(self.xk_temp), _p(self.xv_temp), _p(self.xq), _p(self.kCache[n]),
+                                      _p(self.vCache[n]), _p(self.pos), cfg.numHeads, cfg.numHeadsKV, cfg.headDim, C.c_float(cfg.ropeBase)), "rope_kv")
+                ck(lib.effort_attention(g.ctx, _p(self.xq), _p(self.kCache[n]), _p(self.vCache[n]), _p(self.pos), _p(self.attnOutput),
+                                        cfg.numHeads, cfg.headDim, self.maxTokens), "attention")
             muls(self.attnOutput, [(L.wo, self.attnFfnOut)])                                          # :170
             ck(lib.effort_add_rmsnorm_mul(g.ctx, _p(self.h), _p(self.attnFfnOut), _p(L.ffnNorm), _p(self.fxn), cfg.stateDim), "rmsnorm")
             if L.ffnGate is None:

@@ -147,6 +147,10 @@ EFFORT_API int effort_rope_kv(effort_ctx* ctx, const float* xq_dev, const float*
 /* calcScores (/sqrt(headDim)) + softmax + sumScores over tokens 0..*pos_dev (runNetwork.swift:151-163, aux.metal:185-198,379-447). */
 EFFORT_API int effort_attention(effort_ctx* ctx, const float* q_dev, const float* k_cache_dev, const float* v_cache_dev,
                      const uint32_t* pos_dev, float* out_dev, int numHeads, int headDim, int maxTokens);
+/* effort_rope_kv + effort_attention in one launch (one workgroup per query head; the newest token is attended from LDS). */
+EFFORT_API int effort_rope_attention(effort_ctx* ctx, const float* xq_dev, const float* xk_dev, const float* xv_dev, float* k_cache_dev,
+                          float* v_cache_dev, const uint32_t* pos_dev, float* out_dev, int numHeads, int numHeadsKV, int headDim,
+                          int maxTokens, float ropeBase);
 /* silu(x1, x3, out:) = x3 * x1 / (1 + exp(-x1)) (matrix.metal:25-35). */
 EFFORT_API int effort_silu_mul(effort_ctx* ctx, const float* x1_dev, const float* x3_dev, float* out_dev, int n);
 /* tokEmbeddings.fetchRow(id, out:) (aux.metal:355): row *id_dev of an f16 [vocab][n] table as f32. */

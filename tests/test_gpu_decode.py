@@ -91,6 +91,9 @@ def test_dense_path_matches_torch_reference(small_model):
     assert err < 2e-3, err
     ids2, _, logits2 = dec.run(prompt, steps, dense=True, collect_logits=True)        # replay after reset: same bits
     assert ids2 == ids and torch.equal(logits, logits2)
+    two = Decoder(small_model, maxTokens=16, fused_attention=False)                     # rope_kv + attention as two launches
+    ids3, _, logits3 = two.run(prompt, steps, dense=True, collect_logits=True)
+    assert ids3 == ids and float((logits3 - logits).abs().max() / logits.abs().max()) < 1e-5
 
 
 def test_effort_one_tracks_dense_and_low_effort_degrades(small_model):
