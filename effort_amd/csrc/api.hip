@@ -208,18 +208,46 @@ static bool supported(int W, int E) {
            (W == 4 && (E == 1 || E == 2 || E == 4 || E == 8)) || (W == 2 && (E == 4 || E == 8));
 }
 
-static int choose_geom(const effort_ctx* c, const effort_w* w, int groupSize, MulGeom* g, int* Wout, int* Eout) {
-    // defaults: 8 waves per workgroup; a lane owns 2 columns of a tile (FP16) or 1 word = 4 sub-buckets (Q4).  Large FP16
-    // groups take 4 columns per lane (fewer, fatter items: less fixed work per byte) -- unless that leaves the launch with
-    // between one and three items per CU, where half the chip runs two workgroups per CU in lockstep with the other half's
-    // one, or with less than half an item per CU (measured, 4096x11008: 8 calls 7.9 vs 8.4 us/call, 16 calls 7.2 vs 6.6, 32 calls 5.7 vs 6.3).
-    const int W = c->tuneW ? c->tuneW : 8;
-    int E = c->tuneE ? c->tuneE : (w->fmt == kFp16 ? 2 : 1);
-    if (!c->tuneE && !c->tuneS && w->fmt == kFp16 && groupSize >= 8) {
-        const uint32_t tiles4 = (w->cols + 255) / 256, slices = ((w->inDim + 511) / 512 + 7) / 8 * 8;
-        const uint32_t items4 = (uint32_t)groupSize * tiles4 * slices;
-        if ((items4 > (uint32_t)c->numCU / 2 && items4 <= (uint32_t)c->numCU) || items4 >= 3u * (uint32_t)c->numCU) E = 4;
+// Row slices per call when the launch carries `groupSize` calls and a lane owns E columns.  Measured on MI355X
+// (tools/tune.py, 4096x4096 .. 14336x4096, 10-100 % effort): a workgroup's life is mostly fixed-latency steps (staging,
+// cutoff, selection, hand-off), so FEWER, fatter items win even when they leave CUs idle -- about 3/4 of an item per CU
+// for small groups, with slices between 128 and 512 input rows; from 8 calls on, the fattest slices (512 rows).
+static uint32_t pick_slices(const effort_ctx* c, const effort_w* w, int groupSize, int E) {
+    const uint32_t tiles = (w->cols + 64 * E - 1) / (64 * E);
+    const uint32_t lo = ((w->inDim + 511) / 512 + 7) / 8 * 8, hi = ((w->inDim + 127) / 128 + 7) / 8 * 8;
+    if (groupSize >= 8) return lo;
+    const uint32_t target = (uint32_t)c->numCU * 3u / 4u;
+    uint32_t S = (target / ((uint32_t)groupSize * tiles) + 4u) / 8u * 8u;       // nearest multiple of 8
+    if (S < lo) S = lo;
+    if (S > hi) S = hi;
+    return S;
+}
+
+// Columns per lane for the whole launch (one kernel variant serves all its calls).  FP16: 2; 1 when a small group would
+// otherwise leave most of the chip without an item (small matrices); 4 for groups of >= 8 calls (fewer, fatter items: less
+// fixed work per byte) unless that leaves the launch with between one and three items per CU -- half the chip would then
+// run two workgroups per CU in lockstep with the other half's one -- or with less than half an item per CU (measured,
+// 4096x11008: 8 calls 7.9 vs 8.4 us/call, 16 calls 7.2 vs 6.6, 32 calls 5.7 vs 6.3).  Q4: 1 word = 4 sub-buckets.
+static int pick_elems(const effort_ctx* c, Format fmt, int n, const effort_w* const* ws) {
+    if (c->tuneE) return c->tuneE;
+    if (fmt != kFp16) return 1;
+    if (c->tuneS) return 2;
+    auto items = [&](int E) {
+        uint32_t t = 0;
+        for (int i = 0; i < n; i++) if (ws[i]) t += (ws[i]->cols + 64 * E - 1) / (64 * E) * pick_slices(c, ws[i], n, E);
+        return t;
+    };
+    const uint32_t numCU = (uint32_t)c->numCU;
+    if (n >= 8) {
+        const uint32_t i4 = items(4);
+        return ((i4 > numCU / 2 && i4 <= numCU) || i4 >= 3u * numCU) ? 4 : 2;
     }
+    const uint32_t i2 = items(2);
+    return (i2 * 10u < numCU * 3u / 4u * 6u && items(1) > i2) ? 1 : 2;
+}
+
+static int choose_geom(const effort_ctx* c, const effort_w* w, int groupSize, int E, MulGeom* g, int* Wout, int* Eout) {
+    const int W = c->tuneW ? c->tuneW : 8;                 // 8 waves per workgroup
     if (!supported(W, E)) return EFFORT_ERR_ARG;
     const uint32_t nacc = w->fmt == kFp16 ? 16 : 32;
     g->inDim = w->inDim; g->outDim = w->outDim; g->cols = w->cols; g->rowsPerIn = w->rowsPerIn;
@@ -230,12 +258,7 @@ static int choose_geom(const effort_ctx* c, const effort_w* w, int groupSize, Mu
     uint32_t S;
     if (c->tuneS) S = c->tuneS;                            // any count: the item grid is padded to a multiple of 8 slices
     else {
-        // Measured on MI355X (tools/tune.py, 4096x4096 .. 4096x11008, 10-100 % effort).  A workgroup's life is mostly
-        // fixed-latency steps (staging, cutoff, selection, hand-off), so FEWER, fatter workgroups win even when they
-        // leave CUs idle: slices of 128 input rows for a lone call; and the more calls share a launch, the fatter the
-        // slices (256 rows from 2 calls, 512 from 8), because the other calls' workgroups fill the chip.
-        const uint32_t rows = groupSize >= 8 ? 512u : groupSize >= 2 ? 256u : 128u;
-        const uint32_t want = ((w->inDim + rows - 1) / rows + 7) / 8 * 8;
+        const uint32_t want = pick_slices(c, w, groupSize, E);
         const uint32_t cap = (c->numCU * 2u) / g->tiles / 8 * 8;              // one round of workgroups
         S = cap < want ? cap : want;
     }
@@ -280,6 +303,7 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
     ga.tstamp = c->clock ? c->d_tstamp : nullptr;
     ga.ablate = ablate; ga.split = c->splitCutoff ? 1u : 0u;
     int W = 0, E = 0;
+    const int groupE = pick_elems(c, fmt, n, ws);
     uint32_t nGeoms = 0;
     size_t slabOff = 0; uint32_t tileOff = 0, sliceOff = 0, wg = 0;
     for (int i = 0; i < n; i++) {
@@ -291,7 +315,7 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
         MulGeom g;
         memset(&g, 0, sizeof(g));
         int Wi, Ei;
-        int rc = choose_geom(c, w, n, &g, &Wi, &Ei);
+        int rc = choose_geom(c, w, n, groupE, &g, &Wi, &Ei);
         if (rc != EFFORT_OK) return fail(c, rc, "bucketmul: no launch geometry for this shape/tuning");
         if (i == 0) { W = Wi; E = Ei; }
         else if (Wi != W || Ei != E) return fail(c, EFFORT_ERR_SHAPE, "bucketmul: the calls of a group must agree on the kernel variant");
@@ -350,7 +374,7 @@ extern "C" int effort_calc_dispatch(effort_ctx* c, const effort_w* w, const floa
     if (!c || !w || !v || !dispatch) return fail(c, EFFORT_ERR_ARG, "calc_dispatch: null argument");
     if (!(effort >= 0.0 && effort <= 1.0)) return fail(c, EFFORT_ERR_EFFORT, "calc_dispatch: effort outside [0,1]");
     MulGeom g; int W, E;
-    int rc = choose_geom(c, w, 1, &g, &W, &E);
+    int rc = choose_geom(c, w, 1, pick_elems(c, w->fmt, 1, &w), &g, &W, &E);
     if (rc != EFFORT_OK) return fail(c, rc, "calc_dispatch: geometry");
     const uint32_t q = (uint32_t)(int)((double)(kProbes - 1) * (1.0 - effort));
     HIP_TRY(c, launch_find_cutoff(v, w->probes, expNo, q, c->d_cutoff, c->d_count, nullptr, c->stream));
