@@ -89,7 +89,10 @@ EFFORT_API void effort_weights_free(effort_w* w);
 /* func bucketMul(v:by:expNo:out:effort:) -- bucketMul.swift:11-15 -> BucketMul.fullMul (:54-70):
  * findCutoff32 + prepareDispatch + roundUp/zeroRange32 + bucketMul + bucketIntegrate
  * (bucketMul.metal:11-247).  v_dev f32[inDim], out_dev f32[outDim] (fully overwritten),
- * expNo_dev = device u32 expert index (NULL = expert 0; expertMul.swift:18-22), effort in [0,1]. */
+ * expNo_dev = device u32 expert index (NULL = expert 0; expertMul.swift:18-22), effort in [0,1].
+ * Row selection (cutoff, dispatch set) is bit-exact with the reference's arithmetic.  Products are accumulated in
+ * per-workgroup fixed point: order-free, hence bit-identical run to run; within 2e-5 * max|out| of
+ * an f32 accumulation (measured 1-4e-6). */
 EFFORT_API int effort_bucketmul(effort_ctx* ctx, const effort_w* w, const float* v_dev, const uint32_t* expNo_dev,
                      float* out_dev, double effort);
 
@@ -103,11 +106,11 @@ EFFORT_API int effort_bucketmul_q4(effort_ctx* ctx, const effort_w* w, const flo
 EFFORT_API int effort_dense_gemv(effort_ctx* ctx, const void* W_f16_dev, const float* v_dev, float* out_dev,
                       int inDim, int outDim);
 
-/* ---- reference-visible state / test hooks ------------------------------------------------------ */
-
 /* A GROUP of n (1..32) independent bucketMul calls in ONE kernel launch: call i multiplies vs[i] by ws[i] at
- * efforts[i] into outs[i] (expNos may be NULL, or hold NULL entries = expert 0).  Same results, bit for bit, as n
- * effort_bucketmul calls; the point is throughput: the decode loop issues such groups back to back on unchanged
+ * efforts[i] into outs[i] (expNos may be NULL, or hold NULL entries = expert 0).  Same row selection as n
+ * effort_bucketmul calls, exactly; outputs equal up to the f32 rounding of the per-slice partial sums (the slicing
+ * depends on how many calls share the launch; bit for bit when it is pinned with effort_set_tuning).  The point is
+ * throughput: the decode loop issues such groups back to back on unchanged
  * input -- Wq|Wk|Wv (runNetwork.swift:132-134) and W1|W3 (runNetwork.swift:178-182) -- and the reference's command
  * buffer lets them overlap; here their workgroups share the CUs inside one launch.  All handles of a group are of
  * the same kind; shapes may differ.  effort_group_dispatch_count / effort_group_cutoff read call idx's hooks. */
@@ -117,6 +120,8 @@ EFFORT_API int effort_bucketmul_q4_group(effort_ctx* ctx, int n, const effort_w*
                               const uint32_t* const* expNos_dev, float* const* outs_dev, const double* efforts);
 EFFORT_API int effort_group_dispatch_count(effort_ctx* ctx, int idx, uint32_t* host_out);
 EFFORT_API int effort_group_cutoff(effort_ctx* ctx, int idx, float* host_out);
+
+/* ---- reference-visible state / test hooks ------------------------------------------------------ */
 
 /* dispatch.size after calcDispatch (bucketMul.swift:46-47): number of bucket rows selected by the most
  * recent effort_bucketmul / _q4 / effort_calc_dispatch, before padding.  Synchronises the stream. */
