@@ -122,7 +122,6 @@ __global__ __launch_bounds__(256) void rope_attention_kernel(const float* __rest
     extern __shared__ float sc[];                      // [maxTokens] scores, then probabilities
     __shared__ float red[17];
     __shared__ float qs[256], ks[256], vs[256];        // this head's roped q, roped k and v of the newest token
-    __shared__ float part[256];
     const uint32_t head = blockIdx.x, tid = threadIdx.x, half = headDim / 2;
     const uint32_t pos = min(posPtr[0], maxTokens - 1u), nTok = pos + 1u;
     if (tid < headDim) {
@@ -140,15 +139,36 @@ __global__ __launch_bounds__(256) void rope_attention_kernel(const float* __rest
         kCache[slot] = kr; vCache[slot] = vv;
     }
     __syncthreads();
+    // scores: headDim/8 threads per token, 8 dims each as two float4 loads; four token passes are issued before any is
+    // consumed, so the cache reads overlap instead of costing one memory round trip per token
     const float scale = 1.0f / sqrtf((float)headDim);
-    const int lane = tid & 63, wave = tid >> 6;
-    for (uint32_t t = wave; t < nTok; t += 4) {        // one wave per token: lanes stride the head dimension
-        const float* kh = kCache + ((size_t)t * numHeads + head) * headDim;
-        float dot = 0.0f;
-        for (uint32_t d = lane; d < headDim; d += 64) dot += qs[d] * (t == pos ? ks[d] : kh[d]);
+    const uint32_t lpt = headDim / 8u, tokPerPass = 256u / lpt, sub = tid % lpt, tk = tid / lpt;
+    float q8[8];
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) dot += __shfl_xor(dot, off);
-        if (lane == 0) sc[t] = dot * scale;
+    for (int i = 0; i < 8; i++) q8[i] = qs[sub * 8u + i];
+    for (uint32_t t0 = 0; t0 < nTok; t0 += tokPerPass * 4u) {
+        float4 ka[4], kb[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t t = min(t0 + u * tokPerPass + tk, pos);           // clamped: surplus lanes re-read the newest row
+            const float4* kh = reinterpret_cast<const float4*>(kCache + ((size_t)t * numHeads + head) * headDim + sub * 8u);
+            ka[u] = kh[0]; kb[u] = kh[1];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t t = t0 + u * tokPerPass + tk;
+            float dot;
+            if (t >= pos) {                                                   // the newest token: from LDS (its cache row is being written)
+                dot = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 8; i++) dot += q8[i] * ks[sub * 8u + i];
+            } else {
+                dot = q8[0] * ka[u].x + q8[1] * ka[u].y + q8[2] * ka[u].z + q8[3] * ka[u].w +
+                      q8[4] * kb[u].x + q8[5] * kb[u].y + q8[6] * kb[u].z + q8[7] * kb[u].w;
+            }
+            for (uint32_t off = lpt / 2u; off >= 1u; off >>= 1) dot += __shfl_xor(dot, (int)off);
+            if (sub == 0 && t < nTok) sc[t] = dot * scale;
+        }
     }
     __syncthreads();
     float m = -INFINITY;
@@ -158,16 +178,30 @@ __global__ __launch_bounds__(256) void rope_attention_kernel(const float* __rest
     for (uint32_t t = tid; t < nTok; t += 256) { const float e = expf(sc[t] - m); sc[t] = e; sum += e; }
     sum = block_sum(sum, red);
     const float inv = 1.0f / sum;
-    const uint32_t d = tid % headDim, ph = tid / headDim, nph = 256 / headDim;
-    float acc = 0.0f;
-    if (ph < nph)
-        for (uint32_t t = ph; t < nTok; t += nph) acc += sc[t] * (t == pos ? vs[d] : vCache[((size_t)t * numHeads + head) * headDim + d]);
-    part[tid] = acc;
+    // weighted sum: headDim/4 threads per token phase (one float4 of the head each), 256/(headDim/4) phases; eight
+    // tokens' loads in flight per thread
+    const uint32_t tpr = headDim / 4u, nph = 256u / tpr, d4 = (tid % tpr) * 4u, ph = tid / tpr;
+    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (uint32_t t0 = ph; t0 < nTok; t0 += nph * 8u) {
+        float4 vv[8]; float p8[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const uint32_t t = t0 + u * nph;
+            const uint32_t tc = min(t, pos);
+            vv[u] = *reinterpret_cast<const float4*>(vCache + ((size_t)tc * numHeads + head) * headDim + d4);
+            p8[u] = t < nTok ? sc[t] : 0.0f;
+            if (t == pos) vv[u] = make_float4(vs[d4], vs[d4 + 1], vs[d4 + 2], vs[d4 + 3]);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) { acc.x += p8[u] * vv[u].x; acc.y += p8[u] * vv[u].y; acc.z += p8[u] * vv[u].z; acc.w += p8[u] * vv[u].w; }
+    }
+    __shared__ float4 part4[256];
+    part4[tid] = acc;
     __syncthreads();
-    if (tid < headDim) {
-        float s2 = 0.0f;
-        for (uint32_t p = 0; p < nph; p++) s2 += part[p * headDim + tid];
-        out[head * headDim + tid] = s2 * inv;
+    if (tid < tpr) {
+        float4 s2 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        for (uint32_t p = 0; p < nph; p++) { const float4 x = part4[p * tpr + tid]; s2.x += x.x; s2.y += x.y; s2.z += x.z; s2.w += x.w; }
+        *reinterpret_cast<float4*>(out + head * headDim + d4) = make_float4(s2.x * inv, s2.y * inv, s2.z * inv, s2.w * inv);
     }
 }
 

@@ -93,7 +93,9 @@ def test_dense_path_matches_torch_reference(small_model):
     assert ids2 == ids and torch.equal(logits, logits2)
     two = Decoder(small_model, maxTokens=16, fused_attention=False)                     # rope_kv + attention as two launches
     ids3, _, logits3 = two.run(prompt, steps, dense=True, collect_logits=True)
-    assert ids3 == ids and float((logits3 - logits).abs().max() / logits.abs().max()) < 1e-5
+    # different f32 summation orders, then f16 rounding of the vectors fed to rocBLAS: same bar as against the reference
+    assert ids3 == ids and float((logits3 - logits).abs().max() / logits.abs().max()) < 2e-3
+    assert float((logits3 - want_logits).abs().max() / want_logits.abs().max()) < 2e-3
 
 
 def test_effort_one_tracks_dense_and_low_effort_degrades(small_model):
