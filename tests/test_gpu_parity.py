@@ -526,3 +526,36 @@ def test_ragged_input_dimension(ea, oracle_cpu):
     g.eval()
     for i, (call, (want, n, cutoff)) in enumerate(zip(calls, wants)):
         assert g.last_dispatch_count(i) == n and g.last_cutoff(i) == cutoff and close(call[3].cpu().numpy(), want), i
+
+
+def test_model_file_roundtrip_q4(ea, oracle_cpu, tmp_path):
+    """q4_convert.py's flow on the GPU: convertMistral(q4=True) -> shards named like the reference's Q4 model -> bundles
+    loaded back (stats f32x2, outliers) -> bucketMulQ4 equals the oracle run on the numpy restatement of q4_draft.convert."""
+    from effort_amd import bucketfile as bf
+    from oracle import q4_layout
+    hidden = 4096
+    src = {"model.norm.weight": torch.ones(hidden).half(), "lm_head.weight": torch.zeros(8, hidden).half(),
+           "model.embed_tokens.weight": torch.zeros(8, hidden).half(),
+           "model.layers.0.input_layernorm.weight": torch.ones(hidden).half(),
+           "model.layers.0.post_attention_layernorm.weight": torch.ones(hidden).half()}
+    mats = {}
+    for k in ("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "self_attn.o_proj", "mlp.gate_proj", "mlp.up_proj", "mlp.down_proj"):
+        mats[k] = make_w(hidden, hidden, seed=90 + len(mats))
+        src[f"model.layers.0.{k}.weight"] = torch.from_numpy(mats[k])
+    saver = bf.convertMistral(src, bf.TensorSaver(str(tmp_path), "model", pad_total=False), numLayers=1, q4=True)
+    saver.save()
+    L = bf.TensorLoader(str(tmp_path), "model")
+    assert not L.hasTensor("layers.0.attention.wk.buckets") and L.hasTensor("layers.0.attention.wk.core")     # q4_convert.py:57
+    v = make_v(hidden, seed=8)
+    vd = devf(v)
+    for name, key in (("layers.0.attention.wq", "self_attn.q_proj"), ("layers.0.feed_forward.experts.0.w3", "mlp.up_proj")):
+        ew = bf.loadExpertWeights(L, name, q4=True)
+        want_layout = q4_layout.convert(np.ascontiguousarray(mats[key].T))
+        assert ew.q4 and ew.percentLoad == 8 and ew.outliers.shape == want_layout["outliers"].shape
+        assert ew.buckets.cpu().numpy().view(np.uint16).tobytes() == want_layout["buckets"].view(np.uint16).tobytes()
+        out = torch.full((hidden,), float("nan"), device=DEV)
+        ea.expertMul(vd, ew, out, 0.3)
+        ea.gpu().eval()
+        want, n, cutoff = oracle_cpu.bucket_mul_q4(v, want_layout["buckets"], want_layout["bucket.stats"], want_layout["probes"],
+                                                   want_layout["outliers"], hidden, hidden, 0.3)
+        assert ea.gpu().last_dispatch_count() == n and ea.gpu().last_cutoff() == cutoff and close(out.cpu().numpy(), want), name
