@@ -23,6 +23,8 @@ roofline         = dominant kernel (bucket_mul_kernel: a whole group of calls in
                    launch / its average duration in THIS run's timed configuration.  Kernels of one stream do not
                    overlap, so this is also what `rocprofv3 --kernel-trace --stats` reports for the same command.
 cpu_baseline     = the CPU oracle (a port: the reference ships no CPU path) on the host cores, bounded sample.
+decode           = BASELINE.json configs[4]: end-to-end greedy decode of a random-init Mistral-7B-shaped model through
+                   effort_amd/decode.py (one hipGraph per token): tokens/s dense vs effort 100 % / 25 %, KL vs dense.
 
 N > 1 (one process per GPU, RCCL): independent matrices are partitioned across the ranks (every rank owns 32
 distinct matrices; weak scaling) and the output vectors of a step are exchanged with ONE all-gather (north_star:
@@ -175,6 +177,7 @@ def main():
     ap.add_argument("--partition", choices=["matrices", "columns"], default="matrices")
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-decode", action="store_true", help="skip the end-to-end decode section (BASELINE.json configs[4])")
     ap.add_argument("--headline-only", action="store_true", help="only the timed job (for rocprofv3 passes: every bucket_mul_kernel dispatch is then the timed configuration)")
     ap.add_argument("--tune", default="0,0,0", help="waves,elems,slices of the multiply kernel (0,0,0 = heuristic)")
     args = ap.parse_args()
@@ -407,6 +410,27 @@ def main():
                                                                   for e in (0.25,) for n in (1, 16)}
             del q4w
             result["other_configs"] = other
+        # ---------------- end-to-end greedy decode (BASELINE.json configs[4]; random-init Mistral-7B shapes) ----------
+        if not args.no_decode and not args.no_sweep:
+            try:
+                from effort_amd.decode import Decoder, MistralConfig, Model, kl_divergence
+                g.set_tuning(0, 0, 0)
+                model = Model.random(MistralConfig(), seed=1)
+                dec = Decoder(model, maxTokens=64)
+                prompt, ntok = [1, 733, 16289, 28793, 22557], 48
+                ids_d, dt_d, lg_d = dec.run(prompt, ntok, dense=True, collect_logits=True)
+                forced = prompt + ids_d[len(prompt) - 1:-1]
+                dsec = {"model": "Mistral-7B shapes, 32 layers, random-init weights (no checkpoints offline)", "tokens": ntok,
+                        "dense_rocblas_tokens_per_s": round(1 / dt_d, 1), "effort": {}}
+                for e in (1.0, 0.25):
+                    _, dt_e, _ = dec.run(prompt, ntok, effort=e)
+                    _, _, lg_e = dec.run(forced, ntok, effort=e, forced=True, collect_logits=True)
+                    dsec["effort"][str(e)] = {"tokens_per_s": round(1 / dt_e, 1), "ms_per_token": round(dt_e * 1e3, 3),
+                                              "speedup_vs_dense": round(dt_d / dt_e, 3), "kl_vs_dense": round(kl_divergence(lg_d, lg_e), 5)}
+                result["decode"] = dsec
+                del dec, model
+            except Exception as ex:
+                result["decode"] = {"error": repr(ex)}
         # ---------------- CPU baseline -----------------------------------------------------------------
         if not args.no_cpu:
             try:
