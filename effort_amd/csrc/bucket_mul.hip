@@ -474,24 +474,46 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     if (rstamp) ga.tstamp[23] = wall_clock64();
     typedef uint32_t u4v __attribute__((ext_vector_type(4)));
     const uint32_t sliceStride = g.tiles * (uint32_t)(TILE_F * 4);
+    // G thread groups share the slices when the workgroup has more threads than the tile has float4 columns (E = 1): each
+    // group then has at most 16 slices = ONE round trip; the groups' partial sums meet in LDS and are added in group order.
+    constexpr int kCols4 = TILE_F / 4;
+    constexpr int G = NT / kCols4 >= 2 ? NT / kCols4 : 1;
+    float* const gpart = reinterpret_cast<float*>(smem);            // [G][TILE_F]; the accumulator region is free by now
     auto reduce_tile = [&](auto kc) {
         constexpr int kRed = decltype(kc)::value;          // 16-byte slab loads in flight per thread
-        for (int o = tid * 4; o < TILE_F; o += NT * 4) {
+        const int grp = G > 1 ? tid / kCols4 : 0;
+        const uint32_t per = G > 1 ? ((g.slices + G - 1) / G + 3u) / 4u * 4u : g.slices;   // slices per group, a multiple of 4
+        const uint32_t sl0 = (uint32_t)grp * per, sl1 = min(g.slices, sl0 + per);
+        for (int o = (G > 1 ? tid % kCols4 : tid) * 4; o < TILE_F; o += (G > 1 ? kCols4 : NT) * 4) {
             const uint32_t vo = t * (uint32_t)(TILE_F * 4) + (uint32_t)o * 4u;
             float sm[4][4];                                // [tile slot of this thread][slice % 4]: fixed summation order
 #pragma unroll
             for (int h = 0; h < 4; h++) { sm[h][0] = 0.0f; sm[h][1] = 0.0f; sm[h][2] = 0.0f; sm[h][3] = 0.0f; }
-            for (uint32_t sl = 0; sl < g.slices; sl += kRed) {
+            for (uint32_t sl = sl0; sl < sl1; sl += kRed) {
                 u4v r[kRed];
 #pragma unroll
                 for (int i = 0; i < kRed; i++)
                     r[i] = __builtin_amdgcn_raw_buffer_load_b128(srs, vo, min(sl + i, g.slices - 1u) * sliceStride, kSc1);
 #pragma unroll
                 for (int i = 0; i < kRed; i++) {
-                    if (sl + i < g.slices) {
+                    if (sl + i < sl1) {
 #pragma unroll
                         for (int h = 0; h < 4; h++) sm[h][i & 3] += __uint_as_float(r[i][h]);
                     }
+                }
+            }
+            float tot[4];
+#pragma unroll
+            for (int h = 0; h < 4; h++) tot[h] = (sm[h][0] + sm[h][1]) + (sm[h][2] + sm[h][3]);
+            if (G > 1) {
+#pragma unroll
+                for (int h = 0; h < 4; h++) gpart[grp * TILE_F + o + h] = tot[h];
+                __syncthreads();                           // (every thread of the workgroup runs exactly one such iteration)
+                if (grp != 0) continue;
+#pragma unroll
+                for (int h = 0; h < 4; h++) {
+                    tot[h] = gpart[o + h];
+                    for (int g2 = 1; g2 < G; g2++) tot[h] += gpart[g2 * TILE_F + o + h];
                 }
             }
 #pragma unroll
@@ -499,13 +521,13 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
                 const uint32_t oo = (uint32_t)o + h;
                 const uint32_t lane2 = oo & 63u, sj = oo >> 6, j = sj % E, slot = sj / E;
                 const uint32_t c2 = t * (64u * E) + lane2 * E + j;
-                if (c2 < g.cols) a.out[c2 * NACC + slot] = (sm[h][0] + sm[h][1]) + (sm[h][2] + sm[h][3]);
+                if (c2 < g.cols) a.out[c2 * NACC + slot] = tot[h];
             }
         }
     };
     // (the four running sums take slices i%4; chunk sizes are multiples of 4, so the order does not depend on the chunk.
-    //  Up to 16 slices the whole reduction is ONE memory round trip per thread.)
-    if (g.slices <= 8u) reduce_tile(std::integral_constant<int, 8>{});
+    //  Up to 16 slices per thread group the whole reduction is ONE memory round trip per thread.)
+    if (g.slices <= 8u * G) reduce_tile(std::integral_constant<int, 8>{});
     else reduce_tile(std::integral_constant<int, 16>{});
     if (rstamp) ga.tstamp[24] = wall_clock64();
     if (tid == 0) {
