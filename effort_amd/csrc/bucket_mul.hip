@@ -62,6 +62,12 @@ constexpr int kRounds = 16;  // selection rounds of NT candidate slots a workgro
 #define EFFORT_MIN_WAVES_PER_EU 4
 #endif
 
+// Cache policy of the bucket-row stream.  0 = default.  nt (2) measured WORSE from 16 calls per launch on (6.8 vs 6.6 us/call,
+// 100 % effort 22 vs 18): neighbouring tiles' pieces share the 128-byte lines a 1376-byte row pitch straddles, and nt drops them.
+#ifndef EFFORT_ROW_AUX
+#define EFFORT_ROW_AUX 0
+#endif
+constexpr int kRowAux = EFFORT_ROW_AUX;
 constexpr int kSc1 = 16;     // buffer aux bit: sc1 = write-through store / L1-bypassing load (cross-XCD visible)
 
 template <int FMT> struct Fmt;
@@ -80,20 +86,20 @@ template <> struct MeanT<kQ4> { typedef float type; };        // f32 (stats lane
 template <int E> struct Piece;
 template <> struct Piece<1> {
     uint32_t w;
-    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) { w = __builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, 0); }
+    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) { w = __builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, kRowAux); }
     __device__ __forceinline__ uint32_t word(int) const { return w & 0xFFFFu; }
     __device__ __forceinline__ uint32_t dword(int) const { return w; }
 };
 template <> struct Piece<2> {
     uint32_t w;
-    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) { w = __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0); }
+    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) { w = __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, kRowAux); }
     __device__ __forceinline__ uint32_t word(int j) const { return (w >> (16 * j)) & 0xFFFFu; }
     __device__ __forceinline__ uint32_t dword(int) const { return w; }
 };
 template <> struct Piece<4> {
     uint32_t w[2];
     __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
-        auto t = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0); w[0] = t[0]; w[1] = t[1];
+        auto t = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, kRowAux); w[0] = t[0]; w[1] = t[1];
     }
     __device__ __forceinline__ uint32_t word(int j) const { return (w[j >> 1] >> (16 * (j & 1))) & 0xFFFFu; }
     __device__ __forceinline__ uint32_t dword(int j) const { return w[j >> 1]; }
@@ -101,7 +107,7 @@ template <> struct Piece<4> {
 template <> struct Piece<8> {
     uint32_t w[4];
     __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
-        auto t = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0); w[0] = t[0]; w[1] = t[1]; w[2] = t[2]; w[3] = t[3];
+        auto t = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, kRowAux); w[0] = t[0]; w[1] = t[1]; w[2] = t[2]; w[3] = t[3];
     }
     __device__ __forceinline__ uint32_t word(int j) const { return (w[j >> 1] >> (16 * (j & 1))) & 0xFFFFu; }
     __device__ __forceinline__ uint32_t dword(int j) const { return w[j >> 1]; }
