@@ -22,18 +22,26 @@ def main():
     ap.add_argument("--layers", type=int, default=32)
     ap.add_argument("--tokens", type=int, default=64)
     ap.add_argument("--efforts", default="1.0,0.5,0.25")
+    ap.add_argument("--model-dir", default=None, help="a bucketed model on disk (e.g. kolinko/mistral-buckets: buckets-FP16.safetensors.index.json "
+                                                      "+ shards) instead of random-init weights")
+    ap.add_argument("--model-name", default="buckets-FP16")
+    ap.add_argument("--percent-load", type=int, default=16)
     a = ap.parse_args()
     torch.cuda.set_device(0)
     cfg = MistralConfig(numLayers=a.layers)
     t0 = time.time()
-    model = Model.random(cfg, seed=1)
+    if a.model_dir:
+        from effort_amd.bucketfile import TensorLoader
+        model = Model.load(TensorLoader(a.model_dir, a.model_name), cfg, percentLoad=a.percent_load)
+    else:
+        model = Model.random(cfg, seed=1)
     torch.cuda.synchronize()
-    print(f"model: {a.layers} layers, 7 bucketized matrices each, built + converted in {time.time() - t0:.1f} s", file=sys.stderr)
+    print(f"model: {a.layers} layers, 7 bucketized matrices each, {'loaded' if a.model_dir else 'built + converted'} in {time.time() - t0:.1f} s", file=sys.stderr)
     dec = Decoder(model, maxTokens=max(64, a.tokens + 8))
     prompt = [1, 733, 16289, 28793, 22557]
     ids_d, dt_d, lg_d = dec.run(prompt, a.tokens, dense=True, collect_logits=True)
     forced = prompt + ids_d[len(prompt) - 1:-1]
-    out = {"model": f"Mistral-7B shapes, {a.layers} layers, random init", "tokens": a.tokens, "prompt_tokens": len(prompt),
+    out = {"model": f"Mistral-7B shapes, {a.layers} layers, " + (f"loaded from {a.model_dir}" if a.model_dir else "random init"), "tokens": a.tokens, "prompt_tokens": len(prompt),
            "dense_rocblas": {"ms_per_token": round(dt_d * 1e3, 3), "tokens_per_s": round(1 / dt_d, 1)}, "effort": {}}
     for e in (float(x) for x in a.efforts.split(",")):
         ids_e, dt_e, _ = dec.run(prompt, a.tokens, effort=e)                      # free-running greedy: the speed
