@@ -132,3 +132,36 @@ def test_mixtral_routing(hip_lib_built):
     ids_1, _, lg_1 = dec.run(forced, steps, effort=1.0, forced=True, collect_logits=True)
     assert float(torch.nn.functional.cosine_similarity(lg_1, logits, dim=1).min()) > 0.999
     assert ids_1 == ids
+
+
+def test_model_load_from_bucket_files(hip_lib_built, tmp_path):
+    """HF-named tensors -> convertMistral -> shards on disk -> Model.load -> the decode loop gives the same logits, bit for
+    bit, as a model bucketized in memory from the same matrices (same converter, same layout, same kernels)."""
+    from effort_amd import bucketfile as bf
+    from effort_amd.decode import Decoder, Layer, MistralConfig, Model
+    from effort_amd.weights import ExpertWeights
+    cfg = MistralConfig(stateDim=4096, hiddenDim=4096, numLayers=1, numHeads=32, numHeadsKV=8, headDim=128, vocab=64)
+    g = torch.Generator().manual_seed(3)
+    mat = lambda o, i: (torch.randn(o, i, generator=g) * 0.02).half()                    # noqa: E731
+    vec = lambda n: (1 + 0.1 * torch.randn(n, generator=g)).half()                       # noqa: E731
+    kv = cfg.numHeadsKV * cfg.headDim
+    src = {"model.norm.weight": vec(4096), "lm_head.weight": mat(cfg.vocab, 4096), "model.embed_tokens.weight": torch.randn(cfg.vocab, 4096, generator=g).half(),
+           "model.layers.0.input_layernorm.weight": vec(4096), "model.layers.0.post_attention_layernorm.weight": vec(4096),
+           "model.layers.0.self_attn.q_proj.weight": mat(4096, 4096), "model.layers.0.self_attn.k_proj.weight": mat(kv, 4096),
+           "model.layers.0.self_attn.v_proj.weight": mat(kv, 4096), "model.layers.0.self_attn.o_proj.weight": mat(4096, 4096),
+           "model.layers.0.mlp.gate_proj.weight": mat(4096, 4096), "model.layers.0.mlp.up_proj.weight": mat(4096, 4096),
+           "model.layers.0.mlp.down_proj.weight": mat(4096, 4096)}
+    bf.convertMistral(src, bf.TensorSaver(str(tmp_path), "buckets-FP16"), numLayers=1).save()
+    loaded = Model.load(bf.TensorLoader(str(tmp_path), "buckets-FP16"), cfg)
+    direct = Model(cfg)
+    L = Layer()
+    L.attnNorm, L.ffnNorm, L.ffnGate = src["model.layers.0.input_layernorm.weight"].to(DEV), src["model.layers.0.post_attention_layernorm.weight"].to(DEV), None
+    for name, key in (("wq", "self_attn.q_proj"), ("wk", "self_attn.k_proj"), ("wv", "self_attn.v_proj"), ("wo", "self_attn.o_proj"),
+                      ("w1", "mlp.gate_proj"), ("w3", "mlp.up_proj"), ("w2", "mlp.down_proj")):
+        setattr(L, name, ExpertWeights.from_core(src[f"model.layers.0.{key}.weight"].to(DEV)))
+    direct.layers.append(L)
+    direct.norm, direct.output, direct.tokEmbeddings = src["model.norm.weight"].to(DEV), src["lm_head.weight"].to(DEV), src["model.embed_tokens.weight"].to(DEV)
+    a = Decoder(loaded, maxTokens=16).run([1, 2, 3], 8, effort=0.5, collect_logits=True)
+    b = Decoder(direct, maxTokens=16).run([1, 2, 3], 8, effort=0.5, collect_logits=True)
+    assert a[0] == b[0] and torch.equal(a[2], b[2])
+    assert loaded.layers[0].w1.core is None and loaded.layers[0].wq.core is not None              # convert.swift keeps attention cores only
