@@ -52,15 +52,19 @@ def bucketMulQ4(v: torch.Tensor, by: ExpertWeights, expNo: torch.Tensor | None, 
 def bucketMulGroup(calls, gpu=None):
     """One launch for up to 32 independent multiplies: ``calls`` = [(v, by, expNo, out, effort), ...], all FP16 or all
     Q4 bundles.  Same results as calling bucketMul / bucketMulQ4 on each; the group is how independent projections of
-    the decode loop (Wq|Wk|Wv, W1|W3 -- runNetwork.swift:132-134,178-182) keep the whole chip busy."""
-    calls = list(calls)
+    the decode loop (Wq|Wk|Wv, W1|W3 -- runNetwork.swift:132-134,178-182) keep the whole chip busy.
+
+    A call may carry a 6th element, a dict folding the loop's neighbouring element-wise steps into the launch (FP16):
+    ``{"gate": x3}`` -- input = silu(v) * x3 (runNetwork.swift:181); ``{"norm": w}`` -- input = rmsNorm(v) * w (:121-122);
+    ``{"resid": h}`` -- out = h + product (:172,183; ``h`` may be ``out`` itself)."""
+    calls = [tuple(c) for c in calls]
     if not 1 <= len(calls) <= 32:
         raise ValueError("a group holds 1..32 calls")
     q4 = calls[0][1].q4
     cls = BucketMulQ4 if q4 else BucketMul
     bm = cls.shared() if gpu is None else cls(gpu.device, gpu)
-    for v, ew, expNo, out, _ in calls:
-        bm._validate(v, ew, expNo, out)
+    for c in calls:
+        bm._validate(c[0], c[1], c[2], c[3])
     n = len(calls)
     P = C.c_void_p * n
     addr = lambda x: None if x is None else (x.data_ptr() if isinstance(x, torch.Tensor) else (x.value if hasattr(x, "value") else int(x)))
@@ -71,6 +75,27 @@ def bucketMulGroup(calls, gpu=None):
     eff = (C.c_double * n)(*[float(c[4]) for c in calls])
     g = bm.gpu
     g._bind_stream()
+    extras = [c[5] if len(c) > 5 and c[5] else {} for c in calls]
+    if any(extras):
+        if q4:
+            raise ValueError("fused prologues / epilogues are implemented for FP16 bundles")
+        pre, aux, res = [], [], []
+        for c, x in zip(calls, extras):
+            if set(x) - {"gate", "norm", "resid"} or ("gate" in x and "norm" in x):
+                raise ValueError("a call takes one of gate= / norm=, and optionally resid=")
+            if "gate" in x:
+                _check_vec("gate", x["gate"], c[1].inSize)
+            if "norm" in x:
+                w = x["norm"]
+                if not (w.is_cuda and w.element_size() == 2 and w.is_contiguous() and w.numel() >= c[1].inSize):
+                    raise ValueError("norm weights must be a contiguous f16 CUDA vector of inSize elements")
+            if "resid" in x:
+                _check_vec("resid", x["resid"], c[1].outSize)
+            pre.append(1 if "gate" in x else 2 if "norm" in x else 0)
+            aux.append(addr(x.get("gate", x.get("norm"))))
+            res.append(addr(x.get("resid")))
+        g.check(_lib.lib().effort_bucketmul_group_fused(g.ctx, n, ws, vs, es, outs, eff, (C.c_int * n)(*pre), P(*aux), P(*res)), "bucketMulGroup")
+        return
     fn = _lib.lib().effort_bucketmul_q4_group if q4 else _lib.lib().effort_bucketmul_group
     g.check(fn(g.ctx, n, ws, vs, es, outs, eff), "bucketMulGroup")
 

@@ -291,7 +291,8 @@ static int ensure_timing(effort_ctx* c) {
 
 // One launch for a group of independent calls (a lone call is a group of one).
 static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws, const float* const* vs,
-                    const uint32_t* const* expNos, float* const* outs, const double* efforts) {
+                    const uint32_t* const* expNos, float* const* outs, const double* efforts,
+                    const int* prologues = nullptr, const void* const* vAux = nullptr, const float* const* resids = nullptr) {
     if (!c || !ws || !vs || !outs || !efforts) return fail(c, EFFORT_ERR_ARG, "bucketmul: null argument");
     if (n < 1 || n > kMaxGroup) return fail(c, EFFORT_ERR_ARG, "bucketmul: group size outside 1..32");
     static const uint32_t ablate = getenv("EFFORT_ABLATE") ? (uint32_t)atoi(getenv("EFFORT_ABLATE")) : 0u;   // profiling only
@@ -332,6 +333,10 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
         a.expNo = expNos ? expNos[i] : nullptr; a.out = outs[i];
         a.ol = OutlierIndex{fmt == kQ4 ? w->olRowPtr : nullptr, w->olInIdx, w->olValue};
         a.q = (uint32_t)(int)((double)(kProbes - 1) * (1.0 - efforts[i]));            // bucketMul.swift:39
+        const int pre = prologues ? prologues[i] : 0;
+        if (pre < 0 || pre > 2 || (pre && (!vAux || !vAux[i]))) return fail(c, EFFORT_ERR_ARG, "bucketmul: bad input prologue");
+        if (pre && (fmt != kFp16 || c->splitCutoff)) return fail(c, EFFORT_ERR_KIND, "bucketmul: input prologues need FP16 weights and the fused cutoff");
+        a.pre = (uint16_t)pre; a.vAux = pre ? vAux[i] : nullptr; a.resid = resids ? resids[i] : nullptr;
         a.slabOff = (uint32_t)(slabOff / 256); a.tileOff = (uint16_t)tileOff; a.sliceOff = (uint16_t)sliceOff; a.geom = (uint16_t)gi;
         wg += g.tiles * ((g.slices + 7) / 8 * 8);
         ga.wgEnd[i] = wg;
@@ -363,6 +368,11 @@ extern "C" int effort_bucketmul_q4(effort_ctx* c, const effort_w* w, const float
 extern "C" int effort_bucketmul_group(effort_ctx* c, int n, const effort_w* const* ws, const float* const* vs,
                                       const uint32_t* const* expNos, float* const* outs, const double* efforts) {
     return do_group(c, kFp16, n, ws, vs, expNos, outs, efforts);
+}
+extern "C" int effort_bucketmul_group_fused(effort_ctx* c, int n, const effort_w* const* ws, const float* const* vs,
+                                            const uint32_t* const* expNos, float* const* outs, const double* efforts,
+                                            const int* prologues, const void* const* vAux, const float* const* resids) {
+    return do_group(c, kFp16, n, ws, vs, expNos, outs, efforts, prologues, vAux, resids);
 }
 extern "C" int effort_bucketmul_q4_group(effort_ctx* c, int n, const effort_w* const* ws, const float* const* vs,
                                          const uint32_t* const* expNos, float* const* outs, const double* efforts) {

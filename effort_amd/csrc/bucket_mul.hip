@@ -132,7 +132,7 @@ __host__ __device__ inline uint32_t lds_layout(uint32_t B, uint32_t slots, uint3
 
 // One work item = one (call, tile, slice) of the group: stage, select, stream, hand the partial tile over.
 // `item` numbers the items the way a plain grid would number its blocks (item % 8 = the XCD it should run on).
-template <int FMT, int E, int W>
+template <int FMT, int E, int W, bool FUSED>
 __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t item, char* smem, uint32_t& cachedCall, float& cachedCutoff) {
     constexpr int NACC = Fmt<FMT>::kAcc;
     constexpr int TILE_F = NACC * E * 64;                    // outputs of a tile (slab / out[] granularity)
@@ -194,10 +194,13 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
 #pragma unroll
     for (int i = 0; i < VPT; i++) { vj[i] = 0.0f; prj[i] = 0; }
     const bool needCut = fused && cachedCall != ci;              // uniform: a persistent workgroup evaluates a call's cutoff once
-    if (needCut) {
+    // Input prologue (uniform per call): the multiply's input is v itself, or silu(v) * vAux (the FFN gate,
+    // runNetwork.swift:181), or rmsNorm(v) * vAux (runNetwork.swift:121-122,173-175) -- evaluated here, per workgroup,
+    // instead of in a launch of its own.
+    const uint32_t pre = FUSED ? a.pre : (uint32_t)kPreNone;      // FUSED is a separate instantiation: the plain multiply pays nothing
+    float rawn[VPT];                                              // rmsNorm: the first 4096 raw inputs, loaded with everything else
 #pragma unroll
-        for (int i = 0; i < VPT; i++) { vj[i] = a.v[tid + NT * i]; prj[i] = pr[tid + NT * i]; }
-    }
+    for (int i = 0; i < VPT; i++) rawn[i] = (FUSED && pre == kPreRmsNorm) ? a.v[tid + NT * i] : 0.0f;
     const uint32_t lg = g.sliceLog2;
     const uint32_t nSlots = FMT == kFp16 ? (g.rowsPerIn << lg) : (nb << 3);
     const uint32_t rounds = (nSlots + NT - 1) / NT;              // <= kRounds (checked at launch)
@@ -228,9 +231,40 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
         for (int r = 0; r < kRounds; r++)
             if ((uint32_t)(r * NT) + tid < nSlots) means[r * NT + tid] = tmp[r];
     }
+    float normInv = 1.0f;
+    if (FUSED && pre == kPreRmsNorm) {
+        float ss = 0.0f;
+#pragma unroll
+        for (int i = 0; i < VPT; i++) ss += rawn[i] * rawn[i];
+        for (uint32_t j = 4096u + tid; j < g.inDim; j += NT) { const float x = a.v[j]; ss += x * x; }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off);
+        if (lane == 0) wbound[wave] = ss;
+        __syncthreads();
+        float tot = 0.0f;
+#pragma unroll
+        for (int w2 = 0; w2 < W; w2++) tot += wbound[w2];
+        normInv = 1.0f / sqrtf(tot / (float)g.inDim + 1e-5f);                  // aux.metal:150
+        __syncthreads();                                                         // wbound is reused below
+    }
+    auto input = [&](uint32_t j) -> float {
+        const float x = a.v[j];
+        if (!FUSED) return x;
+        if (pre == kPreSiluGate) return reinterpret_cast<const float*>(a.vAux)[j] * x / (1.0f + expf(-x));
+        if (pre == kPreRmsNorm) return (x * normInv) * half_bits_to_float(reinterpret_cast<const uint16_t*>(a.vAux)[j]);
+        return x;
+    };
+    if (needCut) {
+#pragma unroll
+        for (int i = 0; i < VPT; i++) {
+            vj[i] = (FUSED && pre == kPreRmsNorm) ? (rawn[i] * normInv) * half_bits_to_float(reinterpret_cast<const uint16_t*>(a.vAux)[tid + NT * i])
+                                                  : input(tid + NT * i);
+            prj[i] = pr[tid + NT * i];
+        }
+    }
     // stage the slice of v; its absolute sum bounds every partial sum of this workgroup (see the scale below)
     float bound = 0.0f;
-    for (uint32_t jl = tid; jl < nb; jl += NT) { const float x = a.v[j0 + jl]; vblk[jl] = x; bound += fabsf(x); }
+    for (uint32_t jl = tid; jl < nb; jl += NT) { const float x = input(j0 + jl); vblk[jl] = x; bound += fabsf(x); }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) bound += __shfl_xor(bound, off);
     if (lane == 0) wbound[wave] = bound;
@@ -527,7 +561,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
                 const uint32_t oo = (uint32_t)o + h;
                 const uint32_t lane2 = oo & 63u, sj = oo >> 6, j = sj % E, slot = sj / E;
                 const uint32_t c2 = t * (64u * E) + lane2 * E + j;
-                if (c2 < g.cols) a.out[c2 * NACC + slot] = tot[h];
+                if (c2 < g.cols) { const uint32_t oi = c2 * NACC + slot; a.out[oi] = (FUSED && a.resid) ? a.resid[oi] + tot[h] : tot[h]; }
             }
         }
     };
@@ -560,7 +594,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
 // dispatcher only places ~40 workgroups/us chip-wide and spreads a large grid unevenly over the CUs (measured with
 // tools/microbench.hip: residency probe), so a group launch sizes its grid to the chip -- R workgroups per CU,
 // R fixed by the LDS each one asks for -- and balances the work itself.
-template <int FMT, int E, int W>
+template <int FMT, int E, int W, bool FUSED>
 __global__ __launch_bounds__(64 * W, (W <= 8 ? EFFORT_MIN_WAVES_PER_EU : 4)) void bucket_mul_kernel(const GroupKArgs ga) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ uint32_t s_item;
@@ -578,7 +612,7 @@ __global__ __launch_bounds__(64 * W, (W <= 8 ? EFFORT_MIN_WAVES_PER_EU : 4)) voi
         } else if (it) {
             return;
         }
-        mul_item<FMT, E, W>(ga, item, smem, cachedCall, cachedCutoff);
+        mul_item<FMT, E, W, FUSED>(ga, item, smem, cachedCall, cachedCutoff);
     }
     if (threadIdx.x == 0) {                                // the last workgroup out rewinds the queues for the next launch
         const uint32_t gone = __hip_atomic_fetch_add(&ga.queue[8 * 16], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -637,13 +671,20 @@ static hipError_t launch_mul_t(const GroupKArgs& ga, hipStream_t st) {
         const uint32_t force = (160u * 1024u) / (R + 1u) + 512u;
         if (lds < force && force <= (160u * 1024u) / R) lds = force;
     }
+    bool fusedAny = false;
+    for (uint32_t i = 0; i < ga.count; i++) fusedAny = fusedAny || ga.call[i].pre || ga.call[i].resid;
+    if (fusedAny && FMT != kFp16) return hipErrorInvalidValue;
     if (lds > maxSet) {
-        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&bucket_mul_kernel<FMT, E, W>),
+        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&bucket_mul_kernel<FMT, E, W, false>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (err == hipSuccess && FMT == kFp16)
+            err = hipFuncSetAttribute(reinterpret_cast<const void*>(&bucket_mul_kernel<kFp16, E, W, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (err != hipSuccess) return err;
         maxSet = lds;
     }
-    hipLaunchKernelGGL((bucket_mul_kernel<FMT, E, W>), dim3(grid), dim3(64 * W), lds, st, ga);
+    if (fusedAny) hipLaunchKernelGGL((bucket_mul_kernel<kFp16, E, W, true>), dim3(grid), dim3(64 * W), lds, st, ga);
+    else hipLaunchKernelGGL((bucket_mul_kernel<FMT, E, W, false>), dim3(grid), dim3(64 * W), lds, st, ga);
     return hipGetLastError();
 }
 
@@ -677,8 +718,8 @@ int bucket_mul_occupancy(Format fmt, int W, int E, size_t ldsBytes) {
     int n = 0;
 #define EFFORT_CASE(w, e)                                                                                              \
     if (W == w && E == e) {                                                                                            \
-        const void* f = fmt == kFp16 ? reinterpret_cast<const void*>(&bucket_mul_kernel<kFp16, e, w>)                  \
-                                     : reinterpret_cast<const void*>(&bucket_mul_kernel<kQ4, e, w>);                   \
+        const void* f = fmt == kFp16 ? reinterpret_cast<const void*>(&bucket_mul_kernel<kFp16, e, w, false>)                  \
+                                     : reinterpret_cast<const void*>(&bucket_mul_kernel<kQ4, e, w, false>);                   \
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, f, 64 * w, ldsBytes) != hipSuccess) n = 0;                \
     }
     EFFORT_GEOMS(EFFORT_CASE)

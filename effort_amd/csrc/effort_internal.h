@@ -42,8 +42,9 @@ struct OutlierIndex {          // by-output CSR of the Q4 outliers, built at reg
 // are copied when a launch is captured into a hipGraph): a compact descriptor per call, the few distinct launch
 // geometries of the group, and the bases of the context scratch the calls index into.
 constexpr int kMaxGroup = 32;        // calls per launch
-constexpr int kMaxGeoms = 6;         // distinct (shape, slicing) geometries per launch
-struct CallDesc {                    // 96 bytes
+constexpr int kMaxGeoms = 4;         // distinct (shape, slicing) geometries per launch
+enum Prologue : uint16_t { kPreNone = 0, kPreSiluGate = 1, kPreRmsNorm = 2 };
+struct CallDesc {                    // 112 bytes
     const uint16_t* buckets;
     const void* stats;         // f16x4 (FP16) or f32x2 (Q4) per bucket row
     const float* rankBound;    // [numExperts] sum over ranks of the rank's max |w| (Q4: max row mean): fixed-point bound, from registration
@@ -57,7 +58,10 @@ struct CallDesc {                    // 96 bytes
     uint16_t tileOff;          // ... arrival tickets [tiles]: offset into GroupKArgs::counters
     uint16_t sliceOff;         // ... kept rows per slice [slices] (sum = dispatch.size): offset into GroupKArgs::sliceCounts
     uint16_t geom;             // index into GroupKArgs::geom
-    uint16_t pad_;
+    uint16_t pre;              // Prologue: how the kernel derives its input from v (and vAux)
+    const void* vAux;          // kPreSiluGate: x3 f32 [inDim], input = x3 * v / (1 + exp(-v)) (silu(x1, x3), matrix.metal:25-35);
+                               // kPreRmsNorm: norm weights f16 [inDim], input = v / sqrt(mean(v^2) + 1e-5) * w (rmsNormFast + mul(by:))
+    const float* resid;        // nullable epilogue: out = resid + product (h.add(by:), runNetwork.swift:172,183); may alias out
 };
 struct GroupKArgs {
     CallDesc call[kMaxGroup];
@@ -77,7 +81,7 @@ struct GroupKArgs {
     float* cutoff;                 // [count]: BucketMul.cutoff of every call
     unsigned long long* tstamp;    // nullable profiling stamps: [0]=min start, [1]=max end, [2]=sum, [3]=launches, [16..] phases
 };
-static_assert(sizeof(CallDesc) == 96 && sizeof(GroupKArgs) <= 4000, "the launch descriptor must fit the kernel-argument segment");
+static_assert(sizeof(CallDesc) == 112 && sizeof(GroupKArgs) <= 4000, "the launch descriptor must fit the kernel-argument segment");
 
 // ---- device helpers -------------------------------------------------------------------------
 __device__ __forceinline__ float half_bits_to_float(uint16_t h) { return __half2float(__ushort_as_half(h)); }

@@ -116,6 +116,22 @@ EFFORT_API int effort_dense_gemv(effort_ctx* ctx, const void* W_f16_dev, const f
  * the same kind; shapes may differ.  effort_group_dispatch_count / effort_group_cutoff read call idx's hooks. */
 EFFORT_API int effort_bucketmul_group(effort_ctx* ctx, int n, const effort_w* const* ws, const float* const* vs_dev,
                            const uint32_t* const* expNos_dev, float* const* outs_dev, const double* efforts);
+/* effort_bucketmul_group with the decode loop's neighbouring element-wise steps folded into the launch (FP16 bundles):
+ *   prologues[i] (NULL = all 0): how call i derives its input from vs[i] --
+ *     EFFORT_PRE_NONE      input = v
+ *     EFFORT_PRE_SILU_GATE input = x3 * v / (1 + exp(-v)), x3 = v_aux[i] f32 [inDim]: silu(x1, x3, out: x2) feeding w2
+ *                          (runNetwork.swift:181-182, matrix.metal:25-35)
+ *     EFFORT_PRE_RMSNORM   input = v / sqrt(mean(v^2) + 1e-5) * w, w = v_aux[i] f16 [inDim]: rmsNormFast + mul(by:)
+ *                          feeding wq|wk|wv and w1|w3 (runNetwork.swift:121-122,173-175; aux.metal:113-152)
+ *   resids[i] (NULL array or entry = none): out = resid + product -- h.add(by:) after wo and w2 (runNetwork.swift:172,183);
+ *     resid may alias outs[i] (h += product in place).
+ * Cutoff, dispatch and accumulation see the derived input exactly as if it had been materialised first. */
+#define EFFORT_PRE_NONE 0
+#define EFFORT_PRE_SILU_GATE 1
+#define EFFORT_PRE_RMSNORM 2
+EFFORT_API int effort_bucketmul_group_fused(effort_ctx* ctx, int n, const effort_w* const* ws, const float* const* vs_dev,
+                                 const uint32_t* const* expNos_dev, float* const* outs_dev, const double* efforts,
+                                 const int* prologues, const void* const* v_aux_dev, const float* const* resids_dev);
 EFFORT_API int effort_bucketmul_q4_group(effort_ctx* ctx, int n, const effort_w* const* ws, const float* const* vs_dev,
                               const uint32_t* const* expNos_dev, float* const* outs_dev, const double* efforts);
 EFFORT_API int effort_group_dispatch_count(effort_ctx* ctx, int idx, uint32_t* host_out);

