@@ -20,8 +20,8 @@ value            = effective (dense-equivalent) GB/s = 2*inDim*outDim bytes per 
                    over all ranks.
 tokens_per_s     = the reference's projection 1/(t_call * 4 * 32) (helpers/timeit.swift:26,33-34).
 roofline         = dominant kernel (bucket_mul_kernel: a whole group of calls in one launch): algorithmic bytes per
-                   launch / its average duration in THIS run's timed configuration.  Kernels of one stream do not
-                   overlap, so this is also what `rocprofv3 --kernel-trace --stats` reports for the same command.
+                   launch / its average launch duration = the timed region / its launches.  Kernels of one stream do
+                   not overlap, so this is also what `rocprofv3 --kernel-trace --stats` reports for the same command.
 cpu_baseline     = the CPU oracle (a port: the reference ships no CPU path) on the host cores, bounded sample.
 decode           = BASELINE.json configs[4]: end-to-end greedy decode of a random-init Mistral-7B-shaped model through
                    effort_amd/decode.py (one hipGraph per token): tokens/s dense vs effort 100 % / 25 %, KL vs dense.
@@ -320,16 +320,21 @@ def main():
         except Exception:
             pmc = None
         t_launch = dt / launches                         # launch-to-launch in the timed graph (includes the gap between kernels)
+        # The kernel's average launch duration = the timed region / the launches it holds: one stream, back-to-back launches
+        # of one hipGraph, so this is what HIP events around the region give and what `rocprofv3 --kernel-trace --stats`
+        # reports per launch (profiles/).  The in-kernel device clock (first workgroup start -> last workgroup end) and
+        # per-launch HIP events outside a graph are given beside it.
+        t_kernel = t_launch
         result["roofline"] = {
-            "bound": "hbm", "kernel": "bucket_mul_kernel", "achieved": round(G * kb / kus / 1e3, 1), "peak": HBM_PEAK_GBPS,
-            "unit": "GB/s", "frac": round(G * kb / kus / 1e3 / HBM_PEAK_GBPS, 4), "traffic": traffic,
+            "bound": "hbm", "kernel": "bucket_mul_kernel", "achieved": round(G * kb / t_kernel / 1e9, 1), "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s", "frac": round(G * kb / t_kernel / 1e9 / HBM_PEAK_GBPS, 4), "traffic": traffic,
             "traffic_source": (f"rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE pass of this command ({os.path.relpath(PMC_FILE, ROOT)}), "
                                "corrected as MI355X_MICROARCH.md prescribes") if traffic else None,
-            "calls_per_launch": G, "bytes_per_launch": G * kb, "bytes_per_call": kb, "kernel_us": round(kus, 3), "launches_sampled": nl,
-            "kernel_us_source": "device wall clock, first workgroup start -> last workgroup end, averaged over the launches of the timed graph",
-            "kernel_us_hip_events": round(evt["mul_us"], 3),
-            "launch_to_launch_us": round(t_launch * 1e6, 3),
-            "achieved_incl_launch_gaps": round(G * kb / t_launch / 1e9, 1), "frac_incl_launch_gaps": round(G * kb / t_launch / 1e9 / HBM_PEAK_GBPS, 4),
+            "calls_per_launch": G, "bytes_per_launch": G * kb, "bytes_per_call": kb, "kernel_us": round(t_kernel * 1e6, 3),
+            "kernel_us_source": "timed region / launches (one stream, back-to-back launches of one hipGraph)",
+            "kernel_us_device_clock": round(kus, 3), "launches_sampled_device_clock": nl,
+            "frac_device_clock": round(G * kb / kus / 1e3 / HBM_PEAK_GBPS, 4),
+            "kernel_us_hip_events_outside_graph": round(evt["mul_us"], 3),
         }
         # ---------------- the same step at other group sizes (1 = dependent-chain latency) ------------
         by = {}
