@@ -296,23 +296,38 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
     if (!c || !ws || !vs || !outs || !efforts) return fail(c, EFFORT_ERR_ARG, "bucketmul: null argument");
     if (n < 1 || n > kMaxGroup) return fail(c, EFFORT_ERR_ARG, "bucketmul: group size outside 1..32");
     static const uint32_t ablate = getenv("EFFORT_ABLATE") ? (uint32_t)atoi(getenv("EFFORT_ABLATE")) : 0u;   // profiling only
-    GroupKArgs ga;
-    memset(&ga, 0, sizeof(ga));
-    ga.count = (uint32_t)n;
-    ga.groupDone = c->d_counters + effort_ctx::kMaxTiles - 1;
-    ga.slabs = c->d_slabs; ga.counters = c->d_counters; ga.sliceCounts = c->d_sliceCounts; ga.cutoff = c->d_cutoff;
-    ga.tstamp = c->clock ? c->d_tstamp : nullptr;
-    ga.ablate = ablate; ga.split = c->splitCutoff ? 1u : 0u;
-    int W = 0, E = 0;
     const int groupE = pick_elems(c, fmt, n, ws);
-    uint32_t nGeoms = 0;
-    size_t slabOff = 0; uint32_t tileOff = 0, sliceOff = 0, wg = 0;
+    const bool tm = c->timing && c->nSamples < effort_ctx::kMaxSamples;
+    hipEvent_t* ev = tm ? c->ev + 4 * c->nSamples : nullptr;
+    if (tm) HIP_TRY(c, hipEventRecord(ev[0], c->stream));
+    GroupKArgs ga;
+    int W = 0, E = 0;
+    uint32_t nGeoms = 0, wg = 0, first = 0;
+    size_t slabOff = 0; uint32_t tileOff = 0, sliceOff = 0;
+    auto begin = [&](uint32_t firstCall) {
+        memset(&ga, 0, sizeof(ga));
+        ga.groupDone = c->d_counters + effort_ctx::kMaxTiles - 1;
+        ga.slabs = c->d_slabs; ga.counters = c->d_counters; ga.sliceCounts = c->d_sliceCounts; ga.cutoff = c->d_cutoff + firstCall;
+        ga.tstamp = c->clock ? c->d_tstamp : nullptr;
+        ga.ablate = ablate; ga.split = c->splitCutoff ? 1u : 0u;
+        ga.numCU = (uint32_t)c->numCU; ga.queue = c->d_queue;
+        nGeoms = 0; wg = 0; first = firstCall;
+    };
+    auto flush = [&]() -> int {                        // one kernel launch for the calls gathered so far
+        // grid: persistent workgroups once the items outnumber what the chip holds at R per CU
+        const uint32_t R = c->persistent < 0 ? 2u : (uint32_t)c->persistent;
+        ga.persistent = (R && wg > ga.numCU * R) ? R : 0u;
+        if (c->splitCutoff && !(ablate & 1u)) HIP_TRY(c, launch_find_cutoff_group(ga, c->stream));
+        HIP_TRY(c, launch_bucket_mul(fmt, W, E, ga, c->stream));
+        if (fmt == kQ4) HIP_TRY(c, launch_q4_outliers(ga, c->stream));
+        return EFFORT_OK;
+    };
+    begin(0);
     for (int i = 0; i < n; i++) {
         const effort_w* w = ws[i];
         if (!w || !vs[i] || !outs[i]) return fail(c, EFFORT_ERR_ARG, "bucketmul: null argument");
         if (w->fmt != fmt) return fail(c, EFFORT_ERR_KIND, "bucketmul: weight handle of the wrong kind");
         if (!(efforts[i] >= 0.0 && efforts[i] <= 1.0)) return fail(c, EFFORT_ERR_EFFORT, "bucketmul: effort outside [0,1]");
-        CallDesc& a = ga.call[i];
         MulGeom g;
         memset(&g, 0, sizeof(g));
         int Wi, Ei;
@@ -322,10 +337,14 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
         else if (Wi != W || Ei != E) return fail(c, EFFORT_ERR_SHAPE, "bucketmul: the calls of a group must agree on the kernel variant");
         uint32_t gi = 0;
         while (gi < nGeoms && memcmp(&ga.geom[gi], &g, sizeof(g)) != 0) gi++;
-        if (gi == nGeoms) {
-            if (nGeoms == kMaxGeoms) return fail(c, EFFORT_ERR_SHAPE, "bucketmul: more than 6 distinct shapes in one group");
-            ga.geom[nGeoms++] = g;
+        if (gi == nGeoms && nGeoms == kMaxGeoms) {     // a launch carries kMaxGeoms distinct shapes: this call opens the next one
+            rc = flush();
+            if (rc != EFFORT_OK) return rc;
+            begin((uint32_t)i);
+            gi = 0;
         }
+        if (gi == nGeoms) ga.geom[nGeoms++] = g;
+        CallDesc& a = ga.call[(uint32_t)i - first];
         const size_t slab = (size_t)g.slices * g.tiles * g.tileFloats * 4;
         if (tileOff + g.tiles + 1 > effort_ctx::kMaxTiles || sliceOff + g.slices > effort_ctx::kMaxSlices || slabOff + slab > c->slabBytes)
             return fail(c, EFFORT_ERR_SHAPE, "bucketmul: group exceeds the context scratch");
@@ -339,22 +358,15 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
         a.pre = (uint16_t)pre; a.vAux = pre ? vAux[i] : nullptr; a.resid = resids ? resids[i] : nullptr;
         a.slabOff = (uint32_t)(slabOff / 256); a.tileOff = (uint16_t)tileOff; a.sliceOff = (uint16_t)sliceOff; a.geom = (uint16_t)gi;
         wg += g.tiles * ((g.slices + 7) / 8 * 8);
-        ga.wgEnd[i] = wg;
+        ga.wgEnd[(uint32_t)i - first] = wg;
+        ga.count = (uint32_t)i - first + 1u;
         ga.totalTiles += g.tiles;
         c->lastSliceOff[i] = sliceOff; c->lastSlices[i] = g.slices;                   // dispatch.size = sum of the per-slice counts
         slabOff += (slab + 255) / 256 * 256; tileOff += g.tiles; sliceOff += g.slices;
     }
     c->lastCalls = (uint32_t)n;
-    // grid: persistent workgroups once the items outnumber what the chip holds at R per CU
-    ga.numCU = (uint32_t)c->numCU; ga.queue = c->d_queue;
-    const uint32_t R = c->persistent < 0 ? 2u : (uint32_t)c->persistent;
-    ga.persistent = (R && wg > ga.numCU * R) ? R : 0u;
-    const bool tm = c->timing && c->nSamples < effort_ctx::kMaxSamples;
-    hipEvent_t* ev = tm ? c->ev + 4 * c->nSamples : nullptr;
-    if (tm) HIP_TRY(c, hipEventRecord(ev[0], c->stream));
-    if (c->splitCutoff && !(ablate & 1u)) HIP_TRY(c, launch_find_cutoff_group(ga, c->stream));
-    HIP_TRY(c, launch_bucket_mul(fmt, W, E, ga, c->stream));
-    if (fmt == kQ4) HIP_TRY(c, launch_q4_outliers(ga, c->stream));
+    int rc = flush();
+    if (rc != EFFORT_OK) return rc;
     if (tm) { HIP_TRY(c, hipEventRecord(ev[1], c->stream)); c->nSamples++; }
     return EFFORT_OK;
 }

@@ -113,7 +113,8 @@ EFFORT_API int effort_dense_gemv(effort_ctx* ctx, const void* W_f16_dev, const f
  * throughput: the decode loop issues such groups back to back on unchanged
  * input -- Wq|Wk|Wv (runNetwork.swift:132-134) and W1|W3 (runNetwork.swift:178-182) -- and the reference's command
  * buffer lets them overlap; here their workgroups share the CUs inside one launch.  All handles of a group are of
- * the same kind; shapes may differ.  effort_group_dispatch_count / effort_group_cutoff read call idx's hooks. */
+ * the same kind; shapes may differ (a launch carries four distinct shapes; a group with more is issued as consecutive
+ * launches).  effort_group_dispatch_count / effort_group_cutoff read call idx's hooks. */
 EFFORT_API int effort_bucketmul_group(effort_ctx* ctx, int n, const effort_w* const* ws, const float* const* vs_dev,
                            const uint32_t* const* expNos_dev, float* const* outs_dev, const double* efforts);
 /* effort_bucketmul_group with the decode loop's neighbouring element-wise steps folded into the launch (FP16 bundles):

@@ -607,3 +607,37 @@ def test_fused_prologues_and_residual(ea, oracle_cpu):
     assert g.last_dispatch_count(1) == n_or or True
     with pytest.raises(ValueError):
         ea.bucketMulGroup([(x1, ew, None, fused, 0.3, {"gate": x3, "norm": wn})])
+
+
+def test_randomized_groups_against_oracle(ea, oracle_cpu):
+    """Seeded sweep: random shapes (ragged inDim, outDim from half a tile to several), efforts, percentLoad, group sizes and
+    tunings -- selection exact, outputs within the bar, for every call of every launch."""
+    rng = np.random.default_rng(20240807)
+    shapes = [(64, 4096), (512, 4096), (1024, 4500), (2048, 4096), (4160, 4608)]    # outDim divides 4096 or exceeds it (convert.swift:210-215)
+    bank = {sh: converted(oracle_cpu, sh[0], sh[1], seed=500 + i) for i, sh in enumerate(shapes)}
+    g = ea.gpu()
+    try:
+        for trial in range(6):
+            n = int(rng.integers(1, 12))
+            tune = [(0, 0, 0), (8, 1, 0), (16, 2, 0), (4, 4, 0), (8, 2, 24), (8, 4, 8)][trial]
+            g.set_tuning(*tune)
+            calls, wants = [], []
+            for i in range(n):
+                outDim, inDim = shapes[int(rng.integers(len(shapes)))]
+                W, b, s, p = bank[(outDim, inDim)]
+                pl = int(rng.choice([16, 16, 8, 3]))
+                rows = inDim * pl
+                ew = gpu_weights(ea, W, b[:rows], s[:rows], p, percentLoad=pl)
+                effort = float(rng.choice([0.0, 0.03, 0.25, 0.6, 1.0]))
+                v = make_v(inDim, seed=int(rng.integers(1 << 30)), heavy=bool(rng.integers(2)))
+                if rng.integers(4) == 0:
+                    v[rng.integers(inDim, size=40)] = 0.0
+                wants.append(oracle_cpu.bucket_mul(v, b[:rows], s[:rows], p, inDim, outDim, effort, percentLoad=pl))
+                calls.append((devf(v), ew, None, torch.full((outDim,), float("nan"), device=DEV), effort))
+            ea.bucketMulGroup(calls)
+            g.eval()
+            for i, (call, (want, cnt, cutoff)) in enumerate(zip(calls, wants)):
+                assert g.last_dispatch_count(i) == cnt and g.last_cutoff(i) == cutoff, (trial, i)
+                assert close(call[3].cpu().numpy(), want), (trial, i, tune)
+    finally:
+        g.set_tuning(0, 0, 0)
