@@ -227,10 +227,10 @@ static uint32_t pick_slices(const effort_ctx* c, const effort_w* w, int groupSiz
 // otherwise leave most of the chip without an item (small matrices); 4 for groups of >= 8 calls (fewer, fatter items: less
 // fixed work per byte) unless that leaves the launch with between one and three items per CU -- half the chip would then
 // run two workgroups per CU in lockstep with the other half's one -- or with less than half an item per CU (measured,
-// 4096x11008: 8 calls 7.9 vs 8.4 us/call, 16 calls 7.2 vs 6.6, 32 calls 5.7 vs 6.3).  Q4: 1 word = 4 sub-buckets.
+// 4096x11008: 8 calls 7.9 vs 8.4 us/call, 16 calls 7.2 vs 6.6, 32 calls 5.7 vs 6.3).  Q4 (a word = 4 sub-buckets): 1, or 2 from 8 calls on.
 static int pick_elems(const effort_ctx* c, Format fmt, int n, const effort_w* const* ws) {
     if (c->tuneE) return c->tuneE;
-    if (fmt != kFp16) return 1;
+    if (fmt != kFp16) return n >= 8 ? 2 : 1;        // measured, 4096x11008 Q4: 32 calls 5.3 vs 6.4 us/call, 8 calls 8.3 vs 8.3, 2 calls 20.8 vs 18.8
     if (c->tuneS) return 2;
     auto items = [&](int E) {
         uint32_t t = 0;
