@@ -181,11 +181,12 @@ extern "C" effort_w* effort_weights_q4(effort_ctx* c, const void* buckets, const
     w->inDim = inDim; w->outDim = outDim; w->rowsPerIn = 8; w->numExperts = numExperts; w->cols = outDim / 32;
     if (register_bound(c, w) != EFFORT_OK) { effort_weights_free(w); return nullptr; }
     if (outliers && nOutliers > 0) {
+        if (outDim > 65536) { fail(c, EFFORT_ERR_SHAPE, "effort_weights_q4: outliers need outDim <= 65536"); effort_weights_free(w); return nullptr; }
         hipSetDevice(c->device);
         uint32_t* cursor = nullptr;
         w->nOutliers = (uint64_t)nOutliers;
-        bool ok = hipMalloc(&w->olRowPtr, (size_t)(outDim + 1) * 4) == hipSuccess && hipMalloc(&w->olInIdx, (size_t)nOutliers * 4) == hipSuccess &&
-                  hipMalloc(&w->olValue, (size_t)nOutliers * 4) == hipSuccess && hipMalloc(&cursor, ((size_t)outDim + nOutliers) * 4) == hipSuccess;
+        bool ok = hipMalloc(&w->olRowPtr, ((size_t)outDim + 1 + (outDim + 63) / 64) * 4) == hipSuccess && hipMalloc(&w->olInIdx, (size_t)nOutliers * 4) == hipSuccess &&
+                  hipMalloc(&w->olValue, (size_t)nOutliers * 4) == hipSuccess && hipMalloc(&cursor, ((size_t)outDim + 2 * (size_t)nOutliers) * 4) == hipSuccess;
         if (ok) ok = launch_build_outlier_index(static_cast<const float*>(outliers), w->nOutliers, outDim, w->olRowPtr, w->olInIdx,
                                                 w->olValue, cursor, c->stream) == hipSuccess;
         if (ok) ok = hipStreamSynchronize(c->stream) == hipSuccess;
@@ -270,7 +271,7 @@ static int choose_geom(const effort_ctx* c, const effort_w* w, int groupSize, in
         g->slices = (w->inDim + g->sliceRows - 1) / g->sliceRows;
         g->sliceLog2 = 0; while ((1u << g->sliceLog2) < g->sliceRows) g->sliceLog2++;
         g->slots = w->fmt == kFp16 ? (g->rowsPerIn << g->sliceLog2) : g->sliceRows * 8u;
-        const size_t lds = bucket_mul_lds_bytes(w->fmt, W, E, g->sliceRows, g->slots);
+        const size_t lds = bucket_mul_lds_bytes(w->fmt, W, E, *g);
         const bool fits = lds <= ldsMax && g->sliceRows <= (w->fmt == kFp16 ? 4096u : 8192u) && g->slots <= maxCand;
         const size_t slab = (size_t)g->slices * g->tiles * g->tileFloats * 4;
         if (fits && slab <= c->slabBytes) break;
@@ -319,7 +320,6 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
         ga.persistent = (R && wg > ga.numCU * R) ? R : 0u;
         if (c->splitCutoff && !(ablate & 1u)) HIP_TRY(c, launch_find_cutoff_group(ga, c->stream));
         HIP_TRY(c, launch_bucket_mul(fmt, W, E, ga, c->stream));
-        if (fmt == kQ4) HIP_TRY(c, launch_q4_outliers(ga, c->stream));
         return EFFORT_OK;
     };
     begin(0);

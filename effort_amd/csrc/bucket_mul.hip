@@ -33,8 +33,8 @@
 //      the slot, so a wave's scatter is bank-conflict free.
 //   E. the tile is converted back to f32 into one partial "slab", stored write-through; the workgroup takes a ticket
 //      on its tile's arrival counter, and the LAST workgroup of each tile sums the S slabs in slice order and writes
-//      out[].  The result does not depend on arrival order: deterministic end to end.  (Q4 outliers:
-//      q4_outliers_kernel, launched next.)
+//      out[].  The result does not depend on arrival order: deterministic end to end.  (Q4: before E, phase O adds the
+//      outliers of the item's share of the tile's outputs to its slab.)
 #include <cstring>
 #include <type_traits>
 
@@ -115,18 +115,28 @@ template <> struct Piece<8> {
 
 __host__ __device__ inline uint32_t align_up(uint32_t x, uint32_t a) { return (x + a - 1) / a * a; }
 
+// Q4 outliers: an item adds the outliers of 1/slices of its tile's outputs to its slab (phase O below).
+constexpr int kOlBatch = 16;                               // outlier entries (key + value) in flight per lane
+constexpr uint32_t kOlLdsFloats = 16384;                   // v is staged whole in LDS up to this inDim (64 KB), else gathered from memory
+template <int E> __host__ __device__ inline uint32_t ol_outputs_per_item(const MulGeom& g) { return align_up((32u * E * 64u + g.slices - 1u) / g.slices, 64u); }   // whole interleave blocks
+template <int E> __host__ __device__ inline uint32_t ol_scratch_bytes(const MulGeom& g) {
+    return 2u * align_up(ol_outputs_per_item<E>(g) * 4u, 16u) + (g.inDim <= kOlLdsFloats ? g.inDim * 4u : 0u);      // sums hi | lo | v
+}
+
 // LDS carve (bytes): { acc[tileFloats] i32 | list[slots] u16 }  (the cutoff's lookup table borrows this first region:
-// it is dead before the tile is zeroed and the list written)  | means[slots] f16 / f32 | vblk[B] f32 | misc 2 KB
+// it is dead before the tile is zeroed and the list written)  | means[slots] f16 / f32 | vblk[B] f32 | misc 2 KB.
+// Q4: after the streaming phase list | means | vblk are dead and hold the outlier phase's scratch (sums | whole v).
 template <int FMT, int E, int W>
-__host__ __device__ inline uint32_t lds_layout(uint32_t B, uint32_t slots, uint32_t* offV, uint32_t* offC,
-                                               uint32_t* offL, uint32_t* offM) {
+__host__ __device__ inline uint32_t lds_layout(const MulGeom& g, uint32_t* offV, uint32_t* offC, uint32_t* offL, uint32_t* offM) {
+    const uint32_t B = g.sliceRows, slots = g.slots;
     uint32_t o = (uint32_t)Fmt<FMT>::kSlots * E * 64 * 4;
     *offL = o; o += align_up(slots * 2, 16);
     const uint32_t tbl = cutoff_table_bytes(64 * W);
     if (o < tbl) o = tbl;
     *offM = o; o += align_up(slots * (uint32_t)sizeof(typename MeanT<FMT>::type), 16);
     *offV = o; o += align_up(B * 4, 16);
-    *offC = o; o += 2048;           // [0..255] cutoff scratch, [256..1279] ballot counts [kRounds][W], [1280] flags, [1344..1407] wave bounds
+    if (FMT == kQ4 && o < *offL + ol_scratch_bytes<E>(g)) o = *offL + ol_scratch_bytes<E>(g);
+    *offC = o; o += 2048;           // [0..255] cutoff scratch, [256..1279] ballot counts [kRounds][W], [1280] flags, [1344..1407] wave bounds, [1408..1471] Q4 outlier bounds
     return o;
 }
 
@@ -170,7 +180,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t B = g.sliceRows;
     uint32_t offV, offC, offL, offM;
-    lds_layout<FMT, E, W>(B, g.slots, &offV, &offC, &offL, &offM);
+    lds_layout<FMT, E, W>(g, &offV, &offC, &offL, &offM);
     int* acc = reinterpret_cast<int*>(smem);                                 // ONE fixed-point tile shared by the W waves
     float* vblk = reinterpret_cast<float*>(smem + offV);
     uint32_t* wcnt = reinterpret_cast<uint32_t*>(smem + offC + 256);         // [kRounds][W]
@@ -464,6 +474,84 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     if (stamp) ga.tstamp[20] = wall_clock64();
     if (wstamp) ph[4] = wall_clock64();
 
+    // ---- O. Q4 outliers (calcOutliers, bucketMulQ4.metal:13-21: out[o] += v[in]*value per outlier; the reference fires
+    //         one f32 atomic per outlier in table order).  Registration grouped the outliers by blocks of 64 outputs,
+    //         interleaved inside a block, and packed (output << 16 | input) beside each value (dispatch.hip).  The
+    //         tile's outputs are shared out among its slice items in whole blocks; this item streams the entries of its
+    //         share -- coalesced, kOlBatch per lane in flight -- gathers v from LDS (a 64-address gather from memory
+    //         costs the L1 one line per lane) and adds the products to fixed-point LDS sums like the tile's own
+    //         (neighbouring lanes hold different outputs: no colliding atomics; scale from max|v| * the largest sum of
+    //         |value| over an output of the share, known per block since registration; integer adds commute, so the
+    //         result is deterministic), which join its slab below.  Measured, 4096x11008 with 901 775 outliers, per call at 32
+    //         calls per launch / alone: a kernel of its own with a wave per output 8.3 / 33.5 us; eight lanes per
+    //         output 5.2 / 32.5; this phase 4.6 / 29.0 -- what is left is the 7.2 MB of entries per call, more bytes
+    //         than the 25 %-effort bucket rows (5.6 MB). ---------------------------------------------------------
+    int* const olacc = reinterpret_cast<int*>(smem + offL);
+    const uint32_t olPer = ol_outputs_per_item<E>(g), olLoOff = align_up(olPer * 4u, 16u) / 4u;
+    bool olAny = false;
+    float olUnscale = 0.0f;
+    if constexpr (FMT == kQ4) {
+        olAny = a.ol.rowPtr != nullptr;                                                    // uniform per call
+        if (olAny) {
+            const OutlierIndex& ol = a.ol;
+            int* const ollo = olacc + align_up(olPer * 4u, 16u) / 4u;                        // low parts of the sums (see below)
+            float* const vfull = reinterpret_cast<float*>(ollo + align_up(olPer * 4u, 16u) / 4u);
+            const bool vLds = g.inDim <= kOlLdsFloats;
+            const uint32_t oBeg = min(t * (uint32_t)TILE_F + s * olPer, g.outDim);
+            const uint32_t oEnd = max(oBeg, min(min(t * (uint32_t)TILE_F + (s + 1u) * olPer, (t + 1u) * (uint32_t)TILE_F), g.outDim));
+            const uint32_t kBeg = ol.rowPtr[oBeg], kEnd = ol.rowPtr[oEnd];
+            // bound of this share's sums: max over its blocks of (max over the block's outputs of sum |value|), from registration
+            const uint32_t nBlk = (oEnd - oBeg + 63u) / 64u;                               // <= NT (a tile has at most 16384 outputs)
+            float olBound = (uint32_t)tid < nBlk ? __uint_as_float(ol.rowPtr[g.outDim + 1u + oBeg / 64u + tid]) : 0.0f;
+            float vm = 0.0f;
+            for (uint32_t i0 = 0; i0 < g.inDim; i0 += NT * 8u) {                           // eight loads in flight (clamped, branch-free)
+                float x[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) x[u] = a.v[min(i0 + u * NT + tid, g.inDim - 1u)];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const uint32_t i = i0 + u * NT + tid;
+                    if (vLds && i < g.inDim) vfull[i] = x[u];
+                    vm = fmaxf(vm, fabsf(x[u]));
+                }
+            }
+            for (uint32_t i = tid; i < olPer; i += NT) { olacc[i] = 0; ollo[i] = 0; }
+            float* const wmax = reinterpret_cast<float*>(smem + offC + 1408);              // [W] per-wave max of the block bounds
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) { vm = fmaxf(vm, __shfl_xor(vm, off)); olBound = fmaxf(olBound, __shfl_xor(olBound, off)); }
+            if (lane == 0) { wbound[wave] = vm; wmax[wave] = olBound; }                    // (the slice bounds are dead by now)
+            __syncthreads();
+            vm = 0.0f; olBound = 0.0f;
+#pragma unroll
+            for (int w2 = 0; w2 < W; w2++) { vm = fmaxf(vm, wbound[w2]); olBound = fmaxf(olBound, wmax[w2]); }
+            // 2^k * (max|v| * olBound) < 2^29: no sum can leave int32; powers of two scale exactly
+            const int ex = (int)((__float_as_uint(vm * olBound) >> 23) & 0xFFu);
+            const int kk2 = min(max(155 - ex, -100), 100);
+            const float olScale = __uint_as_float((uint32_t)(kk2 + 127) << 23);
+            olUnscale = __uint_as_float((uint32_t)(127 - kk2) << 23);
+            for (uint32_t k0 = kBeg; k0 < kEnd; k0 += NT * kOlBatch) {                     // uniform
+                uint32_t key[kOlBatch]; float val[kOlBatch];
+#pragma unroll
+                for (int u = 0; u < kOlBatch; u++) {             // clamped, branch-free: all loads of a batch in flight
+                    const uint32_t k = min(k0 + u * NT + tid, kEnd - 1u);
+                    key[u] = ol.inIdx[k];
+                    val[u] = ol.value[k];
+                }
+#pragma unroll
+                for (int u = 0; u < kOlBatch; u++) {
+                    const float x = vLds ? vfull[key[u] & 0xFFFFu] : a.v[key[u] & 0xFFFFu];
+                    // two-level fixed point: the bound can sit far above the sums (one huge input), so the rounding
+                    // remainder of every product -- exact in f32 -- is summed too, 2^23 times finer
+                    const float cs = (x * val[u]) * olScale;
+                    const int qh = __float2int_rn(cs);
+                    const int ql = __float2int_rn((cs - (float)qh) * 8388608.0f);
+                    if (k0 + u * NT + tid < kEnd) { atomicAdd(&olacc[(key[u] >> 16) - oBeg], qh); atomicAdd(&ollo[(key[u] >> 16) - oBeg], ql); }
+                }
+            }
+            __syncthreads();
+        }
+    }
+
     // ---- E. the tile, back in f32 -> one slab (native [slot][j][lane] order), write-through; ticket; last arriver
     //         of the tile reduces the S slabs in slice order and writes out[] -------------------------------
     const size_t slabBytes = (size_t)g.slices * g.tiles * TILE_F * 4;
@@ -473,7 +561,12 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
         if (FMT == kFp16) return (float)acc[o] * unscale;
         const int slot = o / (E * 64), rem = o % (E * 64);          // slot = sub-bucket*8 + position
         const int p = (((slot >> 3) * 16 + (slot & 7)) * E * 64) + rem;
-        return (float)(acc[p] - acc[p + 8 * E * 64]) * unscale;
+        float r = (float)(acc[p] - acc[p + 8 * E * 64]) * unscale;
+        if (olAny) {                                                 // this item's share of the tile's outputs: + their outliers
+            const uint32_t ol_o = (uint32_t)((rem & 63) * E + (rem >> 6)) * 32u + (uint32_t)slot - s * olPer;      // tile-local output, from the share's start
+            if (ol_o < olPer && (uint32_t)(t * TILE_F) + s * olPer + ol_o < g.outDim) r += ((float)olacc[ol_o] + (float)olacc[olLoOff + ol_o] * (1.0f / 8388608.0f)) * olUnscale;
+        }
+        return r;
     };
     for (int o = tid * 2; o < TILE_F; o += NT * 2) {
         const float s0 = tile_out(o), s1 = tile_out(o + 1);
@@ -622,106 +715,6 @@ __global__ __launch_bounds__(64 * W, (W <= 8 ? EFFORT_MIN_WAVES_PER_EU : 4)) voi
     }
 }
 
-// calcOutliers (bucketMulQ4.metal:13-21): out[o] += sum over the outliers of output o of v[in]*value.  The reference
-// fires one atomic per outlier in table order.  Here the outliers sit in a by-output index built at registration, so
-// the outliers of consecutive outputs are consecutive in memory: a wave owns kOlOut outputs, eight lanes each, and every
-// lane strides its output's segment with kOlBatch entries in flight, the next outputs' bounds fetched alongside (a wave
-// per output moved ~650 bytes behind three dependent round trips: 4.3 us per 901 775-outlier call, now 2.2); the input
-// vector is gathered from LDS (from memory: 3.8 us -- a 64-address gather costs the L1 one line per lane); a fixed
-// xor-butterfly adds each output's eight lanes -- no atomics, deterministic.  Measured at 32 calls per launch: 70 us, of
-// which 20 are there without the entry loads (launch, staging, bounds) and the rest is the 230 MB at 4.6 TB/s.
-// Launched right after the multiply kernel on the same stream.
-constexpr int kOlOut = 8, kOlBatch = 16, kOlWaves = 8;
-constexpr uint32_t kOlLdsFloats = 16384;                  // v is staged in LDS up to this inDim (64 KB)
-
-template <bool LDSV>
-__global__ __launch_bounds__(64 * kOlWaves) void q4_outliers_kernel(const GroupKArgs ga) {
-    extern __shared__ float ol_v[];
-    const CallDesc& a = ga.call[blockIdx.y];
-    const OutlierIndex& ol = a.ol;
-    const uint32_t outDim = ga.geom[a.geom].outDim, inDim = ga.geom[a.geom].inDim;
-    if (blockIdx.x * (uint32_t)(kOlWaves * kOlOut) >= outDim || !ol.rowPtr) return;        // uniform per workgroup
-    const float* __restrict__ v = a.v;
-    float* __restrict__ out = a.out;
-    const int lane = threadIdx.x & 63, sub = lane & 7;
-    if (LDSV) {
-        for (uint32_t i = threadIdx.x; i < inDim; i += 64u * kOlWaves) ol_v[i] = v[i];
-        __syncthreads();
-    }
-    // a workgroup stages v once and its waves walk the call's outputs with the grid's stride (few, fat workgroups: the
-    // staging and the launch ramp are paid per workgroup)
-    const uint32_t stride = gridDim.x * (uint32_t)(kOlWaves * kOlOut);
-    uint32_t o0 = (blockIdx.x * kOlWaves + (threadIdx.x >> 6)) * kOlOut;
-    auto fetch = [&](uint32_t oBase, uint32_t& lo, uint32_t& hi, float& old) {                // beyond outDim: an empty segment
-        const uint32_t o = oBase + (uint32_t)(lane >> 3);
-        lo = ol.rowPtr[min(o, outDim)]; hi = ol.rowPtr[min(o + 1u, outDim)];
-        old = (o < outDim && sub == 0) ? out[o] : 0.0f;
-    };
-    uint32_t lo, hi; float old;
-    fetch(o0, lo, hi, old);
-    while (o0 < outDim) {
-        uint32_t nlo, nhi; float nold;
-        fetch(o0 + stride, nlo, nhi, nold);                  // the next item's bounds travel with this item's entries
-        const uint32_t o = o0 + (uint32_t)(lane >> 3);
-        const uint32_t len = hi - lo;
-        uint32_t maxLen = len;
-#pragma unroll
-        for (int off = 32; off >= 8; off >>= 1) maxLen = max(maxLen, (uint32_t)__shfl_xor((int)maxLen, off));
-        maxLen = __builtin_amdgcn_readfirstlane(maxLen);
-        if (maxLen != 0) {                                                                   // uniform per wave
-            uint32_t first = maxLen == len ? lo : 0xFFFFFFFFu;                               // some valid entry (a longest segment's)
-#pragma unroll
-            for (int off = 32; off >= 8; off >>= 1) first = min(first, (uint32_t)__shfl_xor((int)first, off));
-            float part = 0.0f;
-            for (uint32_t base = 0; base < maxLen; base += 8u * kOlBatch) {                  // uniform trip count
-                uint32_t idx[kOlBatch]; float val[kOlBatch];
-#pragma unroll
-                for (int u = 0; u < kOlBatch; u++) {         // clamped, branch-free: all loads of a batch in flight
-                    const uint32_t k = lo + base + u * 8u + sub;
-                    const uint32_t kk = k < hi ? k : first;
-                    idx[u] = ol.inIdx[kk];
-                    val[u] = ol.value[kk];
-                }
-#pragma unroll
-                for (int u = 0; u < kOlBatch; u++) {
-                    const uint32_t k = lo + base + u * 8u + sub;
-                    const float x = LDSV ? ol_v[idx[u]] : v[idx[u]];
-                    part += k < hi ? x * val[u] : 0.0f;
-                }
-            }
-#pragma unroll
-            for (int off = 4; off >= 1; off >>= 1) part += __shfl_xor(part, off);
-            if (o < outDim && sub == 0 && len) out[o] = old + part;
-        }
-        o0 += stride; lo = nlo; hi = nhi; old = nold;
-    }
-}
-
-hipError_t launch_q4_outliers(const GroupKArgs& ga, hipStream_t st) {
-    uint32_t maxOut = 0, maxIn = 0; bool any = false;
-    for (uint32_t i = 0; i < ga.count; i++) {
-        const MulGeom& g = ga.geom[ga.call[i].geom];
-        maxOut = max(maxOut, g.outDim); maxIn = max(maxIn, g.inDim); any = any || ga.call[i].ol.rowPtr;
-    }
-    if (!any) return hipSuccess;
-    const uint32_t chunks = (maxOut + kOlWaves * kOlOut - 1) / (kOlWaves * kOlOut);
-    const uint32_t perCall = min(chunks, max(1u, (ga.numCU * 2u + ga.count - 1u) / ga.count));     // two workgroups per CU in all (1: 74 us, 2: 64, 4: 70 at 32 calls)
-    const dim3 grid(perCall, ga.count), block(64 * kOlWaves);
-    if (maxIn <= kOlLdsFloats) {
-        static bool set = false;
-        if (!set) {
-            hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&q4_outliers_kernel<true>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kOlLdsFloats * 4));
-            if (err != hipSuccess) return err;
-            set = true;
-        }
-        hipLaunchKernelGGL(q4_outliers_kernel<true>, grid, block, maxIn * 4, st, ga);
-    } else {
-        hipLaunchKernelGGL(q4_outliers_kernel<false>, grid, block, 0, st, ga);
-    }
-    return hipGetLastError();
-}
-
 // ---- host side ------------------------------------------------------------------------------
 template <int FMT, int E, int W>
 static hipError_t launch_mul_t(const GroupKArgs& ga, hipStream_t st) {
@@ -729,7 +722,7 @@ static hipError_t launch_mul_t(const GroupKArgs& ga, hipStream_t st) {
     uint32_t lds = 0;
     for (uint32_t i = 0; i < ga.count; i++) {
         const MulGeom& g = ga.geom[ga.call[i].geom];
-        lds = max(lds, lds_layout<FMT, E, W>(g.sliceRows, g.slots, &o1, &o2, &o3, &o4));
+        lds = max(lds, lds_layout<FMT, E, W>(g, &o1, &o2, &o3, &o4));
         if (g.slots > (uint32_t)kRounds * 64 * W || g.slots != (FMT == kFp16 ? (g.rowsPerIn << g.sliceLog2) : g.sliceRows * 8u)) return hipErrorInvalidValue;
         if (ga.wgEnd[i] - (i ? ga.wgEnd[i - 1] : 0u) != g.tiles * align_up(g.slices, 8)) return hipErrorInvalidValue;
     }
@@ -773,12 +766,12 @@ hipError_t launch_bucket_mul(Format fmt, int W, int E, const GroupKArgs& a, hipS
     return fmt == kFp16 ? launch_mul_fmt<kFp16>(W, E, a, st) : launch_mul_fmt<kQ4>(W, E, a, st);
 }
 
-size_t bucket_mul_lds_bytes(Format fmt, int W, int E, uint32_t B, uint32_t slots) {
+size_t bucket_mul_lds_bytes(Format fmt, int W, int E, const MulGeom& g) {
     uint32_t o1, o2, o3, o4;
 #define EFFORT_CASE(w, e)                                                                     \
     if (W == w && E == e)                                                                     \
-        return fmt == kFp16 ? lds_layout<kFp16, e, w>(B, slots, &o1, &o2, &o3, &o4)           \
-                            : lds_layout<kQ4, e, w>(B, slots, &o1, &o2, &o3, &o4);
+        return fmt == kFp16 ? lds_layout<kFp16, e, w>(g, &o1, &o2, &o3, &o4)           \
+                            : lds_layout<kQ4, e, w>(g, &o1, &o2, &o3, &o4);
     EFFORT_GEOMS(EFFORT_CASE)
 #undef EFFORT_CASE
     return 0;

@@ -163,10 +163,13 @@ hipError_t launch_cosine(const float* a, const float* b, uint32_t n, float* out3
     return hipGetLastError();
 }
 
-// ---- Q4 outliers -> by-output CSR (registration time, keeps table order inside each output) -----
-// outliers float4 = (value, inIdx, outIdx, 0) (q4_draft.py:58-67).  Pass 1 counts per output, a
-// one-block scan makes rowPtr, pass 2 places each outlier at rowPtr[out] + (number of earlier table
-// entries with the same output) -- computed with a per-output ordered walk so the order is the table's.
+// ---- Q4 outliers -> index by output (registration time) --------------------------------------------------------
+// outliers float4 = (value, inIdx, outIdx, 0) (q4_draft.py:58-67).  Pass 1 counts per output, a one-block scan makes
+// rowPtr, pass 2 places each outlier in its output's segment (atomic cursor: arbitrary order inside a segment -- the
+// multiply adds the products as integers, so the order does not matter), pass 3 interleaves the segments of every 64
+// consecutive outputs -- first entry of each output, then the second of each ... -- so that the multiply's coalesced
+// stream of entries hands neighbouring lanes DIFFERENT outputs: its LDS atomics then never collide (sorted by output, a
+// wave's 64 entries hit one or two addresses and serialise).  rowPtr[64*b] still bounds block b's entries.
 __global__ void ol_count_kernel(const float4* ol, uint64_t n, uint32_t* rowPtr) {
     const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     if (i < n) atomicAdd(&rowPtr[(uint32_t)ol[i].z + 1], 1u);
@@ -184,39 +187,53 @@ __global__ __launch_bounds__(1024) void ol_scan_kernel(uint32_t* rowPtr, uint32_
     uint32_t run = s_part[threadIdx.x];
     for (uint32_t i = lo; i < hi; i++) { run += rowPtr[i]; rowPtr[i] = run; }
 }
-// Placement uses an atomic cursor (arbitrary order inside an output's segment); ol_sort_segments_kernel
-// then restores table order inside each (short, ~2 % of inDim) segment.
-__global__ void ol_place_kernel(const float4* ol, uint64_t n, const uint32_t* rowPtr, uint32_t* cursor,
-                                uint32_t* inIdx, float* value, uint32_t* tableIdx) {
+__global__ void ol_place_kernel(const float4* ol, uint64_t n, const uint32_t* rowPtr, uint32_t* cursor, uint32_t* key, float* value) {
     const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     const float4 o = ol[i];
     const uint32_t out = (uint32_t)o.z;
     const uint32_t p = rowPtr[out] + atomicAdd(&cursor[out], 1u);
-    inIdx[p] = (uint32_t)o.y; value[p] = o.x; tableIdx[p] = (uint32_t)i;
+    key[p] = (uint32_t)o.y | (out << 16); value[p] = o.x;        // key = output << 16 | input (both < 65536)
 }
-__global__ void ol_sort_segments_kernel(const uint32_t* rowPtr, uint32_t outDim, uint32_t* inIdx, float* value, uint32_t* tableIdx) {
-    const uint32_t out = blockIdx.x * 256u + threadIdx.x;
-    if (out >= outDim) return;
-    const uint32_t lo = rowPtr[out], hi = rowPtr[out + 1];
-    for (uint32_t i = lo + 1; i < hi; i++) {                      // insertion sort by table index
-        const uint32_t ti = tableIdx[i], ii = inIdx[i]; const float vv = value[i];
-        uint32_t k = i;
-        while (k > lo && tableIdx[k - 1] > ti) { tableIdx[k] = tableIdx[k - 1]; inIdx[k] = inIdx[k - 1]; value[k] = value[k - 1]; k--; }
-        tableIdx[k] = ti; inIdx[k] = ii; value[k] = vv;
+// one wave per block of 64 outputs (lane = output): round r moves the r-th entry of every output that has one
+__global__ __launch_bounds__(64) void ol_interleave_kernel(const uint32_t* rowPtr, uint32_t outDim, const uint32_t* keyIn, const float* valIn,
+                                                          uint32_t* keyOut, float* valOut) {
+    const uint32_t out = blockIdx.x * 64u + threadIdx.x;
+    const uint32_t lo = rowPtr[min(out, outDim)], len = out < outDim ? rowPtr[out + 1] - lo : 0u;
+    uint32_t base = rowPtr[blockIdx.x * 64u];
+    for (uint32_t r = 0;; r++) {
+        const unsigned long long active = __ballot(len > r);
+        if (!active) break;
+        if (len > r) {
+            const uint32_t p = base + (uint32_t)__popcll(active & ((1ull << threadIdx.x) - 1ull));
+            keyOut[p] = keyIn[lo + r]; valOut[p] = valIn[lo + r];
+        }
+        base += (uint32_t)__popcll(active);
     }
 }
+// rowPtr[outDim + 1 + b] = bits of max over the outputs of block b (64 outputs) of sum |value|: bounds the multiply's
+// fixed-point outlier sums
+__global__ void ol_bound_kernel(const uint32_t* rowPtr, uint32_t outDim, const float* value, uint32_t* boundBits) {
+    const uint32_t out = blockIdx.x * 256u + threadIdx.x;
+    if (out >= outDim) return;
+    float sum = 0.0f;
+    for (uint32_t i = rowPtr[out]; i < rowPtr[out + 1]; i++) sum += fabsf(value[i]);
+    atomicMax(&boundBits[out / 64u], __float_as_uint(sum));       // non-negative floats order like their bit patterns
+}
+// tmp: [outDim] cursors, then [n] keys and [n] values of the by-output order (before interleaving)
 hipError_t launch_build_outlier_index(const float* outliers, uint64_t n, uint32_t outDim, uint32_t* rowPtr,
-                                      uint32_t* inIdx, float* value, uint32_t* cursor, hipStream_t st) {
-    // cursor doubles as [outDim] atomic cursors followed by [n] table indices
-    hipError_t e = hipMemsetAsync(rowPtr, 0, (size_t)(outDim + 1) * 4, st); if (e != hipSuccess) return e;
-    e = hipMemsetAsync(cursor, 0, (size_t)outDim * 4, st); if (e != hipSuccess) return e;
+                                      uint32_t* key, float* value, uint32_t* tmp, hipStream_t st) {
+    hipError_t e = hipMemsetAsync(rowPtr, 0, ((size_t)outDim + 1 + (outDim + 63) / 64) * 4, st); if (e != hipSuccess) return e;
+    e = hipMemsetAsync(tmp, 0, (size_t)outDim * 4, st); if (e != hipSuccess) return e;
     const float4* ol = reinterpret_cast<const float4*>(outliers);
     const uint32_t nb = (uint32_t)((n + 255) / 256);
+    uint32_t* key0 = tmp + outDim;
+    float* val0 = reinterpret_cast<float*>(key0 + n);
     hipLaunchKernelGGL(ol_count_kernel, dim3(nb), dim3(256), 0, st, ol, n, rowPtr);
     hipLaunchKernelGGL(ol_scan_kernel, dim3(1), dim3(1024), 0, st, rowPtr, outDim);
-    hipLaunchKernelGGL(ol_place_kernel, dim3(nb), dim3(256), 0, st, ol, n, rowPtr, cursor, inIdx, value, cursor + outDim);
-    hipLaunchKernelGGL(ol_sort_segments_kernel, dim3((outDim + 255) / 256), dim3(256), 0, st, rowPtr, outDim, inIdx, value, cursor + outDim);
+    hipLaunchKernelGGL(ol_place_kernel, dim3(nb), dim3(256), 0, st, ol, n, rowPtr, tmp, key0, val0);
+    hipLaunchKernelGGL(ol_bound_kernel, dim3((outDim + 255) / 256), dim3(256), 0, st, rowPtr, outDim, val0, rowPtr + outDim + 1);
+    hipLaunchKernelGGL(ol_interleave_kernel, dim3((outDim + 63) / 64), dim3(64), 0, st, rowPtr, outDim, key0, val0, key, value);
     return hipGetLastError();
 }
 

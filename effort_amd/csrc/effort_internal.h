@@ -29,8 +29,8 @@ struct MulGeom {
 };
 
 struct OutlierIndex {          // by-output CSR of the Q4 outliers, built at registration
-    const uint32_t* rowPtr;    // [outDim+1]  (nullptr: no outliers)
-    const uint32_t* inIdx;     // [n]
+    const uint32_t* rowPtr;    // [outDim+1] entry bounds by output (nullptr: no outliers), then [ceil(outDim/64)] bits of max over a block's outputs of sum |value|
+    const uint32_t* inIdx;     // [n]  output << 16 | input
     const float* value;        // [n]
 };
 
@@ -101,11 +101,10 @@ hipError_t launch_find_cutoff(const float* v, const uint16_t* probes, const uint
 // Returns hipErrorInvalidValue for unsupported (fmt, W, E).
 hipError_t launch_bucket_mul(Format fmt, int wavesPerGroup, int elemsPerLane, const GroupKArgs& ga, hipStream_t st);
 hipError_t launch_find_cutoff_group(const GroupKArgs& ga, hipStream_t st);    // ga.cutoff[i] of every call
-size_t bucket_mul_lds_bytes(Format fmt, int wavesPerGroup, int elemsPerLane, uint32_t sliceRows, uint32_t slots);
+size_t bucket_mul_lds_bytes(Format fmt, int wavesPerGroup, int elemsPerLane, const MulGeom& g);
 uint32_t bucket_mul_max_candidates(int wavesPerGroup);
 int bucket_mul_occupancy(Format fmt, int wavesPerGroup, int elemsPerLane, size_t ldsBytes);
   // rowsPerIn*sliceRows must not exceed this
-hipError_t launch_q4_outliers(const GroupKArgs& ga, hipStream_t st);
 
 hipError_t launch_calc_dispatch(Format fmt, const void* stats, const float* v, const uint32_t* expNo,
                                 const float* cutoff, const MulGeom& g, float* dispatch, uint32_t* count,

@@ -454,6 +454,51 @@ def test_group_launch_q4(ea, oracle_cpu, q4_case):
         ea.bucketMulGroup([calls[0], (calls[0][0],) + (gpu_weights(ea, *converted(oracle_cpu, 256, 4096)),) + calls[0][2:]])   # mixed kinds
 
 
+@pytest.mark.parametrize("inDim,outDim", [(4096, 4160), (16448, 4096)])
+def test_q4_outlier_tables(ea, oracle_cpu, inDim, outDim):
+    """calcOutliers (bucketMulQ4.metal:13-21) on tables the converter never writes but the format allows: every entry
+    on one output, duplicates of one (input, output) pair, outputs without entries, entries on the first and the last
+    output, shuffled table order -- over a synthetic Q4 bundle (any nibble pattern is a valid bucket word).  4160
+    outputs end in a ragged tile ((outDim/16) % 4 == 0 is the reference's own precondition, bucketMul.swift:76); 16448
+    inputs exceed the LDS copy of v (gathered from memory)."""
+    rng = np.random.default_rng(inDim + outDim)
+    rows, cols = inDim * 8, outDim // 32
+    buckets = rng.integers(0, 65536, size=(rows, cols), dtype=np.uint16)
+    mean = np.abs(rng.normal(0, 0.02, size=rows)).astype(np.float32)
+    stats = np.stack([mean, mean], axis=1)
+    probes = rng.normal(0, 0.02, size=4096).astype(np.float16)
+
+    def table(n, outs):
+        t = np.zeros((n, 4), np.float32)
+        t[:, 0] = rng.normal(0, 0.3, size=n).astype(np.float16)       # values of an f16 matrix (q4_draft.py:58-67)
+        t[:, 1] = rng.integers(0, inDim, size=n)
+        t[:, 2] = outs if not np.isscalar(outs) else np.full(n, outs)
+        return t
+    tables = {
+        "one output": table(5000, 77),
+        "first and last": np.concatenate([table(300, 0), table(300, outDim - 1)]),
+        "duplicates": np.repeat(table(64, rng.integers(0, outDim, size=64)), 7, axis=0),
+        "sparse, shuffled": table(20000, rng.choice(np.arange(0, outDim, 3), size=20000)),
+        "dense": table(200000, rng.integers(0, outDim, size=200000)),
+    }
+    v = make_v(inDim, seed=8, heavy=True)
+    vd = devf(v)
+    g = ea.gpu()
+    for name, ol in tables.items():
+        ew = ea.ExpertWeights(dev16(buckets), devf(stats), dev16(probes), inSize=inDim, outSize=outDim, outliers=devf(ol), q4=True)
+        for tune, effort in (((0, 0, 0), 0.25), ((8, 1, 16), 0.1), ((8, 2, 24), 0.5)):
+            want, n, cutoff = oracle_cpu.bucket_mul_q4(v, buckets, stats, probes, ol, inDim, outDim, effort)
+            out = torch.full((outDim,), float("nan"), device=DEV)
+            try:
+                g.set_tuning(*tune)
+                ea.bucketMulQ4(vd, ew, None, out, effort)
+                g.eval()
+            finally:
+                g.set_tuning(0, 0, 0)
+            assert g.last_dispatch_count() == n and g.last_cutoff() == cutoff
+            assert close(out.cpu().numpy(), want), (name, tune, effort)
+
+
 # ---------------------------------------------------------------- on-disk bucket format + model converter driver
 def test_model_file_roundtrip(ea, oracle_cpu, tmp_path):
     """convertMistral on the GPU (one synthetic layer: hidden 4096, kv 256, ffn 1024) -> safetensors shards + index ->
