@@ -78,7 +78,9 @@ EFFORT_API effort_w* effort_weights_fp16(effort_ctx* ctx, const void* buckets_de
  *   stats    f32 [numExperts][inDim*8][2]           (mean|row|, same); .y is read
  *   probes   f16 [numExperts][4096]
  *   outliers f32 [nOutliers][4]                     (value, inIdx, outIdx, 0); may be NULL / 0
- * Borrowed like the FP16 bundle.  Registration builds a by-output index of the outliers in HBM. */
+ * Borrowed like the FP16 bundle, except the outlier table: registration turns it into an index by blocks of 64 outputs
+ * in HBM (8 bytes per outlier: value, output << 16 | input; hence inDim, outDim <= 65536 when there are outliers) and
+ * does not read outliers_dev again. */
 EFFORT_API effort_w* effort_weights_q4(effort_ctx* ctx, const void* buckets_dev, const void* stats_dev,
                             const void* probes_dev, const void* outliers_dev, int64_t nOutliers,
                             int inDim, int outDim, int numExperts);
