@@ -185,13 +185,16 @@ extern "C" effort_w* effort_weights_q4(effort_ctx* c, const void* buckets, const
         hipSetDevice(c->device);
         uint32_t* cursor = nullptr;
         w->nOutliers = (uint64_t)nOutliers;
-        bool ok = hipMalloc(&w->olRowPtr, ((size_t)outDim + 1 + (outDim + 63) / 64) * 4) == hipSuccess && hipMalloc(&w->olInIdx, (size_t)nOutliers * 4) == hipSuccess &&
+        bool ok = hipMalloc(&w->olRowPtr, ((size_t)outDim + 2 + (outDim + 63) / 64) * 4) == hipSuccess && hipMalloc(&w->olInIdx, (size_t)nOutliers * 4) == hipSuccess &&
                   hipMalloc(&w->olValue, (size_t)nOutliers * 4) == hipSuccess && hipMalloc(&cursor, ((size_t)outDim + 2 * (size_t)nOutliers) * 4) == hipSuccess;
         if (ok) ok = launch_build_outlier_index(static_cast<const float*>(outliers), w->nOutliers, outDim, w->olRowPtr, w->olInIdx,
                                                 w->olValue, cursor, c->stream) == hipSuccess;
         if (ok) ok = hipStreamSynchronize(c->stream) == hipSuccess;
         hipFree(cursor);
+        uint32_t longest = 0;
+        if (ok) ok = hipMemcpy(&longest, w->olRowPtr + (size_t)outDim + 1 + (outDim + 63) / 64, 4, hipMemcpyDeviceToHost) == hipSuccess;
         if (!ok) { fail(c, EFFORT_ERR_HIP, "effort_weights_q4: outlier index"); effort_weights_free(w); return nullptr; }
+        if (longest >= (1u << 19)) { fail(c, EFFORT_ERR_SHAPE, "effort_weights_q4: more than 2^19 outliers on one output"); effort_weights_free(w); return nullptr; }
     }
     return w;
 }

@@ -501,8 +501,9 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
             const uint32_t oEnd = max(oBeg, min(min(t * (uint32_t)TILE_F + (s + 1u) * olPer, (t + 1u) * (uint32_t)TILE_F), g.outDim));
             const uint32_t kBeg = ol.rowPtr[oBeg], kEnd = ol.rowPtr[oEnd];
             // bound of this share's sums: max over its blocks of (max over the block's outputs of sum |value|), from registration
-            const uint32_t nBlk = (oEnd - oBeg + 63u) / 64u;                               // <= NT (a tile has at most 16384 outputs)
-            float olBound = (uint32_t)tid < nBlk ? __uint_as_float(ol.rowPtr[g.outDim + 1u + oBeg / 64u + tid]) : 0.0f;
+            const uint32_t nBlk = (oEnd - oBeg + 63u) / 64u;
+            float olBound = 0.0f;
+            for (uint32_t bq = tid; bq < nBlk; bq += NT) olBound = fmaxf(olBound, __uint_as_float(ol.rowPtr[g.outDim + 1u + oBeg / 64u + bq]));
             float vm = 0.0f;
             for (uint32_t i0 = 0; i0 < g.inDim; i0 += NT * 8u) {                           // eight loads in flight (clamped, branch-free)
                 float x[8];
@@ -541,10 +542,11 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
                 for (int u = 0; u < kOlBatch; u++) {
                     const float x = vLds ? vfull[key[u] & 0xFFFFu] : a.v[key[u] & 0xFFFFu];
                     // two-level fixed point: the bound can sit far above the sums (one huge input), so the rounding
-                    // remainder of every product -- exact in f32 -- is summed too, 2^23 times finer
+                    // remainder of every product -- exact in f32 -- is summed too, 2^12 times finer (|ql| <= 2^11: an
+                    // output may have 2^19 entries before that sum could leave int32; registration refuses more)
                     const float cs = (x * val[u]) * olScale;
                     const int qh = __float2int_rn(cs);
-                    const int ql = __float2int_rn((cs - (float)qh) * 8388608.0f);
+                    const int ql = __float2int_rn((cs - (float)qh) * 4096.0f);
                     if (k0 + u * NT + tid < kEnd) { atomicAdd(&olacc[(key[u] >> 16) - oBeg], qh); atomicAdd(&ollo[(key[u] >> 16) - oBeg], ql); }
                 }
             }
@@ -564,7 +566,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
         float r = (float)(acc[p] - acc[p + 8 * E * 64]) * unscale;
         if (olAny) {                                                 // this item's share of the tile's outputs: + their outliers
             const uint32_t ol_o = (uint32_t)((rem & 63) * E + (rem >> 6)) * 32u + (uint32_t)slot - s * olPer;      // tile-local output, from the share's start
-            if (ol_o < olPer && (uint32_t)(t * TILE_F) + s * olPer + ol_o < g.outDim) r += ((float)olacc[ol_o] + (float)olacc[olLoOff + ol_o] * (1.0f / 8388608.0f)) * olUnscale;
+            if (ol_o < olPer && (uint32_t)(t * TILE_F) + s * olPer + ol_o < g.outDim) r += ((float)olacc[ol_o] + (float)olacc[olLoOff + ol_o] * (1.0f / 4096.0f)) * olUnscale;
         }
         return r;
     };

@@ -212,18 +212,19 @@ __global__ __launch_bounds__(64) void ol_interleave_kernel(const uint32_t* rowPt
     }
 }
 // rowPtr[outDim + 1 + b] = bits of max over the outputs of block b (64 outputs) of sum |value|: bounds the multiply's
-// fixed-point outlier sums
+// fixed-point outlier sums; after the blocks, the largest number of entries of one output
 __global__ void ol_bound_kernel(const uint32_t* rowPtr, uint32_t outDim, const float* value, uint32_t* boundBits) {
     const uint32_t out = blockIdx.x * 256u + threadIdx.x;
     if (out >= outDim) return;
     float sum = 0.0f;
     for (uint32_t i = rowPtr[out]; i < rowPtr[out + 1]; i++) sum += fabsf(value[i]);
     atomicMax(&boundBits[out / 64u], __float_as_uint(sum));       // non-negative floats order like their bit patterns
+    atomicMax(&boundBits[(outDim + 63u) / 64u], rowPtr[out + 1] - rowPtr[out]);      // one more word: the longest segment
 }
 // tmp: [outDim] cursors, then [n] keys and [n] values of the by-output order (before interleaving)
 hipError_t launch_build_outlier_index(const float* outliers, uint64_t n, uint32_t outDim, uint32_t* rowPtr,
                                       uint32_t* key, float* value, uint32_t* tmp, hipStream_t st) {
-    hipError_t e = hipMemsetAsync(rowPtr, 0, ((size_t)outDim + 1 + (outDim + 63) / 64) * 4, st); if (e != hipSuccess) return e;
+    hipError_t e = hipMemsetAsync(rowPtr, 0, ((size_t)outDim + 2 + (outDim + 63) / 64) * 4, st); if (e != hipSuccess) return e;
     e = hipMemsetAsync(tmp, 0, (size_t)outDim * 4, st); if (e != hipSuccess) return e;
     const float4* ol = reinterpret_cast<const float4*>(outliers);
     const uint32_t nb = (uint32_t)((n + 255) / 256);

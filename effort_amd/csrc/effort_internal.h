@@ -29,7 +29,7 @@ struct MulGeom {
 };
 
 struct OutlierIndex {          // by-output CSR of the Q4 outliers, built at registration
-    const uint32_t* rowPtr;    // [outDim+1] entry bounds by output (nullptr: no outliers), then [ceil(outDim/64)] bits of max over a block's outputs of sum |value|
+    const uint32_t* rowPtr;    // [outDim+1] entry bounds by output (nullptr: no outliers), then [ceil(outDim/64)] bits of max over a block's outputs of sum |value|, then the longest segment
     const uint32_t* inIdx;     // [n]  output << 16 | input
     const float* value;        // [n]
 };
