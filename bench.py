@@ -357,7 +357,7 @@ def main():
             del gn
         result["two_streams"] = tw
         ts = by["1"]["us_per_call"] * 1e-6
-        # ---------------- dense rocBLAS baseline (basicMul over the rotating cores) -------------------
+        # ---------------- dense baseline (basicMul over the rotating cores) ---------------------------
         four = Step(ea, local, 4)
         dense_out = [torch.zeros(outDim, device=dev) for _ in range(4)]
         ditems = [[(ew, dense_out[i % 4])] for i, ew in enumerate(ews)]
@@ -365,11 +365,16 @@ def main():
         def dense(ctx, chunk):
             for ew, o in chunk:
                 ea.basicMul(v, ew.core, o, gpu=ctx)
-        td1 = time_replays(one.capture(dense, ditems), 30, 5) / N_MATS
-        tdk = time_replays(four.capture(dense, ditems), 30, 5) / N_MATS
-        result["dense_rocblas"] = {"us_per_call_serial": round(td1 * 1e6, 3), "us_per_call_4_streams": round(tdk * 1e6, 3),
-                                   "GBps": round(eff_bytes / min(td1, tdk) / 1e9, 1),
-                                   "speedup_at_effort": round(min(td1, tdk) / t_call, 3), "speedup_serial_vs_serial": round(td1 / ts, 3)}
+        # basicMul (helpers/mps.swift:14-47) twice: through rocBLAS' hssgemv -- the library the north star names -- and
+        # through the package's own streaming kernel (csrc/gemv.hip), the default backend of effort_dense_gemv
+        for name, rocblas in (("dense_rocblas", True), ("dense_hip_kernel", False)):
+            for ctx in one.ctxs + four.ctxs:
+                ctx.set_dense_backend(rocblas)
+            td1 = time_replays(one.capture(dense, ditems), 30, 5) / N_MATS
+            tdk = time_replays(four.capture(dense, ditems), 30, 5) / N_MATS
+            result[name] = {"us_per_call_serial": round(td1 * 1e6, 3), "us_per_call_4_streams": round(tdk * 1e6, 3),
+                            "GBps": round(eff_bytes / min(td1, tdk) / 1e9, 1), "frac_of_hbm_peak": round(eff_bytes / min(td1, tdk) / 1e9 / HBM_PEAK_GBPS, 4),
+                            "speedup_at_effort": round(min(td1, tdk) / t_call, 3), "speedup_serial_vs_serial": round(td1 / ts, 3)}
         # ---------------- effort sweep ----------------------------------------------------------------
         if not args.no_sweep:
             sweep = []
@@ -438,15 +443,20 @@ def main():
                 model = Model.random(MistralConfig(), seed=1)
                 dec = Decoder(model, maxTokens=64)
                 prompt, ntok = [1, 733, 16289, 28793, 22557], 48
+                g.set_dense_backend(True)                    # the dense path through rocBLAS (the north star's baseline) ...
+                _, dt_r, _ = dec.run(prompt, ntok, dense=True)
+                g.set_dense_backend(False)                   # ... and through the package's own GEMV (also the LM head of the effort runs)
+                dec._graphs.clear()
                 ids_d, dt_d, lg_d = dec.run(prompt, ntok, dense=True, collect_logits=True)
                 forced = prompt + ids_d[len(prompt) - 1:-1]
                 dsec = {"model": "Mistral-7B shapes, 32 layers, random-init weights (no checkpoints offline)", "tokens": ntok,
-                        "dense_rocblas_tokens_per_s": round(1 / dt_d, 1), "effort": {}}
+                        "dense_rocblas_tokens_per_s": round(1 / dt_r, 1), "dense_hip_kernel_tokens_per_s": round(1 / dt_d, 1), "effort": {}}
                 for e in (1.0, 0.25):
                     _, dt_e, _ = dec.run(prompt, ntok, effort=e)
                     _, _, lg_e = dec.run(forced, ntok, effort=e, forced=True, collect_logits=True)
                     dsec["effort"][str(e)] = {"tokens_per_s": round(1 / dt_e, 1), "ms_per_token": round(dt_e * 1e3, 3),
-                                              "speedup_vs_dense": round(dt_d / dt_e, 3), "kl_vs_dense": round(kl_divergence(lg_d, lg_e), 5)}
+                                              "speedup_vs_dense_rocblas": round(dt_r / dt_e, 3), "speedup_vs_dense_hip_kernel": round(dt_d / dt_e, 3),
+                                              "kl_vs_dense": round(kl_divergence(lg_d, lg_e), 5)}
                 result["decode"] = dsec
                 del dec, model
             except Exception as ex:

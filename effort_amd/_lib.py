@@ -62,6 +62,7 @@ _SIGS = {
     "effort_top2_softmax": (C.c_int, [_P, _P, C.c_int, _P, _P]),
     "effort_mix2": (C.c_int, [_P, _P, _P, _P, _P, C.c_int]),
     "effort_dense_gemv": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int]),
+    "effort_set_dense_backend": (C.c_int, [_P, C.c_int]),
     "effort_last_dispatch_count": (C.c_int, [_P, C.POINTER(C.c_uint32)]),
     "effort_last_cutoff": (C.c_int, [_P, C.POINTER(C.c_float)]),
     "effort_calc_dispatch": (C.c_int, [_P, _P, _P, _P, C.c_double, _P, _P]),

@@ -38,6 +38,7 @@ struct effort_ctx {
     unsigned long long* d_tstamp = nullptr;   // device-clock stamps of the multiply kernel (timing mode)
     double wallClockKHz = 100000.0;
     rocblas_handle blas = nullptr;
+    bool denseRocblas = false;        // effort_set_dense_backend: basicMul through rocBLAS instead of dense_gemv_kernel
     // tuning overrides (0 = heuristic)
     int tuneW = 0, tuneE = 0, tuneS = 0;
     bool splitCutoff = false;     // run findCutoff32 as its own 1-workgroup kernel instead of inside every workgroup
@@ -436,9 +437,18 @@ extern "C" int effort_last_dispatch_count(effort_ctx* c, uint32_t* host_out) { r
 extern "C" int effort_last_cutoff(effort_ctx* c, float* host_out) { return effort_group_cutoff(c, 0, host_out); }
 
 // ---- dense baseline ------------------------------------------------------------------------------
+extern "C" int effort_set_dense_backend(effort_ctx* c, int rocblas) {
+    if (!c) return EFFORT_ERR_ARG;
+    c->denseRocblas = rocblas != 0;
+    return EFFORT_OK;
+}
 extern "C" int effort_dense_gemv(effort_ctx* c, const void* W, const float* v, float* out, int inDim, int outDim) {
     if (!c || !W || !v || !out || inDim <= 0 || outDim <= 0) return fail(c, EFFORT_ERR_ARG, "dense_gemv: bad argument");
     if (inDim % 16) return fail(c, EFFORT_ERR_SHAPE, "dense_gemv: inDim % 16 != 0 (helpers/mps.swift:18)");
+    if (!c->denseRocblas && dense_gemv_supported((uint32_t)inDim, (uint32_t)outDim)) {
+        HIP_TRY(c, launch_dense_gemv(static_cast<const uint16_t*>(W), v, out, (uint32_t)inDim, (uint32_t)outDim, c->stream));
+        return EFFORT_OK;
+    }
     if (!c->blas) {
         if (rocblas_create_handle(&c->blas) != rocblas_status_success) return fail(c, EFFORT_ERR_BLAS, "rocblas_create_handle");
         rocblas_set_stream(c->blas, c->stream);

@@ -95,6 +95,8 @@ __device__ __forceinline__ float bf16_round(float f) {
 }
 
 // ---- launchers (one per translation unit) ---------------------------------------------------
+bool dense_gemv_supported(uint32_t inDim, uint32_t outDim);
+hipError_t launch_dense_gemv(const uint16_t* W_f16, const float* v, float* out, uint32_t inDim, uint32_t outDim, hipStream_t st);
 hipError_t launch_find_cutoff(const float* v, const uint16_t* probes, const uint32_t* expNo, uint32_t q,
                               float* cutoff, uint32_t* dispatchCount, unsigned long long* tstamp, hipStream_t st);
 

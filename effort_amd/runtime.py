@@ -64,6 +64,10 @@ class Gpu:
     def set_persistent(self, wg_per_cu: int = -1):
         self.check(self._lib.effort_set_persistent(self.ctx, int(wg_per_cu)), "set_persistent")
 
+    def set_dense_backend(self, rocblas: bool = False):
+        """basicMul through the library's hssgemv (True) or the streaming HIP kernel (False, default)."""
+        self.check(self._lib.effort_set_dense_backend(self.ctx, int(bool(rocblas))), "set_dense_backend")
+
     def debug_stamps(self):
         buf = (C.c_ulonglong * 32)()
         self.check(self._lib.effort_debug_stamps(self.ctx, buf), "debug_stamps")

@@ -104,9 +104,12 @@ EFFORT_API int effort_bucketmul_q4(effort_ctx* ctx, const effort_w* w, const flo
                         float* out_dev, double effort);
 
 /* func basicMul(v:by:out:) -- helpers/mps.swift:14-47: dense out = W * f16(v), W f16 [outDim,inDim]
- * row-major, f32 result.  rocBLAS (the MPS equivalent); the "100 % effort dense" baseline. */
+ * row-major, f32 result; the "100 % effort dense" baseline.  A streaming HIP kernel (csrc/gemv.hip) by default;
+ * effort_set_dense_backend(ctx, 1) routes it through rocBLAS' hssgemv instead (the library the north star names: the
+ * bench reports both). */
 EFFORT_API int effort_dense_gemv(effort_ctx* ctx, const void* W_f16_dev, const float* v_dev, float* out_dev,
                       int inDim, int outDim);
+EFFORT_API int effort_set_dense_backend(effort_ctx* ctx, int rocblas);
 
 /* A GROUP of n (1..32) independent bucketMul calls in ONE kernel launch: call i multiplies vs[i] by ws[i] at
  * efforts[i] into outs[i] (expNos may be NULL, or hold NULL entries = expert 0).  Same row selection as n

@@ -279,15 +279,26 @@ def test_q4_quality_vs_dense(ea, oracle_cpu, q4_case):
 
 
 # ---------------------------------------------------------------- dense baseline, errors
-def test_dense_gemv_matches_oracle(ea, oracle_cpu):
-    W = make_w(1024, 4096, seed=3)
-    v = make_v(4096, seed=9)
-    out = torch.zeros(1024, device=DEV)
-    ea.basicMul(devf(v), dev16(W).view(torch.float16), out)
-    ea.gpu().eval()
+@pytest.mark.parametrize("outDim,inDim", [(1024, 4096), (1027, 4112), (8, 16), (300, 14336)])
+def test_dense_gemv_matches_oracle(ea, oracle_cpu, outDim, inDim):
+    """basicMul (helpers/mps.swift:14-47): the streaming kernel (csrc/gemv.hip) and the rocBLAS backend against the f32
+    restatement; ragged sizes: rows not a multiple of the 8 a workgroup takes, inDim not a multiple of the 512-element chunk."""
+    W = make_w(outDim, inDim, seed=3)
+    v = make_v(inDim, seed=9, heavy=True)
     want = oracle_cpu.dense_gemv(W, v, round_v_to_f16=True)             # v.asFloat16(), mps.swift:19
-    # rocBLAS's internal accumulation is a third-party detail (as MPS's is for the reference): 1e-3 band
-    assert np.allclose(out.cpu().numpy(), want, rtol=1e-3, atol=1e-3 * np.abs(want).max())
+    g = ea.gpu()
+    for rocblas in (False, True):
+        out = torch.full((outDim,), float("nan"), device=DEV)
+        try:
+            g.set_dense_backend(rocblas)
+            ea.basicMul(devf(v), dev16(W).view(torch.float16), out)
+            g.eval()
+        finally:
+            g.set_dense_backend(False)
+        # own kernel: f32 sums of exact f16 products in another order than the oracle's (1e-5 band); rocBLAS's internal
+        # accumulation is a third-party detail, as MPS's is for the reference (1e-3 band)
+        tol = 1e-3 if rocblas else 1e-5
+        assert np.allclose(out.cpu().numpy(), want, rtol=tol, atol=tol * np.abs(want).max()), rocblas
 
 
 def test_error_reporting(ea, oracle_cpu):
