@@ -421,8 +421,11 @@ def main():
                     ab = Dx * (outDim_x // 32) * 2 + 8 * inDim_x * 8 + 4096 * 2 + 4 * inDim_x + 4 * outDim_x + 16 * nol
                 else:
                     ab = algorithmic_bytes(Dx, inDim_x, outDim_x)
-                return {"us_per_call": round(tx * 1e6, 3), "dispatch_rows": Dx, "effective_GBps": round(2 * inDim_x * outDim_x / tx / 1e9, 1),
-                        "achieved_GBps": round(ab / tx / 1e9, 1), "frac_of_hbm_peak": round(ab / tx / 1e9 / HBM_PEAK_GBPS, 4)}
+                r = {"us_per_call": round(tx * 1e6, 3), "dispatch_rows": Dx, "effective_GBps": round(2 * inDim_x * outDim_x / tx / 1e9, 1),
+                     "achieved_GBps": round(ab / tx / 1e9, 1), "frac_of_hbm_peak": round(ab / tx / 1e9 / HBM_PEAK_GBPS, 4)}
+                if q4:       # SURVEY 8d prices an outlier at the reference's 16 bytes; the registered index holds 8
+                    r["achieved_GBps_8B_outliers"] = round((ab - 8 * nol) / tx / 1e9, 1)
+                return r
             other = {}
             sq = make_weights(ea, 16, 4096, 4096, 4321, dev, keep_core=False)
             other["4096x4096 fp16"] = {f"effort {e}, {n} per launch": quick(sq, 4096, 4096, e, n) for e in (0.5, 0.25) for n in (1, 16)}
