@@ -17,8 +17,9 @@
 // Per item:
 //   A. stage in LDS, in one memory round trip, the slice of v and the row means of all candidate rows of the slice
 //      (16*B, Q4 8*B); sum |v| (the fixed-point bound, D).
-//   B. the cutoff is evaluated redundantly by every workgroup (cutoff_device.h: bit-exact findCutoff32), which
-//      is cheaper than a kernel boundary or a cross-workgroup flag.
+//   B. the cutoff is evaluated redundantly by every workgroup (cutoff_device.h: bit-exact findCutoff32), which for a
+//      lone call is cheaper than a kernel boundary or a cross-workgroup flag; a persistent launch (many calls) has one
+//      cutoff job per call at the head of its item queues instead, and the items wait for its flag (cutoff_job).
 //   C. the candidate rows are tested exactly as prepareDispatch does (cutoff < (1e5*mean)*|v|) and the survivors
 //      compacted, in ascending bucket-row order, into an LDS list (wave ballots + mbcnt, ONE barrier; no global
 //      atomics, deterministic).
@@ -204,6 +205,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
 #pragma unroll
     for (int i = 0; i < VPT; i++) { vj[i] = 0.0f; prj[i] = 0; }
     const bool needCut = fused && cachedCall != ci;              // uniform: a persistent workgroup evaluates a call's cutoff once
+    const bool viaJob = needCut && ga.cutJobs != 0u;             // uniform: ... or takes it from the call's cutoff job
     // Input prologue (uniform per call): the multiply's input is v itself, or silu(v) * vAux (the FFN gate,
     // runNetwork.swift:181), or rmsNorm(v) * vAux (runNetwork.swift:121-122,173-175) -- evaluated here, per workgroup,
     // instead of in a launch of its own.
@@ -264,14 +266,15 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
         if (pre == kPreRmsNorm) return (x * normInv) * half_bits_to_float(reinterpret_cast<const uint16_t*>(a.vAux)[j]);
         return x;
     };
-    if (needCut) {
+    auto load_cut_inputs = [&]() {
 #pragma unroll
         for (int i = 0; i < VPT; i++) {
             vj[i] = (FUSED && pre == kPreRmsNorm) ? (rawn[i] * normInv) * half_bits_to_float(reinterpret_cast<const uint16_t*>(a.vAux)[tid + NT * i])
                                                   : input(tid + NT * i);
             prj[i] = pr[tid + NT * i];
         }
-    }
+    };
+    if (needCut && !viaJob) load_cut_inputs();
     // stage the slice of v; its absolute sum bounds every partial sum of this workgroup (see the scale below)
     float bound = 0.0f;
     for (uint32_t jl = tid; jl < nb; jl += NT) { const float x = input(j0 + jl); vblk[jl] = x; bound += fabsf(x); }
@@ -286,13 +289,33 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     //         wbound.  Its lookup table borrows the accumulator + list region, which is initialised afterwards. ------
     uint32_t* tbl = reinterpret_cast<uint32_t*>(smem);
     float cutoff;
-    if (needCut) {
+    bool fromJob = false;
+    if (viaJob) {
+        // the call's cutoff job (head of the item queues, see bucket_mul_kernel) publishes the value and raises the flag;
+        // it never waits on anything, so this wait ends -- and should it not within ~4 ms, the cutoff is evaluated here
+        uint32_t* const cutFlags = ga.queue + 9 * 16;
+        if (tid == 0) {
+            uint32_t ok = 0;
+            for (int spin = 0; spin < ((ga.ablate & 32u) ? 0 : 20000) && !ok; spin++) {      // (ablate 32: exercise the fallback)
+                ok = __hip_atomic_load(&cutFlags[ci], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!ok) __builtin_amdgcn_s_sleep(8);
+            }
+            flags[2] = ok;
+            if (ok) flags[3] = __hip_atomic_load(reinterpret_cast<uint32_t*>(a_cutoff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();                                             // publishes means / vblk / wbound, and the verdict
+        fromJob = flags[2] != 0u;
+        if (fromJob) { cutoff = __uint_as_float(flags[3]); cachedCall = ci; cachedCutoff = cutoff; }
+        else load_cut_inputs();
+    }
+    if (fromJob) {
+    } else if (needCut) {
         cutoff = block_find_cutoff<NT>(vj, prj, a.q, smem + offC, tbl, []() {}, stamp ? ga.tstamp + 8 : nullptr);
         cachedCall = ci; cachedCutoff = cutoff;
-        if (b == 0 && tid == 0) a_cutoff[0] = cutoff;             // BucketMul.cutoff (bucketMul.swift:22)
+        if (b == 0 && tid == 0 && !ga.cutJobs) a_cutoff[0] = cutoff;             // BucketMul.cutoff (bucketMul.swift:22)
     } else if (fused) {
         cutoff = cachedCutoff;
-        if (b == 0 && tid == 0) a_cutoff[0] = cutoff;
+        if (b == 0 && tid == 0 && !ga.cutJobs) a_cutoff[0] = cutoff;
         __syncthreads();                                             // publishes means / vblk / wbound
     } else {
         // split mode: the standalone cutoff kernel ran first on this stream (cheaper in aggregate when several
@@ -684,6 +707,30 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     }
 }
 
+// A cutoff job: findCutoff32 of call ci, once for the launch (persistent launches: the first items of every queue, so
+// the first workgroups to run take them; they wait on nothing).  The value goes to ga.cutoff[ci] write-through, then the
+// flag is raised; the call's items pick it up (mul_item, phase B).
+template <int NT>
+__device__ __forceinline__ void cutoff_job(const GroupKArgs& ga, uint32_t ci, char* smem) {
+    constexpr int VPT = 4096 / NT;
+    const CallDesc& a = ga.call[ci];
+    int tid0 = threadIdx.x;
+    asm volatile("" : "+v"(tid0));
+    const int tid = tid0;
+    const uint32_t e = a.expNo ? a.expNo[0] : 0u;
+    const uint16_t* pr = a.probes + (size_t)e * kProbes;
+    float vj[VPT]; uint16_t prj[VPT];
+#pragma unroll
+    for (int i = 0; i < VPT; i++) { vj[i] = a.v[tid + NT * i]; prj[i] = pr[tid + NT * i]; }
+    const float cutoff = block_find_cutoff<NT>(vj, prj, a.q, smem + cutoff_table_bytes(NT), reinterpret_cast<uint32_t*>(smem), []() {}, nullptr);
+    if (tid == 0) {
+        __hip_atomic_store(reinterpret_cast<uint32_t*>(ga.cutoff + ci), __float_as_uint(cutoff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the value has left the CU before the flag does
+        __hip_atomic_store(&ga.queue[9 * 16 + ci], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();                                               // the table region is free for the next item
+}
+
 // The kernel: every workgroup pulls items until the queue of its XCD is dry.  Launched with one item per workgroup it
 // is a plain grid; launched with fewer workgroups than items (ga.persistent) the workgroups are PERSISTENT: the
 // dispatcher only places ~40 workgroups/us chip-wide and spreads a large grid unevenly over the CUs (measured with
@@ -693,7 +740,7 @@ template <int FMT, int E, int W, bool FUSED>
 __global__ __launch_bounds__(64 * W, (W <= 8 ? EFFORT_MIN_WAVES_PER_EU : 4)) void bucket_mul_kernel(const GroupKArgs ga) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ uint32_t s_item;
-    const uint32_t total = ga.wgEnd[ga.count - 1];
+    const uint32_t total = ga.wgEnd[ga.count - 1] + ga.cutJobs;
     uint32_t cachedCall = 0xFFFFFFFFu; float cachedCutoff = 0.0f;
     const uint32_t x = blockIdx.x & 7u;                    // block b sits on XCD b%8; item i wants XCD i%8
     for (uint32_t it = 0;; it++) {
@@ -707,12 +754,17 @@ __global__ __launch_bounds__(64 * W, (W <= 8 ? EFFORT_MIN_WAVES_PER_EU : 4)) voi
         } else if (it) {
             return;
         }
-        mul_item<FMT, E, W, FUSED>(ga, item, smem, cachedCall, cachedCutoff);
+        if (item < ga.cutJobs) {                           // uniform: a cutoff job (the queues hand these out first)
+            if (item < ga.count) cutoff_job<64 * W>(ga, item, smem);
+            continue;
+        }
+        mul_item<FMT, E, W, FUSED>(ga, item - ga.cutJobs, smem, cachedCall, cachedCutoff);
     }
-    if (threadIdx.x == 0) {                                // the last workgroup out rewinds the queues for the next launch
+    if (threadIdx.x == 0) {                                // the last workgroup out rewinds the queues (and flags) for the next launch
         const uint32_t gone = __hip_atomic_fetch_add(&ga.queue[8 * 16], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (gone == gridDim.x - 1u) {
             for (int i = 0; i <= 8; i++) __hip_atomic_store(&ga.queue[i * 16], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int i = 0; i < kMaxGroup; i++) __hip_atomic_store(&ga.queue[9 * 16 + i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }

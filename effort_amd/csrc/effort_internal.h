@@ -71,10 +71,12 @@ struct GroupKArgs {
     uint32_t totalTiles;           // sum of tiles: the workgroup that finishes the last tile folds the timing stamps
     uint32_t persistent;           // 0: one workgroup per item; R > 0: numCU*R persistent workgroups pull items from the queues
     uint32_t numCU;
-    uint32_t ablate;               // profiling only (env EFFORT_ABLATE): 2 = no last-arriver reduce, 4 = no row streaming, 8 = no selection
+    uint32_t ablate;               // profiling only (env EFFORT_ABLATE): 2 = no last-arriver reduce, 4 = no row streaming, 8 = no selection, 32 = never wait for a cutoff job
     uint32_t split;                // 1: the cutoffs were evaluated by find_cutoff_group_kernel (split mode); 0: in the multiply kernel
+    uint32_t cutJobs;              // persistent launches: the first cutJobs items (a multiple of 8 >= count) are cutoff jobs, one per call
+    uint32_t pad0;
     uint32_t* groupDone;           // counter of finished tiles (zero between launches)
-    uint32_t* queue;               // [9][16]: per-XCD item cursors (one cache line each) + exit counter; zero between launches
+    uint32_t* queue;               // [9][16]: per-XCD item cursors (one cache line each) + exit counter, then [32] cutoff-ready flags; zero between launches
     float* slabs;                  // context scratch the calls index into
     uint32_t* counters;
     uint32_t* sliceCounts;
