@@ -40,6 +40,33 @@ __device__ __forceinline__ float block_max(float x, float* red) {
 __global__ __launch_bounds__(1024) void add_rmsnorm_mul_kernel(float* __restrict__ h, const float* __restrict__ delta,
                                                                const uint16_t* __restrict__ w, float* __restrict__ out, uint32_t n) {
     __shared__ float red[17];
+    // One memory round trip: every load (h, delta, the norm weights) is issued before anything is used, the updated state
+    // stays in registers for the second half (n <= 4 * 1024 elements per register slot; a longer state takes the loop
+    // below).  This kernel sits on the decode loop's dependent chain twice per layer.
+    constexpr int K = 4;
+    if (n <= K * 1024u) {
+        float x[K], d[K], wf[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const uint32_t i = min(k * 1024u + threadIdx.x, n - 1u);               // clamped, branch-free
+            x[k] = h[i];
+            d[k] = delta ? delta[i] : 0.0f;
+            wf[k] = half_bits_to_float(w[i]);
+        }
+        float ss = 0.0f;
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const bool live = k * 1024u + threadIdx.x < n;
+            x[k] += d[k];
+            if (live && delta) h[k * 1024u + threadIdx.x] = x[k];
+            ss += live ? x[k] * x[k] : 0.0f;
+        }
+        const float inv = 1.0f / sqrtf(block_sum(ss, red) / (float)n + 1e-5f);            // aux.metal:150
+#pragma unroll
+        for (int k = 0; k < K; k++)
+            if (k * 1024u + threadIdx.x < n) out[k * 1024u + threadIdx.x] = (x[k] * inv) * wf[k];
+        return;
+    }
     float ss = 0.0f;
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
         float x = h[i];
