@@ -195,6 +195,8 @@ def main():
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if rank != 0:
+            os.dup2(2, 1)        # only rank 0 owns stdout (RCCL prints banners there); the others' goes to stderr
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import effort_amd as ea
@@ -478,6 +480,13 @@ def main():
                 result["cpu_baseline"] = {"error": repr(ex)}
 
     if rank == 0:
+        # RCCL writes a version banner to C stdout, which (a pipe) only drains at exit: push it out first so that the JSON
+        # line is the last thing this process prints
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(result), flush=True)
     if dist:
         dist.destroy_process_group()
