@@ -446,6 +446,40 @@ def test_group_launch_persistent_workgroups(ea, oracle_cpu, per_cu, n_calls):
         g.set_tuning(0, 0, 0)
 
 
+def test_cutoff_jobs_under_graph_replay(ea, oracle_cpu):
+    """A persistent 32-call launch evaluates each call's cutoff once, in a job its items wait for (flag in device memory,
+    lowered by the last workgroup out).  Replayed from ONE hipGraph with the inputs changed in place between replays, every
+    replay must see the cutoffs of ITS inputs -- a flag or value left over from the previous replay would show here."""
+    outDim, inDim, n_calls = 4096, 4096, 32
+    W, b, s, p = converted(oracle_cpu, outDim, inDim)
+    ew = gpu_weights(ea, W, b, s, p)
+    g = ea.gpu()
+    vs = [torch.zeros(inDim, device=DEV) for _ in range(n_calls)]
+    outs = [torch.zeros(outDim, device=DEV) for _ in range(n_calls)]
+    calls = [(vs[i], ew, None, outs[i], (0.1, 0.25, 0.5, 0.8)[i % 4]) for i in range(n_calls)]
+    try:
+        g.set_tuning(8, 1, 32)                     # 4 tiles x 32 slices per call = 4096 items: a persistent launch
+        ea.bucketMulGroup(calls)                   # warm
+        g.eval()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            ea.bucketMulGroup(calls)
+        g._bind_stream()
+    finally:
+        g.set_tuning(0, 0, 0)
+    for rep in range(6):
+        hv = [make_v(inDim, seed=1000 * rep + i, heavy=bool((i + rep) & 1)) * (1.0 + rep) for i in range(n_calls)]
+        for i in range(n_calls):
+            vs[i].copy_(devf(hv[i]))
+            outs[i].fill_(float("nan"))
+        graph.replay()
+        g.eval()
+        for i in (0, 5, 17, 31, rep):
+            want, n, cutoff = oracle_cpu.bucket_mul(hv[i], b, s, p, inDim, outDim, calls[i][4])
+            assert g.last_cutoff(i) == cutoff and g.last_dispatch_count(i) == n, (rep, i)
+            assert close(outs[i].cpu().numpy(), want), (rep, i)
+
+
 def test_group_launch_q4(ea, oracle_cpu, q4_case):
     W, L, inDim, outDim = q4_case
     ews = [ea.ExpertWeights(dev16(L["buckets"]), devf(L["bucket.stats"]), dev16(L["probes"]), inSize=inDim, outSize=outDim,
