@@ -72,6 +72,7 @@ _SIGS = {
     "effort_set_tuning": (C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
     "effort_enable_kernel_timing": (C.c_int, [_P, C.c_int]),
     "effort_debug_stamps": (C.c_int, [_P, C.POINTER(C.c_ulonglong)]),
+    "effort_debug_trace": (C.c_int, [_P, C.POINTER(C.c_ulonglong), C.c_int]),
     "effort_kernel_clock": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "effort_kernel_timing": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
 }

@@ -12,6 +12,8 @@
 
 using namespace effort;
 
+static constexpr size_t kStampBytes = (size_t)(kTraceOff + kTraceItems * 8) * 8;   // phase stamps + per-item trace records
+
 struct effort_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -45,6 +47,7 @@ struct effort_ctx {
     // optional per-kernel timing
     bool timing = false;          // HIP events around each kernel
     bool clock = false;           // device wall-clock stamps inside the multiply kernel
+    bool trace = false;           // ... plus one record per work item (effort_debug_trace)
     static constexpr int kMaxSamples = 4096;
     hipEvent_t* ev = nullptr;         // 4 events per sample
     int nSamples = 0;
@@ -94,12 +97,12 @@ extern "C" effort_ctx* effort_create(int device, void* stream) {
     bool ok = hipMalloc(&c->d_cutoff, 512) == hipSuccess && hipMalloc(&c->d_count, 16) == hipSuccess &&
               hipMalloc(&c->d_slabs, c->slabBytes) == hipSuccess && hipMalloc(&c->d_blockScratch, 4096 * 4) == hipSuccess &&
               hipMalloc(&c->d_cos, 16) == hipSuccess && hipMalloc(&c->d_status, 16) == hipSuccess &&
-              hipMalloc(&c->d_tstamp, 4096) == hipSuccess && hipMalloc(&c->d_counters, effort_ctx::kMaxTiles * 4) == hipSuccess &&
+              hipMalloc(&c->d_tstamp, kStampBytes) == hipSuccess && hipMalloc(&c->d_counters, effort_ctx::kMaxTiles * 4) == hipSuccess &&
               hipMalloc(&c->d_sliceCounts, effort_ctx::kMaxSlices * 4) == hipSuccess && hipMalloc(&c->d_queue, 11 * 16 * 4) == hipSuccess;
     if (!ok) { effort_destroy(c); return nullptr; }
     int khz = 0;
     if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0) c->wallClockKHz = khz;
-    hipMemset(c->d_tstamp, 0, 4096);
+    hipMemset(c->d_tstamp, 0, kStampBytes);
     hipMemset(c->d_counters, 0, effort_ctx::kMaxTiles * 4);
     hipMemset(c->d_sliceCounts, 0, effort_ctx::kMaxSlices * 4);
     hipMemset(c->d_queue, 0, 11 * 16 * 4);
@@ -209,7 +212,7 @@ extern "C" void effort_weights_free(effort_w* w) {
 // ---- launch geometry ----------------------------------------------------------------------------
 static bool supported(int W, int E) {
     // must match EFFORT_GEOMS in bucket_mul.hip
-    return (W == 16 && (E == 1 || E == 2)) || (W == 8 && (E == 1 || E == 2 || E == 4)) ||
+    return (W == 16 && (E == 1 || E == 2 || E == 4)) || (W == 8 && (E == 1 || E == 2 || E == 4)) ||
            (W == 4 && (E == 1 || E == 2 || E == 4 || E == 8)) || (W == 2 && (E == 4 || E == 8));
 }
 
@@ -251,7 +254,7 @@ static int pick_elems(const effort_ctx* c, Format fmt, int n, const effort_w* co
     return (i2 * 10u < numCU * 3u / 4u * 6u && items(1) > i2) ? 1 : 2;
 }
 
-static int choose_geom(const effort_ctx* c, const effort_w* w, int groupSize, int E, MulGeom* g, int* Wout, int* Eout) {
+static int choose_geom(const effort_ctx* c, const effort_w* w, int groupSize, int E, MulGeom* g, int* Wout, int* Eout, uint32_t sliceMult = 1) {
     const int W = c->tuneW ? c->tuneW : 8;                 // 8 waves per workgroup
     if (!supported(W, E)) return EFFORT_ERR_ARG;
     const uint32_t nacc = w->fmt == kFp16 ? 16 : 32;
@@ -263,7 +266,7 @@ static int choose_geom(const effort_ctx* c, const effort_w* w, int groupSize, in
     uint32_t S;
     if (c->tuneS) S = c->tuneS;                            // any count: the item grid is padded to a multiple of 8 slices
     else {
-        const uint32_t want = pick_slices(c, w, groupSize, E);
+        const uint32_t want = pick_slices(c, w, groupSize, E) * sliceMult;
         const uint32_t cap = (c->numCU * 2u) / g->tiles / 8 * 8;              // one round of workgroups
         S = cap < want ? cap : want;
     }
@@ -322,7 +325,7 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
         ga.groupDone = c->d_counters + effort_ctx::kMaxTiles - 1;
         ga.slabs = c->d_slabs; ga.counters = c->d_counters; ga.sliceCounts = c->d_sliceCounts; ga.cutoff = c->d_cutoff + firstCall;
         ga.tstamp = c->clock ? c->d_tstamp : nullptr;
-        ga.ablate = ablate; ga.split = c->splitCutoff ? 1u : 0u;
+        ga.ablate = ablate; ga.split = c->splitCutoff ? 1u : 0u; ga.trace = (c->clock && c->trace) ? 1u : 0u;
         ga.numCU = (uint32_t)c->numCU; ga.queue = c->d_queue;
         nGeoms = 0; wg = 0; first = firstCall;
     };
@@ -346,7 +349,17 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
         MulGeom g;
         memset(&g, 0, sizeof(g));
         int Wi, Ei;
-        int rc = choose_geom(c, w, n, groupE, &g, &Wi, &Ei);
+        // The calls at the END of a big group are cut into thinner slices: their items are the last ones the persistent
+        // workgroups pull, and the launch ends when the last item does -- a tail of short items instead of long ones.
+        uint32_t mult = 1;
+        if (n >= 8 && !c->tuneS) {
+            static const int tailCalls = getenv("EFFORT_TAIL_CALLS") ? atoi(getenv("EFFORT_TAIL_CALLS")) : -1;     // profiling knobs
+            static const int tailMult = getenv("EFFORT_TAIL_MULT") ? atoi(getenv("EFFORT_TAIL_MULT")) : 2;
+            const int tc = tailCalls >= 0 ? tailCalls : n / 4;
+            if (i >= n - tc) mult = (uint32_t)tailMult;
+            if (tailMult >= 4 && i >= n - tc && i < n - tc / 2) mult = (uint32_t)tailMult / 2;      // two steps: ... x2 x2 x4 x4
+        }
+        int rc = choose_geom(c, w, n, groupE, &g, &Wi, &Ei, mult);
         if (rc != EFFORT_OK) return fail(c, rc, "bucketmul: no launch geometry for this shape/tuning");
         if (i == 0) { W = Wi; E = Ei; }
         else if (Wi != W || Ei != E) return fail(c, EFFORT_ERR_SHAPE, "bucketmul: the calls of a group must agree on the kernel variant");
@@ -589,8 +602,10 @@ extern "C" int effort_set_split_cutoff(effort_ctx* c, int split) {
 extern "C" int effort_enable_kernel_timing(effort_ctx* c, int enable) {
     if (!c) return EFFORT_ERR_ARG;
     if (enable == 1) { int rc = ensure_timing(c); if (rc != EFFORT_OK) return rc; }
-    c->timing = enable == 1;      // 1: events + device clock, 2: device clock only (graph-capture safe)
+    c->timing = enable == 1;      // 1: events + device clock, 2: device clock only (graph-capture safe), 3: 2 + per-item trace
     c->clock = enable != 0;
+    c->trace = enable == 3;
+    if (c->trace) HIP_TRY(c, hipMemsetAsync(c->d_tstamp + kTraceOff, 0, (size_t)kTraceItems * 64, c->stream));
     c->nSamples = 0;
     HIP_TRY(c, hipMemsetAsync(c->d_tstamp, 0, 4096, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_tstamp, 0xFF, 8, c->stream));
@@ -604,6 +619,13 @@ extern "C" int effort_debug_stamps(effort_ctx* c, unsigned long long* host32) {
     HIP_TRY(c, hipMemcpyAsync(lines, c->d_tstamp + 64, sizeof(lines), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     for (int i = 0; i < 8; i++) { host32[24 + i] = 0; for (int l = 0; l < 32; l++) host32[24 + i] += lines[l * 8 + i]; }   // all-workgroup phase sums
+    return EFFORT_OK;
+}
+
+extern "C" int effort_debug_trace(effort_ctx* c, unsigned long long* host, int maxRecords) {
+    if (!c || !host || maxRecords < 1 || maxRecords > kTraceItems) return EFFORT_ERR_ARG;
+    HIP_TRY(c, hipMemcpyAsync(host, c->d_tstamp + kTraceOff, (size_t)maxRecords * 64, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     return EFFORT_OK;
 }
 

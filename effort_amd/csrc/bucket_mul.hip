@@ -163,7 +163,9 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     float* const a_cutoff = ga.cutoff + ci;
     // XCD-aware id -> (tile, slice): all tiles of a slice run on one XCD (speed only).
     const uint32_t b = item - (ci ? ga.wgEnd[ci - 1] : 0u), xcd = b & 7u, k = b >> 3;
-    const uint32_t s = (k / g.tiles) * 8u + xcd, t = k % g.tiles;
+    // (the slice <-> XCD assignment rotates with the call: calls sharing an input vector -- Wq|Wk|Wv, or a batch on one v --
+    //  have the same heavy and light slices, and an XCD that got the same slice of every call would finish 15 % late)
+    const uint32_t s = (k / g.tiles) * 8u + ((xcd + ci) & 7u), t = k % g.tiles;
     if (s >= g.slices) return;
 
     int tid0 = threadIdx.x;
@@ -605,6 +607,14 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     // the stamps are flushed off the critical path (after the ticket), spread over 32 cache lines
     auto flush_stamps = [&]() {
         if (!wstamp) return;
+        if (ga.trace && item + ga.cutJobs < (uint32_t)kTraceItems) {           // one record per item: who / where / when
+            unsigned long long* rec = ga.tstamp + kTraceOff + (size_t)(item + ga.cutJobs) * 8u;
+            rec[0] = (unsigned long long)(item + ga.cutJobs) | ((unsigned long long)blockIdx.x << 32);
+            rec[1] = (unsigned long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xFu) | ((unsigned long long)(n & 0xFFFFu) << 8) | ((unsigned long long)(t & 0xFFu) << 24) |
+                     ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 32);   // XCC_ID | kept rows | tile | HW_ID
+#pragma unroll
+            for (int i = 0; i < 6; i++) rec[2 + i] = ph[i];
+        }
         unsigned long long* line = ga.tstamp + 64 + (item & 31u) * 8u;
 #pragma unroll
         for (int i = 0; i < 5; i++) atomicAdd(&line[i], ph[i + 1] - ph[i]);
@@ -722,7 +732,14 @@ __device__ __forceinline__ void cutoff_job(const GroupKArgs& ga, uint32_t ci, ch
     float vj[VPT]; uint16_t prj[VPT];
 #pragma unroll
     for (int i = 0; i < VPT; i++) { vj[i] = a.v[tid + NT * i]; prj[i] = pr[tid + NT * i]; }
+    const unsigned long long tj0 = (ga.tstamp && ga.trace) ? wall_clock64() : 0ull;
     const float cutoff = block_find_cutoff<NT>(vj, prj, a.q, smem + cutoff_table_bytes(NT), reinterpret_cast<uint32_t*>(smem), []() {}, nullptr);
+    if (tid == 0 && ga.tstamp && ga.trace) {
+        unsigned long long* rec = ga.tstamp + kTraceOff + (size_t)ci * 8u;
+        rec[0] = (unsigned long long)ci | ((unsigned long long)blockIdx.x << 32) | (1ull << 63);
+        rec[1] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 32);
+        rec[2] = tj0; rec[3] = wall_clock64();
+    }
     if (tid == 0) {
         __hip_atomic_store(reinterpret_cast<uint32_t*>(ga.cutoff + ci), __float_as_uint(cutoff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the value has left the CU before the flag does
@@ -743,10 +760,21 @@ __global__ __launch_bounds__(64 * W, (W <= 8 ? EFFORT_MIN_WAVES_PER_EU : 4)) voi
     const uint32_t total = ga.wgEnd[ga.count - 1] + ga.cutJobs;
     uint32_t cachedCall = 0xFFFFFFFFu; float cachedCutoff = 0.0f;
     const uint32_t x = blockIdx.x & 7u;                    // block b sits on XCD b%8; item i wants XCD i%8
+    uint32_t dry = 0;                                      // (thread 0) queues found empty: when its own XCD's queue is dry a workgroup takes items of the others
     for (uint32_t it = 0;; it++) {
         uint32_t item = blockIdx.x;
         if (ga.persistent) {                               // uniform
-            if (threadIdx.x == 0) s_item = __hip_atomic_fetch_add(&ga.queue[x * 16u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * 8u + x;
+            if (threadIdx.x == 0) {
+                uint32_t got = total;
+                for (uint32_t tries = 0; tries < 8u && got >= total; tries++) {
+                    const uint32_t q = (x + tries) & 7u;
+                    if ((dry >> q) & 1u) continue;
+                    const uint32_t cand = __hip_atomic_fetch_add(&ga.queue[q * 16u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * 8u + q;
+                    if (cand < total) got = cand; else dry |= 1u << q;
+                    if (ga.ablate & 64u) break;            // (ablate 64: no stealing)
+                }
+                s_item = got;
+            }
             __syncthreads();
             item = __builtin_amdgcn_readfirstlane(s_item);   // uniform by construction: keep everything derived from it scalar
             __syncthreads();
@@ -806,7 +834,7 @@ static hipError_t launch_mul_t(const GroupKArgs& ga, hipStream_t st) {
     return hipGetLastError();
 }
 
-#define EFFORT_GEOMS(X) X(16, 1) X(16, 2) X(8, 1) X(8, 2) X(8, 4) X(4, 1) X(4, 2) X(4, 4) X(4, 8) X(2, 4) X(2, 8)
+#define EFFORT_GEOMS(X) X(16, 1) X(16, 2) X(16, 4) X(8, 1) X(8, 2) X(8, 4) X(4, 1) X(4, 2) X(4, 4) X(4, 8) X(2, 4) X(2, 8)
 
 template <int FMT>
 static hipError_t launch_mul_fmt(int W, int E, const GroupKArgs& a, hipStream_t st) {

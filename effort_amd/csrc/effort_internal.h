@@ -42,7 +42,8 @@ struct OutlierIndex {          // by-output CSR of the Q4 outliers, built at reg
 // are copied when a launch is captured into a hipGraph): a compact descriptor per call, the few distinct launch
 // geometries of the group, and the bases of the context scratch the calls index into.
 constexpr int kMaxGroup = 32;        // calls per launch
-constexpr int kMaxGeoms = 4;         // distinct (shape, slicing) geometries per launch
+constexpr int kMaxGeoms = 4;
+constexpr int kTraceOff = 512, kTraceItems = 4096;   // per-item trace records: u64 index into the stamp buffer / capacity         // distinct (shape, slicing) geometries per launch
 enum Prologue : uint16_t { kPreNone = 0, kPreSiluGate = 1, kPreRmsNorm = 2 };
 struct CallDesc {                    // 112 bytes
     const uint16_t* buckets;
@@ -74,7 +75,7 @@ struct GroupKArgs {
     uint32_t ablate;               // profiling only (env EFFORT_ABLATE): 2 = no last-arriver reduce, 4 = no row streaming, 8 = no selection, 32 = never wait for a cutoff job
     uint32_t split;                // 1: the cutoffs were evaluated by find_cutoff_group_kernel (split mode); 0: in the multiply kernel
     uint32_t cutJobs;              // persistent launches: the first cutJobs items (a multiple of 8 >= count) are cutoff jobs, one per call
-    uint32_t pad0;
+    uint32_t trace;                // profiling only: 1 = every item leaves a 64-byte record (who ran it, where, its phase stamps) at tstamp + kTraceOff
     uint32_t* groupDone;           // counter of finished tiles (zero between launches)
     uint32_t* queue;               // [9][16]: per-XCD item cursors (one cache line each) + exit counter, then [32] cutoff-ready flags; zero between launches
     float* slabs;                  // context scratch the calls index into

@@ -73,6 +73,12 @@ class Gpu:
         self.check(self._lib.effort_debug_stamps(self.ctx, buf), "debug_stamps")
         return list(buf)
 
+    def debug_trace(self, n: int = 4096):
+        """Per-item records of the most recent multiply launch in timing mode 3: list of 8-tuples of ints."""
+        buf = (C.c_ulonglong * (8 * n))()
+        self.check(self._lib.effort_debug_trace(self.ctx, buf, n), "debug_trace")
+        return [tuple(buf[8 * i:8 * i + 8]) for i in range(n)]
+
     def kernel_timing(self):
         mul, cut, integ, n = C.c_double(), C.c_double(), C.c_double(), C.c_int()
         self.check(self._lib.effort_kernel_timing(self.ctx, C.byref(mul), C.byref(cut), C.byref(integ), C.byref(n)), "kernel_timing")

@@ -220,7 +220,7 @@ EFFORT_API int effort_set_split_cutoff(effort_ctx* ctx, int split);
 /* Timing hooks.  enable = 1: HIP events are recorded on the context's stream around each of the three
  * kernels of a call (not capturable into a graph) AND the multiply kernel stamps the device wall clock
  * at its first workgroup's start / last workgroup's end; enable = 2: device clock only (works inside
- * hipGraph replays); 0: off.  effort_kernel_timing returns event-to-event averages in microseconds
+ * hipGraph replays); 3: 2 plus a per-item trace (effort_debug_trace); 0: off.  effort_kernel_timing returns event-to-event averages in microseconds
  * (they include the launch gap in front of each kernel); effort_kernel_clock returns the multiply
  * kernel's own average duration (first start -> last end).  Both reset their accumulators. */
 EFFORT_API int effort_enable_kernel_timing(effort_ctx* ctx, int enable);
@@ -229,6 +229,10 @@ EFFORT_API int effort_kernel_clock(effort_ctx* ctx, double* mul_us_avg, int* n_l
 /* resident workgroups per CU the runtime grants the (q4, waves, elems) multiply kernel at ldsBytes of LDS */
 EFFORT_API int effort_debug_occupancy(effort_ctx* ctx, int q4, int waves, int elems, int ldsBytes);
 EFFORT_API int effort_debug_stamps(effort_ctx* ctx, unsigned long long* host32);
+/* enable = 3 (device clock + trace): every work item of the most recent multiply launch leaves a 64-byte record
+ * {item | workgroup << 32 (bit 63: cutoff job), XCC_ID | HW_ID << 32, six device wall-clock stamps: start, staged,
+ * cutoff, selected, streamed, handed over}; copies the first maxRecords (<= 4096) records to host (8 u64 each). */
+EFFORT_API int effort_debug_trace(effort_ctx* ctx, unsigned long long* host, int maxRecords);
 EFFORT_API int effort_kernel_timing(effort_ctx* ctx, double* mul_us_avg, double* cutoff_us_avg,
                          double* integrate_us_avg, int* n_samples);
 
