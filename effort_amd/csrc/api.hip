@@ -279,7 +279,8 @@ static int choose_geom(const effort_ctx* c, const effort_w* w, int groupSize, in
         g->sliceLog2 = 0; while ((1u << g->sliceLog2) < g->sliceRows) g->sliceLog2++;
         g->slots = w->fmt == kFp16 ? (g->rowsPerIn << g->sliceLog2) : g->sliceRows * 8u;
         const size_t lds = bucket_mul_lds_bytes(w->fmt, W, E, *g);
-        const bool fits = lds <= ldsMax && g->sliceRows <= (w->fmt == kFp16 ? 4096u : 8192u) && g->slots <= maxCand;
+        const bool fits = lds <= ldsMax && g->slots <= maxCand && (size_t)g->slots * 4 + (size_t)g->sliceRows * 8 + 1024 <= 65536 &&   // staged regions below 64 KB
+                          (w->fmt == kFp16 ? (1u << g->sliceLog2) <= 64u * (uint32_t)W : g->sliceRows <= 128u * (uint32_t)W);   // a thread stages one (Q4: two) inputs of the slice
         const size_t slab = (size_t)g->slices * g->tiles * g->tileFloats * 4;
         if (fits && slab <= c->slabBytes) break;
         if (!fits) { S += 1; if (S > w->inDim + 8) return EFFORT_ERR_SHAPE; }
@@ -445,6 +446,13 @@ extern "C" int effort_group_dispatch_count(effort_ctx* c, int idx, uint32_t* hos
     for (uint32_t i = 0; i < c->lastSlices[idx]; i++) n += h[i];
     *host_out = n;
     return EFFORT_OK;
+}
+extern "C" int effort_debug_slice_counts(effort_ctx* c, int idx, uint32_t* host, int maxSlices) {
+    if (!c || !host || idx < 0 || (uint32_t)idx >= c->lastCalls || maxSlices < 1) return EFFORT_ERR_ARG;
+    const uint32_t n = c->lastSlices[idx] < (uint32_t)maxSlices ? c->lastSlices[idx] : (uint32_t)maxSlices;
+    if (n) HIP_TRY(c, hipMemcpyAsync(host, c->d_sliceCounts + c->lastSliceOff[idx], (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return (int)n;
 }
 extern "C" int effort_group_cutoff(effort_ctx* c, int idx, float* host_out) {
     if (!c || !host_out || idx < 0 || (uint32_t)idx >= c->lastCalls) return EFFORT_ERR_ARG;

@@ -47,6 +47,12 @@ namespace effort {
 #define EFFORT_KBATCH 16
 #endif
 constexpr int kBatch = EFFORT_KBATCH;   // bucket rows per batch; two batches in flight per wave
+#ifndef EFFORT_KBATCH4
+#define EFFORT_KBATCH4 8
+#endif
+// 8-byte pieces (E = 4) fly 8 per batch: the same bytes in flight per wave as 16 4-byte pieces, in half the registers (the
+// freed ones hold the next item's staged loads across the streaming phase)
+template <int E> __host__ __device__ constexpr int batch_rows() { return E >= 4 ? EFFORT_KBATCH4 : kBatch; }
 constexpr int kRounds = 16;  // selection rounds of NT candidate slots a workgroup can run: slots per slice <= kRounds * NT
 
 // Ablation builds for profiling (-DEFFORT_ABLATE_NOSCATTER=1 / -DEFFORT_ABLATE_NOLOAD=1); never shipped.
@@ -124,49 +130,149 @@ template <int E> __host__ __device__ inline uint32_t ol_scratch_bytes(const MulG
     return 2u * align_up(ol_outputs_per_item<E>(g) * 4u, 16u) + (g.inDim <= kOlLdsFloats ? g.inDim * 4u : 0u);      // sums hi | lo | v
 }
 
-// LDS carve (bytes): { acc[tileFloats] i32 | list[slots] u16 }  (the cutoff's lookup table borrows this first region:
-// it is dead before the tile is zeroed and the list written)  | means[slots] f16 / f32 | vblk[B] f32 | misc 2 KB.
-// Q4: after the streaming phase list | means | vblk are dead and hold the outlier phase's scratch (sums | whole v).
+// LDS carve (bytes), one plan for the whole launch (the largest of its geometries, so that a persistent workgroup can stage
+// its NEXT item -- possibly of another geometry -- while the current one still uses its regions):
+//   means[slots] one dword per candidate slot | vblk[2][B] f32, alternating between consecutive items |
+//   { acc[tileFloats] i32 | list[slots] u16 }  (the cutoff's lookup table and the tile reduction's partial sums borrow this
+//   region: the table is dead before the tile is zeroed and the list written, the tile is dead when it is reduced) | misc 2 KB.
+// means / vblk are filled by LDS-direct buffer loads (stage_issue), whose destination (M0) is kept below 64 KB.  Q4: after
+// the streaming phase means | vblk are dead and hold the outlier phase's scratch (sums | whole v); Q4 items are not
+// pipelined and use vblk[0] only.
+struct LdsPlan { uint32_t offM, offV[2], offA, offL, offC, total; };
 template <int FMT, int E, int W>
-__host__ __device__ inline uint32_t lds_layout(const MulGeom& g, uint32_t* offV, uint32_t* offC, uint32_t* offL, uint32_t* offM) {
-    const uint32_t B = g.sliceRows, slots = g.slots;
-    uint32_t o = (uint32_t)Fmt<FMT>::kSlots * E * 64 * 4;
-    *offL = o; o += align_up(slots * 2, 16);
-    const uint32_t tbl = cutoff_table_bytes(64 * W);
-    if (o < tbl) o = tbl;
-    *offM = o; o += align_up(slots * (uint32_t)sizeof(typename MeanT<FMT>::type), 16);
-    *offV = o; o += align_up(B * 4, 16);
-    if (FMT == kQ4 && o < *offL + ol_scratch_bytes<E>(g)) o = *offL + ol_scratch_bytes<E>(g);
-    *offC = o; o += 2048;           // [0..255] cutoff scratch, [256..1279] ballot counts [kRounds][W], [1280] flags, [1344..1407] wave bounds, [1408..1471] Q4 outlier bounds
-    return o;
+__host__ __device__ inline LdsPlan plan_lds(const MulGeom* geoms, int nGeoms) {
+    uint32_t slots = 0, vrows = 0, ol = 0;
+    for (int i = 0; i < nGeoms; i++) {
+        const MulGeom& g = geoms[i];
+        if (!g.slices) continue;                            // unused entry
+        slots = slots > g.slots ? slots : g.slots;
+        const uint32_t vr = align_up(g.sliceRows, 64);      // the loads land a whole wave (64 dwords) at a time
+        vrows = vrows > vr ? vrows : vr;
+        if (FMT == kQ4) { const uint32_t x = ol_scratch_bytes<E>(g); ol = ol > x ? ol : x; }
+    }
+    LdsPlan p;
+    uint32_t o = 0;
+    p.offM = o; o += align_up(slots, 64) * 4;
+    p.offV[0] = o; o += vrows * 4;
+    p.offV[1] = FMT == kFp16 ? o : p.offV[0];
+    if (FMT == kFp16) o += vrows * 4;
+    if (FMT == kQ4 && o < ol) o = align_up(ol, 16);
+    p.offA = o; o += (uint32_t)Fmt<FMT>::kSlots * E * 64 * 4;
+    p.offL = o; o += align_up(slots * 2, 16);
+    const uint32_t tbl = cutoff_table_bytes(64 * W);        // (>= the tile reduction's [G][tileFloats] partial sums)
+    if (o < p.offA + tbl) o = p.offA + tbl;
+    p.offC = o; o += 2048;           // [0..255] cutoff scratch, [1280] flags, [1344..1407] wave bounds, [1408..1471] Q4 outlier bounds
+    p.total = o;
+    return p;
+}
+// Where a work item sits: which call of the group, which (tile, slice) of it.  All workgroup-uniform.
+struct ItemRef { uint32_t ci, t, s; };
+
+// `item` numbers the items the way a plain grid would number its blocks (item % 8 = the XCD it should run on).
+__device__ __forceinline__ bool locate_item(const GroupKArgs& ga, const uint32_t item, ItemRef& r) {
+    // which call of the group this item belongs to (item ranges are multiples of 8, so item%8 is still the XCD)
+    uint32_t ci = 0;
+    for (uint32_t i = 0; i + 1 < ga.count; i++) if (item >= ga.wgEnd[i]) ci = i + 1;
+    ci = __builtin_amdgcn_readfirstlane(ci);
+    const MulGeom& g = ga.geom[ga.call[ci].geom];
+    // XCD-aware id -> (tile, slice): all tiles of a slice run on one XCD (speed only).
+    const uint32_t b = item - (ci ? ga.wgEnd[ci - 1] : 0u), xcd = b & 7u, k = b >> 3;
+    // (the slice <-> XCD assignment rotates with the call: calls sharing an input vector -- Wq|Wk|Wv, or a batch on one v --
+    //  have the same heavy and light slices, and an XCD that got the same slice of every call would finish 15 % late)
+    r.ci = ci; r.s = (k / g.tiles) * 8u + ((xcd + ci) & 7u); r.t = k % g.tiles;
+    return r.s < g.slices;
+}
+
+// Phase A of an item, issued: the row means of its candidate slots and its slice of v travel from memory straight into
+// LDS (buffer_load ... lds: no registers, nothing to wait for until the item needs them).  A persistent workgroup ISSUES
+// these loads for its NEXT item right before it streams the current one, so the round trip (2-3 us, during which the
+// workgroup would ask nothing of HBM) hides under ~50 us of streaming.
+// Candidate slot c of the slice, in ascending bucket-row order:
+//   FP16 -> rank = c >> lg, jl = c & (2^lg - 1), 2^lg >= B   (rank-major rows, convert.metal:83-100; v index = row % inDim)
+//   Q4   -> jl = c >> 3,  rank = c & 7                        (input-major rows, bucketMulQ4.metal:46)
+// Thread tid owns the slots r*NT + tid: lane l of wave w lands its dword at means[r*NT + w*64 + l] (the destination of an
+// LDS-direct load is a wave-uniform base + 4*lane).  FP16: the dword holding stats lanes .z|.w (the mean the keep test
+// reads is .w, the high half); Q4: stats lane .y as f32.  Slots past the slice load the slice's first row; the keep test
+// knows which slots exist.  v: thread tid lands v[j0 + tid (+ NT)] at vblk[tid (+ NT)] of buffer `par`.
+// One LDS-direct load: every lane's dword at byte offset `voff` of the buffer lands at LDS byte address ldsAddr + 4*lane
+// (ldsAddr wave-uniform, below 64 KB).  Issued from inline asm so that hipcc does not know about it: with the builtin, every
+// later wait on an ordinary load in the same loop degrades to vmcnt(0).  The price: hipcc's counted waits see these loads
+// as its own youngest ones, so the first wait after an issue drains the wave's batches in flight once.  Completion is
+// awaited explicitly (s_waitcnt vmcnt(0)) where the data is read.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void lds_dma_dword(const u32x4 rsrc, const uint32_t voff, const uint32_t ldsAddr) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dword %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(ldsAddr), "s"(rsrc) : "memory");
+}
+__device__ __forceinline__ u32x4 make_rsrc(const void* base, uint32_t bytes) {
+    const uint64_t p = (uint64_t)(size_t)base;
+    u32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((uint32_t)p); r[1] = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32) & 0xFFFFu);
+    r[2] = __builtin_amdgcn_readfirstlane(bytes); r[3] = 0x00020000u;
+    return r;
+}
+
+template <int FMT, int W>
+__device__ __forceinline__ void stage_issue(const GroupKArgs& ga, const ItemRef& r, const int tid, char* smem, const LdsPlan& lp, const uint32_t par) {
+    constexpr int NT = 64 * W;
+    using lds_v = __attribute__((address_space(3))) void;
+    const CallDesc& a = ga.call[__builtin_amdgcn_readfirstlane(r.ci)];
+    const MulGeom& g = ga.geom[a.geom];
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t B = g.sliceRows, j0 = __builtin_amdgcn_readfirstlane(r.s) * B, nb = min(B, g.inDim - j0), lg = g.sliceLog2;
+    const uint32_t e = a.expNo ? a.expNo[0] : 0u;
+    const uint32_t rowBase = e * g.expertRows;
+    const uint32_t rowsPerIn = g.rowsPerIn, inDim = g.inDim, mask = (1u << lg) - 1u;
+    const uint32_t nSlots = FMT == kFp16 ? (rowsPerIn << lg) : (nb << 3);
+    const u32x4 rs = make_rsrc(a.stats, (uint32_t)((size_t)g.numExperts * g.expertRows * 8u));
+    const u32x4 rv = make_rsrc(a.v, inDim * 4u);
+    const uint32_t ldsM = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(lds_v*)(smem + lp.offM));
+    const uint32_t ldsV = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(lds_v*)(smem + lp.offV[par & 1u]));
+#pragma unroll
+    for (int rr = 0; rr < kRounds; rr++) {
+        if ((uint32_t)(rr * NT) + wave * 64u >= nSlots) continue;   // uniform per wave: none of its 64 slots exists
+        const uint32_t c = rr * NT + tid;
+        uint32_t voff;
+        if (FMT == kFp16) {
+            const uint32_t rank = c >> lg, jl = c & mask;
+            const bool ok = rank < rowsPerIn && jl < nb;
+            voff = (rowBase + (ok ? rank * inDim + j0 + jl : j0)) * 8u + 4u;
+        } else {
+            voff = ((rowBase + j0 * 8u + (c < nSlots ? c : 0u)) * 2u + 1u) * 4u;
+        }
+        lds_dma_dword(rs, voff, ldsM + ((uint32_t)(rr * NT) + wave * 64u) * 4u);
+    }
+#pragma unroll
+    for (int u = 0; u < (FMT == kFp16 ? 1 : 2); u++) {
+        if ((uint32_t)(u * NT) + wave * 64u >= nb) continue;    // uniform per wave (reads past inDim return 0; past the slice, a neighbour's input nobody looks at)
+        lds_dma_dword(rv, (j0 + (uint32_t)(u * NT + tid)) * 4u, ldsV + ((uint32_t)(u * NT) + wave * 64u) * 4u);
+    }
 }
 
 // One work item = one (call, tile, slice) of the group: stage, select, stream, hand the partial tile over.
-// `item` numbers the items the way a plain grid would number its blocks (item % 8 = the XCD it should run on).
-template <int FMT, int E, int W, bool FUSED>
-__device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t item, char* smem, uint32_t& cachedCall, float& cachedCutoff) {
+// `staged` (per wave): this wave's share of the item's stage loads was issued while the previous item streamed (into vblk
+// buffer `par`).  `prefetch` is polled by every wave near the end of its streaming loop until it returns true: there the
+// caller pulls the next item from the queue (wave 0) and issues the wave's share of its stage loads (into buffer par ^ 1).
+template <int FMT, int E, int W, bool FUSED, typename Prefetch>
+__device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t item, const ItemRef& ref, char* smem, const LdsPlan& lp, uint32_t& cachedCall,
+                                         float& cachedCutoff, const uint32_t par, const bool staged, Prefetch prefetch) {
     constexpr int NACC = Fmt<FMT>::kAcc;
     constexpr int TILE_F = NACC * E * 64;                    // outputs of a tile (slab / out[] granularity)
     constexpr int TILE_L = Fmt<FMT>::kSlots * E * 64;        // LDS accumulators of a tile
     constexpr int NT = 64 * W;
     constexpr int VPT = 4096 / NT;
+    constexpr int KB = batch_rows<E>();                      // bucket rows per batch; two batches in flight per wave
 
-    // which call of the group this item belongs to (item ranges are multiples of 8, so item%8 is still the XCD)
-    uint32_t ci = 0;
-    for (uint32_t i = 0; i + 1 < ga.count; i++) if (item >= ga.wgEnd[i]) ci = i + 1;
-    ci = __builtin_amdgcn_readfirstlane(ci);
+    // (uniform, and the compiler must know it: everything derived from these -- descriptors, buffer resources -- stays scalar)
+    const uint32_t ci = __builtin_amdgcn_readfirstlane(ref.ci), s = __builtin_amdgcn_readfirstlane(ref.s), t = __builtin_amdgcn_readfirstlane(ref.t);
     const CallDesc& a = ga.call[ci];
     const MulGeom& g = ga.geom[a.geom];
     float* const a_slabs = ga.slabs + (size_t)a.slabOff * 64u;
     uint32_t* const a_counters = ga.counters + a.tileOff;
     uint32_t* const a_sliceCounts = ga.sliceCounts + a.sliceOff;
     float* const a_cutoff = ga.cutoff + ci;
-    // XCD-aware id -> (tile, slice): all tiles of a slice run on one XCD (speed only).
-    const uint32_t b = item - (ci ? ga.wgEnd[ci - 1] : 0u), xcd = b & 7u, k = b >> 3;
-    // (the slice <-> XCD assignment rotates with the call: calls sharing an input vector -- Wq|Wk|Wv, or a batch on one v --
-    //  have the same heavy and light slices, and an XCD that got the same slice of every call would finish 15 % late)
-    const uint32_t s = (k / g.tiles) * 8u + ((xcd + ci) & 7u), t = k % g.tiles;
-    if (s >= g.slices) return;
+    const uint32_t b = item - (ci ? ga.wgEnd[ci - 1] : 0u);
 
     int tid0 = threadIdx.x;
     asm volatile("" : "+v"(tid0));      // opaque per item: keeps the compiler from hoisting every tid-derived value out of the item loop (+50 VGPRs)
@@ -182,25 +288,22 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     if (stamp) ga.tstamp[16] = wall_clock64();
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t B = g.sliceRows;
-    uint32_t offV, offC, offL, offM;
-    lds_layout<FMT, E, W>(g, &offV, &offC, &offL, &offM);
-    int* acc = reinterpret_cast<int*>(smem);                                 // ONE fixed-point tile shared by the W waves
-    float* vblk = reinterpret_cast<float*>(smem + offV);
-    uint32_t* wcnt = reinterpret_cast<uint32_t*>(smem + offC + 256);         // [kRounds][W]
-    uint32_t* flags = reinterpret_cast<uint32_t*>(smem + offC + 1280);
+    const uint32_t offC = __builtin_amdgcn_readfirstlane(lp.offC), offL = __builtin_amdgcn_readfirstlane(lp.offL), offM = __builtin_amdgcn_readfirstlane(lp.offM);
+    const uint32_t offA = __builtin_amdgcn_readfirstlane(lp.offA);
+    int* acc = reinterpret_cast<int*>(smem + offA);                          // ONE fixed-point tile shared by the W waves
+    float* vblk = reinterpret_cast<float*>(smem + __builtin_amdgcn_readfirstlane(lp.offV[par & 1u]));
+    uint32_t* flags = reinterpret_cast<uint32_t*>(smem + offC + 1280);       // [0] last arriver, [2..3] cutoff job verdict, [4] list length
     float* wbound = reinterpret_cast<float*>(smem + offC + 1344);            // [16] per-wave sums of |v_j| over the slice
     uint16_t* list = reinterpret_cast<uint16_t*>(smem + offL);
-    typename MeanT<FMT>::type* means = reinterpret_cast<typename MeanT<FMT>::type*>(smem + offM);
+    const uint32_t* m32 = reinterpret_cast<const uint32_t*>(smem + offM);   // one dword per candidate slot (see stage_issue)
+    const float* means = reinterpret_cast<const float*>(smem + offM);        // Q4: the row means as f32
 
     const uint32_t j0 = s * B;
     const uint32_t nb = min(B, g.inDim - j0);
     const uint32_t e = a.expNo ? a.expNo[0] : 0u;
 
-    // ---- A. stage everything the selection needs in LDS, in one round trip ------------------------
-    // Candidate slot c of the slice, in ascending bucket-row order:
-    //   FP16 -> rank = c >> lg, jl = c & (2^lg - 1), 2^lg >= B   (rank-major rows, convert.metal:83-100; v index = row % inDim)
-    //   Q4   -> jl = c >> 3,  rank = c & 7                        (input-major rows, bucketMulQ4.metal:46)
-    // means[c] = the row mean the keep test reads (f16 bits for FP16, f32 for Q4); slots past the slice hold 0.
+    // ---- A. everything the selection needs lands in LDS (stage_issue): the row means of the candidate slots, the slice of v
+    if (!staged) stage_issue<FMT, W>(ga, ref, tid, smem, lp, par);
     float vj[VPT]; uint16_t prj[VPT];
     const uint16_t* pr = a.probes + (size_t)e * kProbes;
     const bool fused = ga.split == 0u;                           // uniform
@@ -217,34 +320,6 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     for (int i = 0; i < VPT; i++) rawn[i] = (FUSED && pre == kPreRmsNorm) ? a.v[tid + NT * i] : 0.0f;
     const uint32_t lg = g.sliceLog2;
     const uint32_t nSlots = FMT == kFp16 ? (g.rowsPerIn << lg) : (nb << 3);
-    const uint32_t rounds = (nSlots + NT - 1) / NT;              // <= kRounds (checked at launch)
-    {
-        // branch-free: every load is issued (slots past the slice read the slice's first row and are zeroed after),
-        // so the loads go out back to back and the whole staging costs one round trip
-        typename MeanT<FMT>::type tmp[kRounds];
-        const size_t rowBase = (size_t)e * g.expertRows;
-        const uint32_t rowsPerIn = g.rowsPerIn, inDim = g.inDim, mask = (1u << lg) - 1u;
-        const uint16_t* st16 = reinterpret_cast<const uint16_t*>(a.stats);
-        const float* st32 = reinterpret_cast<const float*>(a.stats);
-#pragma unroll
-        for (int r = 0; r < kRounds; r++) {
-            const uint32_t c = r * NT + tid;
-            if (FMT == kFp16) {
-                const uint32_t rank = c >> lg, jl = c & mask;
-                const bool ok = rank < rowsPerIn && jl < nb;
-                const size_t row = rowBase + (ok ? (size_t)rank * inDim + j0 + jl : (size_t)j0);
-                tmp[r] = st16[row * 4 + 3];
-                tmp[r] = ok ? tmp[r] : (uint16_t)0;
-            } else {
-                const bool ok = c < nSlots;
-                tmp[r] = st32[(rowBase + (size_t)j0 * 8u + (ok ? c : 0u)) * 2 + 1];
-                tmp[r] = ok ? tmp[r] : 0.0f;
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < kRounds; r++)
-            if ((uint32_t)(r * NT) + tid < nSlots) means[r * NT + tid] = tmp[r];
-    }
     float normInv = 1.0f;
     if (FUSED && pre == kPreRmsNorm) {
         float ss = 0.0f;
@@ -261,8 +336,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
         normInv = 1.0f / sqrtf(tot / (float)g.inDim + 1e-5f);                  // aux.metal:150
         __syncthreads();                                                         // wbound is reused below
     }
-    auto input = [&](uint32_t j) -> float {
-        const float x = a.v[j];
+    auto xform = [&](float x, uint32_t j) -> float {               // the input prologue applied to v[j]
         if (!FUSED) return x;
         if (pre == kPreSiluGate) return reinterpret_cast<const float*>(a.vAux)[j] * x / (1.0f + expf(-x));
         if (pre == kPreRmsNorm) return (x * normInv) * half_bits_to_float(reinterpret_cast<const uint16_t*>(a.vAux)[j]);
@@ -272,24 +346,35 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
 #pragma unroll
         for (int i = 0; i < VPT; i++) {
             vj[i] = (FUSED && pre == kPreRmsNorm) ? (rawn[i] * normInv) * half_bits_to_float(reinterpret_cast<const uint16_t*>(a.vAux)[tid + NT * i])
-                                                  : input(tid + NT * i);
+                                                  : xform(a.v[tid + NT * i], tid + NT * i);
             prj[i] = pr[tid + NT * i];
         }
     };
     if (needCut && !viaJob) load_cut_inputs();
-    // stage the slice of v; its absolute sum bounds every partial sum of this workgroup (see the scale below)
+    // the staged loads have landed (each thread waits for its own; it reads back only what its own lane loaded until the
+    // next barrier).  The slice's absolute sum bounds every partial sum of this workgroup (see the scale below).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     float bound = 0.0f;
-    for (uint32_t jl = tid; jl < nb; jl += NT) { const float x = input(j0 + jl); vblk[jl] = x; bound += fabsf(x); }
+#pragma unroll
+    for (int u = 0; u < (FMT == kFp16 ? 1 : 2); u++) {
+        const uint32_t jl = tid + u * NT;
+        if (jl < nb) {
+            float x = vblk[jl];
+            if (FUSED) { x = xform(x, j0 + jl); vblk[jl] = x; }
+            bound += fabsf(x);
+        }
+    }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) bound += __shfl_xor(bound, off);
     if (lane == 0) wbound[wave] = bound;
+    if (tid == 0) flags[4] = 0u;                                  // the list is empty
     const float rankBound = a.rankBound[e];
     if (stamp) ga.tstamp[17] = wall_clock64();
     if (wstamp) ph[1] = wall_clock64();
 
-    // ---- B. cutoff (findCutoff32), redundantly per workgroup; its first barrier also publishes means / vblk /
-    //         wbound.  Its lookup table borrows the accumulator + list region, which is initialised afterwards. ------
-    uint32_t* tbl = reinterpret_cast<uint32_t*>(smem);
+    // ---- B. cutoff (findCutoff32), redundantly per workgroup; its first barrier also publishes vblk / wbound.
+    //         Its lookup table borrows the accumulator + list region, which is initialised afterwards. ------
+    uint32_t* tbl = reinterpret_cast<uint32_t*>(smem + offA);
     float cutoff;
     bool fromJob = false;
     if (viaJob) {
@@ -305,7 +390,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
             flags[2] = ok;
             if (ok) flags[3] = __hip_atomic_load(reinterpret_cast<uint32_t*>(a_cutoff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        __syncthreads();                                             // publishes means / vblk / wbound, and the verdict
+        __syncthreads();                                             // publishes vblk / wbound / the list length, and the verdict
         fromJob = flags[2] != 0u;
         if (fromJob) { cutoff = __uint_as_float(flags[3]); cachedCall = ci; cachedCutoff = cutoff; }
         else load_cut_inputs();
@@ -318,12 +403,12 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     } else if (fused) {
         cutoff = cachedCutoff;
         if (b == 0 && tid == 0 && !ga.cutJobs) a_cutoff[0] = cutoff;
-        __syncthreads();                                             // publishes means / vblk / wbound
+        __syncthreads();                                             // publishes vblk / wbound / the list length
     } else {
         // split mode: the standalone cutoff kernel ran first on this stream (cheaper in aggregate when several
         // calls overlap: one workgroup evaluates it instead of all of them)
         cutoff = a_cutoff[0];
-        __syncthreads();                                             // publishes means / vblk / wbound
+        __syncthreads();                                             // publishes vblk / wbound / the list length
     }
     for (int i = tid; i < TILE_L; i += NT) acc[i] = 0;               // the table is dead: zero the tile (barrier in C)
     // Fixed-point scale of this workgroup's tile.  Every product is |v_j| * |w| with |w| <= (max |w| of its rank), so
@@ -341,52 +426,44 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     if (stamp) ga.tstamp[18] = wall_clock64();
     if (wstamp) ph[2] = wall_clock64();
 
-    // ---- C. keep test (bucketMul.metal:69 / bucketMulQ4.metal:47) + ordered compaction -----------
-    // `rounds` rounds of NT slots each.  Pass 1 tests and ballots every round (keeping the verdicts in a bit mask) and
-    // leaves the per-(round, wave) counts in LDS; after ONE barrier each wave derives the list offset of each of its
-    // ballots (kept slots of earlier rounds + earlier waves of the round); pass 2 writes the survivors: list position
-    // = that offset + earlier lanes of the wave.  No atomics, ascending bucket-row order.
-    auto keep_test = [&](uint32_t c) -> bool {
-        if (c >= nSlots || (ga.ablate & 8u)) return false;
-        if (FMT == kFp16) {
-            const uint32_t jl = c & ((1u << lg) - 1u);
-            const float x = jl < nb ? vblk[jl] : 0.0f;
-            return cutoff < (kCutoffScale * half_bits_to_float((uint16_t)means[c])) * fabsf(x);
-        } else {
-            return cutoff < (kCutoffScale * (float)means[c]) * fabsf(vblk[c >> 3]);
-        }
-    };
+    // ---- C. keep test (bucketMul.metal:69 / bucketMulQ4.metal:47) + compaction -------------------
+    // Every thread tests its slot of each round against the means it holds in registers (FP16: all its slots belong to ONE
+    // input row, whose |v| it reads once), ballots, and a wave sums its survivors; ONE LDS atomic per wave reserves that
+    // many list entries, and the survivors are written at (wave base + survivors of the wave's earlier rounds + earlier
+    // lanes of the ballot).  The list order therefore depends on the order in which the waves arrive -- it does not
+    // matter: every listed row is added with integer arithmetic (see D), and the reference's own list is appended with an
+    // atomic counter in no particular order (bucketMul.metal:71).
+    float ax = 0.0f;
+    if (FMT == kFp16) { const uint32_t jl = (uint32_t)tid & ((1u << lg) - 1u); ax = jl < nb ? fabsf(vblk[jl]) : 0.0f; }
     uint32_t keepMask = 0;                                  // bit r: this thread's slot of round r is kept
+    uint32_t before[kRounds];                               // (wave-uniform) survivors of the wave's earlier rounds
+    uint32_t wtot = 0;
 #pragma unroll
-    for (int r = 0; r < kRounds; r++) {
-        if ((uint32_t)(r * NT) >= nSlots) break;            // uniform
-        const bool k = keep_test(r * NT + tid);
-        keepMask |= k ? (1u << r) : 0u;
+    for (int rr = 0; rr < kRounds; rr++) {
+        before[rr] = wtot;
+        if ((uint32_t)(rr * NT) >= nSlots) continue;        // uniform
+        const uint32_t c = rr * NT + tid;
+        bool k;
+        if (FMT == kFp16) k = (c >> lg) < g.rowsPerIn && cutoff < (kCutoffScale * half_bits_to_float((uint16_t)(m32[c] >> 16))) * ax;
+        else k = c < nSlots && cutoff < (kCutoffScale * means[c]) * fabsf(vblk[min(c >> 3, nb - 1u)]);
+        k = k && !(ga.ablate & 8u);
+        keepMask |= k ? (1u << rr) : 0u;
+        wtot += (uint32_t)__popcll(__ballot(k));
+    }
+    uint32_t wbase = 0;
+    if (lane == 0) wbase = atomicAdd(&flags[4], wtot);
+    wbase = __builtin_amdgcn_readfirstlane(wbase);
+#pragma unroll
+    for (int rr = 0; rr < kRounds; rr++) {
+        if ((uint32_t)(rr * NT) >= nSlots) continue;        // uniform
+        const uint32_t c = rr * NT + tid;
+        const bool k = (keepMask >> rr) & 1u;
         const unsigned long long m = __ballot(k);
-        if (lane == 0) wcnt[r * W + wave] = (uint32_t)__popcll(m);
-    }
-    __syncthreads();
-    uint32_t rowsum = 0, part = 0;                        // lane r < rounds: kept in round r (all waves / the earlier waves)
-    if ((uint32_t)lane < rounds) {
-#pragma unroll
-        for (int w2 = 0; w2 < W; w2++) { const uint32_t x = wcnt[lane * W + w2]; rowsum += x; part += (w2 < wave) ? x : 0u; }
-    }
-    uint32_t inc = rowsum;
-#pragma unroll
-    for (int off = 1; off < kRounds; off <<= 1) {
-        const uint32_t o = __shfl_up(inc, off);
-        inc += (lane >= off) ? o : 0u;
-    }
-    const uint32_t basev = inc - rowsum + part;
-    const uint32_t n = __shfl(inc, kRounds - 1);          // lanes >= rounds add nothing: the total
-    for (uint32_t r = 0; r < rounds; r++) {
-        const uint32_t c = r * NT + tid;
-        const bool k = (keepMask >> r) & 1u;
-        const unsigned long long m = __ballot(k);
-        const uint32_t pos = __builtin_amdgcn_readlane(basev, r) + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        const uint32_t pos = wbase + before[rr] + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
         if (k) list[pos] = (uint16_t)(FMT == kFp16 ? (((c >> lg) << 12) | (c & ((1u << lg) - 1u))) : c);
     }
     __syncthreads();
+    const uint32_t n = flags[4];
     if (t == 0 && tid == 0) a_sliceCounts[s] = n;                  // dispatch.size = sum over slices (test hook)
     if (stamp) ga.tstamp[19] = wall_clock64();
     if (wstamp) ph[3] = wall_clock64();
@@ -401,27 +478,27 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     const uint32_t myRows = (nU > (uint32_t)wave) ? (nU - wave + W - 1) / W : 0u;   // entries wave, wave+W, ...
 
     // Software pipeline: the loads of batch k+1 are issued before batch k is accumulated, so a wave keeps
-    // up to 2*kBatch row pieces in flight.  Loads are never predicated: a batch that runs past the wave's
+    // up to 2*KB row pieces in flight.  Loads are never predicated: a batch that runs past the wave's
     // last row re-reads that last row (an L1/L2 hit) -- a branch around a load makes hipcc drain
     // vmcnt(0) -- and the accumulate step skips the surplus with a wave-uniform test.
     auto decode = [&](uint32_t i0, uint32_t& boff, float& dv) {
         // lane u decodes list entry i0+u (clamped); the row loops read it back with v_readlane into SGPRs
         boff = 0; dv = 0.0f;
-        if (lane < kBatch && myRows) {
+        if (lane < KB && myRows) {
             const uint32_t kk = wave + W * min(i0 + (uint32_t)lane, myRows - 1u);
             const uint32_t code = list[kk];
             uint32_t rowIdx;
             if (FMT == kFp16) { const uint32_t rank = code >> 12, jl = code & 4095u; rowIdx = rank * g.inDim + j0 + jl; dv = vblk[jl] * scale; }
             else {   // entry value = v*mean (bucketMulQ4.metal:52), the one magnitude of the row; carried in fixed point
                 rowIdx = j0 * 8u + code;
-                dv = __int_as_float(__float2int_rn((vblk[code >> 3] * (float)means[code]) * scale));
+                dv = __int_as_float(__float2int_rn((vblk[code >> 3] * means[code]) * scale));
             }
             boff = (e * g.expertRows + rowIdx) * g.cols * 2u;       // byte offset of the bucket row (< 4 GiB, checked at registration)
         }
     };
-    auto issue = [&](Piece<E> (&piece)[kBatch], uint32_t boff) {
+    auto issue = [&](Piece<E> (&piece)[KB], uint32_t boff) {
 #pragma unroll
-        for (int u = 0; u < kBatch; u++) piece[u].load(rsrc, voff, EFFORT_ABLATE_NOLOAD ? 0u : __builtin_amdgcn_readlane(boff, u));
+        for (int u = 0; u < KB; u++) piece[u].load(rsrc, voff, EFFORT_ABLATE_NOLOAD ? 0u : __builtin_amdgcn_readlane(boff, u));
     };
     // One row piece -> E (Q4: 4E) integer LDS atomics on the workgroup's tile.  Why fixed point: a float
     // read-add-write needs a PRIVATE tile per wave (W x the LDS, so two workgroups per CU at best) and two LDS
@@ -464,37 +541,45 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
             }
         }
     };
-    auto accumulate = [&](const Piece<E> (&piece)[kBatch], float dv, uint32_t nv) {
+    auto accumulate = [&](const Piece<E> (&piece)[KB], float dv, uint32_t nv) {
         if (EFFORT_ABLATE_NOSCATTER) {       // ablation build: keep the loads live, skip the LDS scatter
 #pragma unroll
-            for (int u = 0; u < kBatch; u++) asm volatile("" ::"v"(piece[u].word(E - 1)), "v"(dv));
+            for (int u = 0; u < KB; u++) asm volatile("" ::"v"(piece[u].word(E - 1)), "v"(dv));
             return;
         }
         if (!colOK) return;                  // lanes past the last column sit the batch out (one exec change)
-        if (nv == (uint32_t)kBatch) {        // uniform: full batch, no per-row test
+        if (nv == (uint32_t)KB) {        // uniform: full batch, no per-row test
 #pragma unroll
-            for (int u = 0; u < kBatch; u++) row(piece[u], __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(dv), u)));
+            for (int u = 0; u < KB; u++) row(piece[u], __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(dv), u)));
         } else {
 #pragma unroll
-            for (int u = 0; u < kBatch; u++)
+            for (int u = 0; u < KB; u++)
                 if ((uint32_t)u < nv) row(piece[u], __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(dv), u)));
         }
     };
 
+    // Near the end of its rows (the last two rounds of the loop: a few microseconds of streaming left) a wave asks for the
+    // next item: late enough that the queue still balances the workgroups, early enough that the staged loads land under
+    // the remaining rows.
+    bool asked = false;
+    // (measured: raising the wave priority of this loop -- s_setprio 2 -- so that a co-resident workgroup's selection does not
+    //  take its issue slots is 8 % SLOWER per launch: the other workgroup's head then takes that much longer)
     if (myRows) {
-        Piece<E> pa[kBatch], pb[kBatch];
+        Piece<E> pa[KB], pb[KB];
         uint32_t boffA, boffB; float dvA, dvB;
         decode(0, boffA, dvA);
         issue(pa, boffA);
-        for (uint32_t i0 = 0; i0 < myRows; i0 += 2 * kBatch) {
-            decode(i0 + kBatch, boffB, dvB);
+        for (uint32_t i0 = 0; i0 < myRows; i0 += 2 * KB) {
+            if (!asked && myRows - i0 <= 4u * KB) asked = prefetch();
+            decode(i0 + KB, boffB, dvB);
             issue(pb, boffB);
-            accumulate(pa, dvA, __builtin_amdgcn_readfirstlane(min((uint32_t)kBatch, myRows - i0)));
-            decode(i0 + 2 * kBatch, boffA, dvA);
+            accumulate(pa, dvA, __builtin_amdgcn_readfirstlane(min((uint32_t)KB, myRows - i0)));
+            decode(i0 + 2 * KB, boffA, dvA);
             issue(pa, boffA);
-            accumulate(pb, dvB, __builtin_amdgcn_readfirstlane(i0 + kBatch < myRows ? min((uint32_t)kBatch, myRows - i0 - kBatch) : 0u));
+            accumulate(pb, dvB, __builtin_amdgcn_readfirstlane(i0 + KB < myRows ? min((uint32_t)KB, myRows - i0 - KB) : 0u));
         }
     }
+    if (!asked) asked = prefetch();            // (a wave without rows; wave 0 always gets an answer: it is the one that pulls)
     __syncthreads();                           // every wave's atomics have landed in the tile
     if (stamp) ga.tstamp[20] = wall_clock64();
     if (wstamp) ph[4] = wall_clock64();
@@ -511,7 +596,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     //         calls per launch / alone: a kernel of its own with a wave per output 8.3 / 33.5 us; eight lanes per
     //         output 5.2 / 32.5; this phase 4.6 / 29.0 -- what is left is the 7.2 MB of entries per call, more bytes
     //         than the 25 %-effort bucket rows (5.6 MB). ---------------------------------------------------------
-    int* const olacc = reinterpret_cast<int*>(smem + offL);
+    int* const olacc = reinterpret_cast<int*>(smem + offM);            // (means | vblk are dead by now)
     const uint32_t olPer = ol_outputs_per_item<E>(g), olLoOff = align_up(olPer * 4u, 16u) / 4u;
     bool olAny = false;
     float olUnscale = 0.0f;
@@ -646,7 +731,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     // group then has at most 16 slices = ONE round trip; the groups' partial sums meet in LDS and are added in group order.
     constexpr int kCols4 = TILE_F / 4;
     constexpr int G = NT / kCols4 >= 2 ? NT / kCols4 : 1;
-    float* const gpart = reinterpret_cast<float*>(smem);            // [G][TILE_F]; the accumulator region is free by now
+    float* const gpart = reinterpret_cast<float*>(smem + offA);     // [G][TILE_F]; the accumulator | list region is free by now
     auto reduce_tile = [&](auto kc) {
         constexpr int kRed = decltype(kc)::value;          // 16-byte slab loads in flight per thread
         const int grp = G > 1 ? tid / kCols4 : 0;
@@ -757,38 +842,77 @@ template <int FMT, int E, int W, bool FUSED>
 __global__ __launch_bounds__(64 * W, (W <= 8 ? EFFORT_MIN_WAVES_PER_EU : 4)) void bucket_mul_kernel(const GroupKArgs ga) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ uint32_t s_item;
+    __shared__ uint32_t s_next[2];                         // the item after the current one, and the generation (item count) it was pulled in
     const uint32_t total = ga.wgEnd[ga.count - 1] + ga.cutJobs;
     uint32_t cachedCall = 0xFFFFFFFFu; float cachedCutoff = 0.0f;
     const uint32_t x = blockIdx.x & 7u;                    // block b sits on XCD b%8; item i wants XCD i%8
     uint32_t dry = 0;                                      // (thread 0) queues found empty: when its own XCD's queue is dry a workgroup takes items of the others
-    for (uint32_t it = 0;; it++) {
-        uint32_t item = blockIdx.x;
-        if (ga.persistent) {                               // uniform
-            if (threadIdx.x == 0) {
-                uint32_t got = total;
-                for (uint32_t tries = 0; tries < 8u && got >= total; tries++) {
-                    const uint32_t q = (x + tries) & 7u;
-                    if ((dry >> q) & 1u) continue;
-                    const uint32_t cand = __hip_atomic_fetch_add(&ga.queue[q * 16u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * 8u + q;
-                    if (cand < total) got = cand; else dry |= 1u << q;
-                    if (ga.ablate & 64u) break;            // (ablate 64: no stealing)
-                }
-                s_item = got;
-            }
-            __syncthreads();
-            item = __builtin_amdgcn_readfirstlane(s_item);   // uniform by construction: keep everything derived from it scalar
-            __syncthreads();
-            if (item >= total) break;
-        } else if (it) {
-            return;
+    // thread 0: the next item of this XCD's queue, or -- that one dry -- of the next queue that still has one; `total` when all are dry
+    auto pull = [&]() -> uint32_t {
+        uint32_t got = total;
+        for (uint32_t tries = 0; tries < 8u && got >= total; tries++) {
+            const uint32_t q = (x + tries) & 7u;
+            if ((dry >> q) & 1u) continue;
+            const uint32_t cand = __hip_atomic_fetch_add(&ga.queue[q * 16u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * 8u + q;
+            if (cand < total) got = cand; else dry |= 1u << q;
+            if (ga.ablate & 64u) break;                    // (ablate 64: no stealing)
         }
+        return got;
+    };
+    auto pull_sync = [&]() -> uint32_t {                   // ... handed to the whole workgroup
+        if (threadIdx.x == 0) s_item = pull();
+        __syncthreads();
+        const uint32_t it = __builtin_amdgcn_readfirstlane(s_item);   // uniform by construction: keep everything derived from it scalar
+        __syncthreads();
+        return it;
+    };
+    // The loop is software-pipelined over the items of a persistent workgroup: near the end of item i's streaming phase wave 0
+    // pulls item i+1 from the queue and publishes it in LDS (s_next: item, generation); every wave that finds it there
+    // issues its share of item i+1's stage loads (row means + slice of v, stage_issue) under its remaining rows.  A wave that
+    // finishes its rows before the answer is there stages its share at the start of item i+1 instead.
+    constexpr bool kPipe = !FUSED && FMT == kFp16;         // (a fused input prologue transforms v in place; Q4's outlier phase reuses the staging region)
+    const LdsPlan lp = plan_lds<FMT, E, W>(ga.geom, kMaxGeoms);
+    uint32_t par = 0;                                      // vblk buffer of the current item
+    bool staged = false;                                   // (per wave) its share of the item's stage loads is already in flight / landed
+    uint32_t gen = 0;                                      // items this workgroup has worked
+    if (threadIdx.x == 0) s_next[1] = 0u;
+    uint32_t item = ga.persistent ? pull_sync() : blockIdx.x;
+    while (item < total) {
         if (item < ga.cutJobs) {                           // uniform: a cutoff job (the queues hand these out first)
             if (item < ga.count) cutoff_job<64 * W>(ga, item, smem);
+            item = ga.persistent ? pull_sync() : total;
             continue;
         }
-        mul_item<FMT, E, W, FUSED>(ga, item - ga.cutJobs, smem, cachedCall, cachedCutoff);
+        ItemRef ref;
+        if (!locate_item(ga, item - ga.cutJobs, ref)) {    // padding of the item grid (slices are dealt in rounds of 8)
+            item = ga.persistent ? pull_sync() : total;
+            continue;
+        }
+        gen++;
+        bool stagedNext = false;
+        mul_item<FMT, E, W, FUSED>(ga, item - ga.cutJobs, ref, smem, lp, cachedCall, cachedCutoff, par, staged, [&]() -> bool {
+            if (!ga.persistent) return true;
+            if (threadIdx.x == 0) {                                // wave 0's first call: pull, publish
+                s_next[0] = pull();
+                s_next[1] = gen;
+            }
+            if (__builtin_amdgcn_readfirstlane(s_next[1]) != gen) return false;   // no answer yet
+            const uint32_t next = __builtin_amdgcn_readfirstlane(s_next[0]);
+            ItemRef nref;
+            if (kPipe && !(ga.ablate & 128u) && next >= ga.cutJobs && next < total && locate_item(ga, next - ga.cutJobs, nref)) {
+                int tid0 = threadIdx.x;
+                asm volatile("" : "+v"(tid0));
+                stage_issue<FMT, W>(ga, nref, tid0, smem, lp, par ^ 1u);
+                stagedNext = true;
+            }
+            return true;
+        });
+        // (mul_item's barriers lie between wave 0's publication and this read)
+        item = ga.persistent ? __builtin_amdgcn_readfirstlane(s_next[0]) : total;
+        staged = stagedNext;
+        par ^= 1u;
     }
-    if (threadIdx.x == 0) {                                // the last workgroup out rewinds the queues (and flags) for the next launch
+    if (ga.persistent && threadIdx.x == 0) {               // the last workgroup out rewinds the queues (and flags) for the next launch
         const uint32_t gone = __hip_atomic_fetch_add(&ga.queue[8 * 16], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (gone == gridDim.x - 1u) {
             for (int i = 0; i <= 8; i++) __hip_atomic_store(&ga.queue[i * 16], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -800,12 +924,13 @@ __global__ __launch_bounds__(64 * W, (W <= 8 ? EFFORT_MIN_WAVES_PER_EU : 4)) voi
 // ---- host side ------------------------------------------------------------------------------
 template <int FMT, int E, int W>
 static hipError_t launch_mul_t(const GroupKArgs& ga, hipStream_t st) {
-    uint32_t o1, o2, o3, o4;
-    uint32_t lds = 0;
+    const LdsPlan lp = plan_lds<FMT, E, W>(ga.geom, kMaxGeoms);
+    uint32_t lds = lp.total;
+    if (lp.offA > 65536u && FMT == kFp16) return hipErrorInvalidValue;     // stage_issue's destinations sit below offA
     for (uint32_t i = 0; i < ga.count; i++) {
         const MulGeom& g = ga.geom[ga.call[i].geom];
-        lds = max(lds, lds_layout<FMT, E, W>(g, &o1, &o2, &o3, &o4));
         if (g.slots > (uint32_t)kRounds * 64 * W || g.slots != (FMT == kFp16 ? (g.rowsPerIn << g.sliceLog2) : g.sliceRows * 8u)) return hipErrorInvalidValue;
+        if (FMT == kFp16 ? (1u << g.sliceLog2) > 64u * W : g.sliceRows > 128u * W) return hipErrorInvalidValue;       // stage_issue: a thread lands one (Q4: two) inputs of the slice
         if (ga.wgEnd[i] - (i ? ga.wgEnd[i - 1] : 0u) != g.tiles * align_up(g.slices, 8)) return hipErrorInvalidValue;
     }
     static uint32_t maxSet = 0;   // per instantiation
@@ -849,11 +974,9 @@ hipError_t launch_bucket_mul(Format fmt, int W, int E, const GroupKArgs& a, hipS
 }
 
 size_t bucket_mul_lds_bytes(Format fmt, int W, int E, const MulGeom& g) {
-    uint32_t o1, o2, o3, o4;
 #define EFFORT_CASE(w, e)                                                                     \
     if (W == w && E == e)                                                                     \
-        return fmt == kFp16 ? lds_layout<kFp16, e, w>(g, &o1, &o2, &o3, &o4)           \
-                            : lds_layout<kQ4, e, w>(g, &o1, &o2, &o3, &o4);
+        return fmt == kFp16 ? plan_lds<kFp16, e, w>(&g, 1).total : plan_lds<kQ4, e, w>(&g, 1).total;
     EFFORT_GEOMS(EFFORT_CASE)
 #undef EFFORT_CASE
     return 0;

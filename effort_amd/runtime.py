@@ -73,6 +73,14 @@ class Gpu:
         self.check(self._lib.effort_debug_stamps(self.ctx, buf), "debug_stamps")
         return list(buf)
 
+    def slice_counts(self, idx: int = 0, n: int = 4096):
+        """Kept rows per row slice of call ``idx`` of the most recent launch (test hook)."""
+        buf = (C.c_uint32 * n)()
+        k = self._lib.effort_debug_slice_counts(self.ctx, int(idx), buf, n)
+        if k < 0:
+            self.check(k, "slice_counts")
+        return list(buf[:k])
+
     def debug_trace(self, n: int = 4096):
         """Per-item records of the most recent multiply launch in timing mode 3: list of 8-tuples of ints."""
         buf = (C.c_ulonglong * (8 * n))()

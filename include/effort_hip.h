@@ -229,6 +229,9 @@ EFFORT_API int effort_kernel_clock(effort_ctx* ctx, double* mul_us_avg, int* n_l
 /* resident workgroups per CU the runtime grants the (q4, waves, elems) multiply kernel at ldsBytes of LDS */
 EFFORT_API int effort_debug_occupancy(effort_ctx* ctx, int q4, int waves, int elems, int ldsBytes);
 EFFORT_API int effort_debug_stamps(effort_ctx* ctx, unsigned long long* host32);
+/* Test hook: kept rows per row slice of call idx of the most recent (group) launch (their sum is dispatch.size); returns the
+ * number of slices copied (<= maxSlices), or a negative error code. */
+EFFORT_API int effort_debug_slice_counts(effort_ctx* ctx, int idx, uint32_t* host, int maxSlices);
 /* enable = 3 (device clock + trace): every work item of the most recent multiply launch leaves a 64-byte record
  * {item | workgroup << 32 (bit 63: cutoff job), XCC_ID | HW_ID << 32, six device wall-clock stamps: start, staged,
  * cutoff, selected, streamed, handed over}; copies the first maxRecords (<= 4096) records to host (8 u64 each). */

@@ -1,0 +1,8 @@
+#!/bin/bash
+# tools/build_variant.sh NAME "-DFLAG=1 ..." : an A/B build of the multiply kernel -> build/variants/NAME.so (tools only)
+set -e
+cd "$(dirname "$0")/../effort_amd/csrc"
+mkdir -p ../../build/variants
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden -I/opt/rocm/include $2 -c bucket_mul.hip -o ../../build/variants/$1_bm.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o ../../build/variants/$1.so api.o ../../build/variants/$1_bm.o cutoff.o dispatch.o convert.o decode.o gemv.o -L/opt/rocm/lib -lrocblas -Wl,-rpath,/opt/rocm/lib
+rm -f ../../build/variants/$1_bm.o

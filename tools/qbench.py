@@ -1,0 +1,77 @@
+#!/usr/bin/env python
+"""Quick A/B timing of grouped bucketMul launches (hipGraph replays over 32 rotating matrices).
+
+    python tools/qbench.py --configs "0,0,0:-1;16,4,0:1" [--shape 4096x11008] [--effort 0.25] [--group 32] [--reps 3] [--q4 0]
+
+A config is waves,elems,slices:workgroups-per-CU.  Prints per config and repetition: us per launch (host clock around 200
+replays) and the in-kernel device-clock span.  Library under test: $EFFORT_HIP_LIB or the in-tree build.
+"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shape", default="4096x11008")
+    ap.add_argument("--effort", type=float, default=0.25)
+    ap.add_argument("--group", type=int, default=32)
+    ap.add_argument("--mats", type=int, default=32)
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--q4", type=int, default=0)
+    ap.add_argument("--configs", default="0,0,0:-1")
+    ap.add_argument("--tag", default="")
+    args = ap.parse_args()
+    inDim, outDim = (int(x) for x in args.shape.split("x"))
+    import effort_amd as ea
+    from bench import make_weights
+    dev = torch.device("cuda", 0)
+    g = ea.gpu(0)
+    ews = make_weights(ea, args.mats, inDim, outDim, 1234, dev, keep_core=False, q4=bool(args.q4))
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(42)
+    v = torch.randn(inDim, generator=gen, device=dev)
+    outs = [torch.zeros(outDim, device=dev) for _ in ews]
+    items = list(zip(ews, outs))
+    chunks = [items[i:i + args.group] for i in range(0, len(items), args.group)]
+    for rep in range(args.reps):
+        for cfg in args.configs.split(";"):
+            tune, per = cfg.split(":")
+            g.set_tuning(*(int(x) for x in tune.split(",")))
+            g.set_persistent(int(per))
+            def run():
+                for ch in chunks:
+                    ea.bucketMulGroup([(v, ew, None, o, args.effort) for ew, o in ch])
+
+            def timed(n):
+                run()
+                torch.cuda.synchronize()
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr):
+                    run()
+                g._bind_stream()
+                for _ in range(30):
+                    gr.replay()
+                torch.cuda.synchronize()
+                g.kernel_clock()
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    gr.replay()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t0) / n / len(chunks)
+            g.enable_kernel_timing(0)
+            dt = timed(300)
+            g.enable_kernel_timing(2)
+            timed(50)
+            kc = g.kernel_clock()
+            g.enable_kernel_timing(0)
+            print(f"{args.tag} rep {rep} cfg {cfg:14s} effort {args.effort} group {args.group}: {dt * 1e6:8.2f} us/launch  device-clock span {kc['mul_us']:8.2f} us", flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -96,6 +96,12 @@ def main():
         per = {}
         for k in order:
             per.setdefault(wg[k], []).append(k)
+        if len(jobs):
+            jwg = ((jobs[:, 0] >> np.uint64(32)) & np.uint64(0x7FFFFFFF)).astype(int)
+            print("   job workgroups:", sorted(jwg.tolist())[:40])
+            print("   next item after job / total:", jobs[:8, 4].tolist(), jobs[:8, 5].tolist())
+            print("   items run by job workgroups:", [len(per.get(w, [])) for w in sorted(jwg.tolist())][:40])
+            print("   workgroups without items:", sorted(set(range(int(wg.max()) + 1)) - set(wg.tolist()))[:40])
         cnt = np.bincount([len(x) for x in per.values()])
         print("   items per workgroup histogram:", {i: int(c) for i, c in enumerate(cnt) if c})
         for x in range(8):
