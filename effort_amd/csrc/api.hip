@@ -12,7 +12,7 @@
 
 using namespace effort;
 
-static constexpr size_t kStampBytes = (size_t)(kTraceOff + kTraceItems * 8) * 8;   // phase stamps + per-item trace records
+static constexpr size_t kStampBytes = (size_t)(kTraceOff + kTraceItems * 12) * 8;   // phase stamps + per-item trace records
 
 struct effort_ctx {
     int device = 0;
@@ -212,7 +212,7 @@ extern "C" void effort_weights_free(effort_w* w) {
 // ---- launch geometry ----------------------------------------------------------------------------
 static bool supported(int W, int E) {
     // must match EFFORT_GEOMS in bucket_mul.hip
-    return (W == 16 && (E == 1 || E == 2 || E == 4)) || (W == 8 && (E == 1 || E == 2 || E == 4)) ||
+    return (W == 16 && (E == 1 || E == 2 || E == 4 || E == 8)) || (W == 8 && (E == 1 || E == 2 || E == 4 || E == 8)) ||
            (W == 4 && (E == 1 || E == 2 || E == 4 || E == 8)) || (W == 2 && (E == 4 || E == 8));
 }
 
@@ -613,7 +613,7 @@ extern "C" int effort_enable_kernel_timing(effort_ctx* c, int enable) {
     c->timing = enable == 1;      // 1: events + device clock, 2: device clock only (graph-capture safe), 3: 2 + per-item trace
     c->clock = enable != 0;
     c->trace = enable == 3;
-    if (c->trace) HIP_TRY(c, hipMemsetAsync(c->d_tstamp + kTraceOff, 0, (size_t)kTraceItems * 64, c->stream));
+    if (c->trace) HIP_TRY(c, hipMemsetAsync(c->d_tstamp + kTraceOff, 0, (size_t)kTraceItems * 96, c->stream));
     c->nSamples = 0;
     HIP_TRY(c, hipMemsetAsync(c->d_tstamp, 0, 4096, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_tstamp, 0xFF, 8, c->stream));
@@ -633,6 +633,8 @@ extern "C" int effort_debug_stamps(effort_ctx* c, unsigned long long* host32) {
 extern "C" int effort_debug_trace(effort_ctx* c, unsigned long long* host, int maxRecords) {
     if (!c || !host || maxRecords < 1 || maxRecords > kTraceItems) return EFFORT_ERR_ARG;
     HIP_TRY(c, hipMemcpyAsync(host, c->d_tstamp + kTraceOff, (size_t)maxRecords * 64, hipMemcpyDeviceToHost, c->stream));
+    // (then, per item, four progress stamps of its streaming phase: wave 0 a quarter / half / three quarters through its rows)
+    HIP_TRY(c, hipMemcpyAsync(host + (size_t)maxRecords * 8, c->d_tstamp + kTraceOff + (size_t)kTraceItems * 8, (size_t)maxRecords * 32, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return EFFORT_OK;
 }

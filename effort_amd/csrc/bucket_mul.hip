@@ -367,7 +367,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) bound += __shfl_xor(bound, off);
     if (lane == 0) wbound[wave] = bound;
-    if (tid == 0) flags[4] = 0u;                                  // the list is empty
+    if (tid == 0) { flags[4] = 0u; flags[5] = 0u; }               // the list is empty, none of it handed out
     const float rankBound = a.rankBound[e];
     if (stamp) ga.tstamp[17] = wall_clock64();
     if (wstamp) ph[1] = wall_clock64();
@@ -475,7 +475,15 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
         const_cast<uint16_t*>(a.buckets), 0, (int)min((size_t)0xFFFFFFFFu, (size_t)g.numExperts * g.expertRows * g.cols * 2u), 0x00020000);
     const uint32_t voff = (colOK ? col : 0u) * 2u;                 // lanes past the last column re-read column 0
     const uint32_t nU = (ga.ablate & 4u) ? 0u : __builtin_amdgcn_readfirstlane(n);   // n is workgroup-uniform; keep it in an SGPR
-    const uint32_t myRows = (nU > (uint32_t)wave) ? (nU - wave + W - 1) / W : 0u;   // entries wave, wave+W, ...
+    // The waves of a workgroup do NOT run at one speed (the older wave wins the arbitration for issue slots and the memory
+    // pipeline: measured, wave 0 gets through a static share of the rows 2-3x sooner than the last wave and then idles at
+    // the barrier), so the list is handed out dynamically: a wave takes the next KB entries with one LDS atomic.
+    uint32_t* const cursor = flags + 5;
+    auto grab = [&]() -> uint32_t {
+        uint32_t bq = 0;
+        if (lane == 0) bq = atomicAdd(cursor, (uint32_t)KB);
+        return __builtin_amdgcn_readfirstlane(bq);
+    };
 
     // Software pipeline: the loads of batch k+1 are issued before batch k is accumulated, so a wave keeps
     // up to 2*KB row pieces in flight.  Loads are never predicated: a batch that runs past the wave's
@@ -484,8 +492,8 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     auto decode = [&](uint32_t i0, uint32_t& boff, float& dv) {
         // lane u decodes list entry i0+u (clamped); the row loops read it back with v_readlane into SGPRs
         boff = 0; dv = 0.0f;
-        if (lane < KB && myRows) {
-            const uint32_t kk = wave + W * min(i0 + (uint32_t)lane, myRows - 1u);
+        if (lane < KB && nU) {
+            const uint32_t kk = min(i0 + (uint32_t)lane, nU - 1u);
             const uint32_t code = list[kk];
             uint32_t rowIdx;
             if (FMT == kFp16) { const uint32_t rank = code >> 12, jl = code & 4095u; rowIdx = rank * g.inDim + j0 + jl; dv = vblk[jl] * scale; }
@@ -564,19 +572,25 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     bool asked = false;
     // (measured: raising the wave priority of this loop -- s_setprio 2 -- so that a co-resident workgroup's selection does not
     //  take its issue slots is 8 % SLOWER per launch: the other workgroup's head then takes that much longer)
-    if (myRows) {
+    {
         Piece<E> pa[KB], pb[KB];
         uint32_t boffA, boffB; float dvA, dvB;
-        decode(0, boffA, dvA);
-        issue(pa, boffA);
-        for (uint32_t i0 = 0; i0 < myRows; i0 += 2 * KB) {
-            if (!asked && myRows - i0 <= 4u * KB) asked = prefetch();
-            decode(i0 + KB, boffB, dvB);
+        uint32_t baseA = grab(), baseB;
+        if (baseA < nU) { decode(baseA, boffA, dvA); issue(pa, boffA); }
+        while (baseA < nU) {
+            if (!asked && nU - baseA <= 4u * KB * W) asked = prefetch();
+            if (wstamp && ga.trace && item + ga.cutJobs < (uint32_t)kTraceItems) {       // progress stamps (trace mode only)
+                const uint32_t q0 = (4u * baseA) / nU, q1 = min(4u, (4u * (baseA + 2u * KB * W)) / nU);
+                for (uint32_t q = q0 + 1u; q <= q1 && q < 4u; q++) ga.tstamp[kTraceOff + (size_t)kTraceItems * 8u + (size_t)(item + ga.cutJobs) * 4u + q - 1u] = wall_clock64();
+            }
+            baseB = grab();
+            decode(baseB, boffB, dvB);
             issue(pb, boffB);
-            accumulate(pa, dvA, __builtin_amdgcn_readfirstlane(min((uint32_t)KB, myRows - i0)));
-            decode(i0 + 2 * KB, boffA, dvA);
+            accumulate(pa, dvA, __builtin_amdgcn_readfirstlane(min((uint32_t)KB, nU - baseA)));
+            baseA = grab();
+            decode(baseA, boffA, dvA);
             issue(pa, boffA);
-            accumulate(pb, dvB, __builtin_amdgcn_readfirstlane(i0 + KB < myRows ? min((uint32_t)KB, myRows - i0 - KB) : 0u));
+            accumulate(pb, dvB, __builtin_amdgcn_readfirstlane(baseB < nU ? min((uint32_t)KB, nU - baseB) : 0u));
         }
     }
     if (!asked) asked = prefetch();            // (a wave without rows; wave 0 always gets an answer: it is the one that pulls)
@@ -959,7 +973,7 @@ static hipError_t launch_mul_t(const GroupKArgs& ga, hipStream_t st) {
     return hipGetLastError();
 }
 
-#define EFFORT_GEOMS(X) X(16, 1) X(16, 2) X(16, 4) X(8, 1) X(8, 2) X(8, 4) X(4, 1) X(4, 2) X(4, 4) X(4, 8) X(2, 4) X(2, 8)
+#define EFFORT_GEOMS(X) X(16, 1) X(16, 2) X(16, 4) X(16, 8) X(8, 1) X(8, 2) X(8, 4) X(8, 8) X(4, 1) X(4, 2) X(4, 4) X(4, 8) X(2, 4) X(2, 8)
 
 template <int FMT>
 static hipError_t launch_mul_fmt(int W, int E, const GroupKArgs& a, hipStream_t st) {

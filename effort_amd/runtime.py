@@ -83,9 +83,9 @@ class Gpu:
 
     def debug_trace(self, n: int = 4096):
         """Per-item records of the most recent multiply launch in timing mode 3: list of 8-tuples of ints."""
-        buf = (C.c_ulonglong * (8 * n))()
+        buf = (C.c_ulonglong * (12 * n))()
         self.check(self._lib.effort_debug_trace(self.ctx, buf, n), "debug_trace")
-        return [tuple(buf[8 * i:8 * i + 8]) for i in range(n)]
+        return [tuple(buf[8 * i:8 * i + 8]) + tuple(buf[8 * n + 4 * i:8 * n + 4 * i + 4]) for i in range(n)]
 
     def kernel_timing(self):
         mul, cut, integ, n = C.c_double(), C.c_double(), C.c_double(), C.c_int()

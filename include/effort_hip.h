@@ -234,7 +234,8 @@ EFFORT_API int effort_debug_stamps(effort_ctx* ctx, unsigned long long* host32);
 EFFORT_API int effort_debug_slice_counts(effort_ctx* ctx, int idx, uint32_t* host, int maxSlices);
 /* enable = 3 (device clock + trace): every work item of the most recent multiply launch leaves a 64-byte record
  * {item | workgroup << 32 (bit 63: cutoff job), XCC_ID | HW_ID << 32, six device wall-clock stamps: start, staged,
- * cutoff, selected, streamed, handed over}; copies the first maxRecords (<= 4096) records to host (8 u64 each). */
+ * cutoff, selected, streamed, handed over}; copies the first maxRecords (<= 4096) records to host (8 u64 each), followed by 4 u64 per item: the device clock when wave 0
+ * was a quarter, half and three quarters through its rows (host must hold 12 * maxRecords u64). */
 EFFORT_API int effort_debug_trace(effort_ctx* ctx, unsigned long long* host, int maxRecords);
 EFFORT_API int effort_kernel_timing(effort_ctx* ctx, double* mul_us_avg, double* cutoff_us_avg,
                          double* integrate_us_avg, int* n_samples);

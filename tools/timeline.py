@@ -85,7 +85,22 @@ def main():
         streaming = [(int(((ph[:, 3] <= t) & (ph[:, 4] > t)).sum())) for t in grid]
         alive = [(int(((ph[:, 0] <= t) & (ph[:, 5] > t)).sum())) for t in grid]
         dur = np.maximum(ph[:, 4] - ph[:, 3], 0.01)
-        rate = [float((nbytes / dur)[(ph[:, 3] <= t) & (ph[:, 4] > t)].sum()) / 1e6 for t in grid]      # TB/s if every item streamed evenly
+        # piecewise-even rate: each quarter of an item's rows between its progress stamps (falls back to the whole phase)
+        qs = us(items[:, 8:11])
+        knots = np.concatenate([ph[:, 3:4], qs, ph[:, 4:5]], axis=1)
+        okq = (items[:, 8:11] != 0).all(axis=1) & (np.diff(knots, axis=1) > 0).all(axis=1)
+        rate = []
+        for t in grid:
+            r = 0.0
+            for q in range(4):
+                m = okq & (knots[:, q] <= t) & (knots[:, q + 1] > t)
+                r += float((nbytes[m] / 4 / (knots[m, q + 1] - knots[m, q])).sum())
+            m = (~okq) & (ph[:, 3] <= t) & (ph[:, 4] > t)
+            r += float((nbytes[m] / dur[m]).sum())
+            rate.append(r / 1e6)
+        qd = np.diff(knots[okq], axis=1)
+        if len(qd):
+            print("   quarter durations of the streaming phase (us), median:", np.median(qd, axis=0).round(1), " items with stamps:", int(okq.sum()))
         print(f"   bytes {nbytes.sum() / 1e6:.1f} MB, per-item stream rate GB/s: med {np.median(nbytes / dur) / 1e3:.1f}; whole-launch {nbytes.sum() / end / 1e6:.2f} TB/s")
         print("   t(us)     " + " ".join(f"{int(t):4d}" for t in grid))
         print("   TB/s(est) " + " ".join(f"{r:4.1f}" for r in rate))
@@ -108,7 +123,7 @@ def main():
             m = xcc == x
             if m.any():
                 print(f"   xcc {x}: {int(m.sum())} items, last end {ph[m, 5].max():.1f}, stream sum {d[m, 3].sum():.0f}")
-        dump[str(n)] = {"ph_us": ph.tolist(), "xcc": xcc.tolist(), "wg": wg.tolist(), "item": (items[:, 0] & np.uint64(0xFFFFFFFF)).astype(int).tolist(),
+        dump[str(n)] = {"knots": knots.tolist(), "nbytes": nbytes.tolist(), "ph_us": ph.tolist(), "xcc": xcc.tolist(), "wg": wg.tolist(), "item": (items[:, 0] & np.uint64(0xFFFFFFFF)).astype(int).tolist(),
                         "hwid": ((items[:, 1] >> np.uint64(32))).astype(int).tolist()}
     os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
     with open(args.out, "w") as f:
