@@ -43,6 +43,9 @@ _SIGS = {
     "effort_weights_fp16": (_P, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int]),
     "effort_weights_q4": (_P, [_P, _P, _P, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_int]),
     "effort_weights_free": (None, [_P]),
+    "effort_weights_refresh": (C.c_int, [_P]),
+    "effort_weights_get_bound": (C.c_int, [_P, C.POINTER(C.c_float)]),
+    "effort_weights_set_bound": (C.c_int, [_P, C.POINTER(C.c_float)]),
     "effort_bucketmul": (C.c_int, [_P, _P, _P, _P, _P, C.c_double]),
     "effort_bucketmul_q4": (C.c_int, [_P, _P, _P, _P, _P, C.c_double]),
     "effort_bucketmul_group": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P]),
@@ -53,12 +56,14 @@ _SIGS = {
     "effort_debug_occupancy": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int]),
     "effort_set_persistent": (C.c_int, [_P, C.c_int]),
     "effort_add_rmsnorm_mul": (C.c_int, [_P, _P, _P, _P, _P, C.c_int]),
-    "effort_rope_kv": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float]),
+    "effort_rope_kv": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float]),
     "effort_attention": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int]),
     "effort_rope_attention": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float]),
     "effort_silu_mul": (C.c_int, [_P, _P, _P, _P, C.c_int]),
     "effort_fetch_row": (C.c_int, [_P, _P, _P, _P, C.c_int]),
-    "effort_argmax": (C.c_int, [_P, _P, C.c_int, _P, _P, _P]),
+    "effort_argmax": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, C.c_int]),
+    "effort_decode_status": (C.c_int, [_P, C.POINTER(C.c_int)]),
+    "effort_convert_status": (C.c_int, [_P, C.POINTER(C.c_int)]),
     "effort_top2_softmax": (C.c_int, [_P, _P, C.c_int, _P, _P]),
     "effort_mix2": (C.c_int, [_P, _P, _P, _P, _P, C.c_int]),
     "effort_dense_gemv": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int]),

@@ -139,8 +139,10 @@ extern "C" int effort_sync(effort_ctx* c) {
 
 // ---- weights ------------------------------------------------------------------------------------
 static int check_shape(uint32_t inDim, uint32_t outDim) {
-    // bucketMul.swift:73-76 (outDim%16, (outDim/16)%4), :52 tmpMulVec 16384 wide; probes need 4096 inputs (:36)
-    if (inDim < (uint32_t)kProbes || outDim == 0 || outDim % 16 || (outDim / 16) % 4 || outDim > 16384) return EFFORT_ERR_SHAPE;
+    // bucketMul.swift:73 (outDim % 16), :52 tmpMulVec 16384 wide; probes need 4096 inputs (:36).  The reference also asserts
+    // (outDim/16) % 4 == 0 (:76: its kernel reads four columns per thread); this kernel masks a ragged last tile, so a
+    // handle -- in particular a column shard of a multi-GPU split, 11008/16/8 = 86 columns -- may have any column count.
+    if (inDim < (uint32_t)kProbes || outDim == 0 || outDim % 16 || outDim > 16384) return EFFORT_ERR_SHAPE;
     return EFFORT_OK;
 }
 
@@ -187,6 +189,16 @@ extern "C" effort_w* effort_weights_q4(effort_ctx* c, const void* buckets, const
     if (outliers && nOutliers > 0) {
         if (outDim > 65536) { fail(c, EFFORT_ERR_SHAPE, "effort_weights_q4: outliers need outDim <= 65536"); effort_weights_free(w); return nullptr; }
         hipSetDevice(c->device);
+        {   // every entry must name an element of THIS matrix (the index is built with unchecked scatters)
+            int bad = 0;
+            bool okv = hipMemsetAsync(c->d_status + 2, 0, 4, c->stream) == hipSuccess &&
+                       launch_validate_outliers(static_cast<const float*>(outliers), (uint64_t)nOutliers, (uint32_t)inDim, (uint32_t)outDim, c->d_status + 2, c->stream) == hipSuccess &&
+                       hipMemcpyAsync(&bad, c->d_status + 2, 4, hipMemcpyDeviceToHost, c->stream) == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess;
+            if (!okv || bad) {
+                fail(c, okv ? EFFORT_ERR_ARG : EFFORT_ERR_HIP, okv ? "effort_weights_q4: outlier entries outside the matrix (inIdx >= inDim or outIdx >= outDim)" : "effort_weights_q4: outlier validation");
+                effort_weights_free(w); return nullptr;
+            }
+        }
         uint32_t* cursor = nullptr;
         w->nOutliers = (uint64_t)nOutliers;
         bool ok = hipMalloc(&w->olRowPtr, ((size_t)outDim + 2 + (outDim + 63) / 64) * 4) == hipSuccess && hipMalloc(&w->olInIdx, (size_t)nOutliers * 4) == hipSuccess &&
@@ -201,6 +213,26 @@ extern "C" effort_w* effort_weights_q4(effort_ctx* c, const void* buckets, const
         if (longest >= (1u << 19)) { fail(c, EFFORT_ERR_SHAPE, "effort_weights_q4: more than 2^19 outliers on one output"); effort_weights_free(w); return nullptr; }
     }
     return w;
+}
+
+// The fixed-point scale of the multiply comes from rankBound, a snapshot of the weights taken at registration: weights
+// rewritten in place afterwards need effort_weights_refresh (the reference's loader.swift buffers are mutable).
+extern "C" int effort_weights_refresh(effort_w* w) {
+    if (!w || !w->ctx) return EFFORT_ERR_ARG;
+    hipFree(w->rankBound); w->rankBound = nullptr;
+    return register_bound(w->ctx, w);
+}
+extern "C" int effort_weights_get_bound(effort_w* w, float* host_out) {
+    if (!w || !w->ctx || !host_out || !w->rankBound) return EFFORT_ERR_ARG;
+    HIP_TRY(w->ctx, hipMemcpy(host_out, w->rankBound, (size_t)w->numExperts * 4, hipMemcpyDeviceToHost));
+    return EFFORT_OK;
+}
+extern "C" int effort_weights_set_bound(effort_w* w, const float* host_in) {
+    if (!w || !w->ctx || !host_in || !w->rankBound) return EFFORT_ERR_ARG;
+    for (uint32_t e = 0; e < w->numExperts; e++) if (!(host_in[e] >= 0.0f)) return EFFORT_ERR_ARG;
+    HIP_TRY(w->ctx, hipStreamSynchronize(w->ctx->stream));
+    HIP_TRY(w->ctx, hipMemcpy(w->rankBound, host_in, (size_t)w->numExperts * 4, hipMemcpyHostToDevice));
+    return EFFORT_OK;
 }
 
 extern "C" void effort_weights_free(effort_w* w) {
@@ -531,11 +563,11 @@ extern "C" int effort_add_rmsnorm_mul(effort_ctx* c, float* h, const float* delt
     return EFFORT_OK;
 }
 extern "C" int effort_rope_kv(effort_ctx* c, const float* xq, const float* xk, const float* xv, float* qOut, float* kCache,
-                              float* vCache, const uint32_t* pos, int numHeads, int numHeadsKV, int headDim, float ropeBase) {
+                              float* vCache, const uint32_t* pos, int numHeads, int numHeadsKV, int headDim, int maxTokens, float ropeBase) {
     if (!c || !xq || !xk || !xv || !qOut || !kCache || !vCache || !pos) return fail(c, EFFORT_ERR_ARG, "rope_kv: null argument");
-    if (numHeads <= 0 || numHeadsKV <= 0 || numHeads % numHeadsKV || headDim < 2 || headDim > 1024 || headDim % 2 || !(ropeBase > 1.0f))
+    if (numHeads <= 0 || numHeadsKV <= 0 || numHeads % numHeadsKV || headDim < 2 || headDim > 1024 || headDim % 2 || !(ropeBase > 1.0f) || maxTokens <= 0)
         return fail(c, EFFORT_ERR_SHAPE, "rope_kv: bad head geometry");
-    HIP_TRY(c, launch_rope_kv(xq, xk, xv, qOut, kCache, vCache, pos, numHeads, numHeadsKV, headDim, ropeBase, c->stream));
+    HIP_TRY(c, launch_rope_kv(xq, xk, xv, qOut, kCache, vCache, pos, numHeads, numHeadsKV, headDim, ropeBase, (uint32_t)maxTokens, c->d_status + 1, c->stream));
     return EFFORT_OK;
 }
 extern "C" int effort_attention(effort_ctx* c, const float* q, const float* kCache, const float* vCache, const uint32_t* pos,
@@ -552,7 +584,7 @@ extern "C" int effort_rope_attention(effort_ctx* c, const float* xq, const float
     if (numHeads <= 0 || numHeadsKV <= 0 || numHeads % numHeadsKV || maxTokens <= 0 || maxTokens > 8192 || !(ropeBase > 1.0f) ||
         (headDim != 64 && headDim != 128 && headDim != 256))
         return fail(c, EFFORT_ERR_SHAPE, "rope_attention: headDim 64/128/256, maxTokens <= 8192");
-    HIP_TRY(c, launch_rope_attention(xq, xk, xv, kCache, vCache, pos, out, numHeads, numHeadsKV, headDim, maxTokens, ropeBase, c->stream));
+    HIP_TRY(c, launch_rope_attention(xq, xk, xv, kCache, vCache, pos, out, numHeads, numHeadsKV, headDim, maxTokens, ropeBase, c->d_status + 1, c->stream));
     return EFFORT_OK;
 }
 extern "C" int effort_silu_mul(effort_ctx* c, const float* x1, const float* x3, float* out, int n) {
@@ -575,9 +607,28 @@ extern "C" int effort_mix2(effort_ctx* c, const float* f0, const float* f1, cons
     HIP_TRY(c, launch_mix2(f0, f1, val2, out, (uint32_t)n, c->stream));
     return EFFORT_OK;
 }
-extern "C" int effort_argmax(effort_ctx* c, const float* logits, int n, uint32_t* idOut, uint32_t* pos, uint32_t* history) {
-    if (!c || !logits || !idOut || !pos || n <= 0) return fail(c, EFFORT_ERR_ARG, "argmax: bad argument");
-    HIP_TRY(c, launch_argmax(logits, (uint32_t)n, idOut, pos, history, c->stream));
+extern "C" int effort_argmax(effort_ctx* c, const float* logits, int n, uint32_t* idOut, uint32_t* pos, uint32_t* history, int historyLen) {
+    if (!c || !logits || !idOut || !pos || n <= 0 || (history && historyLen <= 0)) return fail(c, EFFORT_ERR_ARG, "argmax: bad argument");
+    HIP_TRY(c, launch_argmax(logits, (uint32_t)n, idOut, pos, history, (uint32_t)(history ? historyLen : 0), c->d_status + 1, c->stream));
+    return EFFORT_OK;
+}
+// Device-side conditions the decode glue could not report through a return code (the position lives in device memory):
+// bit 0 = a step ran past the key/value cache or the history buffer (nothing was written there), bit 1 = argmax over NaN
+// logits (token 0 returned).  Reads and clears the word.
+extern "C" int effort_decode_status(effort_ctx* c, int* host_out) {
+    if (!c || !host_out) return EFFORT_ERR_ARG;
+    HIP_TRY(c, hipMemcpyAsync(host_out, c->d_status + 1, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_status + 1, 0, 4, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return EFFORT_OK;
+}
+// Rows of the last effort_convert_fp16 calls whose bucket 0 overflowed in the literal preBucketize path (zero padding
+// tying with real zeros, convert.metal:40-61: the reference drops those elements silently).  Reads and clears the count.
+extern "C" int effort_convert_status(effort_ctx* c, int* host_out) {
+    if (!c || !host_out) return EFFORT_ERR_ARG;
+    HIP_TRY(c, hipMemcpyAsync(host_out, c->d_status, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_status, 0, 4, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     return EFFORT_OK;
 }
 

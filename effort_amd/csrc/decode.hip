@@ -81,8 +81,13 @@ __global__ __launch_bounds__(1024) void add_rmsnorm_mul_kernel(float* __restrict
 // base 1e-6 <=> theta 1e6), rotate_half convention of rope_mx.
 __global__ void rope_kv_kernel(const float* __restrict__ xq, const float* __restrict__ xk, const float* __restrict__ xv,
                                float* __restrict__ qOut, float* __restrict__ kCache, float* __restrict__ vCache,
-                               const uint32_t* __restrict__ posPtr, uint32_t numHeads, uint32_t kvRepeats, float logBase) {
+                               const uint32_t* __restrict__ posPtr, uint32_t numHeads, uint32_t kvRepeats, float logBase,
+                               uint32_t maxTokens, int* __restrict__ status) {
     const uint32_t head = blockIdx.x, d = threadIdx.x, headDim = blockDim.x, half = headDim / 2, pos = posPtr[0];
+    if (pos >= maxTokens) {                            // past the cache: nothing is written, the context's status word says so
+        if (head == 0 && d == 0) atomicOr(status, 1);
+        return;
+    }
     const uint32_t j = d % half;
     const float freq = (float)exp((double)logBase * (-(double)j / (double)half));          // Float(freq), model.swift:707
     const float angle = (float)pos * freq;
@@ -145,12 +150,16 @@ __global__ __launch_bounds__(256) void rope_attention_kernel(const float* __rest
                                                              const float* __restrict__ xv, float* __restrict__ kCache,
                                                              float* __restrict__ vCache, const uint32_t* __restrict__ posPtr,
                                                              float* __restrict__ out, uint32_t numHeads, uint32_t kvRepeats,
-                                                             uint32_t headDim, uint32_t maxTokens, float logBase) {
+                                                             uint32_t headDim, uint32_t maxTokens, float logBase, int* __restrict__ status) {
     extern __shared__ float sc[];                      // [maxTokens] scores, then probabilities
     __shared__ float red[17];
     __shared__ float qs[256], ks[256], vs[256];        // this head's roped q, roped k and v of the newest token
     const uint32_t head = blockIdx.x, tid = threadIdx.x, half = headDim / 2;
-    const uint32_t pos = min(posPtr[0], maxTokens - 1u), nTok = pos + 1u;
+    if (posPtr[0] >= maxTokens) {                      // past the cache (uniform): nothing is written, the status word says so
+        if (head == 0 && tid == 0) atomicOr(status, 1);
+        return;
+    }
+    const uint32_t pos = posPtr[0], nTok = pos + 1u;
     if (tid < headDim) {
         const uint32_t d = tid, j = d % half;
         const float freq = (float)exp((double)logBase * (-(double)j / (double)half));
@@ -244,7 +253,8 @@ __global__ void fetch_row_kernel(const uint16_t* __restrict__ emb, const uint32_
 
 // one workgroup: greedy next token = index of the largest logit (lowest index on ties); advances the position
 __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ logits, uint32_t n, uint32_t* __restrict__ idOut,
-                                                      uint32_t* __restrict__ posPtr, uint32_t* __restrict__ history) {
+                                                      uint32_t* __restrict__ posPtr, uint32_t* __restrict__ history,
+                                                      uint32_t historyLen, int* __restrict__ status) {
     __shared__ float bv[16];
     __shared__ uint32_t bi[16];
     float best = -INFINITY; uint32_t idx = 0xFFFFFFFFu;
@@ -262,8 +272,12 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ 
     if (threadIdx.x == 0) {
         for (uint32_t w = 1; w < (blockDim.x >> 6); w++)
             if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
+        if (idx >= n) { idx = 0; atomicOr(status, 2); }           // every logit NaN: a valid id all the same (the next fetch_row reads row idx)
         idOut[0] = idx;
-        if (history) history[posPtr[0]] = idx;
+        if (history) {
+            if (posPtr[0] < historyLen) history[posPtr[0]] = idx;
+            else atomicOr(status, 1);                                 // past the history buffer: not written
+        }
         posPtr[0] += 1u;
     }
 }
@@ -301,9 +315,10 @@ hipError_t launch_add_rmsnorm_mul(float* h, const float* delta, const uint16_t* 
     return hipGetLastError();
 }
 hipError_t launch_rope_kv(const float* xq, const float* xk, const float* xv, float* qOut, float* kCache, float* vCache,
-                          const uint32_t* pos, uint32_t numHeads, uint32_t numHeadsKV, uint32_t headDim, float ropeBase, hipStream_t st) {
+                          const uint32_t* pos, uint32_t numHeads, uint32_t numHeadsKV, uint32_t headDim, float ropeBase, uint32_t maxTokens,
+                          int* status, hipStream_t st) {
     hipLaunchKernelGGL(rope_kv_kernel, dim3(numHeads), dim3(headDim), 0, st, xq, xk, xv, qOut, kCache, vCache, pos, numHeads,
-                       numHeads / numHeadsKV, logf(ropeBase));
+                       numHeads / numHeadsKV, logf(ropeBase), maxTokens, status);
     return hipGetLastError();
 }
 hipError_t launch_attention(const float* q, const float* kCache, const float* vCache, const uint32_t* pos, float* out,
@@ -313,9 +328,9 @@ hipError_t launch_attention(const float* q, const float* kCache, const float* vC
 }
 hipError_t launch_rope_attention(const float* xq, const float* xk, const float* xv, float* kCache, float* vCache, const uint32_t* pos,
                                  float* out, uint32_t numHeads, uint32_t numHeadsKV, uint32_t headDim, uint32_t maxTokens, float ropeBase,
-                                 hipStream_t st) {
+                                 int* status, hipStream_t st) {
     hipLaunchKernelGGL(rope_attention_kernel, dim3(numHeads), dim3(256), maxTokens * sizeof(float), st, xq, xk, xv, kCache, vCache, pos, out,
-                       numHeads, numHeads / numHeadsKV, headDim, maxTokens, logf(ropeBase));
+                       numHeads, numHeads / numHeadsKV, headDim, maxTokens, logf(ropeBase), status);
     return hipGetLastError();
 }
 hipError_t launch_silu_mul(const float* x1, const float* x3, float* out, uint32_t n, hipStream_t st) {
@@ -326,8 +341,9 @@ hipError_t launch_fetch_row(const uint16_t* emb, const uint32_t* id, float* out,
     hipLaunchKernelGGL(fetch_row_kernel, dim3((n + 255) / 256), dim3(256), 0, st, emb, id, out, n);
     return hipGetLastError();
 }
-hipError_t launch_argmax(const float* logits, uint32_t n, uint32_t* idOut, uint32_t* pos, uint32_t* history, hipStream_t st) {
-    hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, st, logits, n, idOut, pos, history);
+hipError_t launch_argmax(const float* logits, uint32_t n, uint32_t* idOut, uint32_t* pos, uint32_t* history, uint32_t historyLen,
+                         int* status, hipStream_t st) {
+    hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, st, logits, n, idOut, pos, history, historyLen, status);
     return hipGetLastError();
 }
 

@@ -170,6 +170,17 @@ hipError_t launch_cosine(const float* a, const float* b, uint32_t n, float* out3
 // consecutive outputs -- first entry of each output, then the second of each ... -- so that the multiply's coalesced
 // stream of entries hands neighbouring lanes DIFFERENT outputs: its LDS atomics then never collide (sorted by output, a
 // wave's 64 entries hit one or two addresses and serialise).  rowPtr[64*b] still bounds block b's entries.
+// entries the format does not allow: an index outside the matrix (or NaN) -- e.g. a full-matrix table handed to a column shard
+__global__ void ol_validate_kernel(const float4* ol, uint64_t n, uint32_t inDim, uint32_t outDim, int* bad) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float4 o = ol[i];
+    if (!(o.y >= 0.0f && o.y < (float)inDim && o.z >= 0.0f && o.z < (float)outDim)) atomicAdd(bad, 1);
+}
+hipError_t launch_validate_outliers(const float* outliers, uint64_t n, uint32_t inDim, uint32_t outDim, int* bad, hipStream_t st) {
+    hipLaunchKernelGGL(ol_validate_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const float4*>(outliers), n, inDim, outDim, bad);
+    return hipGetLastError();
+}
 __global__ void ol_count_kernel(const float4* ol, uint64_t n, uint32_t* rowPtr) {
     const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     if (i < n) atomicAdd(&rowPtr[(uint32_t)ol[i].z + 1], 1u);

@@ -123,20 +123,23 @@ hipError_t launch_rank_bound(Format fmt, const uint16_t* buckets, const void* st
 // decode-loop glue (decode.hip)
 hipError_t launch_add_rmsnorm_mul(float* h, const float* delta, const uint16_t* w, float* out, uint32_t n, hipStream_t st);
 hipError_t launch_rope_kv(const float* xq, const float* xk, const float* xv, float* qOut, float* kCache, float* vCache,
-                          const uint32_t* pos, uint32_t numHeads, uint32_t numHeadsKV, uint32_t headDim, float ropeBase, hipStream_t st);
+                          const uint32_t* pos, uint32_t numHeads, uint32_t numHeadsKV, uint32_t headDim, float ropeBase, uint32_t maxTokens,
+                          int* status, hipStream_t st);
 hipError_t launch_attention(const float* q, const float* kCache, const float* vCache, const uint32_t* pos, float* out,
                             uint32_t numHeads, uint32_t headDim, uint32_t maxTokens, hipStream_t st);
 hipError_t launch_rope_attention(const float* xq, const float* xk, const float* xv, float* kCache, float* vCache, const uint32_t* pos,
                                  float* out, uint32_t numHeads, uint32_t numHeadsKV, uint32_t headDim, uint32_t maxTokens, float ropeBase,
-                                 hipStream_t st);
+                                 int* status, hipStream_t st);
 hipError_t launch_silu_mul(const float* x1, const float* x3, float* out, uint32_t n, hipStream_t st);
 hipError_t launch_fetch_row(const uint16_t* emb, const uint32_t* id, float* out, uint32_t n, hipStream_t st);
 hipError_t launch_top2_softmax(const float* gate, uint32_t n, uint32_t* idx, float* val, hipStream_t st);
 hipError_t launch_mix2(const float* f0, const float* f1, const float* val, float* out, uint32_t n, hipStream_t st);
-hipError_t launch_argmax(const float* logits, uint32_t n, uint32_t* idOut, uint32_t* pos, uint32_t* history, hipStream_t st);
+hipError_t launch_argmax(const float* logits, uint32_t n, uint32_t* idOut, uint32_t* pos, uint32_t* history, uint32_t historyLen,
+                         int* status, hipStream_t st);
 
 hipError_t launch_f32_to_f16(const float* in, uint16_t* out, uint32_t n, hipStream_t st);
 hipError_t launch_cosine(const float* a, const float* b, uint32_t n, float* out3, hipStream_t st);
+hipError_t launch_validate_outliers(const float* outliers, uint64_t n, uint32_t inDim, uint32_t outDim, int* bad, hipStream_t st);
 hipError_t launch_build_outlier_index(const float* outliers, uint64_t n, uint32_t outDim, uint32_t* rowPtr,
                                       uint32_t* inIdx, float* value, uint32_t* cursor, hipStream_t st);
 

@@ -186,7 +186,7 @@ class Decoder:
                 bucketMulGroup([(self.x1, L.w2, None, self.h, effort, {"gate": self.x3, "resid": self.h})])    # :181-183, h += w2(silu)
             ck(lib.effort_add_rmsnorm_mul(g.ctx, _p(self.h), None, _p(m.norm), _p(self.outNormed), cfg.stateDim), "rmsnorm")
             basicMul(self.outNormed, m.output, self.logits)                                           # :222
-            ck(lib.effort_argmax(g.ctx, _p(self.logits), cfg.vocab, _p(self.tokId), _p(self.pos), _p(self.history)), "argmax")
+            ck(lib.effort_argmax(g.ctx, _p(self.logits), cfg.vocab, _p(self.tokId), _p(self.pos), _p(self.history), int(self.history.numel())), "argmax")
             return
         for n, L in enumerate(m.layers):
             ck(lib.effort_add_rmsnorm_mul(g.ctx, _p(self.h), _p(delta), _p(L.attnNorm), _p(self.h_norm), cfg.stateDim), "rmsnorm")
@@ -197,7 +197,7 @@ class Decoder:
                                              C.c_float(cfg.ropeBase)), "rope_attention")
             else:
                 ck(lib.effort_rope_kv(g.ctx, _p(self.xq_temp), _p(self.xk_temp), _p(self.xv_temp), _p(self.xq), _p(self.kCache[n]),
-                                      _p(self.vCache[n]), _p(self.pos), cfg.numHeads, cfg.numHeadsKV, cfg.headDim, C.c_float(cfg.ropeBase)), "rope_kv")
+                                      _p(self.vCache[n]), _p(self.pos), cfg.numHeads, cfg.numHeadsKV, cfg.headDim, self.maxTokens, C.c_float(cfg.ropeBase)), "rope_kv")
                 ck(lib.effort_attention(g.ctx, _p(self.xq), _p(self.kCache[n]), _p(self.vCache[n]), _p(self.pos), _p(self.attnOutput),
                                         cfg.numHeads, cfg.headDim, self.maxTokens), "attention")
             muls(self.attnOutput, [(L.wo, self.attnFfnOut)])                                          # :170
@@ -225,7 +225,7 @@ class Decoder:
                 delta = self.ffnMix
         ck(lib.effort_add_rmsnorm_mul(g.ctx, _p(self.h), _p(delta), _p(m.norm), _p(self.outNormed), cfg.stateDim), "rmsnorm")
         basicMul(self.outNormed, m.output, self.logits)                                               # :222
-        ck(lib.effort_argmax(g.ctx, _p(self.logits), cfg.vocab, _p(self.tokId), _p(self.pos), _p(self.history)), "argmax")
+        ck(lib.effort_argmax(g.ctx, _p(self.logits), cfg.vocab, _p(self.tokId), _p(self.pos), _p(self.history), int(self.history.numel())), "argmax")
 
     def _dense_experts(self, L, e0, e1):
         """Dense baseline of the routed FFN: the picked experts' cores are gathered on the device (index_select keeps the
@@ -249,6 +249,14 @@ class Decoder:
             self.g._bind_stream()
             self._graphs[key] = gr
         return self._graphs[key]
+
+    def status(self) -> int:
+        """Device-side conditions of the steps since the last call (effort_decode_status): bit 0 = a step ran past the cache or
+        the history buffer (it wrote nothing there), bit 1 = argmax over NaN logits.  Reads and clears."""
+        st = C.c_int(0)
+        self.g._bind_stream()
+        self.g.check(_lib.lib().effort_decode_status(self.g.ctx, C.byref(st)), "decode_status")
+        return int(st.value)
 
     def reset(self):
         self.pos.zero_()
@@ -283,6 +291,9 @@ class Decoder:
         dt = (time.perf_counter() - t0) / timed if t0 is not None and timed else float("nan")
         steps = min(numTokens, len(tokenIds)) if forced else numTokens
         picked = self.history[:steps].cpu().tolist()
+        st = self.status()
+        if st:
+            raise RuntimeError(f"decode loop: device status {st} (1: a step past maxTokens / the history buffer, 2: NaN logits)")
         return picked, dt, (torch.stack(logits) if collect_logits else None)
 
 

@@ -29,10 +29,23 @@ class Gpu:
 
     # -- helpers ---------------------------------------------------------------------------------
     def _bind_stream(self):
-        stream = torch.cuda.current_stream(self.device).cuda_stream
+        """Follow torch's current stream.  ALL per-call scratch (partial tiles, arrival tickets, item queues, cutoffs) lives in
+        this one context, so two streams must never run its launches concurrently: when the stream changes, the new stream
+        first waits for the work already enqueued on the old one.  (Inside a graph capture the capture's own stream order
+        applies, and no cross-stream wait may be recorded: independent multiplies that should overlap take one Gpu context
+        each -- ``effort_amd.Gpu(device)`` -- as bench.py's Step does.)"""
+        cur = torch.cuda.current_stream(self.device)
+        stream = cur.cuda_stream
         if stream != self._stream:
+            old = getattr(self, "_stream_obj", None)
+            if old is not None and not torch.cuda.is_current_stream_capturing():
+                try:
+                    cur.wait_stream(old)
+                except RuntimeError:
+                    pass                                   # the old stream belonged to a finished capture
             self._lib.effort_set_stream(self.ctx, C.c_void_p(stream))
             self._stream = stream
+        self._stream_obj = cur
 
     def check(self, rc: int, where: str):
         if rc != 0:
@@ -67,6 +80,12 @@ class Gpu:
     def set_dense_backend(self, rocblas: bool = False):
         """basicMul through the library's hssgemv (True) or the streaming HIP kernel (False, default)."""
         self.check(self._lib.effort_set_dense_backend(self.ctx, int(bool(rocblas))), "set_dense_backend")
+
+    def convert_status(self) -> int:
+        """Elements the bucketize() calls since the last query could not place (effort_convert_status); reads and clears."""
+        n = C.c_int(0)
+        self.check(self._lib.effort_convert_status(self.ctx, C.byref(n)), "convert_status")
+        return int(n.value)
 
     def debug_stamps(self):
         buf = (C.c_ulonglong * 32)()

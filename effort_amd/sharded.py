@@ -4,7 +4,9 @@ The reference is single-device (helpers/gpu.swift:36-38); sharding is new.  One 
 (torch.distributed, backend "nccl" == RCCL over xGMI).  Rank g holds bucket columns
 [g*C/G, (g+1)*C/G) of every bucket row of a matrix, plus the FULL stats and probes -- those are
 row-global (convert.metal:105-119), so every rank computes the identical cutoff and selects the identical
-rows, and the concatenation of the per-rank outputs is exactly the single-GPU result.  The only exchange
+rows (dispatch count and cutoff are bit-identical), and the concatenation of the per-rank outputs is the single-GPU
+result to the multiply's rounding (a shard takes the full matrix's fixed-point bound; its launch geometry -- hence the
+grid its partial sums are rounded on -- may differ from the unsharded call's: |delta| <= 2e-5 max|out|).  The only exchange
 is an all-gather of outDim/G f32 per rank (KB-scale: latency-bound over xGMI, never bandwidth-bound), so
 matrices that share an input vector (Wq|Wk|Wv, W1|W3) are gathered together in ONE collective.
 """
@@ -21,7 +23,7 @@ def shard_columns(buckets: torch.Tensor, rank: int, world: int) -> torch.Tensor:
     C = buckets.shape[-1]
     if C % world:
         raise ValueError(f"{C} bucket columns do not divide across {world} ranks")
-    per = C // world
+    per = C // world                                 # any even split: 4096x11008 over 8 ranks = 86 columns (1376 outputs) each
     return buckets[..., rank * per:(rank + 1) * per].contiguous()
 
 
@@ -29,6 +31,8 @@ def shard_outliers(outliers: torch.Tensor | None, rank: int, world: int, outDim:
     """Q4 outliers (value, inIdx, outIdx, 0) whose output falls in this rank's slice, re-based to it."""
     if outliers is None:
         return None
+    if outDim % world:
+        raise ValueError(f"{outDim} outputs do not divide across {world} ranks")
     per = outDim // world
     lo, hi = rank * per, (rank + 1) * per
     m = (outliers[:, 2] >= lo) & (outliers[:, 2] < hi)

@@ -104,21 +104,32 @@ class ExpertWeights:
         return ExpertWeights(self.buckets[:, :rows].contiguous(), self.stats[:, :rows].contiguous(), self.probes,
                              self.inSize, self.outSize, percentLoad, self.numExperts, core=self.core)
 
+    def refresh(self):
+        """The buffers were rewritten in place: re-read the bound the multiply's fixed-point scale comes from."""
+        if self._handle is not None:
+            self._gpu.check(_lib.lib().effort_weights_refresh(self._handle), "ExpertWeights.refresh")
+
+    def rank_bound(self) -> list[float]:
+        buf = (C.c_float * self.numExperts)()
+        self._gpu.check(_lib.lib().effort_weights_get_bound(self.handle, buf), "ExpertWeights.rank_bound")
+        return list(buf)
+
+    def set_rank_bound(self, bound):
+        buf = (C.c_float * self.numExperts)(*[float(x) for x in bound])
+        self._gpu.check(_lib.lib().effort_weights_set_bound(self.handle, buf), "ExpertWeights.set_rank_bound")
+
     def column_shard(self, rank: int, world: int) -> "ExpertWeights":
         """Bucket-column (output) shard for multi-GPU: columns [rank*C/G, (rank+1)*C/G) of every bucket row,
-        stats and probes replicated (they are row-global), so every rank selects the same rows."""
-        cols = self.buckets.shape[2]
-        assert cols % world == 0, "bucket columns must divide evenly across ranks"
-        per = cols // world
+        stats and probes replicated (they are row-global), so every rank selects the same rows.  Any even split is
+        valid (the multiply masks a ragged last tile: 11008 outputs over 8 ranks = 86 columns each).  The shard takes
+        the full matrix's fixed-point bound, so its products are rounded on the same grid as the unsharded call's."""
+        from .sharded import shard_columns, shard_outliers
+        b = shard_columns(self.buckets, rank, world)
         unit = 32 if self.q4 else 16
-        assert ((per * unit) // 16) % 4 == 0, "shard violates (outDim/16) % 4 == 0 (bucketMul.swift:76)"
-        b = self.buckets[:, :, rank * per:(rank + 1) * per].contiguous()
-        ol = None
-        if self.outliers is not None:
-            lo, hi = rank * per * unit, (rank + 1) * per * unit
-            m = (self.outliers[:, 2] >= lo) & (self.outliers[:, 2] < hi)
-            ol = self.outliers[m].clone()
-            ol[:, 2] -= lo
+        per = b.shape[2]
+        ol = shard_outliers(self.outliers, rank, world, self.outSize)
         core = None if self.core is None else self.core[rank * per * unit:(rank + 1) * per * unit]
-        return ExpertWeights(b, self.stats, self.probes, self.inSize, per * unit, self.percentLoad, self.numExperts,
-                             outliers=ol, core=core, q4=self.q4)
+        sh = ExpertWeights(b, self.stats, self.probes, self.inSize, per * unit, self.percentLoad, self.numExperts,
+                           outliers=ol, core=core, q4=self.q4)
+        sh.set_rank_bound(self.rank_bound())
+        return sh

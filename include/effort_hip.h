@@ -85,6 +85,14 @@ EFFORT_API effort_w* effort_weights_q4(effort_ctx* ctx, const void* buckets_dev,
                             const void* probes_dev, const void* outliers_dev, int64_t nOutliers,
                             int inDim, int outDim, int numExperts);
 EFFORT_API void effort_weights_free(effort_w* w);
+/* The multiply accumulates in fixed point; its scale comes from a per-expert bound on the weights (sum over ranks of the
+ * rank's largest |w|; Q4: largest row mean) read at registration.  If the borrowed buffers are REWRITTEN afterwards (the
+ * reference's loader.swift buffers are mutable) call effort_weights_refresh before the next multiply: with a stale bound
+ * the sums of larger weights wrap.  get/set copy the bound ([numExperts] floats, host memory): a column shard of a
+ * multi-GPU split can take the full matrix's bound, so that every rank rounds its products on the same grid. */
+EFFORT_API int effort_weights_refresh(effort_w* w);
+EFFORT_API int effort_weights_get_bound(effort_w* w, float* host_out);
+EFFORT_API int effort_weights_set_bound(effort_w* w, const float* host_in);
 
 /* ---- the hot path ------------------------------------------------------------------------------ */
 
@@ -170,7 +178,7 @@ EFFORT_API int effort_add_rmsnorm_mul(effort_ctx* ctx, float* h_dev, const float
  * (runNetwork.swift:128-149, aux.metal:218-261, createFreqsCis2 model.swift:693-717; caches f32 [maxTokens][numHeads][headDim]). */
 EFFORT_API int effort_rope_kv(effort_ctx* ctx, const float* xq_dev, const float* xk_dev, const float* xv_dev, float* q_out_dev,
                    float* k_cache_dev, float* v_cache_dev, const uint32_t* pos_dev, int numHeads, int numHeadsKV, int headDim,
-                   float ropeBase);
+                   int maxTokens, float ropeBase);
 /* calcScores (/sqrt(headDim)) + softmax + sumScores over tokens 0..*pos_dev (runNetwork.swift:151-163, aux.metal:185-198,379-447). */
 EFFORT_API int effort_attention(effort_ctx* ctx, const float* q_dev, const float* k_cache_dev, const float* v_cache_dev,
                      const uint32_t* pos_dev, float* out_dev, int numHeads, int headDim, int maxTokens);
@@ -188,7 +196,12 @@ EFFORT_API int effort_top2_softmax(effort_ctx* ctx, const float* gate_dev, int n
 EFFORT_API int effort_mix2(effort_ctx* ctx, const float* f0_dev, const float* f1_dev, const float* val2_dev, float* out_dev, int n);
 /* greedy pick: *id_out_dev = argmax(logits) (the reference takes mpsTopK[0], helpers/mps.swift:52-84); if history_dev is
  * given, history_dev[*pos_dev] = the pick; then *pos_dev += 1. */
-EFFORT_API int effort_argmax(effort_ctx* ctx, const float* logits_dev, int n, uint32_t* id_out_dev, uint32_t* pos_dev, uint32_t* history_dev);
+EFFORT_API int effort_argmax(effort_ctx* ctx, const float* logits_dev, int n, uint32_t* id_out_dev, uint32_t* pos_dev, uint32_t* history_dev,
+                  int historyLen);
+/* The position lives in device memory, so the glue cannot refuse a step with a return code: a step at *pos_dev >= maxTokens
+ * (effort_rope_kv, effort_rope_attention) or >= historyLen (effort_argmax) writes NOTHING to the cache / history and raises
+ * bit 0 of the context's decode status; an argmax over NaN logits returns token 0 and raises bit 1.  Reads and clears it. */
+EFFORT_API int effort_decode_status(effort_ctx* ctx, int* host_out);
 
 /* ---- weight layout converter ------------------------------------------------------------------- */
 
@@ -198,6 +211,10 @@ EFFORT_API int effort_argmax(effort_ctx* ctx, const float* logits_dev, int n, ui
  * percentLoad 16, one expert.  Runs on the GPU (all device pointers), enqueued on the stream. */
 EFFORT_API int effort_convert_fp16(effort_ctx* ctx, const void* W_f16_dev, int outDim, int inDim,
                         void* buckets_dev, void* stats_dev, void* probes_dev);
+/* Elements the last effort_convert_fp16 calls could not place: the reference's preBucketize (convert.metal:40-61) drops an
+ * element whose bucket is already full, which happens when zero padding of a non-power-of-two row ties with real zeros;
+ * the converter reproduces that and counts the drops here.  Reads and clears the count (0 = every element was placed). */
+EFFORT_API int effort_convert_status(effort_ctx* ctx, int* host_out);
 
 /* VectorFloat.cosineSimilarityTo (model.swift:511-519; aux.metal:293-312).  Synchronises. */
 EFFORT_API int effort_cosine(effort_ctx* ctx, const float* a_dev, const float* b_dev, int n, float* host_out);

@@ -170,3 +170,27 @@ def test_model_load_from_bucket_files(hip_lib_built, tmp_path):
     b = Decoder(direct, maxTokens=16).run([1, 2, 3], 8, effort=0.5, collect_logits=True)
     assert a[0] == b[0] and torch.equal(a[2], b[2])
     assert loaded.layers[0].w1.core is None and loaded.layers[0].wq.core is not None              # convert.swift keeps attention cores only
+
+
+@pytest.mark.parametrize("fused_attention", [True, False])
+def test_steps_past_the_cache_write_nothing_and_are_reported(small_model, fused_attention):
+    """A token step at pos >= maxTokens (a graph replayed once too often, or token_step called directly) must not write past
+    the key/value cache or the history buffer: the glue skips the writes and raises the context's decode status."""
+    from effort_amd.decode import Decoder
+    dec = Decoder(small_model, maxTokens=4, fused_attention=fused_attention)
+    ids, _, _ = dec.run([3, 77], 4, dense=True)
+    assert len(ids) == 4 and dec.status() == 0
+    guard_k = [k.clone() for k in dec.kCache]
+    hist = dec.history.clone()
+    dec.token_step(0.25, True)                          # pos == maxTokens now
+    dec.g.eval()
+    assert dec.status() == 1 and dec.status() == 0      # reported once, then cleared
+    assert all(torch.equal(a, b) for a, b in zip(guard_k, dec.kCache)) and torch.equal(hist, dec.history)
+    dec.logits.fill_(float("nan"))                      # argmax over NaN: a valid token id all the same
+    import ctypes as C
+    from effort_amd import _lib
+    p = lambda t: C.c_void_p(t.data_ptr())              # noqa: E731
+    dec.pos.zero_()
+    dec.g.check(_lib.lib().effort_argmax(dec.g.ctx, p(dec.logits), small_model.cfg.vocab, p(dec.tokId), p(dec.pos), p(dec.history), 4), "argmax")
+    dec.g.eval()
+    assert int(dec.tokId.item()) == 0 and dec.status() == 2

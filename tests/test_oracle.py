@@ -70,6 +70,56 @@ def test_docs_cutoff_example_cosine(oracle_cpu):
     assert abs(oracle_cpu.cosine(approx, full) - 0.99989) < 2e-5
 
 
+def test_docs_layout_example_second_row(oracle_cpu):
+    """docs/bucketmul.html: the second input row (v_1) of the 12x12 example -- its four rank rows and their means as printed
+    (0.747 / 0.503 / 0.28 / 0.16).  The page prints -0.42 with position 2; in its own matrix -0.42 is element 1 of the
+    third bucket [.5, -.42, -.23, .02], which is what the layout (and this test) holds."""
+    row = np.float16([-.87, .11, .03, .5, .43, .87, -.49, .59, .5, -.42, -.23, .02])
+    ranked, oob = oracle_cpu.bucketize_row(row, 4)
+    assert oob == 0
+    want_vals = [[-.87, .87, .5], [.5, .59, -.42], [.11, -.49, -.23], [.03, .43, .02]]
+    want_pos = [[0, 1, 0], [3, 3, 1], [1, 2, 2], [2, 0, 3]]
+    bits = ranked.view(np.uint16)
+    assert (bits & 3).tolist() == want_pos
+    vals = (bits & 0xFFFC).view(np.float16).astype(np.float32)
+    assert np.allclose(vals, want_vals, rtol=4e-3, atol=2e-3)    # the low 2 mantissa bits carry the position
+    means = np.abs(np.float32(want_vals)).mean(axis=1)
+    assert np.allclose(means, [0.747, 0.503, 0.28, 0.16], atol=4e-3)
+    assert np.allclose(np.abs(ranked.astype(np.float32)).mean(axis=1), means, rtol=2e-2, atol=2e-3)
+    # the first row's last rank row: the page prints 0.233 once and 0.223 once; (.19 + .18 + .33) / 3 = 0.2333
+    assert abs(float(np.abs(np.float32([-.19, .18, .33])).mean()) - 0.2333) < 1e-4
+
+
+def test_docs_cutoff_example_through_prepare_dispatch(oracle_cpu):
+    """docs/equations.html:312-358 driven through the oracle's prepareDispatch (bucketMul.metal:47-79): inputs (1, 10, 1000),
+    each input row's weights sorted descending -- 256 8 2 / 13 3 1 / 1 1 0.1 with output positions 3 2 1 / 1 3 2 / 1 3 2 --
+    and the page's cutoff of 100.  A rank row here is one weight, so its mean IS the weight and the keep test
+    cutoff < (1e5 * mean) * |v| is the page's  el_v * el_w  against the cutoff.  The page keeps the product that equals
+    100 exactly ("the 0.1 weight made the cut") while its pseudocode says ">": any cutoff in (30, 100) * 1e5 gives the
+    page's kept set; 99e5 is used.  Result (1130, 100, 1256), cos-sim 0.99989 against (1132, 118, 1286)."""
+    inDim, ranks = 3, 3
+    v = np.float32([1, 10, 1000])
+    w = np.float32([[256, 8, 2], [13, 3, 1], [1, 1, 0.1]])                 # [input j][rank]
+    pos = np.array([[3, 2, 1], [1, 3, 2], [1, 3, 2]]) - 1                   # output index of that weight
+    stats = np.zeros((ranks * inDim, 4), np.float16)
+    for r in range(ranks):
+        for j in range(inDim):
+            stats[r * inDim + j, :] = w[j, r]                               # rank-major rows: row = rank * inDim + j (convert.metal:83-100)
+    disp, n = oracle_cpu.prepare_dispatch(v, stats, 0, 99e5, inDim, 1, percentLoad=ranks)
+    assert n == 5
+    rows = disp[:n, 1].astype(int).tolist()
+    assert rows == [0, 1, 2, 5, 8]                                          # 256*1, 13*10, 1*1000 | 1*1000 | 0.1*1000
+    assert disp[:n, 0].tolist() == [1, 10, 1000, 1000, 1000]
+    out = np.zeros(3, np.float32)
+    for val, row in disp[:n]:
+        r, j = divmod(int(row), inDim)
+        out[pos[j, r]] += np.float32(val) * np.float32(np.float16(w[j, r]))
+    assert np.allclose(out, [1130, 100, 1256], rtol=3e-4)                   # f16(0.1) * 1000 = 99.98
+    assert abs(oracle_cpu.cosine(out, np.float32([1132, 118, 1286])) - 0.99989) < 2e-5
+    # nine products in all: five kept = "55 % of the calculations"
+    assert abs(n / 9 - 0.55) < 0.01
+
+
 # ---------------------------------------------------------------- Q4 layout / multiply pinned by the reference's q4_draft.py
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "q4_*.npz"))), ids=os.path.basename)
 def test_q4_layout_matches_reference_fixture(path):

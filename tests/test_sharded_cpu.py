@@ -82,3 +82,44 @@ def test_shard_helpers():
     ol = torch.tensor([[0.5, 3, 0, 0], [1.5, 2, 65, 0], [-2.0, 1, 127, 0], [3.0, 0, 64, 0]])
     got = [shard_outliers(ol, r, 2, 128) for r in range(2)]
     assert got[0][:, 2].tolist() == [0] and got[1][:, 2].tolist() == [1, 63, 0]
+
+
+def test_column_sharding_of_11008_over_8_ranks(oracle_cpu):
+    """The BASELINE shape through shard_columns / shard_outliers for a world of 8: 688 bucket columns -> 86 per rank (1376
+    outputs: (outDim/16) % 4 != 0, which only the reference's own kernel minds).  Every rank computes the full call's
+    cutoff and dispatch list from the replicated stats / probes; its columns of the product are bit-equal to the full
+    product's (findCutoff32 / prepareDispatch / bucketMul / bucketIntegrate restated by the oracle, per column)."""
+    from effort_amd.sharded import shard_columns, shard_outliers
+    from oracle import cpu
+    inDim, outDim, world = 4096, 11008, 8
+    W = make_w(outDim, inDim, seed=5)
+    buckets, stats, probes, _ = cpu.convert_fp16(W)
+    v = make_v(inDim, seed=8, heavy=True)
+    full, n_full, cutoff = cpu.bucket_mul(v, buckets, stats, probes, inDim, outDim, 0.25)
+    cols = outDim // 16
+    bt = torch.from_numpy(np.ascontiguousarray(buckets).view(np.int16).reshape(1, 16 * inDim, cols))
+    got = []
+    for r in range(world):
+        lb = shard_columns(bt, r, world)
+        assert lb.shape[-1] == 86
+        lbn = lb.numpy().view(np.uint16).reshape(16 * inDim, 86)
+        cut_r, _ = cpu.find_cutoff(v, probes, 0, 0.25)
+        disp, n = cpu.prepare_dispatch(v, stats, 0, cut_r, inDim, 86)
+        assert (n, cut_r) == (n_full, cutoff)
+        D = cpu.round_up_pad(disp, n)
+        got.append(cpu.bucket_mul_dispatch(lbn, disp, D, 86, 86 * 16))
+    assert np.array_equal(np.concatenate(got), full)
+    # outliers follow their output column, re-based to the shard
+    rng = np.random.default_rng(1)
+    ol = np.zeros((1000, 4), np.float32)
+    ol[:, 0] = rng.normal(size=1000)
+    ol[:, 1] = rng.integers(0, inDim, 1000)
+    ol[:, 2] = rng.integers(0, outDim, 1000)
+    parts = [shard_outliers(torch.from_numpy(ol), r, world, outDim) for r in range(world)]
+    assert sum(p.shape[0] for p in parts) == 1000
+    for r, p in enumerate(parts):
+        assert ((p[:, 2] >= 0) & (p[:, 2] < outDim // world)).all()
+        back = p.clone()
+        back[:, 2] += r * (outDim // world)
+        keep = (ol[:, 2] >= r * 1376) & (ol[:, 2] < (r + 1) * 1376)
+        assert np.array_equal(back.numpy(), ol[keep])
