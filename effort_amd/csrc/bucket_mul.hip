@@ -256,7 +256,7 @@ __device__ __forceinline__ void stage_issue(const GroupKArgs& ga, const ItemRef&
 // caller pulls the next item from the queue (wave 0) and issues the wave's share of its stage loads (into buffer par ^ 1).
 template <int FMT, int E, int W, bool FUSED, typename Prefetch>
 __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t item, const ItemRef& ref, char* smem, const LdsPlan& lp, uint32_t& cachedCall,
-                                         float& cachedCutoff, const uint32_t par, const bool staged, Prefetch prefetch) {
+                                         float& cachedCutoff, const uint32_t par, const bool staged, const bool firstItem, Prefetch prefetch) {
     constexpr int NACC = Fmt<FMT>::kAcc;
     constexpr int TILE_F = NACC * E * 64;                    // outputs of a tile (slab / out[] granularity)
     constexpr int TILE_L = Fmt<FMT>::kSlots * E * 64;        // LDS accumulators of a tile
@@ -310,7 +310,9 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
 #pragma unroll
     for (int i = 0; i < VPT; i++) { vj[i] = 0.0f; prj[i] = 0; }
     const bool needCut = fused && cachedCall != ci;              // uniform: a persistent workgroup evaluates a call's cutoff once
-    const bool viaJob = needCut && ga.cutJobs != 0u;             // uniform: ... or takes it from the call's cutoff job
+    // ... or takes it from the call's cutoff job -- except for its FIRST item: the launch has just started, no job can have
+    // finished, and evaluating the cutoff here (5 us, its inputs loaded beside the stage loads) beats waiting for one
+    const bool viaJob = needCut && ga.cutJobs != 0u && !firstItem;
     // Input prologue (uniform per call): the multiply's input is v itself, or silu(v) * vAux (the FFN gate,
     // runNetwork.swift:181), or rmsNorm(v) * vAux (runNetwork.swift:121-122,173-175) -- evaluated here, per workgroup,
     // instead of in a launch of its own.
@@ -433,20 +435,28 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     // lanes of the ballot).  The list order therefore depends on the order in which the waves arrive -- it does not
     // matter: every listed row is added with integer arithmetic (see D), and the reference's own list is appended with an
     // atomic counter in no particular order (bucketMul.metal:71).
+    // (branch-free: all sixteen reads of a thread go out together, rounds past the slice test as "slot does not exist")
     float ax = 0.0f;
     if (FMT == kFp16) { const uint32_t jl = (uint32_t)tid & ((1u << lg) - 1u); ax = jl < nb ? fabsf(vblk[jl]) : 0.0f; }
+    const uint32_t slotCap = __builtin_amdgcn_readfirstlane((lp.offV[0] - lp.offM) / 4u) - 1u;      // last dword of the means region
+    uint32_t mraw[kRounds]; float vq[kRounds];
+#pragma unroll
+    for (int rr = 0; rr < kRounds; rr++) {
+        const uint32_t c = min((uint32_t)(rr * NT + tid), slotCap);
+        mraw[rr] = m32[c];
+        vq[rr] = FMT == kQ4 ? vblk[min(c >> 3, nb - 1u)] : 0.0f;
+    }
+    const bool sel = !(ga.ablate & 8u);
     uint32_t keepMask = 0;                                  // bit r: this thread's slot of round r is kept
     uint32_t before[kRounds];                               // (wave-uniform) survivors of the wave's earlier rounds
     uint32_t wtot = 0;
 #pragma unroll
     for (int rr = 0; rr < kRounds; rr++) {
         before[rr] = wtot;
-        if ((uint32_t)(rr * NT) >= nSlots) continue;        // uniform
         const uint32_t c = rr * NT + tid;
         bool k;
-        if (FMT == kFp16) k = (c >> lg) < g.rowsPerIn && cutoff < (kCutoffScale * half_bits_to_float((uint16_t)(m32[c] >> 16))) * ax;
-        else k = c < nSlots && cutoff < (kCutoffScale * means[c]) * fabsf(vblk[min(c >> 3, nb - 1u)]);
-        k = k && !(ga.ablate & 8u);
+        if (FMT == kFp16) k = (cutoff < (kCutoffScale * half_bits_to_float((uint16_t)(mraw[rr] >> 16))) * ax) & ((c >> lg) < g.rowsPerIn) & sel;
+        else k = (cutoff < (kCutoffScale * __uint_as_float(mraw[rr])) * fabsf(vq[rr])) & (c < nSlots) & sel;
         keepMask |= k ? (1u << rr) : 0u;
         wtot += (uint32_t)__popcll(__ballot(k));
     }
@@ -455,7 +465,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     wbase = __builtin_amdgcn_readfirstlane(wbase);
 #pragma unroll
     for (int rr = 0; rr < kRounds; rr++) {
-        if ((uint32_t)(rr * NT) >= nSlots) continue;        // uniform
+        if ((uint32_t)(rr * NT) >= nSlots) break;           // uniform
         const uint32_t c = rr * NT + tid;
         const bool k = (keepMask >> rr) & 1u;
         const unsigned long long m = __ballot(k);
@@ -593,6 +603,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
             accumulate(pb, dvB, __builtin_amdgcn_readfirstlane(baseB < nU ? min((uint32_t)KB, nU - baseB) : 0u));
         }
     }
+    // (measured too: everything BUT this loop at raised priority -- no effect, 173.9 vs 173.5 us per 32-call launch)
     if (!asked) asked = prefetch();            // (a wave without rows; wave 0 always gets an answer: it is the one that pulls)
     __syncthreads();                           // every wave's atomics have landed in the tile
     if (stamp) ga.tstamp[20] = wall_clock64();
@@ -904,7 +915,7 @@ __global__ __launch_bounds__(64 * W, (W <= 8 ? EFFORT_MIN_WAVES_PER_EU : 4)) voi
         }
         gen++;
         bool stagedNext = false;
-        mul_item<FMT, E, W, FUSED>(ga, item - ga.cutJobs, ref, smem, lp, cachedCall, cachedCutoff, par, staged, [&]() -> bool {
+        mul_item<FMT, E, W, FUSED>(ga, item - ga.cutJobs, ref, smem, lp, cachedCall, cachedCutoff, par, staged, gen == 1u && (ga.ablate & 512u) != 0u /* (measured: evaluating the first item's cutoff locally instead of waiting for the job is 1 us slower per 32-call launch; kept as an ablation) */, [&]() -> bool {
             if (!ga.persistent) return true;
             if (threadIdx.x == 0) {                                // wave 0's first call: pull, publish
                 s_next[0] = pull();

@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--q4", type=int, default=0)
     ap.add_argument("--configs", default="0,0,0:-1")
     ap.add_argument("--tag", default="")
+    ap.add_argument("--streams", type=int, default=1, help="spread the launches of a step round-robin over K streams / contexts")
+    ap.add_argument("--steps-per-graph", type=int, default=1, help="steps captured into one graph")
     args = ap.parse_args()
     inDim, outDim = (int(x) for x in args.shape.split("x"))
     import effort_amd as ea
@@ -44,9 +46,31 @@ def main():
             tune, per = cfg.split(":")
             g.set_tuning(*(int(x) for x in tune.split(",")))
             g.set_persistent(int(per))
+            K = args.streams
+            if K > 1 and not hasattr(main, "ctxs"):
+                main.ctxs = [ea.Gpu(0) for _ in range(K)]
+                main.sts = [torch.cuda.Stream() for _ in range(K)]
+            if K > 1:
+                for c in main.ctxs:
+                    c.set_tuning(*(int(x) for x in tune.split(",")))
+                    c.set_persistent(int(per))
+
             def run():
-                for ch in chunks:
-                    ea.bucketMulGroup([(v, ew, None, o, args.effort) for ew, o in ch])
+                for rep_ in range(args.steps_per_graph):
+                    if K == 1:
+                        for ch in chunks:
+                            ea.bucketMulGroup([(v, ew, None, o, args.effort) for ew, o in ch])
+                    else:                                # step `rep_` of the graph goes to stream rep_ % K (own context: own scratch)
+                        s0 = torch.cuda.current_stream()
+                        st, cx = main.sts[rep_ % K], main.ctxs[rep_ % K]
+                        if rep_ < K:
+                            st.wait_stream(s0)
+                        with torch.cuda.stream(st):
+                            for ch in chunks:
+                                ea.bucketMulGroup([(v, ew, None, o, args.effort) for ew, o in ch], gpu=cx)
+                if K > 1:
+                    for st in main.sts:
+                        torch.cuda.current_stream().wait_stream(st)
 
             def timed(n):
                 run()
@@ -63,7 +87,7 @@ def main():
                 for _ in range(n):
                     gr.replay()
                 torch.cuda.synchronize()
-                return (time.perf_counter() - t0) / n / len(chunks)
+                return (time.perf_counter() - t0) / n / len(chunks) / args.steps_per_graph
             g.enable_kernel_timing(0)
             dt = timed(300)
             g.enable_kernel_timing(2)

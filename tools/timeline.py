@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--q4", type=int, default=0)
     ap.add_argument("--persistent", type=int, default=-1)
     ap.add_argument("--out", default="gpurun_out/timeline.json")
+    ap.add_argument("--replay", type=int, default=0, help="trace the last of N back-to-back graph replays instead of one eager launch")
     args = ap.parse_args()
     inDim, outDim = (int(x) for x in args.shape.split("x"))
     import effort_amd as ea
@@ -48,8 +49,19 @@ def main():
             ea.bucketMulGroup(calls)
         g.eval()
         g.enable_kernel_timing(3)
-        ea.bucketMulGroup(calls)
-        g.eval()
+        if args.replay:                                  # sustained: the launch traced is the last of `replay` back-to-back graph replays
+            ea.bucketMulGroup(calls)
+            g.eval()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                ea.bucketMulGroup(calls)
+            g._bind_stream()
+            for _ in range(args.replay):
+                gr.replay()
+            g.eval()
+        else:
+            ea.bucketMulGroup(calls)
+            g.eval()
         rec = np.array(g.debug_trace(4096), dtype=np.uint64)
         g.enable_kernel_timing(0)
         rec = rec[rec[:, 2] != 0]
