@@ -1,35 +1,39 @@
 #!/usr/bin/env python
 """bench.py -- bucketMul throughput on MI355X (driver contract: DESIGN.md "Measurement").
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--group 32] [--effort 0.25]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--group 32] [--streams 4] [--effort 0.25]
 
 Workload (BASELINE.json configs[1]): Mistral-7B-FFN-shaped matrix 4096 x 11008, fp16 buckets, bucketMul at
 25 % effort (the north-star operating point), plus an effort sweep 10..100 % in the same JSON line.
 One STEP = one pass of the hot path over one batch of synthetic input = 32 bucketMul calls, one per DISTINCT
 converted matrix (rotation i % 32 exactly like benchmarks/benchmark.swift:206,255 -- 2.9 GB of buckets, so
 reads come from HBM, not the 256 MB Infinity Cache), all on the same input vector, each writing its own output
-vector.  Inputs are resident in HBM before the timed region.  The 32 calls of a step are replayed from ONE
-hipGraph on ONE stream, so the host is not in the timed path (the reference's timeIt, helpers/timeit.swift:10-34,
-likewise enqueues everything and waits once).  The calls of a step are independent (as Wq|Wk|Wv or W1|W3 are in the
-decode loop), so they are issued `--group` at a time through effort_bucketmul_group: ONE kernel launch per group.
-`by_group_size` in the output gives the same step at 1, 2, 3, 4, 8, 16 and 32 calls per launch; group size 1 is the
-dependent-chain latency (every call waits for the previous one).  `two_streams` spreads the launches over two HIP
-streams (the head of one launch then overlaps the tail of another).
+vector.  Inputs are resident in HBM before the timed region.  The calls of a step are independent (as Wq|Wk|Wv or
+W1|W3 are in the decode loop), so they are issued `--group` at a time through effort_bucketmul_group: ONE kernel
+launch per group.  The K steps of the job are independent too (a serving loop's batches are), so the whole job is
+ONE hipGraph in which step i runs on HIP stream i % S with its own context (scratch) and its own output set: up to
+S = `--streams` launches are in flight, and the head of one (staging, cutoffs, selection: HBM idle) runs under the
+streaming phase of the others.  The host is not in the timed path (the reference's timeIt, helpers/timeit.swift:10-34,
+likewise enqueues everything and waits once).
 
 value            = effective (dense-equivalent) GB/s = 2*inDim*outDim bytes per call / time per call, whole job
                    over all ranks.
 tokens_per_s     = the reference's projection 1/(t_call * 4 * 32) (helpers/timeit.swift:26,33-34).
-roofline         = dominant kernel (bucket_mul_kernel: a whole group of calls in one launch): algorithmic bytes per
-                   launch / its average launch duration = the timed region / its launches.  Kernels of one stream do
-                   not overlap, so this is also what `rocprofv3 --kernel-trace --stats` reports for the same command.
+roofline         = dominant kernel (bucket_mul_kernel: a whole group of calls in one launch).  achieved = algorithmic
+                   bytes the timed region moved / the timed region = bytes per launch / (timed region / launches): with S
+                   launches in flight that is the chip's rate, not one kernel's; `single_stream` gives the same job with
+                   ONE launch in flight (launch duration = timed region / launches, which is what `rocprofv3
+                   --kernel-trace --stats` reports per launch when kernels do not overlap: profiles/).
+by_group_size    = the step at 1, 2, 3, 4, 8, 16, 32 calls per launch on one stream (1 = the dependent-chain latency).
+by_streams       = the job at 1..4 launches in flight.
 cpu_baseline     = the CPU oracle (a port: the reference ships no CPU path) on the host cores, bounded sample.
 decode           = BASELINE.json configs[4]: end-to-end greedy decode of a random-init Mistral-7B-shaped model through
                    effort_amd/decode.py (one hipGraph per token): tokens/s dense vs effort 100 % / 25 %, KL vs dense.
 
 N > 1 (one process per GPU, RCCL): independent matrices are partitioned across the ranks (every rank owns 32
 distinct matrices; weak scaling) and the output vectors of a step are exchanged with ONE all-gather (north_star:
-"partition independent weight matrices ... RCCL all-gather of the output vectors").  `--partition columns` runs
-the bucket-column sharding of SURVEY 8e instead (strong scaling).
+"partition independent weight matrices ... RCCL all-gather of the output vectors").  The bucket-column sharding of
+SURVEY 8e (strong scaling: every rank multiplies its columns of all 32 matrices) is measured beside it (`columns`).
 """
 from __future__ import annotations
 
@@ -48,7 +52,7 @@ IN_DIM, OUT_DIM = 4096, 11008
 N_MATS = 32
 SWEEP = [0.10, 0.15, 0.20, 0.25, 0.30, 0.40, 0.50, 0.60, 0.70, 0.80, 0.90, 1.00]
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PMC_FILE = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")   # written from a rocprofv3 --pmc pass (tools/pmc_traffic.py)
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")   # written from a rocprofv3 --pmc pass (tools/pmc_traffic.py)
 
 
 def log(*a):
@@ -66,6 +70,9 @@ def mul_kernel_bytes(D: int, inDim: int, outDim: int) -> int:
     return algorithmic_bytes(D, inDim, outDim)
 
 
+ALIGN_ROWS = True    # (--no-align) bucket rows re-pitched to whole 128-byte lines at registration: effort_weights_align_rows
+
+
 def make_weights(ea, n, inDim, outDim, seed0, dev, keep_core=True, q4=False):
     ews = []
     gen = torch.Generator(device=dev)
@@ -81,76 +88,77 @@ def make_weights(ea, n, inDim, outDim, seed0, dev, keep_core=True, q4=False):
         if not keep_core:
             ew.core = None
         ew.handle
+        if ALIGN_ROWS:
+            ew.align_rows()
         ews.append(ew)
     ea.gpu().eval()
     return ews
-
-
-class Step:
-    """One step = one call per (matrix, output) item.  `group` calls per launch on the context's stream; with K > 1
-    the launches are additionally spread round-robin over K HIP streams / contexts (used for the dense baseline,
-    which has no grouped form).  capture() returns the step as one hipGraph."""
-
-    def __init__(self, ea, device, K=1):
-        self.ea, self.K = ea, K
-        self.ctxs = [ea.gpu(device)] if K == 1 else [ea.Gpu(device) for _ in range(K)]
-        self.streams = [None] if K == 1 else [torch.cuda.Stream(device=device) for _ in range(K)]
-
-    def _enqueue(self, fn, chunks):
-        if self.K == 1:
-            for ch in chunks:
-                fn(self.ctxs[0], ch)
-            return
-        s0 = torch.cuda.current_stream()
-        for st in self.streams:
-            st.wait_stream(s0)
-        for i, ch in enumerate(chunks):
-            with torch.cuda.stream(self.streams[i % self.K]):
-                fn(self.ctxs[i % self.K], ch)
-        for st in self.streams:
-            s0.wait_stream(st)
-
-    def capture(self, fn, chunks):
-        self._enqueue(fn, chunks)                    # warm: handles, kernel attributes, rocBLAS workspaces
-        torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            self._enqueue(fn, chunks)
-        for c in self.ctxs:
-            c._bind_stream()
-        return g
 
 
 def chunked(items, n):
     return [items[i:i + n] for i in range(0, len(items), n)]
 
 
-def time_replays(g, steps, warmup, barrier=None, after=None):
-    for _ in range(warmup):
-        g.replay()
-        if after:
-            after()
+class Job:
+    """K independent steps as ONE hipGraph: step i is enqueued on stream i % S through context i % S (a context owns the
+    scratch of its launches) into output set i % S; the streams fork from / join the capturing stream inside the graph.
+    `step(ctx, slot)` enqueues one step's launches on the current stream.  S = 1: everything on the capturing stream."""
+
+    def __init__(self, ea, device, streams=1, tune=(0, 0, 0)):
+        self.ea, self.S = ea, max(1, streams)
+        self.ctxs = [ea.gpu(device)] + [ea.Gpu(device) for _ in range(self.S - 1)]
+        self.streams = [None] + [torch.cuda.Stream(device=device) for _ in range(self.S - 1)]
+        for c in self.ctxs:
+            c.set_tuning(*tune)
+
+    def _enqueue(self, step, nsteps):
+        s0 = torch.cuda.current_stream()
+        used = min(self.S, nsteps)
+        for k in range(1, used):
+            self.streams[k].wait_stream(s0)
+        for i in range(nsteps):
+            k = i % self.S
+            if k == 0:
+                step(self.ctxs[0], 0)
+            else:
+                with torch.cuda.stream(self.streams[k]):
+                    step(self.ctxs[k], k)
+        for k in range(1, used):
+            s0.wait_stream(self.streams[k])
+
+    def capture(self, step, nsteps):
+        self._enqueue(step, min(nsteps, self.S))     # warm: handles, kernel attributes, rocBLAS workspaces
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._enqueue(step, nsteps)
+        for c in self.ctxs:
+            c._bind_stream()
+        return g
+
+
+def time_graph(g_timed, g_warm, barrier=None, reps=1):
+    """W warm-up steps (one replay of the warm-up graph), then the timed graph `reps` times: seconds per replay."""
+    (g_warm if g_warm is not None else g_timed).replay()      # (no warm-up graph: one untimed replay of the timed one -- the first replay of a graph uploads it)
     if barrier:
         barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        g.replay()
-        if after:
-            after()
+    for _ in range(reps):
+        g_timed.replay()
     torch.cuda.synchronize()
     if barrier:
         barrier()
-    return (time.perf_counter() - t0) / steps
+    return (time.perf_counter() - t0) / reps
 
 
-def cpu_baseline(ews, v, effort, inDim, outDim, budget_s=12.0):
-    """CPU oracle ("port") on the host cores: same converted weights (4 of the matrices), same v, same effort."""
+def cpu_baseline(ews, v, effort, inDim, outDim, budget_s=10.0, nmat=4):
+    """CPU oracle ("port") on the host cores: same converted weights (a few of the matrices), same v, same effort."""
     import numpy as np
 
     from oracle import cpu
     mats = []
-    for ew in ews[:4]:
+    for ew in ews[:nmat]:
         mats.append((ew.buckets[0].cpu().numpy().view(np.float16), ew.stats[0].cpu().numpy().view(np.float16),
                      ew.probes[0].cpu().numpy().view(np.float16)))
     vh = v.cpu().numpy()
@@ -158,30 +166,52 @@ def cpu_baseline(ews, v, effort, inDim, outDim, budget_s=12.0):
     cpu.bucket_mul(vh, *mats[0], inDim, outDim, effort, scratch=sc)                # warm
     n, t0 = 0, time.perf_counter()
     while time.perf_counter() - t0 < budget_s:
-        out, D, _ = cpu.bucket_mul(vh, *mats[n % 4], inDim, outDim, effort, scratch=sc)
+        cpu.bucket_mul(vh, *mats[n % nmat], inDim, outDim, effort, scratch=sc)
         n += 1
     dt = (time.perf_counter() - t0) / n
     return {"value": round(2 * inDim * outDim / dt / 1e9, 3), "unit": "GB/s", "cores": os.cpu_count(),
             "kind": "port", "us_per_call": round(dt * 1e6, 1),
-            "sample": f"{n} bucketMul calls at effort {effort} over 4 of the {N_MATS} converted {inDim}x{outDim} matrices "
-                      f"(OpenMP over bucket columns, {os.cpu_count()} threads), {budget_s:.0f} s budget"}, out, (n - 1) % 4
+            "sample": f"{n} bucketMul calls at effort {effort} over {nmat} of the converted {inDim}x{outDim} matrices "
+                      f"(OpenMP over bucket columns, {os.cpu_count()} threads), {budget_s:.0f} s budget"}
+
+
+def oracle_outputs(ews, v, effort, inDim, outDim, idxs):
+    """The CPU oracle's product for the matrices `idxs` (test infrastructure used as the CHECKER of the bench's outputs)."""
+    import numpy as np
+
+    from oracle import cpu
+    vh = v.cpu().numpy()
+    sc = cpu.Scratch(inDim * 16)
+    res = {}
+    for k in idxs:
+        ew = ews[k]
+        out, D, cutoff = cpu.bucket_mul(vh, ew.buckets[0].cpu().numpy().view(np.float16), ew.stats[0].cpu().numpy().view(np.float16),
+                                        ew.probes[0].cpu().numpy().view(np.float16), inDim, outDim, effort, scratch=sc)
+        res[k] = (out, D, cutoff)
+    return res
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--effort", type=float, default=0.25)
     ap.add_argument("--group", type=int, default=32, help="independent calls per kernel launch (1..32)")
+    ap.add_argument("--streams", type=int, default=4, help="steps (launches) in flight: HIP streams inside the job's hipGraph")
     ap.add_argument("--partition", choices=["matrices", "columns"], default="matrices")
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-decode", action="store_true", help="skip the end-to-end decode section (BASELINE.json configs[4])")
     ap.add_argument("--headline-only", action="store_true", help="only the timed job (for rocprofv3 passes: every bucket_mul_kernel dispatch is then the timed configuration)")
+    ap.add_argument("--no-align", action="store_true", help="stream the converter's rows as they are (2*cols bytes apart) instead of the handle's line-aligned copy")
     ap.add_argument("--tune", default="0,0,0", help="waves,elems,slices of the multiply kernel (0,0,0 = heuristic)")
     args = ap.parse_args()
+    global ALIGN_ROWS
+    ALIGN_ROWS = not args.no_align
     G = max(1, min(32, args.group))
+    S = max(1, min(8, args.streams))
+    tune = tuple(int(x) for x in args.tune.split(","))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -201,25 +231,17 @@ def main():
 
     import effort_amd as ea
     g = ea.gpu(local)
-    g.set_tuning(*(int(x) for x in args.tune.split(",")))
+    g.set_tuning(*tune)
 
     inDim, outDim = IN_DIM, OUT_DIM
     t_setup = time.perf_counter()
-    columns = world > 1 and args.partition == "columns"
-    seed0 = 1234 if (columns or world == 1) else 1234 + rank * N_MATS
-    ews_full = make_weights(ea, N_MATS, inDim, outDim, seed0, dev, keep_core=(rank == 0))
-    if columns:
-        from effort_amd.sharded import ShardedExpertWeights
-        ews = [ShardedExpertWeights.from_full(e, rank, world).local for e in ews_full]
-        localOut = outDim // world
-    else:
-        ews, localOut = ews_full, outDim
+    seed0 = 1234 if world == 1 else 1234 + rank * N_MATS
+    ews = make_weights(ea, N_MATS, inDim, outDim, seed0, dev, keep_core=(rank == 0))
     gen = torch.Generator(device=dev)
     gen.manual_seed(42)
     v = torch.randn(inDim, generator=gen, device=dev, dtype=torch.float32)
-    outs_all = torch.zeros((N_MATS, localOut), device=dev)
-    outs = [outs_all[k] for k in range(N_MATS)]
-    gathered = torch.zeros((world, N_MATS * localOut), device=dev) if dist else None
+    out_sets = [torch.zeros((N_MATS, outDim), device=dev) for _ in range(S)]          # one output set per stream
+    outs = [out_sets[0][k] for k in range(N_MATS)]
     torch.cuda.synchronize()
     log(f"[rank {rank}] setup {time.perf_counter() - t_setup:.1f} s: {N_MATS} matrices {inDim}x{outDim} converted on the GPU")
 
@@ -227,92 +249,144 @@ def main():
         if dist:
             dist.barrier()
 
-    def mul(effort):
-        return lambda ctx, chunk: ea.bucketMulGroup([(v, ew, None, o, effort) for ew, o in chunk], gpu=ctx)
+    def mul_step(effort, weights=ews, vec=v, sets=out_sets, group=G):
+        """One step: the group launches of the matrices in `weights`, outputs into set `slot`."""
+        def step(ctx, slot):
+            items = [(vec, ew, None, sets[slot][k], effort) for k, ew in enumerate(weights)]
+            for ch in chunked(items, group):
+                ea.bucketMulGroup(ch, gpu=ctx)
+        return step
 
-    items = list(zip(ews, outs))
-    one = Step(ea, local)
+    job = Job(ea, local, S, tune)
+    one = Job(ea, local, 1, tune) if S > 1 else job
+    launches_per_step = (N_MATS + G - 1) // G
 
     # ---------------- the timed job: K steps at the headline effort --------------------------------
-    graph = one.capture(mul(args.effort), chunked(items, G))
-    D = g.last_dispatch_count((N_MATS - 1) % G)
     if dist:
-        # Pipelined exchange: step i's all-gather runs on a communication stream while step i+1 computes into the other
-        # of two output buffers (the steps are independent); a buffer is recomputed only after its gather has finished.
-        outs_b = torch.zeros((N_MATS, localOut), device=dev)
-        graph_b = one.capture(mul(args.effort), chunked(list(zip(ews, [outs_b[k] for k in range(N_MATS)])), G))
-        gathered_b = torch.zeros_like(gathered)
+        # every rank: its 32 matrices per step, then ONE all-gather of the step's output vectors.  Pipelined exchange: step
+        # i's all-gather runs on a communication stream while step i+1 computes into the other of two output buffers.
+        graph_a = one.capture(mul_step(args.effort, sets=[out_sets[0]]), 1)
+        buf_b = torch.zeros((N_MATS, outDim), device=dev)
+        graph_b = one.capture(mul_step(args.effort, sets=[buf_b]), 1)
+        gathered = [torch.zeros((world, N_MATS * outDim), device=dev) for _ in range(2)]
         comm = torch.cuda.Stream(device=dev)
-        bufs = [(graph, outs_all, gathered, torch.cuda.Event(), torch.cuda.Event()),
-                (graph_b, outs_b, gathered_b, torch.cuda.Event(), torch.cuda.Event())]
+        bufs = [(graph_a, out_sets[0], gathered[0], torch.cuda.Event(), torch.cuda.Event()),
+                (graph_b, buf_b, gathered[1], torch.cuda.Event(), torch.cuda.Event())]
 
-        def run(n):
+        def run(n, exchange=True):
             main = torch.cuda.current_stream()
             for i in range(n):
                 gr, src, dst, computed, gathered_ev = bufs[i & 1]
-                main.wait_event(gathered_ev)             # the previous gather out of this buffer is done
+                if exchange:
+                    main.wait_event(gathered_ev)             # the previous gather out of this buffer is done
                 gr.replay()
-                computed.record(main)
-                with torch.cuda.stream(comm):
-                    comm.wait_event(computed)
-                    dist.all_gather_into_tensor(dst.view(-1), src.view(-1))
-                    gathered_ev.record(comm)
+                if exchange:
+                    computed.record(main)
+                    with torch.cuda.stream(comm):
+                        comm.wait_event(computed)
+                        dist.all_gather_into_tensor(dst.view(-1), src.view(-1))
+                        gathered_ev.record(comm)
             main.wait_stream(comm)
 
-        run(args.warmup)
-        barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        run(args.steps)
-        torch.cuda.synchronize()
-        barrier()
-        dt = (time.perf_counter() - t0) / args.steps
+        def timed(exchange):
+            run(args.warmup, exchange)
+            barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run(args.steps, exchange)
+            torch.cuda.synchronize()
+            barrier()
+            x = torch.tensor([(time.perf_counter() - t0) / args.steps], device=dev, dtype=torch.float64)
+            dist.all_reduce(x, op=dist.ReduceOp.MAX)
+            return float(x.item())
+        dt_kernel = timed(False)                             # the steps without the exchange (kernel only)
+        dt = timed(True)
+        D = g.last_dispatch_count((N_MATS - 1) % G)
+        in_flight = 1
     else:
-        dt = time_replays(graph, args.steps, args.warmup, barrier)
-    if dist:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    calls_per_step = N_MATS * (world if not columns else 1)          # whole job
-    t_call = dt / N_MATS                                            # per-rank time per bucketMul call
+        g_warm = job.capture(mul_step(args.effort), args.warmup) if args.warmup > 0 else None
+        g_timed = job.capture(mul_step(args.effort), args.steps)
+        D = job.ctxs[(args.steps - 1) % S].last_dispatch_count((N_MATS - 1) % G)
+        dt = time_graph(g_timed, g_warm, barrier) / args.steps
+        in_flight = min(S, args.steps)
+    calls_per_step = N_MATS * world                                  # whole job
+    t_call = dt / N_MATS                                             # per-rank time per bucketMul call
     eff_bytes = 2 * inDim * outDim
     value = calls_per_step * eff_bytes / dt / 1e9
+    kb = mul_kernel_bytes(D, inDim, outDim)
 
     result = {
         "metric": "effective GB/s + tokens/s vs effort %, Mistral-7B FFN 4096x11008 fp16",
         "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(dt * 1e3, 5), "higher_is_better": True, "scaling": "strong" if columns else "weak",
+        "ms_per_step": round(dt * 1e3, 5), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f16", "data": "synthetic",
         "config": {"workload": f"bucketMul {inDim}x{outDim} fp16 buckets, effort {args.effort}, {N_MATS} distinct matrices rotated "
                                f"(one call each per step), fixed-point accumulate (f32 out); {G} independent calls per fused "
-                               f"kernel launch, one stream, one hipGraph", "effort": args.effort, "matrices_per_step": N_MATS,
-                   "inDim": inDim, "outDim": outDim, "calls_per_launch": G, "kernel_geometry(waves,elems,slices)": args.tune if args.tune != "0,0,0" else "heuristic",
-                   "partition": ("columns" if columns else "matrices") if world > 1 else "none", "dispatch_rows": D},
+                               f"kernel launch; the job's steps are independent: ONE hipGraph, {in_flight} step(s) in flight "
+                               f"({in_flight} HIP stream(s), one context each)", "effort": args.effort, "matrices_per_step": N_MATS,
+                   "inDim": inDim, "outDim": outDim, "calls_per_launch": G, "steps_in_flight": in_flight,
+                   "bucket_row_pitch_bytes": (outDim // 16 * 2 + 127) // 128 * 128 if ALIGN_ROWS else outDim // 16 * 2,
+                   "kernel_geometry(waves,elems,slices)": args.tune if args.tune != "0,0,0" else "heuristic",
+                   "partition": "matrices" if world > 1 else "none", "dispatch_rows": D},
         "us_per_call": round(t_call * 1e6, 3),
         "tokens_per_s": round(1.0 / (t_call * 4 * 32), 2),
+        "timed_region_ms": round(dt * args.steps * 1e3, 3),
     }
+    if dt * args.steps < 0.05:
+        result["timed_region_note"] = "timed region < 50 ms: clocks and caches are still settling, longer runs (--steps 200) read a few % faster"
+    if dist:
+        result["rccl_ranks"] = dist.get_world_size()
+        result["multi_gpu"] = {"partition": "matrices (weak scaling: every rank its own 32 matrices)", "ms_per_step_kernel_only": round(dt_kernel * 1e3, 5),
+                               "ms_per_step_with_all_gather": round(dt * 1e3, 5), "all_gather_bytes_per_rank_per_step": N_MATS * outDim * 4}
+        # bucket-column sharding (SURVEY 8e): every rank multiplies ITS columns of the same 32 matrices (seed 1234 on every
+        # rank), one all-gather per step of [world, 32 * outDim/world] floats; strong scaling
+        try:
+            from effort_amd.sharded import ShardedExpertWeights
+            full = ews if seed0 == 1234 else make_weights(ea, N_MATS, inDim, outDim, 1234, dev, keep_core=False)
+            shards = [ShardedExpertWeights.from_full(e, rank, world).local for e in full]
+            lo = outDim // world
+            send = [torch.zeros((N_MATS, lo), device=dev) for _ in range(2)]
+            recv = [torch.zeros((world, N_MATS * lo), device=dev) for _ in range(2)]
+            cg = [one.capture(mul_step(args.effort, weights=shards, sets=[send[i]]), 1) for i in range(2)]
+            evs = [(torch.cuda.Event(), torch.cuda.Event()) for _ in range(2)]
+
+            def crun(n, exchange):
+                main = torch.cuda.current_stream()
+                for i in range(n):
+                    b = i & 1
+                    if exchange:
+                        main.wait_event(evs[b][1])
+                    cg[b].replay()
+                    if exchange:
+                        evs[b][0].record(main)
+                        with torch.cuda.stream(comm):
+                            comm.wait_event(evs[b][0])
+                            dist.all_gather_into_tensor(recv[b].view(-1), send[b].view(-1))
+                            evs[b][1].record(comm)
+                main.wait_stream(comm)
+
+            def ctimed(exchange):
+                crun(args.warmup, exchange)
+                barrier()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                crun(args.steps, exchange)
+                torch.cuda.synchronize()
+                barrier()
+                x = torch.tensor([(time.perf_counter() - t0) / args.steps], device=dev, dtype=torch.float64)
+                dist.all_reduce(x, op=dist.ReduceOp.MAX)
+                return float(x.item())
+            ck, ca = ctimed(False), ctimed(True)
+            result["multi_gpu"]["columns"] = {
+                "partition": f"bucket columns: {outDim // 16 // world} of {outDim // 16} columns per rank, stats / probes replicated (strong scaling: the same 32 matrices on every N)",
+                "ms_per_step_kernel_only": round(ck * 1e3, 5), "ms_per_step_with_all_gather": round(ca * 1e3, 5),
+                "effective_GBps_whole_job": round(N_MATS * eff_bytes / ca / 1e9, 1), "all_gather_bytes_per_rank_per_step": N_MATS * lo * 4}
+            del shards, cg
+        except Exception as ex:
+            result["multi_gpu"]["columns"] = {"error": repr(ex)}
 
     if rank == 0 and world == 1 and not args.headline_only:
-        kb = mul_kernel_bytes(D, inDim, outDim)
-        launches = (N_MATS + G - 1) // G
         # ---------------- roofline of the dominant kernel, in the timed configuration -----------------
-        g.enable_kernel_timing(2)                        # device wall clock inside the kernel (graph safe)
-        gt = one.capture(mul(args.effort), chunked(items, G))
-        for _ in range(5):
-            gt.replay()
-        g.kernel_clock()
-        for _ in range(20):
-            gt.replay()
-        kc = g.kernel_clock()
-        kus, nl = kc["mul_us"], kc["launches"]
-        del gt
-        g.enable_kernel_timing(1)                        # HIP events on the launch stream, queue pre-filled
-        torch.cuda._sleep(20_000_000)                    # keep the GPU busy while the host enqueues
-        for r in range(4):
-            for ch in chunked(items, G):
-                ea.bucketMulGroup([(v, ew, None, o, args.effort) for ew, o in ch])
-        evt = g.kernel_timing()
-        g.enable_kernel_timing(0)
         traffic = None
         try:
             with open(PMC_FILE) as f:
@@ -321,102 +395,130 @@ def main():
                 traffic = pmc["hbm_bytes_per_launch"]
         except Exception:
             pmc = None
-        t_launch = dt / launches                         # launch-to-launch in the timed graph (includes the gap between kernels)
-        # The kernel's average launch duration = the timed region / the launches it holds: one stream, back-to-back launches
-        # of one hipGraph, so this is what HIP events around the region give and what `rocprofv3 --kernel-trace --stats`
-        # reports per launch (profiles/).  The in-kernel device clock (first workgroup start -> last workgroup end) and
-        # per-launch HIP events outside a graph are given beside it.
-        t_kernel = t_launch
+        t_launch = dt / launches_per_step                # the timed region's share per launch
         result["roofline"] = {
-            "bound": "hbm", "kernel": "bucket_mul_kernel", "achieved": round(G * kb / t_kernel / 1e9, 1), "peak": HBM_PEAK_GBPS,
-            "unit": "GB/s", "frac": round(G * kb / t_kernel / 1e9 / HBM_PEAK_GBPS, 4), "traffic": traffic,
+            "bound": "hbm", "kernel": "bucket_mul_kernel", "achieved": round(G * kb / t_launch / 1e9, 1), "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s", "frac": round(G * kb / t_launch / 1e9 / HBM_PEAK_GBPS, 4), "traffic": traffic,
             "traffic_source": (f"rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE pass of this command ({os.path.relpath(PMC_FILE, ROOT)}), "
                                "corrected as MI355X_MICROARCH.md prescribes") if traffic else None,
-            "calls_per_launch": G, "bytes_per_launch": G * kb, "bytes_per_call": kb, "kernel_us": round(t_kernel * 1e6, 3),
-            "kernel_us_source": "timed region / launches (one stream, back-to-back launches of one hipGraph)",
-            "kernel_us_device_clock": round(kus, 3), "launches_sampled_device_clock": nl,
-            "frac_device_clock": round(G * kb / kus / 1e3 / HBM_PEAK_GBPS, 4),
-            "kernel_us_hip_events_outside_graph": round(evt["mul_us"], 3),
+            "calls_per_launch": G, "bytes_per_launch": G * kb, "bytes_per_call": kb, "launches_in_flight": in_flight,
+            "kernel_us": round(t_launch * 1e6, 3),
+            "kernel_us_source": ("timed region / launches.  With one launch in flight this is the kernel's duration; with "
+                                 f"{in_flight} in flight it is the chip's time per launch (each launch lasts about {in_flight}x as long and "
+                                 "rocprofv3 reports that), so `achieved` is the rate of the CHIP over the timed region; see single_stream"),
         }
-        # ---------------- the same step at other group sizes (1 = dependent-chain latency) ------------
+        # the same job with ONE launch in flight: launch duration = timed region / launches (kernels do not overlap)
+        if S > 1:
+            g1w = one.capture(mul_step(args.effort), min(args.warmup, 10))
+            g1 = one.capture(mul_step(args.effort), args.steps)
+            dt1 = time_graph(g1, g1w) / args.steps
+            del g1w, g1
+        else:
+            dt1 = dt
+        g.enable_kernel_timing(2)                        # device wall clock inside the kernel (graph safe)
+        gt = one.capture(mul_step(args.effort), 25)
+        gt.replay()
+        g.kernel_clock()
+        gt.replay()
+        kc = g.kernel_clock()
+        del gt
+        g.enable_kernel_timing(1)                        # HIP events on the launch stream, queue pre-filled
+        torch.cuda._sleep(20_000_000)                    # keep the GPU busy while the host enqueues
+        for r in range(4):
+            mul_step(args.effort)(g, 0)
+        evt = g.kernel_timing()
+        g.enable_kernel_timing(0)
+        t1 = dt1 / launches_per_step
+        result["roofline"]["single_stream"] = {
+            "achieved": round(G * kb / t1 / 1e9, 1), "frac": round(G * kb / t1 / 1e9 / HBM_PEAK_GBPS, 4), "kernel_us": round(t1 * 1e6, 3),
+            "kernel_us_source": "timed region / launches (one stream, back-to-back kernel nodes of one hipGraph): the launch duration rocprofv3 --kernel-trace --stats reports for this configuration",
+            "kernel_us_device_clock": round(kc["mul_us"], 3), "frac_device_clock": round(G * kb / kc["mul_us"] / 1e3 / HBM_PEAK_GBPS, 4),
+            "kernel_us_hip_events_outside_graph": round(evt["mul_us"], 3)}
+        # ---------------- the step at other group sizes, one stream (1 = dependent-chain latency) ------
         by = {}
         for n in (1, 2, 3, 4, 8, 16, 32):
-            gn = one.capture(mul(args.effort), chunked(items, n))
-            tn = time_replays(gn, 40, 10) / N_MATS
+            gn = one.capture(mul_step(args.effort, group=n), 8)
+            tn = time_graph(gn, None, reps=6) / 8 / N_MATS
             by[str(n)] = {"us_per_call": round(tn * 1e6, 3), "effective_GBps": round(eff_bytes / tn / 1e9, 1),
                           "achieved_GBps": round(kb / tn / 1e9, 1), "tokens_per_s": round(1.0 / (tn * 4 * 32), 1)}
             del gn
         result["by_group_size"] = by
-        two = Step(ea, local, 2)
-        for c in two.ctxs:
-            c.set_tuning(*(int(x) for x in args.tune.split(",")))
-        tw = {}
-        for n in (8, 16, 32):
-            gn = two.capture(mul(args.effort), chunked(items, n))
-            tn = time_replays(gn, 40, 10) / N_MATS
-            tw[str(n)] = {"us_per_call": round(tn * 1e6, 3), "effective_GBps": round(eff_bytes / tn / 1e9, 1),
-                          "achieved_GBps": round(kb / tn / 1e9, 1), "frac_of_hbm_peak": round(kb / tn / 1e9 / HBM_PEAK_GBPS, 4)}
+        bs = {}
+        for ns in (1, 2, 3, 4):
+            jb = Job(ea, local, ns, tune) if ns not in (1, S) else (one if ns == 1 else job)
+            while len(out_sets) < ns:
+                out_sets.append(torch.zeros((N_MATS, outDim), device=dev))
+            gn = jb.capture(mul_step(args.effort), 48)
+            tn = time_graph(gn, None, reps=2) / 48 / N_MATS
+            bs[str(ns)] = {"us_per_call": round(tn * 1e6, 3), "effective_GBps": round(eff_bytes / tn / 1e9, 1),
+                           "achieved_GBps": round(kb / tn / 1e9, 1), "frac_of_hbm_peak": round(kb / tn / 1e9 / HBM_PEAK_GBPS, 4)}
             del gn
-        result["two_streams"] = tw
+        result["by_streams"] = bs
         ts = by["1"]["us_per_call"] * 1e-6
         # ---------------- dense baseline (basicMul over the rotating cores) ---------------------------
-        four = Step(ea, local, 4)
-        dense_out = [torch.zeros(outDim, device=dev) for _ in range(4)]
-        ditems = [[(ew, dense_out[i % 4])] for i, ew in enumerate(ews)]
+        dense_sets = [torch.zeros((N_MATS, outDim), device=dev) for _ in range(4)]
+        four = Job(ea, local, 4, tune)
 
-        def dense(ctx, chunk):
-            for ew, o in chunk:
-                ea.basicMul(v, ew.core, o, gpu=ctx)
+        def dense_step(ctx, slot):
+            for k, ew in enumerate(ews):
+                ea.basicMul(v, ew.core, dense_sets[slot][k], gpu=ctx)
         # basicMul (helpers/mps.swift:14-47) twice: through rocBLAS' hssgemv -- the library the north star names -- and
         # through the package's own streaming kernel (csrc/gemv.hip), the default backend of effort_dense_gemv
         for name, rocblas in (("dense_rocblas", True), ("dense_hip_kernel", False)):
             for ctx in one.ctxs + four.ctxs:
                 ctx.set_dense_backend(rocblas)
-            td1 = time_replays(one.capture(dense, ditems), 30, 5) / N_MATS
-            tdk = time_replays(four.capture(dense, ditems), 30, 5) / N_MATS
+            td1 = time_graph(one.capture(dense_step, 4), None, reps=3) / 4 / N_MATS
+            tdk = time_graph(four.capture(dense_step, 8), None, reps=3) / 8 / N_MATS
             result[name] = {"us_per_call_serial": round(td1 * 1e6, 3), "us_per_call_4_streams": round(tdk * 1e6, 3),
                             "GBps": round(eff_bytes / min(td1, tdk) / 1e9, 1), "frac_of_hbm_peak": round(eff_bytes / min(td1, tdk) / 1e9 / HBM_PEAK_GBPS, 4),
                             "speedup_at_effort": round(min(td1, tdk) / t_call, 3), "speedup_serial_vs_serial": round(td1 / ts, 3)}
+        dense_out = dense_sets[0]
         # ---------------- effort sweep ----------------------------------------------------------------
         if not args.no_sweep:
+            import numpy as np
+            last = N_MATS - 1
             sweep = []
             for e in SWEEP:
-                ge = one.capture(mul(e), chunked(items, G))
-                De = g.last_dispatch_count((N_MATS - 1) % G)
-                te = time_replays(ge, 40, 10) / N_MATS
-                ea.basicMul(v, ews[N_MATS - 1].core, dense_out[0])
-                cs = ea.cosineSimilarityTo(outs[N_MATS - 1], dense_out[0])
+                ge = job.capture(mul_step(e), 24)
+                De = job.ctxs[(24 - 1) % S].last_dispatch_count((N_MATS - 1) % G)
+                te = time_graph(ge, None, reps=2) / 24 / N_MATS
+                ea.basicMul(v, ews[last].core, dense_out[0])
+                cs = ea.cosineSimilarityTo(out_sets[(24 - 1) % S][last], dense_out[0])
+                want, Do, _ = oracle_outputs(ews, v, e, inDim, outDim, [last])[last]
+                got = out_sets[(24 - 1) % S][last].cpu().numpy().astype(np.float64)
+                co = float(got @ want.astype(np.float64) / (np.linalg.norm(got) * np.linalg.norm(want) + 1e-300))
                 sweep.append({"effort": e, "dispatch_rows": De, "us_per_call": round(te * 1e6, 3),
                               "effective_GBps": round(eff_bytes / te / 1e9, 1),
                               "achieved_GBps": round(algorithmic_bytes(De, inDim, outDim) / te / 1e9, 1),
                               "frac_of_hbm_peak": round(algorithmic_bytes(De, inDim, outDim) / te / 1e9 / HBM_PEAK_GBPS, 4),
-                              "tokens_per_s": round(1.0 / (te * 4 * 32), 1), "cos_vs_dense": round(cs, 5)})
+                              "tokens_per_s": round(1.0 / (te * 4 * 32), 1), "cos_vs_dense": round(cs, 5),
+                              "cos_vs_oracle": round(co, 9), "dispatch_rows_oracle": int(Do)})
                 del ge
             result["sweep"] = sweep
             # heavy-tailed input (a real rms-normed state has outlier channels): v * exp(N(0,1)), same seeds
             vh = v * torch.exp(torch.randn(inDim, generator=gen, device=dev, dtype=torch.float32))
             heavy = {}
             for e in (0.25, 0.5):
-                fh = lambda ctx, chunk: ea.bucketMulGroup([(vh, ew, None, o, e) for ew, o in chunk], gpu=ctx)    # noqa: E731
-                gh = one.capture(fh, chunked(items, G))
-                Dh = g.last_dispatch_count((N_MATS - 1) % G)
-                th = time_replays(gh, 40, 10) / N_MATS
-                ea.basicMul(vh, ews[N_MATS - 1].core, dense_out[0])
+                gh = job.capture(mul_step(e, vec=vh), 24)
+                Dh = job.ctxs[(24 - 1) % S].last_dispatch_count((N_MATS - 1) % G)
+                th = time_graph(gh, None, reps=2) / 24 / N_MATS
+                ea.basicMul(vh, ews[last].core, dense_out[0])
                 heavy[str(e)] = {"dispatch_rows": Dh, "us_per_call": round(th * 1e6, 3),
                                  "achieved_GBps": round(algorithmic_bytes(Dh, inDim, outDim) / th / 1e9, 1),
                                  "frac_of_hbm_peak": round(algorithmic_bytes(Dh, inDim, outDim) / th / 1e9 / HBM_PEAK_GBPS, 4),
-                                 "cos_vs_dense": round(ea.cosineSimilarityTo(outs[N_MATS - 1], dense_out[0]), 5)}
+                                 "cos_vs_dense": round(ea.cosineSimilarityTo(out_sets[(24 - 1) % S][last], dense_out[0]), 5)}
                 del gh
             result["heavy_tailed_input"] = heavy
         # ---------------- the other shapes / formats BASELINE.json names ------------------------------------
         if not args.no_sweep:
-            def quick(ews_x, outDim_x, inDim_x, effort, n, q4=False):
+            def quick(ews_x, outDim_x, inDim_x, effort, n, streams, q4=False):
                 vx = v if inDim_x == inDim else torch.randn(inDim_x, generator=gen, device=dev, dtype=torch.float32)
-                ox = [torch.zeros(outDim_x, device=dev) for _ in ews_x]
-                fnx = lambda ctx, ch: ea.bucketMulGroup([(vx, ew, None, o, effort) for ew, o in ch], gpu=ctx)    # noqa: E731
-                gx = one.capture(fnx, chunked(list(zip(ews_x, ox)), n))
-                Dx = g.last_dispatch_count((len(ews_x) - 1) % n)
-                tx = time_replays(gx, 40, 10) / len(ews_x)
+                sets_x = [torch.zeros((len(ews_x), outDim_x), device=dev) for _ in range(streams)]
+                jb = one if streams == 1 else job
+                nst = 8 if streams == 1 else 16
+                gx = jb.capture(mul_step(effort, weights=ews_x, vec=vx, sets=sets_x, group=n), nst)
+                Dx = jb.ctxs[(nst - 1) % jb.S].last_dispatch_count((len(ews_x) - 1) % n)
+                tx = time_graph(gx, None, reps=3) / nst / len(ews_x)
                 del gx
                 if q4:
                     nol = ews_x[0].outliers.shape[0]
@@ -428,16 +530,28 @@ def main():
                 if q4:       # SURVEY 8d prices an outlier at the reference's 16 bytes; the registered index holds 8
                     r["achieved_GBps_8B_outliers"] = round((ab - 8 * nol) / tx / 1e9, 1)
                 return r
+
+            def three(ews_x, outDim_x, inDim_x, effort, q4=False):
+                return {f"effort {effort}, 1 per launch": quick(ews_x, outDim_x, inDim_x, effort, 1, 1, q4),
+                        f"effort {effort}, 16 per launch": quick(ews_x, outDim_x, inDim_x, effort, 16, 1, q4),
+                        f"effort {effort}, 16 per launch, {S} in flight": quick(ews_x, outDim_x, inDim_x, effort, 16, S, q4)}
             other = {}
             sq = make_weights(ea, 16, 4096, 4096, 4321, dev, keep_core=False)
-            other["4096x4096 fp16"] = {f"effort {e}, {n} per launch": quick(sq, 4096, 4096, e, n) for e in (0.5, 0.25) for n in (1, 16)}
+            other["4096x4096 fp16"] = {**three(sq, 4096, 4096, 0.5), **three(sq, 4096, 4096, 0.25)}
+            if not args.no_cpu:
+                try:             # BASELINE.json configs[0]: one 4096x4096 bucketMul at 50 % effort on the CPU path
+                    other["4096x4096 fp16"]["cpu_baseline effort 0.5 (BASELINE.json configs[0])"] = cpu_baseline(sq, v, 0.5, 4096, 4096, budget_s=5.0)
+                except Exception as ex:
+                    other["4096x4096 fp16"]["cpu_baseline effort 0.5 (BASELINE.json configs[0])"] = {"error": repr(ex)}
             del sq
+            up = make_weights(ea, 16, 4096, 14336, 7321, dev, keep_core=False)       # W1/W3 of Mistral's FFN: 4096 -> 14336, the shape benchmarks/benchmark.swift:251-257 times
+            other["4096x14336 fp16 (the reference's timed shape)"] = three(up, 14336, 4096, 0.25)
+            del up
             dn = make_weights(ea, 16, 14336, 4096, 5321, dev, keep_core=False)       # W2 of the FFN: 14336 -> 4096
-            other["14336x4096 fp16"] = {f"effort {e}, {n} per launch": quick(dn, 4096, 14336, e, n) for e in (0.25,) for n in (1, 16)}
+            other["14336x4096 fp16"] = three(dn, 4096, 14336, 0.25)
             del dn
             q4w = make_weights(ea, 16, inDim, outDim, 6321, dev, keep_core=False, q4=True)
-            other["4096x11008 q4 (bucketMulQ4, 2 % outliers)"] = {f"effort {e}, {n} per launch": quick(q4w, outDim, inDim, e, n, q4=True)
-                                                                  for e in (0.25,) for n in (1, 16)}
+            other["4096x11008 q4 (bucketMulQ4, 2 % outliers)"] = three(q4w, outDim, inDim, 0.25, q4=True)
             del q4w
             result["other_configs"] = other
         # ---------------- end-to-end greedy decode (BASELINE.json configs[4]; random-init Mistral-7B shapes) ----------
@@ -466,15 +580,24 @@ def main():
                 del dec, model
             except Exception as ex:
                 result["decode"] = {"error": repr(ex)}
-        # ---------------- CPU baseline -----------------------------------------------------------------
+        # ---------------- CPU baseline + every output of the timed step against the oracle -------------
         if not args.no_cpu:
             try:
                 import numpy as np
-                cb, cpu_out, k_last = cpu_baseline(ews, v, args.effort, inDim, outDim)
-                graph.replay()
+                cb = cpu_baseline(ews, v, args.effort, inDim, outDim)
+                g1c = one.capture(mul_step(args.effort), 1)
+                g1c.replay()
                 torch.cuda.synchronize()
-                hip = outs[k_last].cpu().numpy()
-                cb["gpu_vs_cpu_max_rel_err"] = float(np.abs(hip - cpu_out).max() / (np.abs(cpu_out).max() + 1e-30))
+                hip = out_sets[0].cpu().numpy()
+                worst, bad = 0.0, 0
+                ref = oracle_outputs(ews, v, args.effort, inDim, outDim, range(N_MATS))
+                for k in range(N_MATS):
+                    want, Do, _ = ref[k]
+                    worst = max(worst, float(np.abs(hip[k] - want).max() / (np.abs(want).max() + 1e-30)))
+                    bad += int(g.last_dispatch_count(k % G) != Do) if G == N_MATS else 0
+                cb["gpu_vs_cpu_max_rel_err"] = worst
+                cb["gpu_vs_cpu_outputs_checked"] = N_MATS
+                cb["gpu_vs_cpu_dispatch_count_mismatches"] = bad
                 result["cpu_baseline"] = cb
             except Exception as ex:  # the oracle is optional infrastructure for the bench
                 result["cpu_baseline"] = {"error": repr(ex)}

@@ -44,6 +44,8 @@ _SIGS = {
     "effort_weights_q4": (_P, [_P, _P, _P, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_int]),
     "effort_weights_free": (None, [_P]),
     "effort_weights_refresh": (C.c_int, [_P]),
+    "effort_weights_align_rows": (C.c_int, [_P]),
+    "effort_weights_row_pitch": (C.c_int, [_P]),
     "effort_weights_get_bound": (C.c_int, [_P, C.POINTER(C.c_float)]),
     "effort_weights_set_bound": (C.c_int, [_P, C.POINTER(C.c_float)]),
     "effort_bucketmul": (C.c_int, [_P, _P, _P, _P, _P, C.c_double]),

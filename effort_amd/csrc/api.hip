@@ -57,7 +57,10 @@ struct effort_ctx {
 struct effort_w {
     effort_ctx* ctx = nullptr;
     Format fmt = kFp16;
-    const uint16_t* buckets = nullptr;
+    const uint16_t* buckets = nullptr;    // what the multiply reads: the caller's buffer, or `aligned`
+    const uint16_t* bucketsSrc = nullptr; // the caller's buffer (borrowed)
+    uint16_t* aligned = nullptr;          // own copy with rows padded to whole 128-byte lines (effort_weights_align_rows)
+    uint32_t rowPitch = 0;                // bytes between rows of `buckets`
     const void* stats = nullptr;
     const uint16_t* probes = nullptr;
     uint32_t inDim = 0, outDim = 0, rowsPerIn = 0, numExperts = 1, cols = 0;
@@ -153,7 +156,7 @@ static int register_bound(effort_ctx* c, effort_w* w) {
     const size_t rows = (size_t)w->numExperts * w->rowsPerIn * w->inDim;
     float* scratch = nullptr;
     bool ok = hipMalloc(&w->rankBound, (size_t)w->numExperts * 4) == hipSuccess && hipMalloc(&scratch, rows * 4) == hipSuccess;
-    if (ok) ok = launch_rank_bound(w->fmt, w->buckets, w->stats, w->numExperts, w->rowsPerIn, w->inDim, w->cols, scratch, w->rankBound, c->stream) == hipSuccess;
+    if (ok) ok = launch_rank_bound(w->fmt, w->bucketsSrc, w->stats, w->numExperts, w->rowsPerIn, w->inDim, w->cols, scratch, w->rankBound, c->stream) == hipSuccess;
     if (ok) ok = hipStreamSynchronize(c->stream) == hipSuccess;
     hipFree(scratch);
     return ok ? EFFORT_OK : fail(c, EFFORT_ERR_HIP, "weight registration: rank bound");
@@ -170,6 +173,7 @@ extern "C" effort_w* effort_weights_fp16(effort_ctx* c, const void* buckets, con
     w->ctx = c; w->fmt = kFp16;
     w->buckets = static_cast<const uint16_t*>(buckets); w->stats = stats; w->probes = static_cast<const uint16_t*>(probes);
     w->inDim = inDim; w->outDim = outDim; w->rowsPerIn = percentLoad; w->numExperts = numExperts; w->cols = outDim / 16;
+    w->bucketsSrc = w->buckets; w->rowPitch = w->cols * 2u;
     if (register_bound(c, w) != EFFORT_OK) { effort_weights_free(w); return nullptr; }
     return w;
 }
@@ -185,6 +189,7 @@ extern "C" effort_w* effort_weights_q4(effort_ctx* c, const void* buckets, const
     w->ctx = c; w->fmt = kQ4;
     w->buckets = static_cast<const uint16_t*>(buckets); w->stats = stats; w->probes = static_cast<const uint16_t*>(probes);
     w->inDim = inDim; w->outDim = outDim; w->rowsPerIn = 8; w->numExperts = numExperts; w->cols = outDim / 32;
+    w->bucketsSrc = w->buckets; w->rowPitch = w->cols * 2u;
     if (register_bound(c, w) != EFFORT_OK) { effort_weights_free(w); return nullptr; }
     if (outliers && nOutliers > 0) {
         if (outDim > 65536) { fail(c, EFFORT_ERR_SHAPE, "effort_weights_q4: outliers need outDim <= 65536"); effort_weights_free(w); return nullptr; }
@@ -217,11 +222,42 @@ extern "C" effort_w* effort_weights_q4(effort_ctx* c, const void* buckets, const
 
 // The fixed-point scale of the multiply comes from rankBound, a snapshot of the weights taken at registration: weights
 // rewritten in place afterwards need effort_weights_refresh (the reference's loader.swift buffers are mutable).
+static int copy_aligned(effort_w* w) {
+    const size_t rows = (size_t)w->numExperts * w->rowsPerIn * w->inDim;
+    HIP_TRY(w->ctx, hipMemcpy2DAsync(w->aligned, w->rowPitch, w->bucketsSrc, (size_t)w->cols * 2, (size_t)w->cols * 2, rows, hipMemcpyDeviceToDevice, w->ctx->stream));
+    HIP_TRY(w->ctx, hipStreamSynchronize(w->ctx->stream));
+    return EFFORT_OK;
+}
 extern "C" int effort_weights_refresh(effort_w* w) {
     if (!w || !w->ctx) return EFFORT_ERR_ARG;
+    hipSetDevice(w->ctx->device);
     hipFree(w->rankBound); w->rankBound = nullptr;
-    return register_bound(w->ctx, w);
+    int rc = register_bound(w->ctx, w);
+    if (rc == EFFORT_OK && w->aligned) rc = copy_aligned(w);
+    return rc;
 }
+// The converter's rows are 2*cols bytes apart (1376 for 11008 outputs): a 512-byte piece of a row then straddles 128-byte
+// lines, the three column tiles of a row fetch 14 lines where 11 would do, and the stream runs at 5.4-5.6 TB/s instead of
+// the 6.1-6.9 TB/s it reaches on line-aligned rows (measured: 4096x11264 / 12288 / 8192).  This call gives the handle its
+// OWN copy of the buckets with every row starting on a 128-byte line (pitch = 2*cols rounded up to 128); the multiply
+// reads the copy, and the caller's buffer is no longer read (it may be freed; effort_weights_refresh re-reads it, so
+// keep it if the weights are going to change).  No-op when the pitch is line-aligned already.  Results are bit-identical.
+extern "C" int effort_weights_align_rows(effort_w* w) {
+    if (!w || !w->ctx) return EFFORT_ERR_ARG;
+    if (w->aligned || (w->cols * 2u) % 128u == 0u) return EFFORT_OK;
+    hipSetDevice(w->ctx->device);
+    const uint32_t pitch = (w->cols * 2u + 127u) / 128u * 128u;
+    const size_t rows = (size_t)w->numExperts * w->rowsPerIn * w->inDim;
+    if (rows * pitch > 0xFFFFFFFFull) return fail(w->ctx, EFFORT_ERR_SHAPE, "effort_weights_align_rows: the padded buckets would reach 4 GiB");
+    if (hipMalloc(&w->aligned, rows * pitch) != hipSuccess) return fail(w->ctx, EFFORT_ERR_HIP, "effort_weights_align_rows: out of device memory");
+    HIP_TRY(w->ctx, hipMemsetAsync(w->aligned, 0, rows * pitch, w->ctx->stream));
+    w->rowPitch = pitch;
+    const int rc = copy_aligned(w);
+    if (rc != EFFORT_OK) { hipFree(w->aligned); w->aligned = nullptr; w->rowPitch = w->cols * 2u; return rc; }
+    w->buckets = w->aligned;
+    return EFFORT_OK;
+}
+extern "C" int effort_weights_row_pitch(const effort_w* w) { return w ? (int)w->rowPitch : EFFORT_ERR_ARG; }
 extern "C" int effort_weights_get_bound(effort_w* w, float* host_out) {
     if (!w || !w->ctx || !host_out || !w->rankBound) return EFFORT_ERR_ARG;
     HIP_TRY(w->ctx, hipMemcpy(host_out, w->rankBound, (size_t)w->numExperts * 4, hipMemcpyDeviceToHost));
@@ -237,7 +273,7 @@ extern "C" int effort_weights_set_bound(effort_w* w, const float* host_in) {
 
 extern "C" void effort_weights_free(effort_w* w) {
     if (!w) return;
-    hipFree(w->olRowPtr); hipFree(w->olInIdx); hipFree(w->olValue); hipFree(w->rankBound);
+    hipFree(w->olRowPtr); hipFree(w->olInIdx); hipFree(w->olValue); hipFree(w->rankBound); hipFree(w->aligned);
     delete w;
 }
 
@@ -293,7 +329,8 @@ static int choose_geom(const effort_ctx* c, const effort_w* w, int groupSize, in
     g->inDim = w->inDim; g->outDim = w->outDim; g->cols = w->cols; g->rowsPerIn = w->rowsPerIn;
     g->expertRows = w->rowsPerIn * w->inDim; g->numExperts = w->numExperts;
     g->tiles = (w->cols + 64 * E - 1) / (64 * E);
-    g->tileFloats = nacc * E * 64;
+    g->rowPitch = w->rowPitch;
+    const uint32_t tileFloats = nacc * E * 64;
     const size_t ldsMax = 160 * 1024;
     uint32_t S;
     if (c->tuneS) S = c->tuneS;                            // any count: the item grid is padded to a multiple of 8 slices
@@ -313,7 +350,7 @@ static int choose_geom(const effort_ctx* c, const effort_w* w, int groupSize, in
         const size_t lds = bucket_mul_lds_bytes(w->fmt, W, E, *g);
         const bool fits = lds <= ldsMax && g->slots <= maxCand && (size_t)g->slots * 4 + (size_t)g->sliceRows * 8 + 1024 <= 65536 &&   // staged regions below 64 KB
                           (w->fmt == kFp16 ? (1u << g->sliceLog2) <= 64u * (uint32_t)W : g->sliceRows <= 128u * (uint32_t)W);   // a thread stages one (Q4: two) inputs of the slice
-        const size_t slab = (size_t)g->slices * g->tiles * g->tileFloats * 4;
+        const size_t slab = (size_t)g->slices * g->tiles * tileFloats * 4;
         if (fits && slab <= c->slabBytes) break;
         if (!fits) { S += 1; if (S > w->inDim + 8) return EFFORT_ERR_SHAPE; }
         else return EFFORT_ERR_SHAPE;
@@ -382,13 +419,13 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
         MulGeom g;
         memset(&g, 0, sizeof(g));
         int Wi, Ei;
-        // The calls at the END of a big group are cut into thinner slices: their items are the last ones the persistent
-        // workgroups pull, and the launch ends when the last item does -- a tail of short items instead of long ones.
+        // (knob, off by default) The calls at the END of a big group can be cut into thinner slices: their items are the last
+        // ones the persistent workgroups pull, and the launch ends when the last item does.
         uint32_t mult = 1;
         if (n >= 8 && !c->tuneS) {
             static const int tailCalls = getenv("EFFORT_TAIL_CALLS") ? atoi(getenv("EFFORT_TAIL_CALLS")) : -1;     // profiling knobs
             static const int tailMult = getenv("EFFORT_TAIL_MULT") ? atoi(getenv("EFFORT_TAIL_MULT")) : 2;
-            const int tc = tailCalls >= 0 ? tailCalls : n / 4;
+            const int tc = tailCalls >= 0 ? tailCalls : 0;     // measured (r02): with several launches in flight the tail of one launch runs under the next one's head, and thin slices only add items: 125.8 vs 124.3 us per step; kept as a knob
             if (i >= n - tc) mult = (uint32_t)tailMult;
             if (tailMult >= 4 && i >= n - tc && i < n - tc / 2) mult = (uint32_t)tailMult / 2;      // two steps: ... x2 x2 x4 x4
         }
@@ -406,7 +443,7 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
         }
         if (gi == nGeoms) ga.geom[nGeoms++] = g;
         CallDesc& a = ga.call[(uint32_t)i - first];
-        const size_t slab = (size_t)g.slices * g.tiles * g.tileFloats * 4;
+        const size_t slab = (size_t)g.slices * g.tiles * ((fmt == kFp16 ? 16u : 32u) * (uint32_t)Ei * 64u) * 4;
         if (tileOff + g.tiles + 1 > effort_ctx::kMaxTiles || sliceOff + g.slices > effort_ctx::kMaxSlices || slabOff + slab > c->slabBytes)
             return fail(c, EFFORT_ERR_SHAPE, "bucketmul: group exceeds the context scratch");
         a.buckets = w->buckets; a.stats = w->stats; a.rankBound = w->rankBound; a.probes = w->probes; a.v = vs[i];

@@ -482,7 +482,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     const uint32_t col = t * (64u * E) + (uint32_t)lane * E;
     const bool colOK = col < g.cols;                               // a piece past the last column is skipped whole
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint16_t*>(a.buckets), 0, (int)min((size_t)0xFFFFFFFFu, (size_t)g.numExperts * g.expertRows * g.cols * 2u), 0x00020000);
+        const_cast<uint16_t*>(a.buckets), 0, (int)min((size_t)0xFFFFFFFFu, (size_t)g.numExperts * g.expertRows * g.rowPitch), 0x00020000);
     const uint32_t voff = (colOK ? col : 0u) * 2u;                 // lanes past the last column re-read column 0
     const uint32_t nU = (ga.ablate & 4u) ? 0u : __builtin_amdgcn_readfirstlane(n);   // n is workgroup-uniform; keep it in an SGPR
     // The waves of a workgroup do NOT run at one speed (the older wave wins the arbitration for issue slots and the memory
@@ -511,7 +511,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
                 rowIdx = j0 * 8u + code;
                 dv = __int_as_float(__float2int_rn((vblk[code >> 3] * means[code]) * scale));
             }
-            boff = (e * g.expertRows + rowIdx) * g.cols * 2u;       // byte offset of the bucket row (< 4 GiB, checked at registration)
+            boff = (e * g.expertRows + rowIdx) * g.rowPitch;        // byte offset of the bucket row (< 4 GiB, checked at registration)
         }
     };
     auto issue = [&](Piece<E> (&piece)[KB], uint32_t boff) {

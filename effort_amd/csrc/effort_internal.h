@@ -24,7 +24,7 @@ struct MulGeom {
     uint32_t sliceRows;    // B: input rows per slice
     uint32_t sliceLog2;    // ceil(log2(B)): FP16 candidate slots are laid out [rank][2^sliceLog2]
     uint32_t slots;        // candidate slots per slice: rowsPerIn << sliceLog2 (FP16) or 8*B (Q4)
-    uint32_t tileFloats;   // accumulators per tile = NACC*E*64
+    uint32_t rowPitch;     // bytes from one bucket row to the next: 2*cols as converted, or padded to whole 128-byte lines (effort_weights_align_rows)
     uint32_t numExperts;   // experts stacked in the buffers (bounds of the buffer descriptor)
 };
 

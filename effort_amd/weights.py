@@ -104,6 +104,13 @@ class ExpertWeights:
         return ExpertWeights(self.buckets[:, :rows].contiguous(), self.stats[:, :rows].contiguous(), self.probes,
                              self.inSize, self.outSize, percentLoad, self.numExperts, core=self.core)
 
+    def align_rows(self) -> int:
+        """Give the handle its own copy of the buckets with every row on a 128-byte line (effort_weights_align_rows): the
+        multiply's row pieces then stop straddling lines (+~10 % throughput for 11008 outputs when HBM is saturated), for
+        one more copy of the buckets in device memory.  Returns the row pitch in bytes."""
+        self._gpu.check(_lib.lib().effort_weights_align_rows(self.handle), "ExpertWeights.align_rows")
+        return int(_lib.lib().effort_weights_row_pitch(self.handle))
+
     def refresh(self):
         """The buffers were rewritten in place: re-read the bound the multiply's fixed-point scale comes from."""
         if self._handle is not None:

@@ -898,3 +898,51 @@ def test_column_shards_of_the_baseline_shapes(ea, oracle_cpu, q4_case, q4_11008,
         for (kind, outDim, full, oracle), sh, o in zip(fp, shs, outs):
             want, n, cutoff = oracle(v, 0.5)
             assert close(o.cpu().numpy(), want[r * sh.localOut:(r + 1) * sh.localOut]), (outDim, world, r)
+
+
+def test_aligned_row_pitch_is_bit_identical(ea, oracle_cpu, q4_11008):
+    """effort_weights_align_rows: the handle's own copy of the buckets with rows on 128-byte lines (1376 -> 1408 bytes for
+    11008 outputs; Q4: 688 -> 768) gives the same bits as the converter's pitch -- lone calls, a grouped launch, and after
+    a refresh of rewritten weights."""
+    outDim, inDim = 11008, 4096
+    W, b, s, p = converted(oracle_cpu, outDim, inDim)
+    plain, padded = gpu_weights(ea, W, b, s, p), gpu_weights(ea, W, b, s, p)
+    assert padded.align_rows() == 1408 and padded.align_rows() == 1408          # idempotent
+    g = ea.gpu()
+    v = make_v(inDim, seed=17, heavy=True)
+    vd = devf(v)
+    for effort in (0.1, 0.25, 1.0):
+        o1, o2 = torch.zeros(outDim, device=DEV), torch.zeros(outDim, device=DEV)
+        ea.bucketMul(vd, plain, None, o1, effort)
+        g.eval()
+        n1, c1 = g.last_dispatch_count(), g.last_cutoff()
+        ea.bucketMul(vd, padded, None, o2, effort)
+        g.eval()
+        assert (g.last_dispatch_count(), g.last_cutoff()) == (n1, c1) and torch.equal(o1, o2), effort
+    outs = [torch.zeros(outDim, device=DEV) for _ in range(12)]
+    ea.bucketMulGroup([(vd, padded if i & 1 else plain, None, outs[i], 0.25) for i in range(12)])
+    g.eval()
+    want, n, cutoff = oracle_cpu.bucket_mul(v, b, s, p, inDim, outDim, 0.25)
+    for i in range(12):                              # (the last quarter of a big group is cut into thinner slices: its own rounding grid)
+        assert g.last_dispatch_count(i) == n and torch.equal(outs[i], outs[0 if i < 9 else 9]) and close(outs[i].cpu().numpy(), want), i
+    o2 = torch.zeros(outDim, device=DEV)
+    ea.bucketMul(vd, padded, None, o2, 0.25)
+    g.eval()
+    # rewritten weights reach the copy through refresh
+    padded.buckets.copy_(dev16(np.ascontiguousarray(b).view(np.uint16) ^ np.uint16(0x8000)).reshape(padded.buckets.shape))   # every weight negated
+    padded.refresh()
+    o3 = torch.zeros(outDim, device=DEV)
+    ea.bucketMul(vd, padded, None, o3, 0.25)
+    g.eval()
+    assert close(o3.cpu().numpy(), -want) and not torch.equal(o3, o2)          # (exactly -o2 up to the rounding mode's ties: floor(x + 1/2))
+    # Q4
+    Wq, L, inDim, outDim = q4_11008
+    mk = lambda: ea.ExpertWeights(dev16(L["buckets"]), devf(L["bucket.stats"]), dev16(L["probes"]), inSize=inDim, outSize=outDim,   # noqa: E731
+                                  outliers=devf(L["outliers"]), q4=True)
+    q1, q2 = mk(), mk()
+    assert q2.align_rows() == 768
+    o1, o2 = torch.zeros(outDim, device=DEV), torch.zeros(outDim, device=DEV)
+    ea.bucketMulQ4(vd, q1, None, o1, 0.25)
+    ea.bucketMulQ4(vd, q2, None, o2, 0.25)
+    g.eval()
+    assert torch.equal(o1, o2)
