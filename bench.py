@@ -129,8 +129,10 @@ class Job:
     def capture(self, step, nsteps):
         self._enqueue(step, min(nsteps, self.S))     # warm: handles, kernel attributes, rocBLAS workspaces
         torch.cuda.synchronize()
+        if hasattr(step, "reset"):
+            step.reset()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):   # (another thread -- RCCL's watchdog -- may query events meanwhile)
             self._enqueue(step, nsteps)
         for c in self.ctxs:
             c._bind_stream()
@@ -263,46 +265,74 @@ def main():
 
     # ---------------- the timed job: K steps at the headline effort --------------------------------
     if dist:
-        # every rank: its 32 matrices per step, then ONE all-gather of the step's output vectors.  Pipelined exchange: step
-        # i's all-gather runs on a communication stream while step i+1 computes into the other of two output buffers.
-        graph_a = one.capture(mul_step(args.effort, sets=[out_sets[0]]), 1)
-        buf_b = torch.zeros((N_MATS, outDim), device=dev)
-        graph_b = one.capture(mul_step(args.effort, sets=[buf_b]), 1)
-        gathered = [torch.zeros((world, N_MATS * outDim), device=dev) for _ in range(2)]
+        # Every rank: its 32 matrices per step; the steps run S at a time (one ROUND = one hipGraph with S steps in flight, as
+        # on one GPU) and ONE all-gather per round exchanges the round's output vectors.  Pipelined: round r's all-gather runs
+        # on a communication stream while round r+1 computes into the other of two buffers.
         comm = torch.cuda.Stream(device=dev)
-        bufs = [(graph_a, out_sets[0], gathered[0], torch.cuda.Event(), torch.cuda.Event()),
-                (graph_b, buf_b, gathered[1], torch.cuda.Event(), torch.cuda.Event())]
 
-        def run(n, exchange=True):
-            main = torch.cuda.current_stream()
-            for i in range(n):
-                gr, src, dst, computed, gathered_ev = bufs[i & 1]
-                if exchange:
-                    main.wait_event(gathered_ev)             # the previous gather out of this buffer is done
-                gr.replay()
-                if exchange:
-                    computed.record(main)
-                    with torch.cuda.stream(comm):
-                        comm.wait_event(computed)
-                        dist.all_gather_into_tensor(dst.view(-1), src.view(-1))
-                        gathered_ev.record(comm)
-            main.wait_stream(comm)
+        def round_step(weights, send):
+            """Step i of a round writes output set i of `send` ([R, 32, localOut]); Job hands out (ctx, slot = i % S)."""
+            count = [0]
 
-        def timed(exchange):
-            run(args.warmup, exchange)
-            barrier()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            run(args.steps, exchange)
-            torch.cuda.synchronize()
-            barrier()
-            x = torch.tensor([(time.perf_counter() - t0) / args.steps], device=dev, dtype=torch.float64)
-            dist.all_reduce(x, op=dist.ReduceOp.MAX)
-            return float(x.item())
-        dt_kernel = timed(False)                             # the steps without the exchange (kernel only)
-        dt = timed(True)
-        D = g.last_dispatch_count((N_MATS - 1) % G)
-        in_flight = 1
+            def step(ctx, slot):
+                i = count[0]
+                count[0] += 1
+                items = [(v, ew, None, send[i % send.shape[0]][k], args.effort) for k, ew in enumerate(weights)]
+                for ch in chunked(items, G):
+                    ea.bucketMulGroup(ch, gpu=ctx)
+            step.reset = lambda: count.__setitem__(0, 0)
+            return step
+
+        class Exchange:
+            def __init__(self, weights, localOut):
+                self.lo = localOut
+                self.R = 2 * S                           # steps per round: two per stream, so that heads and tails overlap inside a round too
+                self.send = [torch.zeros((self.R, N_MATS, localOut), device=dev) for _ in range(2)]
+                self.recv = [torch.zeros(world * self.R * N_MATS * localOut, device=dev) for _ in range(2)]
+                self.ev = [(torch.cuda.Event(), torch.cuda.Event()) for _ in range(2)]
+                self.weights, self.graphs = weights, {}
+
+            def graph(self, b, n):                       # n steps (<= R) into buffer b: step i -> stream i % S, output set i
+                if (b, n) not in self.graphs:
+                    self.graphs[(b, n)] = job.capture(round_step(self.weights, self.send[b]), n)
+                return self.graphs[(b, n)]
+
+            def run(self, nsteps, exchange=True):
+                main = torch.cuda.current_stream()
+                rounds = [self.R] * (nsteps // self.R) + ([nsteps % self.R] if nsteps % self.R else [])
+                for r, n in enumerate(rounds):
+                    b = r & 1
+                    if exchange:
+                        main.wait_event(self.ev[b][1])    # the previous gather out of this buffer is done
+                    self.graph(b, n).replay()
+                    if exchange:
+                        self.ev[b][0].record(main)
+                        with torch.cuda.stream(comm):
+                            comm.wait_event(self.ev[b][0])
+                            cnt = n * N_MATS * self.lo
+                            dist.all_gather_into_tensor(self.recv[b][:world * cnt], self.send[b].view(-1)[:cnt])
+                            self.ev[b][1].record(comm)
+                main.wait_stream(comm)
+
+            def timed(self, exchange):
+                for b in (0, 1):                         # captures happen outside the timed region
+                    for n in {self.R, args.steps % self.R, args.warmup % self.R} - {0}:
+                        self.graph(b, n)
+                self.run(args.warmup, exchange)
+                barrier()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                self.run(args.steps, exchange)
+                torch.cuda.synchronize()
+                barrier()
+                x = torch.tensor([(time.perf_counter() - t0) / args.steps], device=dev, dtype=torch.float64)
+                dist.all_reduce(x, op=dist.ReduceOp.MAX)
+                return float(x.item())
+        ex = Exchange(ews, outDim)
+        dt_kernel = ex.timed(False)                          # the steps without the exchange (kernel only)
+        dt = ex.timed(True)
+        D = job.ctxs[0].last_dispatch_count((N_MATS - 1) % G)
+        in_flight = min(S, args.steps)
     else:
         g_warm = job.capture(mul_step(args.effort), args.warmup) if args.warmup > 0 else None
         g_timed = job.capture(mul_step(args.effort), args.steps)
@@ -337,53 +367,28 @@ def main():
     if dist:
         result["rccl_ranks"] = dist.get_world_size()
         result["multi_gpu"] = {"partition": "matrices (weak scaling: every rank its own 32 matrices)", "ms_per_step_kernel_only": round(dt_kernel * 1e3, 5),
-                               "ms_per_step_with_all_gather": round(dt * 1e3, 5), "all_gather_bytes_per_rank_per_step": N_MATS * outDim * 4}
+                               "ms_per_step_with_all_gather": round(dt * 1e3, 5), "steps_per_round": 2 * S, "all_gather_bytes_per_rank_per_round": 2 * S * N_MATS * outDim * 4}
         # bucket-column sharding: every rank multiplies ITS columns of the same 32 matrices (seed 1234 on every
-        # rank), one all-gather per step of [world, 32 * outDim/world] floats; strong scaling
+        # rank), one all-gather per round of [world, S * 32 * outDim/world] floats; strong scaling
         try:
             from effort_amd.sharded import ShardedExpertWeights
             full = ews if seed0 == 1234 else make_weights(ea, N_MATS, inDim, outDim, 1234, dev, keep_core=False)
-            shards = [ShardedExpertWeights.from_full(e, rank, world).local for e in full]
-            lo = outDim // world
-            send = [torch.zeros((N_MATS, lo), device=dev) for _ in range(2)]
-            recv = [torch.zeros((world, N_MATS * lo), device=dev) for _ in range(2)]
-            cg = [one.capture(mul_step(args.effort, weights=shards, sets=[send[i]]), 1) for i in range(2)]
-            evs = [(torch.cuda.Event(), torch.cuda.Event()) for _ in range(2)]
-
-            def crun(n, exchange):
-                main = torch.cuda.current_stream()
-                for i in range(n):
-                    b = i & 1
-                    if exchange:
-                        main.wait_event(evs[b][1])
-                    cg[b].replay()
-                    if exchange:
-                        evs[b][0].record(main)
-                        with torch.cuda.stream(comm):
-                            comm.wait_event(evs[b][0])
-                            dist.all_gather_into_tensor(recv[b].view(-1), send[b].view(-1))
-                            evs[b][1].record(comm)
-                main.wait_stream(comm)
-
-            def ctimed(exchange):
-                crun(args.warmup, exchange)
-                barrier()
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                crun(args.steps, exchange)
-                torch.cuda.synchronize()
-                barrier()
-                x = torch.tensor([(time.perf_counter() - t0) / args.steps], device=dev, dtype=torch.float64)
-                dist.all_reduce(x, op=dist.ReduceOp.MAX)
-                return float(x.item())
-            ck, ca = ctimed(False), ctimed(True)
+            shards = []
+            for e in full:
+                sh = ShardedExpertWeights.from_full(e, rank, world).local
+                sh.handle
+                if ALIGN_ROWS:
+                    sh.align_rows()
+                shards.append(sh)
+            exc = Exchange(shards, outDim // world)
+            ck, ca = exc.timed(False), exc.timed(True)
             result["multi_gpu"]["columns"] = {
                 "partition": f"bucket columns: {outDim // 16 // world} of {outDim // 16} columns per rank, stats / probes replicated (strong scaling: the same 32 matrices on every N)",
                 "ms_per_step_kernel_only": round(ck * 1e3, 5), "ms_per_step_with_all_gather": round(ca * 1e3, 5),
-                "effective_GBps_whole_job": round(N_MATS * eff_bytes / ca / 1e9, 1), "all_gather_bytes_per_rank_per_step": N_MATS * lo * 4}
-            del shards, cg
-        except Exception as ex:
-            result["multi_gpu"]["columns"] = {"error": repr(ex)}
+                "effective_GBps_whole_job": round(N_MATS * eff_bytes / ca / 1e9, 1), "all_gather_bytes_per_rank_per_round": 2 * S * N_MATS * (outDim // world) * 4}
+            del shards, exc
+        except Exception as ex2:
+            result["multi_gpu"]["columns"] = {"error": repr(ex2)}
 
     if rank == 0 and world == 1 and not args.headline_only:
         # ---------------- roofline of the dominant kernel, in the timed configuration -----------------

@@ -244,7 +244,7 @@ class Decoder:
             self.token_step(effort, dense)                       # warm (handles, kernel attributes, rocBLAS)
             torch.cuda.synchronize()
             gr = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gr):
+            with torch.cuda.graph(gr, capture_error_mode="thread_local"):
                 self.token_step(effort, dense)
             self.g._bind_stream()
             self._graphs[key] = gr
