@@ -67,9 +67,9 @@ struct effort_w {
     float* rankBound = nullptr;       // [numExperts] fixed-point bound of the multiply (see launch_rank_bound)
     // Q4 outliers
     uint64_t nOutliers = 0;
-    uint32_t* olRowPtr = nullptr;
-    uint32_t* olInIdx = nullptr;
-    float* olValue = nullptr;
+    uint32_t* olRowPtr = nullptr;     // by-output bounds (registration), then the per-64-output bounds the multiply reads
+    uint32_t* olBlockPtr = nullptr;
+    uint32_t* olEntry = nullptr;      // 4 bytes per outlier
 };
 
 static int fail(effort_ctx* c, int code, const char* what, hipError_t e = hipSuccess) {
@@ -194,24 +194,27 @@ extern "C" effort_w* effort_weights_q4(effort_ctx* c, const void* buckets, const
     if (outliers && nOutliers > 0) {
         if (outDim > 65536) { fail(c, EFFORT_ERR_SHAPE, "effort_weights_q4: outliers need outDim <= 65536"); effort_weights_free(w); return nullptr; }
         hipSetDevice(c->device);
-        {   // every entry must name an element of THIS matrix (the index is built with unchecked scatters)
-            int bad = 0;
-            bool okv = hipMemsetAsync(c->d_status + 2, 0, 4, c->stream) == hipSuccess &&
+        {   // every entry must name an element of THIS matrix (the index is built with unchecked scatters) and carry an f16 value
+            int bad[2] = {0, 0};
+            bool okv = hipMemsetAsync(c->d_status + 2, 0, 8, c->stream) == hipSuccess &&
                        launch_validate_outliers(static_cast<const float*>(outliers), (uint64_t)nOutliers, (uint32_t)inDim, (uint32_t)outDim, c->d_status + 2, c->stream) == hipSuccess &&
-                       hipMemcpyAsync(&bad, c->d_status + 2, 4, hipMemcpyDeviceToHost, c->stream) == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess;
-            if (!okv || bad) {
-                fail(c, okv ? EFFORT_ERR_ARG : EFFORT_ERR_HIP, okv ? "effort_weights_q4: outlier entries outside the matrix (inIdx >= inDim or outIdx >= outDim)" : "effort_weights_q4: outlier validation");
+                       hipMemcpyAsync(bad, c->d_status + 2, 8, hipMemcpyDeviceToHost, c->stream) == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess;
+            if (!okv || bad[0] || bad[1]) {
+                fail(c, okv ? EFFORT_ERR_ARG : EFFORT_ERR_HIP, !okv ? "effort_weights_q4: outlier validation" :
+                     bad[0] ? "effort_weights_q4: outlier entries outside the matrix (inIdx >= inDim or outIdx >= outDim)"
+                            : "effort_weights_q4: outlier values that are not f16 numbers (the table comes from an f16 matrix, q4_draft.py:58-67)");
                 effort_weights_free(w); return nullptr;
             }
         }
-        uint32_t* cursor = nullptr;
+        uint32_t* tmp = nullptr;
         w->nOutliers = (uint64_t)nOutliers;
-        bool ok = hipMalloc(&w->olRowPtr, ((size_t)outDim + 2 + (outDim + 63) / 64) * 4) == hipSuccess && hipMalloc(&w->olInIdx, (size_t)nOutliers * 4) == hipSuccess &&
-                  hipMalloc(&w->olValue, (size_t)nOutliers * 4) == hipSuccess && hipMalloc(&cursor, ((size_t)outDim + 2 * (size_t)nOutliers) * 4) == hipSuccess;
-        if (ok) ok = launch_build_outlier_index(static_cast<const float*>(outliers), w->nOutliers, outDim, w->olRowPtr, w->olInIdx,
-                                                w->olValue, cursor, c->stream) == hipSuccess;
+        const uint32_t olBs = 1u << (16u - ol_bits_in((uint32_t)inDim)), olBlocks = ((uint32_t)outDim + olBs - 1) / olBs;
+        bool ok = hipMalloc(&w->olRowPtr, ((size_t)outDim + 2 + (outDim + 63) / 64) * 4) == hipSuccess && hipMalloc(&w->olBlockPtr, ((size_t)olBlocks + 1) * 4) == hipSuccess &&
+                  hipMalloc(&w->olEntry, (size_t)nOutliers * 4) == hipSuccess && hipMalloc(&tmp, ((size_t)outDim + 2 * (size_t)nOutliers) * 4) == hipSuccess;
+        if (ok) ok = launch_build_outlier_index(static_cast<const float*>(outliers), w->nOutliers, (uint32_t)inDim, (uint32_t)outDim, w->olRowPtr, w->olBlockPtr,
+                                                w->olEntry, tmp, c->stream) == hipSuccess;
         if (ok) ok = hipStreamSynchronize(c->stream) == hipSuccess;
-        hipFree(cursor);
+        hipFree(tmp);
         uint32_t longest = 0;
         if (ok) ok = hipMemcpy(&longest, w->olRowPtr + (size_t)outDim + 1 + (outDim + 63) / 64, 4, hipMemcpyDeviceToHost) == hipSuccess;
         if (!ok) { fail(c, EFFORT_ERR_HIP, "effort_weights_q4: outlier index"); effort_weights_free(w); return nullptr; }
@@ -273,7 +276,7 @@ extern "C" int effort_weights_set_bound(effort_w* w, const float* host_in) {
 
 extern "C" void effort_weights_free(effort_w* w) {
     if (!w) return;
-    hipFree(w->olRowPtr); hipFree(w->olInIdx); hipFree(w->olValue); hipFree(w->rankBound); hipFree(w->aligned);
+    hipFree(w->olRowPtr); hipFree(w->olBlockPtr); hipFree(w->olEntry); hipFree(w->rankBound); hipFree(w->aligned);
     delete w;
 }
 
@@ -448,7 +451,7 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
             return fail(c, EFFORT_ERR_SHAPE, "bucketmul: group exceeds the context scratch");
         a.buckets = w->buckets; a.stats = w->stats; a.rankBound = w->rankBound; a.probes = w->probes; a.v = vs[i];
         a.expNo = expNos ? expNos[i] : nullptr; a.out = outs[i];
-        a.ol = OutlierIndex{fmt == kQ4 ? w->olRowPtr : nullptr, w->olInIdx, w->olValue};
+        a.ol = OutlierIndex{fmt == kQ4 ? w->olBlockPtr : nullptr, w->olEntry, w->olRowPtr ? w->olRowPtr + w->outDim + 1 : nullptr};
         a.q = (uint32_t)(int)((double)(kProbes - 1) * (1.0 - efforts[i]));            // bucketMul.swift:39
         const int pre = prologues ? prologues[i] : 0;
         a.pre = (uint16_t)pre; a.vAux = pre ? vAux[i] : nullptr; a.resid = resids ? resids[i] : nullptr;

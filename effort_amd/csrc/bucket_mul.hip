@@ -123,11 +123,12 @@ template <> struct Piece<8> {
 __host__ __device__ inline uint32_t align_up(uint32_t x, uint32_t a) { return (x + a - 1) / a * a; }
 
 // Q4 outliers: an item adds the outliers of 1/slices of its tile's outputs to its slab (phase O below).
-constexpr int kOlBatch = 16;                               // outlier entries (key + value) in flight per lane
+constexpr int kOlBatch = 16;                               // outlier entries in flight per lane
 constexpr uint32_t kOlLdsFloats = 16384;                   // v is staged whole in LDS up to this inDim (64 KB), else gathered from memory
 template <int E> __host__ __device__ inline uint32_t ol_outputs_per_item(const MulGeom& g) { return align_up((32u * E * 64u + g.slices - 1u) / g.slices, 64u); }   // whole interleave blocks
 template <int E> __host__ __device__ inline uint32_t ol_scratch_bytes(const MulGeom& g) {
-    return 2u * align_up(ol_outputs_per_item<E>(g) * 4u, 16u) + (g.inDim <= kOlLdsFloats ? g.inDim * 4u : 0u);      // sums hi | lo | v
+    return 2u * align_up(ol_outputs_per_item<E>(g) * 4u, 16u) + (g.inDim <= kOlLdsFloats ? g.inDim * 4u : 0u) +     // sums hi | lo | v
+           align_up((ol_outputs_per_item<E>(g) + 1u) * 4u, 16u);                                                       // | block bounds of the share (at most one block per output)
 }
 
 // LDS carve (bytes), one plan for the whole launch (the largest of its geometries, so that a persistent workgroup can stage
@@ -610,35 +611,38 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     if (wstamp) ph[4] = wall_clock64();
 
     // ---- O. Q4 outliers (calcOutliers, bucketMulQ4.metal:13-21: out[o] += v[in]*value per outlier; the reference fires
-    //         one f32 atomic per outlier in table order).  Registration grouped the outliers by blocks of 64 outputs,
-    //         interleaved inside a block, and packed (output << 16 | input) beside each value (dispatch.hip).  The
-    //         tile's outputs are shared out among its slice items in whole blocks; this item streams the entries of its
-    //         share -- coalesced, kOlBatch per lane in flight -- gathers v from LDS (a 64-address gather from memory
-    //         costs the L1 one line per lane) and adds the products to fixed-point LDS sums like the tile's own
-    //         (neighbouring lanes hold different outputs: no colliding atomics; scale from max|v| * the largest sum of
-    //         |value| over an output of the share, known per block since registration; integer adds commute, so the
-    //         result is deterministic), which join its slab below.  Measured, 4096x11008 with 901 775 outliers, per call at 32
-    //         calls per launch / alone: a kernel of its own with a wave per output 8.3 / 33.5 us; eight lanes per
-    //         output 5.2 / 32.5; this phase 4.6 / 29.0 -- what is left is the 7.2 MB of entries per call, more bytes
-    //         than the 25 %-effort bucket rows (5.6 MB). ---------------------------------------------------------
+    //         one f32 atomic per outlier in table order).  Registration packed the table into FOUR bytes per outlier (f16
+    //         value | output within its block | input), grouped by blocks of 2^(16 - bits of inDim) outputs and
+    //         interleaved inside a block (dispatch.hip).  The tile's outputs are shared out among its slice items in
+    //         whole runs of 64; the waves of this item take the blocks of its share in turn and stream their entries --
+    //         coalesced, kOlBatch per lane in flight -- gather v from LDS (a 64-address gather from memory costs the L1
+    //         one line per lane) and add the products to fixed-point LDS sums like the tile's own (scale from max|v| * the
+    //         largest sum of |value| over an output of the share, known per 64 outputs since registration; integer adds
+    //         commute, so the result is deterministic), which join its slab below.  Measured, 4096x11008 with 901 775
+    //         outliers, per call at 32 calls per launch / alone: a kernel of its own with a wave per output 8.3 / 33.5 us;
+    //         eight lanes per output 5.2 / 32.5; this phase with 8-byte entries 4.6 / 29.0 -- the entries were 7.2 MB per
+    //         call then, more bytes than the 25 %-effort bucket rows (5.6 MB); 3.6 MB now. --------------------------
     int* const olacc = reinterpret_cast<int*>(smem + offM);            // (means | vblk are dead by now)
     const uint32_t olPer = ol_outputs_per_item<E>(g), olLoOff = align_up(olPer * 4u, 16u) / 4u;
     bool olAny = false;
     float olUnscale = 0.0f;
     if constexpr (FMT == kQ4) {
-        olAny = a.ol.rowPtr != nullptr;                                                    // uniform per call
+        olAny = a.ol.blockPtr != nullptr;                                                  // uniform per call
         if (olAny) {
             const OutlierIndex& ol = a.ol;
             int* const ollo = olacc + align_up(olPer * 4u, 16u) / 4u;                        // low parts of the sums (see below)
             float* const vfull = reinterpret_cast<float*>(ollo + align_up(olPer * 4u, 16u) / 4u);
+            uint32_t* const sPtr = reinterpret_cast<uint32_t*>(vfull + (g.inDim <= kOlLdsFloats ? g.inDim : 0u));   // the share's block bounds
             const bool vLds = g.inDim <= kOlLdsFloats;
             const uint32_t oBeg = min(t * (uint32_t)TILE_F + s * olPer, g.outDim);
             const uint32_t oEnd = max(oBeg, min(min(t * (uint32_t)TILE_F + (s + 1u) * olPer, (t + 1u) * (uint32_t)TILE_F), g.outDim));
-            const uint32_t kBeg = ol.rowPtr[oBeg], kEnd = ol.rowPtr[oEnd];
-            // bound of this share's sums: max over its blocks of (max over the block's outputs of sum |value|), from registration
+            const uint32_t bitsIn = ol_bits_in(g.inDim), bsLog = 16u - bitsIn, inMask = (1u << bitsIn) - 1u;
+            const uint32_t bFirst = oBeg >> bsLog, nB = ((oEnd + (1u << bsLog) - 1u) >> bsLog) - bFirst;     // (oBeg is a multiple of 64 >= the block size)
+            for (uint32_t i = tid; i <= nB; i += NT) sPtr[i] = ol.blockPtr[bFirst + i];
+            // bound of this share's sums: max over its runs of 64 outputs of (max over the outputs of sum |value|), from registration
             const uint32_t nBlk = (oEnd - oBeg + 63u) / 64u;
             float olBound = 0.0f;
-            for (uint32_t bq = tid; bq < nBlk; bq += NT) olBound = fmaxf(olBound, __uint_as_float(ol.rowPtr[g.outDim + 1u + oBeg / 64u + bq]));
+            for (uint32_t bq = tid; bq < nBlk; bq += NT) olBound = fmaxf(olBound, __uint_as_float(ol.bound64[oBeg / 64u + bq]));
             float vm = 0.0f;
             for (uint32_t i0 = 0; i0 < g.inDim; i0 += NT * 8u) {                           // eight loads in flight (clamped, branch-free)
                 float x[8];
@@ -665,24 +669,34 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
             const int kk2 = min(max(155 - ex, -100), 100);
             const float olScale = __uint_as_float((uint32_t)(kk2 + 127) << 23);
             olUnscale = __uint_as_float((uint32_t)(127 - kk2) << 23);
-            for (uint32_t k0 = kBeg; k0 < kEnd; k0 += NT * kOlBatch) {                     // uniform
-                uint32_t key[kOlBatch]; float val[kOlBatch];
+            // uniform per wave: the blocks of the share in turn; a share with fewer blocks than the workgroup has waves (a lone
+            // call's thin slices) splits every block's entries among `parts` waves.  (Measured, 4096x11008 / 901 775
+            // outliers, us per call alone / 16 per launch / 16 per launch x 4 launches in flight: 8-byte entries
+            // 27.3 / 5.52 / 3.28; this 27.3 / 5.51 / 3.27 -- half the outlier bytes at the same speed: the Q4 multiply is
+            // bound by its LDS atomics (four per 16-bit word of a bucket row), not by HBM.)
+            const uint32_t parts = (nB && nB < (uint32_t)W) ? (uint32_t)W / nB : 1u;
+            for (uint32_t q = (uint32_t)wave; q < nB * parts; q += W) {
+                const uint32_t bq = q / parts, part = q % parts;
+                const uint32_t kB0 = __builtin_amdgcn_readfirstlane(sPtr[bq]), kE0 = __builtin_amdgcn_readfirstlane(sPtr[bq + 1u]);
+                const uint32_t chunk = align_up((kE0 - kB0 + parts - 1u) / parts, 64u);
+                const uint32_t kB = min(kE0, kB0 + part * chunk), kE = min(kE0, kB + chunk);
+                const uint32_t outBase = ((bFirst + bq) << bsLog) - oBeg;
+                for (uint32_t k0 = kB; k0 < kE; k0 += 64u * kOlBatch) {
+                    uint32_t ent[kOlBatch];
 #pragma unroll
-                for (int u = 0; u < kOlBatch; u++) {             // clamped, branch-free: all loads of a batch in flight
-                    const uint32_t k = min(k0 + u * NT + tid, kEnd - 1u);
-                    key[u] = ol.inIdx[k];
-                    val[u] = ol.value[k];
-                }
+                    for (int u = 0; u < kOlBatch; u++) ent[u] = ol.entry[min(k0 + u * 64u + (uint32_t)lane, kE - 1u)];   // clamped, branch-free: the batch in flight
 #pragma unroll
-                for (int u = 0; u < kOlBatch; u++) {
-                    const float x = vLds ? vfull[key[u] & 0xFFFFu] : a.v[key[u] & 0xFFFFu];
-                    // two-level fixed point: the bound can sit far above the sums (one huge input), so the rounding
-                    // remainder of every product -- exact in f32 -- is summed too, 2^12 times finer (|ql| <= 2^11: an
-                    // output may have 2^19 entries before that sum could leave int32; registration refuses more)
-                    const float cs = (x * val[u]) * olScale;
-                    const int qh = __float2int_rn(cs);
-                    const int ql = __float2int_rn((cs - (float)qh) * 4096.0f);
-                    if (k0 + u * NT + tid < kEnd) { atomicAdd(&olacc[(key[u] >> 16) - oBeg], qh); atomicAdd(&ollo[(key[u] >> 16) - oBeg], ql); }
+                    for (int u = 0; u < kOlBatch; u++) {
+                        const uint32_t in = ent[u] & inMask, o = outBase + ((ent[u] & 0xFFFFu) >> bitsIn);
+                        const float x = vLds ? vfull[in] : a.v[in];
+                        // two-level fixed point: the bound can sit far above the sums (one huge input), so the rounding
+                        // remainder of every product -- exact in f32 -- is summed too, 2^12 times finer (|ql| <= 2^11: an
+                        // output may have 2^19 entries before that sum could leave int32; registration refuses more)
+                        const float cs = (x * half_bits_to_float((uint16_t)(ent[u] >> 16))) * olScale;
+                        const int qh = __float2int_rn(cs);
+                        const int ql = __float2int_rn((cs - (float)qh) * 4096.0f);
+                        if (k0 + u * 64u + (uint32_t)lane < kE) { atomicAdd(&olacc[o], qh); atomicAdd(&ollo[o], ql); }
+                    }
                 }
             }
             __syncthreads();

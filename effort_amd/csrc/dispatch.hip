@@ -163,19 +163,23 @@ hipError_t launch_cosine(const float* a, const float* b, uint32_t n, float* out3
     return hipGetLastError();
 }
 
-// ---- Q4 outliers -> index by output (registration time) --------------------------------------------------------
+// ---- Q4 outliers -> index (registration time) -------------------------------------------------------------------
 // outliers float4 = (value, inIdx, outIdx, 0) (q4_draft.py:58-67).  Pass 1 counts per output, a one-block scan makes
 // rowPtr, pass 2 places each outlier in its output's segment (atomic cursor: arbitrary order inside a segment -- the
-// multiply adds the products as integers, so the order does not matter), pass 3 interleaves the segments of every 64
-// consecutive outputs -- first entry of each output, then the second of each ... -- so that the multiply's coalesced
-// stream of entries hands neighbouring lanes DIFFERENT outputs: its LDS atomics then never collide (sorted by output, a
-// wave's 64 entries hit one or two addresses and serialise).  rowPtr[64*b] still bounds block b's entries.
-// entries the format does not allow: an index outside the matrix (or NaN) -- e.g. a full-matrix table handed to a column shard
+// multiply adds the products as integers, so the order does not matter), pass 3 packs the segments of every block of
+// 2^(16 - bitsIn) consecutive outputs into 4-byte entries (f16 value | output in block | input), interleaved -- first
+// entry of each output, then the second of each ... -- so that neighbouring lanes of the multiply's coalesced stream
+// mostly hold different outputs (their LDS atomics collide 64 / blockOutputs ways instead of 64).
+// entries the format does not allow: an index outside the matrix (or NaN) -- e.g. a full-matrix table handed to a column
+// shard -- or a value that is not an f16 number (the table comes from an f16 matrix; the 4-byte entry keeps 16 bits of it)
 __global__ void ol_validate_kernel(const float4* ol, uint64_t n, uint32_t inDim, uint32_t outDim, int* bad) {
     const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     const float4 o = ol[i];
-    if (!(o.y >= 0.0f && o.y < (float)inDim && o.z >= 0.0f && o.z < (float)outDim)) atomicAdd(bad, 1);
+    const bool idx = o.y >= 0.0f && o.y < (float)inDim && o.z >= 0.0f && o.z < (float)outDim;
+    const bool f16 = __half2float(__float2half_rn(o.x)) == o.x;
+    if (!idx) atomicAdd(bad, 1);
+    else if (!f16) atomicAdd(bad + 1, 1);
 }
 hipError_t launch_validate_outliers(const float* outliers, uint64_t n, uint32_t inDim, uint32_t outDim, int* bad, hipStream_t st) {
     hipLaunchKernelGGL(ol_validate_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const float4*>(outliers), n, inDim, outDim, bad);
@@ -198,28 +202,36 @@ __global__ __launch_bounds__(1024) void ol_scan_kernel(uint32_t* rowPtr, uint32_
     uint32_t run = s_part[threadIdx.x];
     for (uint32_t i = lo; i < hi; i++) { run += rowPtr[i]; rowPtr[i] = run; }
 }
-__global__ void ol_place_kernel(const float4* ol, uint64_t n, const uint32_t* rowPtr, uint32_t* cursor, uint32_t* key, float* value) {
+__global__ void ol_place_kernel(const float4* ol, uint64_t n, const uint32_t* rowPtr, uint32_t* cursor, uint32_t* inIdx, float* value) {
     const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     const float4 o = ol[i];
     const uint32_t out = (uint32_t)o.z;
     const uint32_t p = rowPtr[out] + atomicAdd(&cursor[out], 1u);
-    key[p] = (uint32_t)o.y | (out << 16); value[p] = o.x;        // key = output << 16 | input (both < 65536)
+    inIdx[p] = (uint32_t)o.y; value[p] = o.x;
 }
-// one wave per block of 64 outputs (lane = output): round r moves the r-th entry of every output that has one
-__global__ __launch_bounds__(64) void ol_interleave_kernel(const uint32_t* rowPtr, uint32_t outDim, const uint32_t* keyIn, const float* valIn,
-                                                          uint32_t* keyOut, float* valOut) {
-    const uint32_t out = blockIdx.x * 64u + threadIdx.x;
+// one wave per 64 outputs (lane = output), which hold 64 / bs blocks of bs outputs: round r moves the r-th entry of every
+// output that has one; inside its block an output's entry lands after those of the block's lower outputs of that round
+__global__ __launch_bounds__(64) void ol_pack_kernel(const uint32_t* rowPtr, uint32_t outDim, uint32_t bitsIn, const uint32_t* inIdx,
+                                                     const float* valIn, uint32_t* entry, uint32_t* blockPtr) {
+    const uint32_t out = blockIdx.x * 64u + threadIdx.x, lane = threadIdx.x;
+    const uint32_t bs = 1u << (16u - bitsIn);                                  // outputs per block (a power of two <= 64... 32768 for bitsIn = 1: clamped below)
+    const uint32_t bsl = min(bs, 64u);                                         // lanes of this wave per block
     const uint32_t lo = rowPtr[min(out, outDim)], len = out < outDim ? rowPtr[out + 1] - lo : 0u;
-    uint32_t base = rowPtr[blockIdx.x * 64u];
+    const uint32_t first = lane / bsl * bsl;                                   // first lane of this lane's block (within the wave)
+    const unsigned long long blockMask = (bsl == 64u ? ~0ull : ((1ull << bsl) - 1ull)) << first;
+    uint32_t base = rowPtr[min(blockIdx.x * 64u + first, outDim)];
+    if (lane == first && blockIdx.x * 64u + first < outDim) blockPtr[(blockIdx.x * 64u + first) / bs] = base;      // (bs <= 16: inDim >= 4096)
     for (uint32_t r = 0;; r++) {
         const unsigned long long active = __ballot(len > r);
         if (!active) break;
+        const unsigned long long mine = active & blockMask;
         if (len > r) {
-            const uint32_t p = base + (uint32_t)__popcll(active & ((1ull << threadIdx.x) - 1ull));
-            keyOut[p] = keyIn[lo + r]; valOut[p] = valIn[lo + r];
+            const uint32_t p = base + (uint32_t)__popcll(mine & ((1ull << lane) - 1ull));
+            const uint32_t h = (uint32_t)__half_as_ushort(__float2half_rn(valIn[lo + r]));
+            entry[p] = (h << 16) | ((out & (bs - 1u)) << bitsIn) | inIdx[lo + r];
         }
-        base += (uint32_t)__popcll(active);
+        base += (uint32_t)__popcll(mine);
     }
 }
 // rowPtr[outDim + 1 + b] = bits of max over the outputs of block b (64 outputs) of sum |value|: bounds the multiply's
@@ -232,20 +244,26 @@ __global__ void ol_bound_kernel(const uint32_t* rowPtr, uint32_t outDim, const f
     atomicMax(&boundBits[out / 64u], __float_as_uint(sum));       // non-negative floats order like their bit patterns
     atomicMax(&boundBits[(outDim + 63u) / 64u], rowPtr[out + 1] - rowPtr[out]);      // one more word: the longest segment
 }
-// tmp: [outDim] cursors, then [n] keys and [n] values of the by-output order (before interleaving)
-hipError_t launch_build_outlier_index(const float* outliers, uint64_t n, uint32_t outDim, uint32_t* rowPtr,
-                                      uint32_t* key, float* value, uint32_t* tmp, hipStream_t st) {
+__global__ void ol_block_end_kernel(const uint32_t* rowPtr, uint32_t outDim, uint32_t nBlocks, uint32_t* blockPtr) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) blockPtr[nBlocks] = rowPtr[outDim];
+}
+// rowPtr: [outDim + 1] by-output bounds, then [ceil(outDim/64)] bound bits, then the longest segment (kept: bound64 points
+// into it).  tmp: [outDim] cursors, then [n] inputs and [n] values of the by-output order (before packing)
+hipError_t launch_build_outlier_index(const float* outliers, uint64_t n, uint32_t inDim, uint32_t outDim, uint32_t* rowPtr,
+                                      uint32_t* blockPtr, uint32_t* entry, uint32_t* tmp, hipStream_t st) {
     hipError_t e = hipMemsetAsync(rowPtr, 0, ((size_t)outDim + 2 + (outDim + 63) / 64) * 4, st); if (e != hipSuccess) return e;
     e = hipMemsetAsync(tmp, 0, (size_t)outDim * 4, st); if (e != hipSuccess) return e;
     const float4* ol = reinterpret_cast<const float4*>(outliers);
     const uint32_t nb = (uint32_t)((n + 255) / 256);
-    uint32_t* key0 = tmp + outDim;
-    float* val0 = reinterpret_cast<float*>(key0 + n);
+    const uint32_t bitsIn = ol_bits_in(inDim), bs = 1u << (16u - bitsIn), nBlocks = (outDim + bs - 1) / bs;
+    uint32_t* in0 = tmp + outDim;
+    float* val0 = reinterpret_cast<float*>(in0 + n);
     hipLaunchKernelGGL(ol_count_kernel, dim3(nb), dim3(256), 0, st, ol, n, rowPtr);
     hipLaunchKernelGGL(ol_scan_kernel, dim3(1), dim3(1024), 0, st, rowPtr, outDim);
-    hipLaunchKernelGGL(ol_place_kernel, dim3(nb), dim3(256), 0, st, ol, n, rowPtr, tmp, key0, val0);
+    hipLaunchKernelGGL(ol_place_kernel, dim3(nb), dim3(256), 0, st, ol, n, rowPtr, tmp, in0, val0);
     hipLaunchKernelGGL(ol_bound_kernel, dim3((outDim + 255) / 256), dim3(256), 0, st, rowPtr, outDim, val0, rowPtr + outDim + 1);
-    hipLaunchKernelGGL(ol_interleave_kernel, dim3((outDim + 63) / 64), dim3(64), 0, st, rowPtr, outDim, key0, val0, key, value);
+    hipLaunchKernelGGL(ol_pack_kernel, dim3((outDim + 63) / 64), dim3(64), 0, st, rowPtr, outDim, bitsIn, in0, val0, entry, blockPtr);
+    hipLaunchKernelGGL(ol_block_end_kernel, dim3(1), dim3(64), 0, st, rowPtr, outDim, nBlocks, blockPtr);
     return hipGetLastError();
 }
 

@@ -28,11 +28,16 @@ struct MulGeom {
     uint32_t numExperts;   // experts stacked in the buffers (bounds of the buffer descriptor)
 };
 
-struct OutlierIndex {          // by-output CSR of the Q4 outliers, built at registration
-    const uint32_t* rowPtr;    // [outDim+1] entry bounds by output (nullptr: no outliers), then [ceil(outDim/64)] bits of max over a block's outputs of sum |value|, then the longest segment
-    const uint32_t* inIdx;     // [n]  output << 16 | input
-    const float* value;        // [n]
+// The Q4 outliers, indexed at registration (dispatch.hip): FOUR bytes per outlier.  An entry packs the f16 value (the table
+// comes from an f16 matrix, q4_draft.py:58-67) with 16 bits naming (output within its block, input): bitsIn = bits of
+// inDim - 1, blocks of 2^(16 - bitsIn) consecutive outputs (16 outputs for 4096 inputs).  blockPtr bounds a block's entries;
+// inside a block the entries are interleaved over its outputs (first of each, second of each ...).
+struct OutlierIndex {
+    const uint32_t* blockPtr;  // [ceil(outDim / blockOutputs) + 1] entry bounds by block (nullptr: no outliers)
+    const uint32_t* entry;     // [n]  f16 value << 16 | output-in-block << bitsIn | input
+    const uint32_t* bound64;   // [ceil(outDim/64)] f32 bits: max over the 64 outputs of sum |value| (bounds the fixed-point sums); then the longest run of one output
 };
+__host__ __device__ inline uint32_t ol_bits_in(uint32_t inDim) { uint32_t b = 1; while ((1u << b) < inDim) b++; return b; }     // inDim <= 65536
 
 // One launch = a GROUP of up to kMaxGroup independent bucketMul calls (own weights, v, out, effort, scratch):
 // the decode loop's Wq|Wk|Wv and W1|W3 (runNetwork.swift:132-134,178-182) are such groups.  A lone call's
@@ -140,7 +145,7 @@ hipError_t launch_argmax(const float* logits, uint32_t n, uint32_t* idOut, uint3
 hipError_t launch_f32_to_f16(const float* in, uint16_t* out, uint32_t n, hipStream_t st);
 hipError_t launch_cosine(const float* a, const float* b, uint32_t n, float* out3, hipStream_t st);
 hipError_t launch_validate_outliers(const float* outliers, uint64_t n, uint32_t inDim, uint32_t outDim, int* bad, hipStream_t st);
-hipError_t launch_build_outlier_index(const float* outliers, uint64_t n, uint32_t outDim, uint32_t* rowPtr,
-                                      uint32_t* inIdx, float* value, uint32_t* cursor, hipStream_t st);
+hipError_t launch_build_outlier_index(const float* outliers, uint64_t n, uint32_t inDim, uint32_t outDim, uint32_t* rowPtr,
+                                      uint32_t* blockPtr, uint32_t* entry, uint32_t* tmp, hipStream_t st);
 
 }  // namespace effort

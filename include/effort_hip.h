@@ -78,9 +78,10 @@ EFFORT_API effort_w* effort_weights_fp16(effort_ctx* ctx, const void* buckets_de
  *   stats    f32 [numExperts][inDim*8][2]           (mean|row|, same); .y is read
  *   probes   f16 [numExperts][4096]
  *   outliers f32 [nOutliers][4]                     (value, inIdx, outIdx, 0); may be NULL / 0
- * Borrowed like the FP16 bundle, except the outlier table: registration turns it into an index by blocks of 64 outputs
- * in HBM (8 bytes per outlier: value, output << 16 | input; hence inDim, outDim <= 65536 when there are outliers) and
- * does not read outliers_dev again. */
+ * Borrowed like the FP16 bundle, except the outlier table: registration turns it into an index in HBM of FOUR bytes per
+ * outlier (f16 value | output within a block of 2^(16 - bits of inDim) outputs | input: hence inDim, outDim <= 65536 when there
+ * are outliers) and does not read outliers_dev again.  Every entry must name an element of this matrix and carry a value that
+ * is an f16 number (the table comes from an f16 matrix, q4_draft.py:58-67): otherwise NULL is returned (EFFORT_ERR_ARG). */
 EFFORT_API effort_w* effort_weights_q4(effort_ctx* ctx, const void* buckets_dev, const void* stats_dev,
                             const void* probes_dev, const void* outliers_dev, int64_t nOutliers,
                             int inDim, int outDim, int numExperts);

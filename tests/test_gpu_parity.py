@@ -322,6 +322,8 @@ def test_error_reporting(ea, oracle_cpu):
         with pytest.raises(effort_amd.EffortError, match="outlier"):
             ea.ExpertWeights(qb, qs, dev16(p), inSize=4096, outSize=256, outliers=torch.tensor(bad, device=DEV), q4=True).handle
     ea.ExpertWeights(qb, qs, dev16(p), inSize=4096, outSize=256, outliers=torch.tensor([[0.5, 4095.0, 255.0, 0.0]], device=DEV), q4=True).handle
+    with pytest.raises(effort_amd.EffortError, match="f16"):           # the 4-byte index entry keeps the value as f16 (the table comes from an f16 matrix)
+        ea.ExpertWeights(qb, qs, dev16(p), inSize=4096, outSize=256, outliers=torch.tensor([[0.1, 5.0, 5.0, 0.0]], device=DEV), q4=True).handle
 
 
 def test_weights_rewritten_in_place_need_a_refresh(ea, oracle_cpu):
