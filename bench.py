@@ -45,6 +45,7 @@ import time
 
 import torch
 
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")     # the CPU oracle's OpenMP workers must sleep, not spin, between its calls: timed GPU sections follow
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -482,24 +483,22 @@ def main():
         if not args.no_sweep:
             import numpy as np
             last = N_MATS - 1
-            sweep = []
+            sweep, got_all = [], []
             for e in SWEEP:
                 ge = job.capture(mul_step(e), 24)
                 De = job.ctxs[(24 - 1) % S].last_dispatch_count((N_MATS - 1) % G)
                 te = time_graph(ge, None, reps=2) / 24 / N_MATS
                 ea.basicMul(v, ews[last].core, dense_out[0])
                 cs = ea.cosineSimilarityTo(out_sets[(24 - 1) % S][last], dense_out[0])
-                want, Do, _ = oracle_outputs(ews, v, e, inDim, outDim, [last])[last]
-                got = out_sets[(24 - 1) % S][last].cpu().numpy().astype(np.float64)
-                co = float(got @ want.astype(np.float64) / (np.linalg.norm(got) * np.linalg.norm(want) + 1e-300))
+                got_all.append(out_sets[(24 - 1) % S][last].cpu().numpy().astype(np.float64))
                 sweep.append({"effort": e, "dispatch_rows": De, "us_per_call": round(te * 1e6, 3),
                               "effective_GBps": round(eff_bytes / te / 1e9, 1),
                               "achieved_GBps": round(algorithmic_bytes(De, inDim, outDim) / te / 1e9, 1),
                               "frac_of_hbm_peak": round(algorithmic_bytes(De, inDim, outDim) / te / 1e9 / HBM_PEAK_GBPS, 4),
-                              "tokens_per_s": round(1.0 / (te * 4 * 32), 1), "cos_vs_dense": round(cs, 5),
-                              "cos_vs_oracle": round(co, 9), "dispatch_rows_oracle": int(Do)})
+                              "tokens_per_s": round(1.0 / (te * 4 * 32), 1), "cos_vs_dense": round(cs, 5)})
                 del ge
             result["sweep"] = sweep
+            sweep_check = (sweep, got_all, last)             # against the oracle after the timed sections (its threads would disturb them)
             # heavy-tailed input (a real rms-normed state has outlier channels): v * exp(N(0,1)), same seeds
             vh = v * torch.exp(torch.randn(inDim, generator=gen, device=dev, dtype=torch.float32))
             heavy = {}
@@ -514,6 +513,25 @@ def main():
                                  "cos_vs_dense": round(ea.cosineSimilarityTo(out_sets[(24 - 1) % S][last], dense_out[0]), 5)}
                 del gh
             result["heavy_tailed_input"] = heavy
+            # one STRUCTURED matrix (effort_amd.decode.structured_matrix) and a state as a norm layer with outlier channels
+            # leaves it: the reference's own check (benchmarks/benchmark.swift:166-177: cos-sim of expertMul vs basicMul)
+            try:
+                from effort_amd.decode import structured_matrix, structured_norm_weights
+                Ws = structured_matrix(outDim, inDim, gen, dev)
+                es = ea.ExpertWeights.from_core(Ws)
+                es.handle
+                x = torch.randn(inDim, generator=gen, device=dev, dtype=torch.float32)
+                vs_ = (x / x.pow(2).mean().sqrt()) * structured_norm_weights(inDim, gen, dev).float()
+                os_, od_ = torch.zeros(outDim, device=dev), torch.zeros(outDim, device=dev)
+                ea.basicMul(vs_, Ws, od_)
+                ss = []
+                for e in SWEEP:
+                    ea.bucketMul(vs_, es, None, os_, e)
+                    ss.append({"effort": e, "dispatch_rows": g.last_dispatch_count(), "cos_vs_dense": round(ea.cosineSimilarityTo(os_, od_), 5)})
+                result["sweep_structured"] = ss
+                del es, Ws
+            except Exception as ex:
+                result["sweep_structured"] = {"error": repr(ex)}
         # ---------------- the other shapes / formats BASELINE.json names ------------------------------------
         if not args.no_sweep:
             def quick(ews_x, outDim_x, inDim_x, effort, n, streams, q4=False):
@@ -543,11 +561,6 @@ def main():
             other = {}
             sq = make_weights(ea, 16, 4096, 4096, 4321, dev, keep_core=False)
             other["4096x4096 fp16"] = {**three(sq, 4096, 4096, 0.5), **three(sq, 4096, 4096, 0.25)}
-            if not args.no_cpu:
-                try:             # BASELINE.json configs[0]: one 4096x4096 bucketMul at 50 % effort on the CPU path
-                    other["4096x4096 fp16"]["cpu_baseline effort 0.5 (BASELINE.json configs[0])"] = cpu_baseline(sq, v, 0.5, 4096, 4096, budget_s=5.0)
-                except Exception as ex:
-                    other["4096x4096 fp16"]["cpu_baseline effort 0.5 (BASELINE.json configs[0])"] = {"error": repr(ex)}
             del sq
             up = make_weights(ea, 16, 4096, 14336, 7321, dev, keep_core=False)       # W1/W3 of Mistral's FFN: 4096 -> 14336, the shape benchmarks/benchmark.swift:251-257 times
             other["4096x14336 fp16 (the reference's timed shape)"] = three(up, 14336, 4096, 0.25)
@@ -583,8 +596,31 @@ def main():
                                               "kl_vs_dense": round(kl_divergence(lg_d, lg_e), 5)}
                 result["decode"] = dsec
                 del dec, model
+                # quality on STRUCTURED synthetic weights (heavy tails, channel scales, outlier norm channels: what trained
+                # models have and i.i.d. Gaussians lack), the reference's protocol (benchmarks/benchmark.swift:128-156):
+                # greedy text at effort 1.0, then teacher-forced predictions at every effort against the effort-1.0 ones
+                torch.cuda.empty_cache()
+                model = Model.random(MistralConfig(), seed=2, structured=True)
+                ntq = 224
+                dec = Decoder(model, maxTokens=ntq + 8)
+                ids_1, _, _ = dec.run(prompt, ntq, effort=1.0)
+                forced = prompt + ids_1[len(prompt) - 1:-1]
+                _, _, lg_dn = dec.run(forced, ntq, dense=True, forced=True, collect_logits=True)
+                _, _, lg_1 = dec.run(forced, ntq, effort=1.0, forced=True, collect_logits=True)
+                control = lg_1.argmax(-1)
+                q = {"model": "Mistral-7B shapes, 32 layers, STRUCTURED random weights (effort_amd.decode.structured_matrix)", "tokens": ntq,
+                     "protocol": "benchmarks/benchmark.swift:128-156: teacher-forced on the effort-1.0 greedy text; agreement = predictions equal to the effort-1.0 predictions",
+                     "effort": {}}
+                for e in (1.0, 0.7, 0.5, 0.35, 0.25, 0.15, 0.1):
+                    _, dt_e, _ = dec.run(prompt, 40, effort=e)
+                    _, _, lg_e = dec.run(forced, ntq, effort=e, forced=True, collect_logits=True)
+                    q["effort"][str(e)] = {"agreement_vs_effort_1.0": round(float((lg_e.argmax(-1) == control).float().mean()), 4),
+                                           "agreement_vs_dense": round(float((lg_e.argmax(-1) == lg_dn.argmax(-1)).float().mean()), 4),
+                                           "kl_vs_dense": round(kl_divergence(lg_dn, lg_e), 5), "tokens_per_s": round(1 / dt_e, 1)}
+                result["decode"]["quality_structured"] = q
+                del dec, model
             except Exception as ex:
-                result["decode"] = {"error": repr(ex)}
+                result.setdefault("decode", {})["error"] = repr(ex)
         # ---------------- CPU baseline + every output of the timed step against the oracle -------------
         if not args.no_cpu:
             try:
@@ -600,6 +636,18 @@ def main():
                     want, Do, _ = ref[k]
                     worst = max(worst, float(np.abs(hip[k] - want).max() / (np.abs(want).max() + 1e-30)))
                     bad += int(g.last_dispatch_count(k % G) != Do) if G == N_MATS else 0
+                if not args.no_sweep:                        # every sweep point's output against the oracle at that effort
+                    sw, gots, last = sweep_check
+                    for row, got in zip(sw, gots):
+                        want, Do, _ = oracle_outputs(ews, v, row["effort"], inDim, outDim, [last])[last]
+                        row["cos_vs_oracle"] = round(float(got @ want.astype(np.float64) / (np.linalg.norm(got) * np.linalg.norm(want) + 1e-300)), 9)
+                        row["dispatch_rows_oracle"] = int(Do)
+                try:             # BASELINE.json configs[0]: one 4096x4096 bucketMul at 50 % effort on the CPU path
+                    sq4 = make_weights(ea, 4, 4096, 4096, 4321, dev, keep_core=False)
+                    cb["config0_4096x4096_effort_0.5"] = cpu_baseline(sq4, v, 0.5, 4096, 4096, budget_s=5.0)
+                    del sq4
+                except Exception as ex:
+                    cb["config0_4096x4096_effort_0.5"] = {"error": repr(ex)}
                 cb["gpu_vs_cpu_max_rel_err"] = worst
                 cb["gpu_vs_cpu_outputs_checked"] = N_MATS
                 cb["gpu_vs_cpu_dispatch_count_mismatches"] = bad
