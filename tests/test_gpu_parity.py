@@ -948,3 +948,65 @@ def test_aligned_row_pitch_is_bit_identical(ea, oracle_cpu, q4_11008):
     ea.bucketMulQ4(vd, q2, None, o2, 0.25)
     g.eval()
     assert torch.equal(o1, o2)
+
+
+def test_launches_in_flight_on_several_streams(ea, oracle_cpu):
+    """The bench's job shape: ONE hipGraph whose steps run on four HIP streams, one effort_ctx (own scratch: slabs, tickets,
+    queues, cutoffs) per stream, up to four grouped launches in flight.  Every step has its own input vector; every output
+    of every step, its dispatch counts and cutoffs are checked against the oracle -- shared scratch between contexts, or a
+    queue / flag left over by a launch that overlapped another, would show here."""
+    outDim, inDim, n_mats, S, steps = 4096, 4096, 12, 4, 8
+    W, b, s, p = converted(oracle_cpu, outDim, inDim)
+    plain, padded = gpu_weights(ea, W, b, s, p), gpu_weights(ea, W, b, s, p)
+    padded.align_rows()
+    ews = [padded if k & 1 else plain for k in range(n_mats)]
+    ctxs = [ea.gpu(0)] + [ea.Gpu(0) for _ in range(S - 1)]
+    streams = [None] + [torch.cuda.Stream() for _ in range(S - 1)]
+    vs = [torch.zeros(inDim, device=DEV) for _ in range(steps)]
+    outs = [[torch.zeros(outDim, device=DEV) for _ in range(n_mats)] for _ in range(steps)]
+    efforts = (0.1, 0.25, 0.5)
+    for c in ctxs:
+        c.set_tuning(8, 1, 32)                         # 4 tiles x 32 slices per call: persistent launches with cutoff jobs
+
+    def step(i):
+        ea.bucketMulGroup([(vs[i], ews[k], None, outs[i][k], efforts[(i + k) % 3]) for k in range(n_mats)], gpu=ctxs[i % S])
+
+    def enqueue():
+        s0 = torch.cuda.current_stream()
+        for k in range(1, S):
+            streams[k].wait_stream(s0)
+        for i in range(steps):
+            if i % S == 0:
+                step(i)
+            else:
+                with torch.cuda.stream(streams[i % S]):
+                    step(i)
+        for k in range(1, S):
+            s0.wait_stream(streams[k])
+    try:
+        enqueue()
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            enqueue()
+        for c in ctxs:
+            c._bind_stream()
+    finally:
+        for c in ctxs:
+            c.set_tuning(0, 0, 0)
+    for rep in range(2):
+        hv = [make_v(inDim, seed=7000 + 10 * rep + i, heavy=bool(i & 1)) for i in range(steps)]
+        for i in range(steps):
+            vs[i].copy_(devf(hv[i]))
+            for o in outs[i]:
+                o.fill_(float("nan"))
+        graph.replay()
+        torch.cuda.synchronize()
+        for i in range(steps):
+            for k in range(n_mats):
+                want, n, cutoff = oracle_cpu.bucket_mul(hv[i], b, s, p, inDim, outDim, efforts[(i + k) % 3])
+                assert close(outs[i][k].cpu().numpy(), want), (rep, i, k)
+                if i >= steps - S:                 # the contexts remember their LAST launch
+                    assert ctxs[i % S].last_dispatch_count(k) == n and ctxs[i % S].last_cutoff(k) == cutoff, (rep, i, k)
+    for c in ctxs[1:]:
+        c.close()
