@@ -66,6 +66,8 @@ _SIGS = {
     "effort_argmax": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, C.c_int]),
     "effort_decode_status": (C.c_int, [_P, C.POINTER(C.c_int)]),
     "effort_convert_status": (C.c_int, [_P, C.POINTER(C.c_int)]),
+    "effort_q4_outlier_count": (C.c_int64, [C.c_int, C.c_int, C.c_double]),
+    "effort_convert_q4": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_double, _P, _P, _P, _P]),
     "effort_top2_softmax": (C.c_int, [_P, _P, C.c_int, _P, _P]),
     "effort_mix2": (C.c_int, [_P, _P, _P, _P, _P, C.c_int]),
     "effort_dense_gemv": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int]),

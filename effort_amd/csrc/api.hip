@@ -588,6 +588,24 @@ extern "C" int effort_convert_fp16(effort_ctx* c, const void* W, int outDim, int
     return EFFORT_OK;
 }
 
+// q4_draft.convert (q4_draft.py:70-322) on the GPU: core2 = W.T, f16 [inDim][outDim].
+extern "C" int64_t effort_q4_outlier_count(int inDim, int outDim, double perc) {
+    if (inDim <= 0 || outDim <= 0 || !(perc >= 0.0 && perc <= 1.0)) return EFFORT_ERR_ARG;
+    return (int64_t)((double)((int64_t)inDim * outDim) * perc);           // int(len(flat) * perc), q4_draft.py:76
+}
+extern "C" int effort_convert_q4(effort_ctx* c, const void* core2, int inDim, int outDim, double perc, void* buckets, void* stats, void* probes,
+                                 void* outliers) {
+    if (!c || !core2 || !buckets || !stats || !probes) return fail(c, EFFORT_ERR_ARG, "convert_q4: null argument");
+    if (inDim <= 0 || outDim <= 0 || outDim % 32 || (int64_t)inDim * outDim >= (1ll << 32) || !(perc >= 0.0 && perc <= 1.0))
+        return fail(c, EFFORT_ERR_CONVERT, "convert_q4: outDim % 32 != 0 (q4_draft.py:299), or a matrix of 2^32 elements or more");
+    const int64_t cnt = effort_q4_outlier_count(inDim, outDim, perc);
+    if (cnt > 0 && !outliers) return fail(c, EFFORT_ERR_ARG, "convert_q4: outliers buffer missing");
+    hipSetDevice(c->device);
+    HIP_TRY(c, launch_convert_q4(static_cast<const uint16_t*>(core2), (uint32_t)inDim, (uint32_t)outDim, (uint32_t)cnt, static_cast<uint16_t*>(buckets),
+                                 static_cast<float*>(stats), static_cast<uint16_t*>(probes), static_cast<float*>(outliers), c->numCU, c->stream));
+    return EFFORT_OK;
+}
+
 extern "C" int effort_cosine(effort_ctx* c, const float* a, const float* b, int n, float* host_out) {
     if (!c || !a || !b || !host_out || n <= 0) return EFFORT_ERR_ARG;
     HIP_TRY(c, launch_cosine(a, b, n, c->d_cos, c->stream));

@@ -123,6 +123,9 @@ hipError_t launch_calc_dispatch(Format fmt, const void* stats, const float* v, c
 hipError_t launch_convert_fp16(const uint16_t* W, uint32_t outDim, uint32_t inDim, uint16_t* buckets,
                                uint16_t* stats, uint16_t* probes, uint16_t* scratchVals, int* status, hipStream_t st);
 
+hipError_t launch_convert_q4(const uint16_t* core2, uint32_t inDim, uint32_t outDim, uint32_t cnt, uint16_t* buckets, float* stats, uint16_t* probes,
+                             float* outliers, int numCU, hipStream_t st);
+
 hipError_t launch_rank_bound(Format fmt, const uint16_t* buckets, const void* stats, uint32_t numExperts, uint32_t rowsPerIn,
                              uint32_t inDim, uint32_t cols, float* rowScratch, float* rankBound, hipStream_t st);
 // decode-loop glue (decode.hip)

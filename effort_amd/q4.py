@@ -48,11 +48,40 @@ def _np_pairwise_sum_f32(a: torch.Tensor) -> torch.Tensor:
 
 
 def convert(core2: torch.Tensor, perc: float = 0.02) -> dict:
+    """GPU tensors go through the C ABI (effort_convert_q4: HIP kernels, csrc/convert_q4.hip); CPU tensors through the
+    tensor-op restatement below (the host mirror: small inputs, no GPU needed) -- both bit-identical to the reference."""
     if core2.dtype != torch.float16 or core2.dim() != 2:
         raise ValueError("core2 must be a float16 matrix [inDim, outDim] (= W.T)")
     inDim, outDim = core2.shape
     if outDim % 32:
         raise ValueError("outDim must be a multiple of 32 (q4_draft.py:299)")
+    if core2.is_cuda:
+        return _convert_hip(core2.contiguous(), perc)
+    return convert_tensor_ops(core2, perc)
+
+
+def _convert_hip(core2: torch.Tensor, perc: float) -> dict:
+    import ctypes as C
+
+    from . import _lib
+    from .runtime import gpu as _gpu
+    inDim, outDim = core2.shape
+    dev = core2.device
+    g, lib = _gpu(dev.index), _lib.lib()
+    n = int(lib.effort_q4_outlier_count(inDim, outDim, float(perc)))
+    out = {"buckets": torch.empty((inDim * 8, outDim // 32), dtype=torch.int16, device=dev),
+           "bucket.stats": torch.empty((inDim * 8, 2), dtype=torch.float32, device=dev),
+           "probes": torch.empty(min(inDim, outDim), dtype=torch.float16, device=dev),
+           "outliers": torch.empty((n, 4), dtype=torch.float32, device=dev)}
+    p = lambda t: C.c_void_p(t.data_ptr())                                       # noqa: E731
+    g._bind_stream()
+    g.check(lib.effort_convert_q4(g.ctx, p(core2), inDim, outDim, C.c_double(float(perc)), p(out["buckets"]), p(out["bucket.stats"]),
+                                  p(out["probes"]), p(out["outliers"]) if n else None), "q4_convert")
+    return out
+
+
+def convert_tensor_ops(core2: torch.Tensor, perc: float = 0.02) -> dict:
+    inDim, outDim = core2.shape
     core = core2.contiguous().clone()
     dev = core.device
 

@@ -225,6 +225,17 @@ EFFORT_API int effort_convert_fp16(effort_ctx* ctx, const void* W_f16_dev, int o
  * the converter reproduces that and counts the drops here.  Reads and clears the count (0 = every element was placed). */
 EFFORT_API int effort_convert_status(effort_ctx* ctx, int* host_out);
 
+/* q4_draft.convert(core2) (q4_draft.py:70-322; driver q4_convert.py:41-81) for one matrix, on the GPU.  core2_f16_dev is
+ * W.T: f16 [inDim][outDim], outDim % 32 == 0.  Outputs (device buffers of the caller): buckets u16 [inDim*8][outDim/32],
+ * stats f32 [inDim*8][2], probes f16 [min(inDim, outDim)] (the diagonal after outlier removal), outliers f32 [n][4] =
+ * (value, inIdx, outIdx, 0) with n = effort_q4_outlier_count(inDim, outDim, perc) = int(inDim*outDim*perc), ordered by |w|
+ * descending, flat index ascending on ties (the reference's unstable argsort leaves ties unspecified).  Bit-identical to
+ * the reference's outputs (tests/golden/q4_*.npz).  Synchronises the stream; allocates its scratch (4*inDim*outDim bytes
+ * + the sort's) for the duration of the call. */
+EFFORT_API int64_t effort_q4_outlier_count(int inDim, int outDim, double perc);
+EFFORT_API int effort_convert_q4(effort_ctx* ctx, const void* core2_f16_dev, int inDim, int outDim, double perc, void* buckets_dev,
+                      void* stats_dev, void* probes_dev, void* outliers_dev);
+
 /* VectorFloat.cosineSimilarityTo (model.swift:511-519; aux.metal:293-312).  Synchronises. */
 EFFORT_API int effort_cosine(effort_ctx* ctx, const float* a_dev, const float* b_dev, int n, float* host_out);
 

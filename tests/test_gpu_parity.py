@@ -1010,3 +1010,39 @@ def test_launches_in_flight_on_several_streams(ea, oracle_cpu):
                     assert ctxs[i % S].last_dispatch_count(k) == n and ctxs[i % S].last_cutoff(k) == cutoff, (rep, i, k)
     for c in ctxs[1:]:
         c.close()
+
+
+def test_hip_q4_converter(ea, q4_case, q4_11008):
+    """effort_convert_q4 (HIP kernels behind the C ABI: csrc/convert_q4.hip): the reference-generated fixtures
+    (tests/golden/q4_*.npz: what q4_draft.convert returned), the full-size layouts of the oracle's restatement (4096x4096,
+    4096x11008: bit-identical buckets, stats, probes, outlier table in the same order), numpy's pairwise summation at the
+    row lengths that matter, ties at the 2 % boundary and signed zeros; and the tensor-op host mirror agrees."""
+    import glob
+    import os
+    from effort_amd import q4
+    for path in sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "q4_*.npz"))):
+        gd = np.load(path)
+        out = ea.q4_convert(torch.from_numpy(gd["core2"]).to(DEV))
+        assert np.array_equal(out["buckets"].cpu().numpy().view(np.uint16), gd["buckets_u16"]), path
+        assert np.array_equal(out["bucket.stats"].cpu().numpy(), gd["bucket_stats"]), path
+        assert np.array_equal(out["probes"].cpu().numpy().view(np.uint16), gd["probes"].view(np.uint16)), path
+        a, b = out["outliers"].cpu().numpy(), gd["outliers"]                 # same set (the reference's order is its unstable sort's)
+        assert np.array_equal(a[np.lexsort((a[:, 2], a[:, 1]))], b[np.lexsort((b[:, 2], b[:, 1]))]), path
+    for W, L, inDim, outDim in (q4_case, q4_11008):
+        out = ea.q4_convert(dev16(np.ascontiguousarray(W.T)).view(torch.float16))
+        assert out["buckets"].cpu().numpy().view(np.uint16).tobytes() == L["buckets"].view(np.uint16).tobytes()
+        assert out["bucket.stats"].cpu().numpy().tobytes() == L["bucket.stats"].tobytes()
+        assert out["probes"].cpu().numpy().view(np.uint16).tobytes() == L["probes"].view(np.uint16)[:min(inDim, outDim)].tobytes()
+        assert out["outliers"].cpu().numpy().tobytes() == L["outliers"].tobytes()
+    # many ties at the boundary (values from a 16-level grid), -0.0 among them, ragged pairwise lengths (nb = 36 .. 1500)
+    rng = np.random.default_rng(12)
+    from oracle import q4_layout
+    for inDim, outDim in ((96, 288), (64, 1056), (40, 12000)):
+        core2 = (rng.integers(-8, 9, size=(inDim, outDim)) / 16).astype(np.float16)
+        core2[rng.integers(0, inDim, 50), rng.integers(0, outDim, 50)] = np.float16(-0.0)
+        L = q4_layout.convert(core2)
+        for out in (ea.q4_convert(torch.from_numpy(core2).to(DEV)), q4.convert_tensor_ops(torch.from_numpy(core2).to(DEV))):
+            assert out["buckets"].cpu().numpy().view(np.uint16).tobytes() == L["buckets"].view(np.uint16).tobytes(), (inDim, outDim)
+            assert out["bucket.stats"].cpu().numpy().tobytes() == L["bucket.stats"].tobytes(), (inDim, outDim)
+            assert out["outliers"].cpu().numpy().tobytes() == L["outliers"].tobytes(), (inDim, outDim)
+            assert out["probes"].cpu().numpy().view(np.uint16).tobytes() == L["probes"].view(np.uint16).tobytes()
