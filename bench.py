@@ -266,7 +266,7 @@ def main():
 
     # ---------------- the timed job: K steps at the headline effort --------------------------------
     if dist:
-        # Every rank: its 32 matrices per step; the steps run S at a time (one ROUND = one hipGraph with S steps in flight, as
+        # Every rank: its 32 matrices per step; the steps run a ROUND (4S steps: one hipGraph with S steps in flight, as
         # on one GPU) and ONE all-gather per round exchanges the round's output vectors.  Pipelined: round r's all-gather runs
         # on a communication stream while round r+1 computes into the other of two buffers.
         comm = torch.cuda.Stream(device=dev)
@@ -287,7 +287,7 @@ def main():
         class Exchange:
             def __init__(self, weights, localOut):
                 self.lo = localOut
-                self.R = 2 * S                           # steps per round: two per stream, so that heads and tails overlap inside a round too
+                self.R = 4 * S                           # steps per round: four per stream, so that heads and tails overlap inside a round too
                 self.send = [torch.zeros((self.R, N_MATS, localOut), device=dev) for _ in range(2)]
                 self.recv = [torch.zeros(world * self.R * N_MATS * localOut, device=dev) for _ in range(2)]
                 self.ev = [(torch.cuda.Event(), torch.cuda.Event()) for _ in range(2)]
@@ -368,7 +368,7 @@ def main():
     if dist:
         result["rccl_ranks"] = dist.get_world_size()
         result["multi_gpu"] = {"partition": "matrices (weak scaling: every rank its own 32 matrices)", "ms_per_step_kernel_only": round(dt_kernel * 1e3, 5),
-                               "ms_per_step_with_all_gather": round(dt * 1e3, 5), "steps_per_round": 2 * S, "all_gather_bytes_per_rank_per_round": 2 * S * N_MATS * outDim * 4}
+                               "ms_per_step_with_all_gather": round(dt * 1e3, 5), "steps_per_round": 4 * S, "all_gather_bytes_per_rank_per_round": 4 * S * N_MATS * outDim * 4}
         # bucket-column sharding: every rank multiplies ITS columns of the same 32 matrices (seed 1234 on every
         # rank), one all-gather per round of [world, S * 32 * outDim/world] floats; strong scaling
         try:
@@ -386,7 +386,7 @@ def main():
             result["multi_gpu"]["columns"] = {
                 "partition": f"bucket columns: {outDim // 16 // world} of {outDim // 16} columns per rank, stats / probes replicated (strong scaling: the same 32 matrices on every N)",
                 "ms_per_step_kernel_only": round(ck * 1e3, 5), "ms_per_step_with_all_gather": round(ca * 1e3, 5),
-                "effective_GBps_whole_job": round(N_MATS * eff_bytes / ca / 1e9, 1), "all_gather_bytes_per_rank_per_round": 2 * S * N_MATS * (outDim // world) * 4}
+                "effective_GBps_whole_job": round(N_MATS * eff_bytes / ca / 1e9, 1), "all_gather_bytes_per_rank_per_round": 4 * S * N_MATS * (outDim // world) * 4}
             del shards, exc
         except Exception as ex2:
             result["multi_gpu"]["columns"] = {"error": repr(ex2)}
