@@ -305,6 +305,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
 
     // ---- A. everything the selection needs lands in LDS (stage_issue): the row means of the candidate slots, the slice of v
     if (!staged) stage_issue<FMT, W>(ga, ref, tid, smem, lp, par);
+    const float rankBound = a.rankBound[e];                       // (asked for here: its round trip runs under the staged loads')
     float vj[VPT]; uint16_t prj[VPT];
     const uint16_t* pr = a.probes + (size_t)e * kProbes;
     const bool fused = ga.split == 0u;                           // uniform
@@ -354,6 +355,11 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
         }
     };
     if (needCut && !viaJob) load_cut_inputs();
+    // the call's cutoff job publishes ONE word: the cutoff's bits (a non-negative float) with the sign bit raised.  Thread 0
+    // asks for it here, before the staged loads are awaited
+    uint32_t* const cutWords = ga.queue + 9 * 16;
+    uint32_t cutWord = 0;
+    if (viaJob && tid == 0 && !(ga.ablate & 32u)) cutWord = __hip_atomic_load(&cutWords[ci], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // the staged loads have landed (each thread waits for its own; it reads back only what its own lane loaded until the
     // next barrier).  The slice's absolute sum bounds every partial sum of this workgroup (see the scale below).
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -371,7 +377,6 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     for (int off = 32; off >= 1; off >>= 1) bound += __shfl_xor(bound, off);
     if (lane == 0) wbound[wave] = bound;
     if (tid == 0) { flags[4] = 0u; flags[5] = 0u; }               // the list is empty, none of it handed out
-    const float rankBound = a.rankBound[e];
     if (stamp) ga.tstamp[17] = wall_clock64();
     if (wstamp) ph[1] = wall_clock64();
 
@@ -383,15 +388,13 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     if (viaJob) {
         // the call's cutoff job (head of the item queues, see bucket_mul_kernel) publishes the value and raises the flag;
         // it never waits on anything, so this wait ends -- and should it not within ~4 ms, the cutoff is evaluated here
-        uint32_t* const cutFlags = ga.queue + 9 * 16;
         if (tid == 0) {
-            uint32_t ok = 0;
-            for (int spin = 0; spin < ((ga.ablate & 32u) ? 0 : 20000) && !ok; spin++) {      // (ablate 32: exercise the fallback)
-                ok = __hip_atomic_load(&cutFlags[ci], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (!ok) __builtin_amdgcn_s_sleep(8);
+            for (int spin = 0; spin < ((ga.ablate & 32u) ? 0 : 20000) && !(cutWord >> 31); spin++) {      // (ablate 32: exercise the fallback)
+                __builtin_amdgcn_s_sleep(8);
+                cutWord = __hip_atomic_load(&cutWords[ci], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            flags[2] = ok;
-            if (ok) flags[3] = __hip_atomic_load(reinterpret_cast<uint32_t*>(a_cutoff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            flags[2] = cutWord >> 31;
+            flags[3] = cutWord & 0x7FFFFFFFu;
         }
         __syncthreads();                                             // publishes vblk / wbound / the list length, and the verdict
         fromJob = flags[2] != 0u;
@@ -865,9 +868,8 @@ __device__ __forceinline__ void cutoff_job(const GroupKArgs& ga, uint32_t ci, ch
         rec[2] = tj0; rec[3] = wall_clock64();
     }
     if (tid == 0) {
-        __hip_atomic_store(reinterpret_cast<uint32_t*>(ga.cutoff + ci), __float_as_uint(cutoff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the value has left the CU before the flag does
-        __hip_atomic_store(&ga.queue[9 * 16 + ci], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&ga.queue[9 * 16 + ci], __float_as_uint(cutoff) | 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // value and "ready" in one word
+        __hip_atomic_store(reinterpret_cast<uint32_t*>(ga.cutoff + ci), __float_as_uint(cutoff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // BucketMul.cutoff, for the host
     }
     __syncthreads();                                               // the table region is free for the next item
 }
