@@ -34,6 +34,8 @@ struct effort_ctx {
     uint32_t* d_sliceCounts = nullptr;
     uint32_t* d_queue = nullptr;      // item queues of persistent launches
     int persistent = -1;              // workgroups per CU of group launches: -1 heuristic, 0 plain grid, R > 0 persistent
+    int streamMode = getenv("EFFORT_STREAM") ? atoi(getenv("EFFORT_STREAM")) : 0;   // 1: big FP16 groups run as one continuous stream per CU (stream_mul.inc)
+    int streamLaunches = 0;           // launches that took that path since the last effort_stream_kernel_status
     // where each call of the last (group) launch keeps its per-slice counts; slices == 0: dispatch.size is d_count
     uint32_t lastCalls = 1, lastSliceOff[effort::kMaxGroup] = {0}, lastSlices[effort::kMaxGroup] = {0};
     static constexpr uint32_t kMaxTiles = 1024, kMaxSlices = 4096;
@@ -412,6 +414,12 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
         for (uint32_t i = 0; i < ga.count; i++) plain = plain && !ga.call[i].pre;
         static const bool noJobs = getenv("EFFORT_NO_CUTJOBS") != nullptr;
         ga.cutJobs = (ga.persistent && !c->splitCutoff && plain && !noJobs) ? (ga.count + 7u) / 8u * 8u : 0u;
+        if (c->streamMode && fmt == kFp16 && ga.persistent && ga.cutJobs && !ga.trace && stream_mul_fits(E, ga.geom, kMaxGeoms)) {
+            ga.persistent = 1u; ga.cutJobs = 0u;
+            HIP_TRY(c, launch_stream_mul(E, ga, c->stream));
+            c->streamLaunches++;
+            return EFFORT_OK;
+        }
         if (c->splitCutoff && !(ablate & 1u)) HIP_TRY(c, launch_find_cutoff_group(ga, c->stream));
         HIP_TRY(c, launch_bucket_mul(fmt, W, E, ga, c->stream));
         return EFFORT_OK;
@@ -707,6 +715,23 @@ extern "C" int effort_debug_occupancy(effort_ctx* c, int q4, int W, int E, int l
 extern "C" int effort_set_persistent(effort_ctx* c, int wgPerCU) {
     if (!c || wgPerCU < -1 || wgPerCU > 8) return EFFORT_ERR_ARG;
     c->persistent = wgPerCU;
+    return EFFORT_OK;
+}
+
+extern "C" int effort_set_stream_kernel(effort_ctx* c, int mode) {
+    if (!c || mode < 0 || mode > 1) return EFFORT_ERR_ARG;
+    c->streamMode = mode;
+    return EFFORT_OK;
+}
+
+extern "C" int effort_stream_kernel_status(effort_ctx* c, int* host_out, int* launches) {
+    if (!c || !host_out) return EFFORT_ERR_ARG;
+    if (launches) { *launches = c->streamLaunches; c->streamLaunches = 0; }
+    uint32_t h = 0;
+    HIP_TRY(c, hipMemcpyAsync(&h, c->d_queue + 8 * 16 + 3, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_queue + 8 * 16 + 3, 0, 4, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *host_out = (int)h;
     return EFFORT_OK;
 }
 

@@ -966,6 +966,8 @@ __global__ __launch_bounds__(64 * W, (W <= 8 ? EFFORT_MIN_WAVES_PER_EU : 4)) voi
     }
 }
 
+#include "stream_mul.inc"
+
 // ---- host side ------------------------------------------------------------------------------
 template <int FMT, int E, int W>
 static hipError_t launch_mul_t(const GroupKArgs& ga, hipStream_t st) {

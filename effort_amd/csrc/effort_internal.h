@@ -82,7 +82,8 @@ struct GroupKArgs {
     uint32_t cutJobs;              // persistent launches: the first cutJobs items (a multiple of 8 >= count) are cutoff jobs, one per call
     uint32_t trace;                // profiling only: 1 = every item leaves a 64-byte record (who ran it, where, its phase stamps) at tstamp + kTraceOff
     uint32_t* groupDone;           // counter of finished tiles (zero between launches)
-    uint32_t* queue;               // [9][16]: per-XCD item cursors (one cache line each) + exit counter, then [32] cutoff-ready flags; zero between launches
+    uint32_t* queue;               // [9][16]: per-XCD item cursors (one cache line each), line 8 = exit counter | stream kernel: cutoff-job cursor, reduce-job cursor, error word (sticky);
+                                   // then [32] cutoff words (value | ready bit) of the calls; all but the error word zero between launches
     float* slabs;                  // context scratch the calls index into
     uint32_t* counters;
     uint32_t* sliceCounts;
@@ -110,6 +111,9 @@ hipError_t launch_find_cutoff(const float* v, const uint16_t* probes, const uint
 
 // Returns hipErrorInvalidValue for unsupported (fmt, W, E).
 hipError_t launch_bucket_mul(Format fmt, int wavesPerGroup, int elemsPerLane, const GroupKArgs& ga, hipStream_t st);
+// The same group as one continuous stream per CU (stream_mul.inc): FP16, plain calls, E = 2 or 4.
+hipError_t launch_stream_mul(int elemsPerLane, const GroupKArgs& ga, hipStream_t st);
+bool stream_mul_fits(int elemsPerLane, const MulGeom* geoms, int nGeoms);
 hipError_t launch_find_cutoff_group(const GroupKArgs& ga, hipStream_t st);    // ga.cutoff[i] of every call
 size_t bucket_mul_lds_bytes(Format fmt, int wavesPerGroup, int elemsPerLane, const MulGeom& g);
 uint32_t bucket_mul_max_candidates(int wavesPerGroup);

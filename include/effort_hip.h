@@ -252,6 +252,14 @@ EFFORT_API int effort_set_tuning(effort_ctx* ctx, int wavesPerGroup, int elemsPe
 /* Group launches with more work items than wgPerCU workgroups per CU run as that many PERSISTENT workgroups pulling
  * items from per-XCD queues.  -1 = heuristic (default), 0 = always one workgroup per item. */
 EFFORT_API int effort_set_persistent(effort_ctx* ctx, int wgPerCU);
+/* Tuning knob: 1 = FP16 group launches whose items outnumber the chip run as one continuous stream per compute unit
+ * (one 16-wave workgroup per CU, items double-buffered in LDS, no workgroup barrier between items); 0 = the phased kernel.
+ * Results are bit-identical either way. */
+EFFORT_API int effort_set_stream_kernel(effort_ctx* ctx, int mode);
+/* Reads and clears the stream kernel's error word: 0, or a bit per bounded wait of its protocol that ran out (the results of
+ * that launch are undefined); `launches` (nullable) receives the number of launches that took the stream path since the
+ * last query (launches recorded into a hipGraph count once, at capture).  Synchronises the stream. */
+EFFORT_API int effort_stream_kernel_status(effort_ctx* ctx, int* host_out, int* launches);
 EFFORT_API int effort_set_split_cutoff(effort_ctx* ctx, int split);
 
 /* Timing hooks.  enable = 1: HIP events are recorded on the context's stream around each of the three
