@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--tag", default="")
     ap.add_argument("--streams", type=int, default=1, help="spread the launches of a step round-robin over K streams / contexts")
     ap.add_argument("--steps-per-graph", type=int, default=1, help="steps captured into one graph")
+    ap.add_argument("--split", type=int, default=0, help="1: the cutoffs in a kernel of their own before the multiply (the device-clock span then covers the multiply alone)")
     args = ap.parse_args()
     inDim, outDim = (int(x) for x in args.shape.split("x"))
     import effort_amd as ea
@@ -46,6 +47,7 @@ def main():
             tune, per = cfg.split(":")
             g.set_tuning(*(int(x) for x in tune.split(",")))
             g.set_persistent(int(per))
+            g.set_split_cutoff(bool(args.split))
             K = args.streams
             if K > 1 and not hasattr(main, "ctxs"):
                 main.ctxs = [ea.Gpu(0) for _ in range(K)]
