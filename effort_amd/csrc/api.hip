@@ -67,6 +67,7 @@ struct effort_w {
     const uint16_t* probes = nullptr;
     uint32_t inDim = 0, outDim = 0, rowsPerIn = 0, numExperts = 1, cols = 0;
     float* rankBound = nullptr;       // [numExperts] fixed-point bound of the multiply (see launch_rank_bound)
+    uint16_t* means16 = nullptr;      // FP16: the row means alone (stats lane .w), one u16 per bucket row (launch_compact_means)
     // Q4 outliers
     uint64_t nOutliers = 0;
     uint32_t* olRowPtr = nullptr;     // by-output bounds (registration), then the per-64-output bounds the multiply reads
@@ -159,6 +160,10 @@ static int register_bound(effort_ctx* c, effort_w* w) {
     float* scratch = nullptr;
     bool ok = hipMalloc(&w->rankBound, (size_t)w->numExperts * 4) == hipSuccess && hipMalloc(&scratch, rows * 4) == hipSuccess;
     if (ok) ok = launch_rank_bound(w->fmt, w->bucketsSrc, w->stats, w->numExperts, w->rowsPerIn, w->inDim, w->cols, scratch, w->rankBound, c->stream) == hipSuccess;
+    if (ok && w->fmt == kFp16) {
+        ok = hipMalloc(&w->means16, rows * 2) == hipSuccess;
+        if (ok) ok = launch_compact_means(w->stats, w->means16, (uint32_t)rows, c->stream) == hipSuccess;
+    }
     if (ok) ok = hipStreamSynchronize(c->stream) == hipSuccess;
     hipFree(scratch);
     return ok ? EFFORT_OK : fail(c, EFFORT_ERR_HIP, "weight registration: rank bound");
@@ -237,6 +242,7 @@ extern "C" int effort_weights_refresh(effort_w* w) {
     if (!w || !w->ctx) return EFFORT_ERR_ARG;
     hipSetDevice(w->ctx->device);
     hipFree(w->rankBound); w->rankBound = nullptr;
+    hipFree(w->means16); w->means16 = nullptr;
     int rc = register_bound(w->ctx, w);
     if (rc == EFFORT_OK && w->aligned) rc = copy_aligned(w);
     return rc;
@@ -278,7 +284,7 @@ extern "C" int effort_weights_set_bound(effort_w* w, const float* host_in) {
 
 extern "C" void effort_weights_free(effort_w* w) {
     if (!w) return;
-    hipFree(w->olRowPtr); hipFree(w->olBlockPtr); hipFree(w->olEntry); hipFree(w->rankBound); hipFree(w->aligned);
+    hipFree(w->olRowPtr); hipFree(w->olBlockPtr); hipFree(w->olEntry); hipFree(w->rankBound); hipFree(w->aligned); hipFree(w->means16);
     delete w;
 }
 
@@ -414,6 +420,21 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
         for (uint32_t i = 0; i < ga.count; i++) plain = plain && !ga.call[i].pre;
         static const bool noJobs = getenv("EFFORT_NO_CUTJOBS") != nullptr;
         ga.cutJobs = (ga.persistent && !c->splitCutoff && plain && !noJobs) ? (ga.count + 7u) / 8u * 8u : 0u;
+        // FP16: the multiply stages the compact row means where every slice starts on an even row (an LDS-direct load lands two)
+        static const bool noCompact = getenv("EFFORT_NO_COMPACT_MEANS") != nullptr;
+        // (persistent launches only: the plain grids of lone calls and small groups are latency chains that a second code path
+        //  in the kernel slows by 3 % -- measured -- and whose staged bytes do not matter)
+        bool compact = fmt == kFp16 && !noCompact && ga.persistent != 0u && plain;
+        for (uint32_t i = 0; compact && i < ga.count; i++) compact = !ga.call[i].resid;
+        for (uint32_t i = 0; compact && i < ga.count; i++) {
+            const MulGeom& g = ga.geom[ga.call[i].geom];
+            compact = ws[first + i]->means16 != nullptr && g.inDim % 2u == 0u && g.sliceRows % 2u == 0u;
+        }
+        const bool streamLaunch = c->streamMode && fmt == kFp16 && ga.persistent && ga.cutJobs && !ga.trace && stream_mul_fits(E, ga.geom, kMaxGeoms);
+        if (compact && !streamLaunch) {
+            for (uint32_t i = 0; i < ga.count; i++) ga.call[i].stats = ws[first + i]->means16;
+            ga.split |= 4u;
+        }
         if (c->streamMode && fmt == kFp16 && ga.persistent && ga.cutJobs && !ga.trace && stream_mul_fits(E, ga.geom, kMaxGeoms)) {
             ga.persistent = 1u; ga.cutJobs = 0u;
             HIP_TRY(c, launch_stream_mul(E, ga, c->stream));

@@ -214,7 +214,7 @@ __device__ __forceinline__ u32x4 make_rsrc(const void* base, uint32_t bytes) {
     return r;
 }
 
-template <int FMT, int W>
+template <int FMT, int W, bool COMPACT>
 __device__ __forceinline__ void stage_issue(const GroupKArgs& ga, const ItemRef& r, const int tid, char* smem, const LdsPlan& lp, const uint32_t par) {
     constexpr int NT = 64 * W;
     using lds_v = __attribute__((address_space(3))) void;
@@ -226,10 +226,22 @@ __device__ __forceinline__ void stage_issue(const GroupKArgs& ga, const ItemRef&
     const uint32_t rowBase = e * g.expertRows;
     const uint32_t rowsPerIn = g.rowsPerIn, inDim = g.inDim, mask = (1u << lg) - 1u;
     const uint32_t nSlots = FMT == kFp16 ? (rowsPerIn << lg) : (nb << 3);
-    const u32x4 rs = make_rsrc(a.stats, (uint32_t)((size_t)g.numExperts * g.expertRows * 8u));
+    constexpr bool compact = COMPACT && FMT == kFp16;              // a.stats = the row means alone, u16 per bucket row (persistent launches)
+    const u32x4 rs = make_rsrc(a.stats, (uint32_t)((size_t)g.numExperts * g.expertRows * (compact ? 2u : 8u)));
     const u32x4 rv = make_rsrc(a.v, inDim * 4u);
     const uint32_t ldsM = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(lds_v*)(smem + lp.offM));
     const uint32_t ldsV = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(lds_v*)(smem + lp.offV[par & 1u]));
+    if constexpr (compact) {
+        // one dword = the means of candidate slots 2d and 2d+1 (rows j and j+1 of one rank: neighbours in memory; every slice
+        // starts on an even row -- the host checks -- so the dword is aligned): half the loads, means[] holds u16 per slot
+#pragma unroll
+        for (int rr = 0; rr < kRounds / 2; rr++) {
+            if (((uint32_t)(rr * NT) + wave * 64u) * 2u >= nSlots) continue;   // uniform per wave
+            const uint32_t c = ((uint32_t)(rr * NT) + (uint32_t)tid) * 2u, rank = c >> lg, jl = c & mask;
+            const bool ok = rank < rowsPerIn && jl < nb;
+            lds_dma_dword(rs, (rowBase + (ok ? rank * inDim + j0 + jl : j0)) * 2u, ldsM + ((uint32_t)(rr * NT) + wave * 64u) * 4u);
+        }
+    } else
 #pragma unroll
     for (int rr = 0; rr < kRounds; rr++) {
         if ((uint32_t)(rr * NT) + wave * 64u >= nSlots) continue;   // uniform per wave: none of its 64 slots exists
@@ -255,7 +267,7 @@ __device__ __forceinline__ void stage_issue(const GroupKArgs& ga, const ItemRef&
 // `staged` (per wave): this wave's share of the item's stage loads was issued while the previous item streamed (into vblk
 // buffer `par`).  `prefetch` is polled by every wave near the end of its streaming loop until it returns true: there the
 // caller pulls the next item from the queue (wave 0) and issues the wave's share of its stage loads (into buffer par ^ 1).
-template <int FMT, int E, int W, bool FUSED, typename Prefetch>
+template <int FMT, int E, int W, bool FUSED, bool COMPACT, typename Prefetch>
 __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t item, const ItemRef& ref, char* smem, const LdsPlan& lp, uint32_t& cachedCall,
                                          float& cachedCutoff, const uint32_t par, const bool staged, const bool firstItem, Prefetch prefetch) {
     constexpr int NACC = Fmt<FMT>::kAcc;
@@ -304,11 +316,11 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     const uint32_t e = a.expNo ? a.expNo[0] : 0u;
 
     // ---- A. everything the selection needs lands in LDS (stage_issue): the row means of the candidate slots, the slice of v
-    if (!staged) stage_issue<FMT, W>(ga, ref, tid, smem, lp, par);
+    if (!staged) stage_issue<FMT, W, COMPACT>(ga, ref, tid, smem, lp, par);
     const float rankBound = a.rankBound[e];                       // (asked for here: its round trip runs under the staged loads')
     float vj[VPT]; uint16_t prj[VPT];
     const uint16_t* pr = a.probes + (size_t)e * kProbes;
-    const bool fused = ga.split == 0u;                           // uniform
+    const bool fused = (ga.split & 1u) == 0u;                    // uniform
 #pragma unroll
     for (int i = 0; i < VPT; i++) { vj[i] = 0.0f; prj[i] = 0; }
     const bool needCut = fused && cachedCall != ci;              // uniform: a persistent workgroup evaluates a call's cutoff once
@@ -444,6 +456,11 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     if (FMT == kFp16) { const uint32_t jl = (uint32_t)tid & ((1u << lg) - 1u); ax = jl < nb ? fabsf(vblk[jl]) : 0.0f; }
     const uint32_t slotCap = __builtin_amdgcn_readfirstlane((lp.offV[0] - lp.offM) / 4u) - 1u;      // last dword of the means region
     uint32_t mraw[kRounds]; float vq[kRounds];
+    if constexpr (COMPACT && FMT == kFp16) {                      // compact means: u16 per slot, kept in the high half as below
+        const uint16_t* m16 = reinterpret_cast<const uint16_t*>(m32);
+#pragma unroll
+        for (int rr = 0; rr < kRounds; rr++) { mraw[rr] = (uint32_t)m16[min((uint32_t)(rr * NT + tid), slotCap)] << 16; vq[rr] = 0.0f; }
+    } else
 #pragma unroll
     for (int rr = 0; rr < kRounds; rr++) {
         const uint32_t c = min((uint32_t)(rr * NT + tid), slotCap);
@@ -879,7 +896,7 @@ __device__ __forceinline__ void cutoff_job(const GroupKArgs& ga, uint32_t ci, ch
 // dispatcher only places ~40 workgroups/us chip-wide and spreads a large grid unevenly over the CUs (measured with
 // tools/microbench.hip: residency probe), so a group launch sizes its grid to the chip -- R workgroups per CU,
 // R fixed by the LDS each one asks for -- and balances the work itself.
-template <int FMT, int E, int W, bool FUSED>
+template <int FMT, int E, int W, bool FUSED, bool COMPACT = false>
 __global__ __launch_bounds__(64 * W, (W <= 8 ? EFFORT_MIN_WAVES_PER_EU : 4)) void bucket_mul_kernel(const GroupKArgs ga) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ uint32_t s_item;
@@ -935,7 +952,7 @@ __global__ __launch_bounds__(64 * W, (W <= 8 ? EFFORT_MIN_WAVES_PER_EU : 4)) voi
         }
         gen++;
         bool stagedNext = false;
-        mul_item<FMT, E, W, FUSED>(ga, item - ga.cutJobs, ref, smem, lp, cachedCall, cachedCutoff, par, staged, gen == 1u && (ga.ablate & 512u) != 0u /* (measured: evaluating the first item's cutoff locally instead of waiting for the job is 1 us slower per 32-call launch; kept as an ablation) */, [&]() -> bool {
+        mul_item<FMT, E, W, FUSED, COMPACT>(ga, item - ga.cutJobs, ref, smem, lp, cachedCall, cachedCutoff, par, staged, gen == 1u && (ga.ablate & 512u) != 0u /* (measured: evaluating the first item's cutoff locally instead of waiting for the job is 1 us slower per 32-call launch; kept as an ablation) */, [&]() -> bool {
             if (!ga.persistent) return true;
             if (threadIdx.x == 0) {                                // wave 0's first call: pull, publish
                 s_next[0] = pull();
@@ -947,7 +964,7 @@ __global__ __launch_bounds__(64 * W, (W <= 8 ? EFFORT_MIN_WAVES_PER_EU : 4)) voi
             if (kPipe && !(ga.ablate & 128u) && next >= ga.cutJobs && next < total && locate_item(ga, next - ga.cutJobs, nref)) {
                 int tid0 = threadIdx.x;
                 asm volatile("" : "+v"(tid0));
-                stage_issue<FMT, W>(ga, nref, tid0, smem, lp, par ^ 1u);
+                stage_issue<FMT, W, COMPACT>(ga, nref, tid0, smem, lp, par ^ 1u);
                 stagedNext = true;
             }
             return true;
@@ -998,10 +1015,16 @@ static hipError_t launch_mul_t(const GroupKArgs& ga, hipStream_t st) {
         if (err == hipSuccess && FMT == kFp16)
             err = hipFuncSetAttribute(reinterpret_cast<const void*>(&bucket_mul_kernel<kFp16, E, W, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (err == hipSuccess && FMT == kFp16)
+            err = hipFuncSetAttribute(reinterpret_cast<const void*>(&bucket_mul_kernel<kFp16, E, W, false, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (err != hipSuccess) return err;
         maxSet = lds;
     }
+    const bool compact = (ga.split & 4u) != 0u;                   // (api.hip: persistent FP16 launches of plain calls)
+    if (compact && (FMT != kFp16 || fusedAny)) return hipErrorInvalidValue;
     if (fusedAny) hipLaunchKernelGGL((bucket_mul_kernel<kFp16, E, W, true>), dim3(grid), dim3(64 * W), lds, st, ga);
+    else if (compact) hipLaunchKernelGGL((bucket_mul_kernel<kFp16, E, W, false, true>), dim3(grid), dim3(64 * W), lds, st, ga);
     else hipLaunchKernelGGL((bucket_mul_kernel<FMT, E, W, false>), dim3(grid), dim3(64 * W), lds, st, ga);
     return hipGetLastError();
 }

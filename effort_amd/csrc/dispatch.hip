@@ -139,6 +139,17 @@ hipError_t launch_rank_bound(Format fmt, const uint16_t* buckets, const void* st
     return hipGetLastError();
 }
 
+// The FP16 multiply's keep test reads ONE half of every bucket row's stats (lane .w, the row mean): a copy of just those
+// halves, made at registration, is a quarter of the bytes to stage per item (and to keep in L2 between a slice's tiles).
+__global__ void compact_means_kernel(const uint16_t* stats4, uint16_t* means, uint32_t rows) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < rows) means[r] = stats4[(size_t)r * 4u + 3u];
+}
+hipError_t launch_compact_means(const void* stats, uint16_t* means, uint32_t rows, hipStream_t st) {
+    hipLaunchKernelGGL(compact_means_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, static_cast<const uint16_t*>(stats), means, rows);
+    return hipGetLastError();
+}
+
 hipError_t launch_f32_to_f16(const float* in, uint16_t* out, uint32_t n, hipStream_t st) {
     hipLaunchKernelGGL(f32_to_f16_kernel, dim3((n + 255) / 256), dim3(256), 0, st, in, out, n);
     return hipGetLastError();

@@ -78,7 +78,8 @@ struct GroupKArgs {
     uint32_t persistent;           // 0: one workgroup per item; R > 0: numCU*R persistent workgroups pull items from the queues
     uint32_t numCU;
     uint32_t ablate;               // profiling only (env EFFORT_ABLATE): 2 = no last-arriver reduce, 4 = no row streaming, 8 = no selection, 32 = never wait for a cutoff job
-    uint32_t split;                // 1: the cutoffs were evaluated by find_cutoff_group_kernel (split mode); 0: in the multiply kernel
+    uint32_t split;                // bit 0: the cutoffs were evaluated by find_cutoff_group_kernel (split mode), else in the multiply kernel;
+                                   // bit 2: FP16 calls' `stats` point at the compact row means (u16 per bucket row), not at the f16x4 stats
     uint32_t cutJobs;              // persistent launches: the first cutJobs items (a multiple of 8 >= count) are cutoff jobs, one per call
     uint32_t trace;                // profiling only: 1 = every item leaves a 64-byte record (who ran it, where, its phase stamps) at tstamp + kTraceOff
     uint32_t* groupDone;           // counter of finished tiles (zero between launches)
@@ -130,6 +131,7 @@ hipError_t launch_convert_fp16(const uint16_t* W, uint32_t outDim, uint32_t inDi
 hipError_t launch_convert_q4(const uint16_t* core2, uint32_t inDim, uint32_t outDim, uint32_t cnt, uint16_t* buckets, float* stats, uint16_t* probes,
                              float* outliers, int numCU, hipStream_t st);
 
+hipError_t launch_compact_means(const void* stats_f16x4, uint16_t* means, uint32_t rows, hipStream_t st);
 hipError_t launch_rank_bound(Format fmt, const uint16_t* buckets, const void* stats, uint32_t numExperts, uint32_t rowsPerIn,
                              uint32_t inDim, uint32_t cols, float* rowScratch, float* rankBound, hipStream_t st);
 // decode-loop glue (decode.hip)
