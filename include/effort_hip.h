@@ -90,7 +90,9 @@ EFFORT_API void effort_weights_free(effort_w* w);
  * rank's largest |w|; Q4: largest row mean) read at registration.  If the borrowed buffers are REWRITTEN afterwards (the
  * reference's loader.swift buffers are mutable) call effort_weights_refresh before the next multiply: with a stale bound
  * the sums of larger weights wrap.  get/set copy the bound ([numExperts] floats, host memory): a column shard of a
- * multi-GPU split can take the full matrix's bound, so that every rank rounds its products on the same grid. */
+ * multi-GPU split can take the full matrix's bound, so that every rank rounds its products on the same grid.
+ * FP16 handles also keep a compact copy of the row means (stats lane .w, 2 bytes per bucket row: +0.15 % of the buckets'
+ * size) that big launches stage instead of the 8-byte stats; effort_weights_refresh re-reads it with the bound. */
 EFFORT_API int effort_weights_refresh(effort_w* w);
 /* Row pitch.  The converter's bucket rows are 2*cols bytes apart (1376 for 11008 outputs), so the row pieces the multiply
  * streams straddle 128-byte lines and HBM delivers 5.4-5.6 TB/s instead of 6.1-6.9 (measured on line-aligned shapes).
