@@ -350,6 +350,17 @@ def test_weights_rewritten_in_place_need_a_refresh(ea, oracle_cpu):
     ea.bucketMul(vd, ew, None, out, 0.5)
     ea.gpu().eval()
     assert ea.gpu().last_dispatch_count() == n and ea.gpu().last_cutoff() == cutoff and close(out.cpu().numpy(), want)
+    # ... and by a PERSISTENT launch, which stages the row means from the compact copy made at registration (refreshed too)
+    g = ea.gpu()
+    outs = [torch.full((outDim,), float("nan"), device=DEV) for _ in range(32)]
+    try:
+        g.set_tuning(8, 1, 64)                           # 64 slices per call: thousands of items
+        ea.bucketMulGroup([(vd, ew, None, o, 0.5) for o in outs])
+        g.eval()
+    finally:
+        g.set_tuning(0, 0, 0)
+    for i in (0, 13, 31):
+        assert g.last_dispatch_count(i) == n and g.last_cutoff(i) == cutoff and close(outs[i].cpu().numpy(), want), i
 
 
 def test_converter_reports_dropped_elements(ea, oracle_cpu):
