@@ -26,7 +26,6 @@ roofline         = dominant kernel (bucket_mul_kernel: a whole group of calls in
                    --kernel-trace --stats` reports per launch when kernels do not overlap: profiles/).
 by_group_size    = the step at 1, 2, 3, 4, 8, 16, 32 calls per launch on one stream (1 = the dependent-chain latency).
 by_streams       = the job at 1..4 launches in flight.
-stream_kernel_by_streams = the same through the opt-in boundary-free kernel (stream_mul.inc), 1 and S launches in flight.
 cpu_baseline     = the CPU oracle (a port: the reference ships no CPU path) on the host cores, bounded sample.
 decode           = BASELINE.json configs[4]: end-to-end greedy decode of a random-init Mistral-7B-shaped model through
                    effort_amd/decode.py (one hipGraph per token): tokens/s dense vs effort 100 % / 25 %, KL vs dense.
@@ -464,27 +463,6 @@ def main():
                            "achieved_GBps": round(kb / tn / 1e9, 1), "frac_of_hbm_peak": round(kb / tn / 1e9 / HBM_PEAK_GBPS, 4)}
             del gn
         result["by_streams"] = bs
-        # ---------------- the same job through the opt-in stream kernel (csrc/stream_mul.inc: one 16-wave workgroup per CU
-        # streaming across item boundaries).  Measured beside the default so the comparison is on record. ----------------
-        sk = {}
-        for ns, jb in ((1, one), (S, job)):
-            for c in jb.ctxs:
-                c.set_stream_kernel(True)
-                c.stream_kernel_status()
-            try:
-                gn = jb.capture(mul_step(args.effort), 48)
-                tn = time_graph(gn, None, reps=2) / 48 / N_MATS
-                del gn
-            finally:
-                errs = 0
-                for c in jb.ctxs:
-                    errs |= c.stream_kernel_status()[0]
-                    c.set_stream_kernel(False)
-            sk[str(ns)] = {"us_per_call": round(tn * 1e6, 3), "us_per_step": round(tn * 1e6 * N_MATS, 1), "frac_of_hbm_peak": round(kb / tn / 1e9 / HBM_PEAK_GBPS, 4),
-                           "vs_default": round(bs[str(ns)]["us_per_call"] / (tn * 1e6), 3), "protocol_errors": errs}
-            if ns == S:
-                break
-        result["stream_kernel_by_streams"] = sk
         ts = by["1"]["us_per_call"] * 1e-6
         # ---------------- dense baseline (basicMul over the rotating cores) ---------------------------
         dense_sets = [torch.zeros((N_MATS, outDim), device=dev) for _ in range(4)]

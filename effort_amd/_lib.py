@@ -1,4 +1,4 @@
-"""ctypes binding of libeffort_hip.so (include/effort_hip.h).
+"""ctypes binding of libeffort_hip.so (include/effort_hip.h; the profiling hooks of include/effort_hip_debug.h).
 
 There is NO fallback: if the HIP library is missing or a call fails, this module raises.
 """
@@ -57,8 +57,7 @@ _SIGS = {
     "effort_group_cutoff": (C.c_int, [_P, C.c_int, C.POINTER(C.c_float)]),
     "effort_debug_occupancy": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int]),
     "effort_set_persistent": (C.c_int, [_P, C.c_int]),
-    "effort_set_stream_kernel": (C.c_int, [_P, C.c_int]),
-    "effort_stream_kernel_status": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "effort_debug_set_prefetch": (C.c_int, [_P, C.c_int]),
     "effort_add_rmsnorm_mul": (C.c_int, [_P, _P, _P, _P, _P, C.c_int]),
     "effort_rope_kv": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float]),
     "effort_attention": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int]),

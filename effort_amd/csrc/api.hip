@@ -8,6 +8,7 @@
 #include <new>
 
 #include "../../include/effort_hip.h"
+#include "../../include/effort_hip_debug.h"
 #include "effort_internal.h"
 
 using namespace effort;
@@ -34,8 +35,7 @@ struct effort_ctx {
     uint32_t* d_sliceCounts = nullptr;
     uint32_t* d_queue = nullptr;      // item queues of persistent launches
     int persistent = -1;              // workgroups per CU of group launches: -1 heuristic, 0 plain grid, R > 0 persistent
-    int streamMode = getenv("EFFORT_STREAM") ? atoi(getenv("EFFORT_STREAM")) : 0;   // 1: big FP16 groups run as one continuous stream per CU (stream_mul.inc)
-    int streamLaunches = 0;           // launches that took that path since the last effort_stream_kernel_status
+    bool prefetch = !(getenv("EFFORT_PREFETCH") && atoi(getenv("EFFORT_PREFETCH")) == 0);   // plain grids prefetch rows under the cutoff's serial part
     // where each call of the last (group) launch keeps its per-slice counts; slices == 0: dispatch.size is d_count
     uint32_t lastCalls = 1, lastSliceOff[effort::kMaxGroup] = {0}, lastSlices[effort::kMaxGroup] = {0};
     static constexpr uint32_t kMaxTiles = 1024, kMaxSlices = 4096;
@@ -148,20 +148,24 @@ static int check_shape(uint32_t inDim, uint32_t outDim) {
     // bucketMul.swift:73 (outDim % 16), :52 tmpMulVec 16384 wide; probes need 4096 inputs (:36).  The reference also asserts
     // (outDim/16) % 4 == 0 (:76: its kernel reads four columns per thread); this kernel masks a ragged last tile, so a
     // handle -- in particular a column shard of a multi-GPU split, 11008/16/8 = 86 columns -- may have any column count.
-    if (inDim < (uint32_t)kProbes || outDim == 0 || outDim % 16 || outDim > 16384) return EFFORT_ERR_SHAPE;
+    // (an EVEN count: the row pieces are dword / dwordx2 loads, so rows must stay 4-byte aligned -- outDim % 32 == 0)
+    if (inDim < (uint32_t)kProbes || outDim == 0 || outDim % 32 || outDim > 16384) return EFFORT_ERR_SHAPE;
     return EFFORT_OK;
 }
 
 // The multiply accumulates in fixed point; its scale needs a bound on the weights: per expert, the sum over ranks
 // of the largest |w| of that rank (Q4: of the largest row mean).  One pass over the buckets at registration.
 static int register_bound(effort_ctx* c, effort_w* w) {
+    // (Re)computed IN PLACE: launches copy these pointers by value, and a captured hipGraph bakes them in, so a refresh must
+    // never move them.  rankBound holds [numExperts] bounds, then [numExperts] cutoff hints (see CallDesc::rankBound).
     hipSetDevice(c->device);
     const size_t rows = (size_t)w->numExperts * w->rowsPerIn * w->inDim;
     float* scratch = nullptr;
-    bool ok = hipMalloc(&w->rankBound, (size_t)w->numExperts * 4) == hipSuccess && hipMalloc(&scratch, rows * 4) == hipSuccess;
+    bool ok = (w->rankBound || hipMalloc(&w->rankBound, (size_t)w->numExperts * 8) == hipSuccess) && hipMalloc(&scratch, rows * 4) == hipSuccess;
     if (ok) ok = launch_rank_bound(w->fmt, w->bucketsSrc, w->stats, w->numExperts, w->rowsPerIn, w->inDim, w->cols, scratch, w->rankBound, c->stream) == hipSuccess;
+    if (ok) ok = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(w->rankBound + w->numExperts), 0x7F800000, w->numExperts, c->stream) == hipSuccess;   // +inf: no hint
     if (ok && w->fmt == kFp16) {
-        ok = hipMalloc(&w->means16, rows * 2) == hipSuccess;
+        ok = w->means16 || hipMalloc(&w->means16, rows * 2) == hipSuccess;
         if (ok) ok = launch_compact_means(w->stats, w->means16, (uint32_t)rows, c->stream) == hipSuccess;
     }
     if (ok) ok = hipStreamSynchronize(c->stream) == hipSuccess;
@@ -241,9 +245,7 @@ static int copy_aligned(effort_w* w) {
 extern "C" int effort_weights_refresh(effort_w* w) {
     if (!w || !w->ctx) return EFFORT_ERR_ARG;
     hipSetDevice(w->ctx->device);
-    hipFree(w->rankBound); w->rankBound = nullptr;
-    hipFree(w->means16); w->means16 = nullptr;
-    int rc = register_bound(w->ctx, w);
+    int rc = register_bound(w->ctx, w);          // in place: graphs captured earlier keep valid pointers
     if (rc == EFFORT_OK && w->aligned) rc = copy_aligned(w);
     return rc;
 }
@@ -430,17 +432,15 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
             const MulGeom& g = ga.geom[ga.call[i].geom];
             compact = ws[first + i]->means16 != nullptr && g.inDim % 2u == 0u && g.sliceRows % 2u == 0u;
         }
-        const bool streamLaunch = c->streamMode && fmt == kFp16 && ga.persistent && ga.cutJobs && !ga.trace && stream_mul_fits(E, ga.geom, kMaxGeoms);
-        if (compact && !streamLaunch) {
+        if (compact) {
             for (uint32_t i = 0; i < ga.count; i++) ga.call[i].stats = ws[first + i]->means16;
             ga.split |= 4u;
         }
-        if (c->streamMode && fmt == kFp16 && ga.persistent && ga.cutJobs && !ga.trace && stream_mul_fits(E, ga.geom, kMaxGeoms)) {
-            ga.persistent = 1u; ga.cutJobs = 0u;
-            HIP_TRY(c, launch_stream_mul(E, ga, c->stream));
-            c->streamLaunches++;
-            return EFFORT_OK;
-        }
+        // plain grids of plain FP16 calls (lone calls, small groups: latency chains): rows are prefetched into L2 with the handle's
+        // previous cutoff while the exact one is bisected (bucket_mul.hip, PREF)
+        bool pref = fmt == kFp16 && c->prefetch && !ga.persistent && plain && !c->splitCutoff && !ga.trace;
+        for (uint32_t i = 0; pref && i < ga.count; i++) pref = !ga.call[i].resid;
+        if (pref) ga.split |= 8u;
         if (c->splitCutoff && !(ablate & 1u)) HIP_TRY(c, launch_find_cutoff_group(ga, c->stream));
         HIP_TRY(c, launch_bucket_mul(fmt, W, E, ga, c->stream));
         return EFFORT_OK;
@@ -739,20 +739,9 @@ extern "C" int effort_set_persistent(effort_ctx* c, int wgPerCU) {
     return EFFORT_OK;
 }
 
-extern "C" int effort_set_stream_kernel(effort_ctx* c, int mode) {
-    if (!c || mode < 0 || mode > 1) return EFFORT_ERR_ARG;
-    c->streamMode = mode;
-    return EFFORT_OK;
-}
-
-extern "C" int effort_stream_kernel_status(effort_ctx* c, int* host_out, int* launches) {
-    if (!c || !host_out) return EFFORT_ERR_ARG;
-    if (launches) { *launches = c->streamLaunches; c->streamLaunches = 0; }
-    uint32_t h = 0;
-    HIP_TRY(c, hipMemcpyAsync(&h, c->d_queue + 8 * 16 + 3, 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->d_queue + 8 * 16 + 3, 0, 4, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    *host_out = (int)h;
+extern "C" int effort_debug_set_prefetch(effort_ctx* c, int on) {
+    if (!c) return EFFORT_ERR_ARG;
+    c->prefetch = on != 0;
     return EFFORT_OK;
 }
 

@@ -267,7 +267,7 @@ __device__ __forceinline__ void stage_issue(const GroupKArgs& ga, const ItemRef&
 // `staged` (per wave): this wave's share of the item's stage loads was issued while the previous item streamed (into vblk
 // buffer `par`).  `prefetch` is polled by every wave near the end of its streaming loop until it returns true: there the
 // caller pulls the next item from the queue (wave 0) and issues the wave's share of its stage loads (into buffer par ^ 1).
-template <int FMT, int E, int W, bool FUSED, bool COMPACT, typename Prefetch>
+template <int FMT, int E, int W, bool FUSED, bool COMPACT, bool PREF, typename Prefetch>
 __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t item, const ItemRef& ref, char* smem, const LdsPlan& lp, uint32_t& cachedCall,
                                          float& cachedCutoff, const uint32_t par, const bool staged, const bool firstItem, Prefetch prefetch) {
     constexpr int NACC = Fmt<FMT>::kAcc;
@@ -318,6 +318,9 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     // ---- A. everything the selection needs lands in LDS (stage_issue): the row means of the candidate slots, the slice of v
     if (!staged) stage_issue<FMT, W, COMPACT>(ga, ref, tid, smem, lp, par);
     const float rankBound = a.rankBound[e];                       // (asked for here: its round trip runs under the staged loads')
+    // PREF (plain grids of lone calls / small groups): the cutoff this handle's previous call ended with, kept beside the
+    // bound; +inf until there was one.  A HINT only: see prefetch_rows below.
+    const float estCut = PREF ? a.rankBound[g.numExperts + e] : 0.0f;
     float vj[VPT]; uint16_t prj[VPT];
     const uint16_t* pr = a.probes + (size_t)e * kProbes;
     const bool fused = (ga.split & 1u) == 0u;                    // uniform
@@ -413,11 +416,42 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
         if (fromJob) { cutoff = __uint_as_float(flags[3]); cachedCall = ci; cachedCutoff = cutoff; }
         else load_cut_inputs();
     }
+    // PREF: while wave 0 runs the serial bisection (1.5-3 us during which this workgroup asks nothing of memory) the other
+    // waves walk the slice's candidate slots with the PREVIOUS call's cutoff for these weights and touch every 128-byte
+    // line of the rows that one would keep: by the time the exact cutoff is known and the rows are streamed (phase D) they
+    // sit in this XCD's L2 instead of HBM.  Nothing is accumulated from these loads -- selection and sums come from the exact
+    // cutoff alone, so results do not depend on the hint; a bad hint costs bandwidth a lone call does not use anyway.
+    uint32_t pfSink = 0;                                          // the one register every prefetch load lands in (kept live until they have)
+    auto prefetch_rows = [&]() {
+        if constexpr (PREF && FMT == kFp16 && !FUSED) {
+            if (wave == 0 || !(estCut < 3.0e38f)) return;         // uniform per wave
+            const u32x4 rr4 = make_rsrc(a.buckets, (uint32_t)min((size_t)0xFFFFFFFFu, (size_t)g.numExperts * g.expertRows * g.rowPitch));
+            const uint32_t lgp = g.sliceLog2, nS = g.rowsPerIn << lgp, maskp = (1u << lgp) - 1u;
+            const uint32_t tileOff = t * (uint32_t)(128 * E), rowB = e * g.expertRows + j0;
+            for (uint32_t c = (uint32_t)(wave - 1) * 64u + (uint32_t)lane; c < nS; c += (uint32_t)(W - 1) * 64u) {
+                const uint32_t rank = c >> lgp, jl = c & maskp;
+                const bool ok = jl < nb;
+                const float ax2 = ok ? fabsf(vblk[jl]) : 0.0f;
+                const uint32_t mr = (COMPACT ? (uint32_t)reinterpret_cast<const uint16_t*>(m32)[c] : (m32[c] >> 16));
+                if (ok && estCut < (kCutoffScale * half_bits_to_float((uint16_t)mr)) * ax2) {
+                    const uint32_t bo = (rowB + rank * g.inDim + jl) * g.rowPitch + tileOff;
+#pragma unroll
+                    for (int k = 0; k <= E; k++) {                // every line a 128*E-byte piece can touch, whatever its alignment
+                        const uint32_t o = bo + (k < E ? (uint32_t)k * 128u : (uint32_t)(128 * E - 4));
+                        asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "+v"(pfSink) : "v"(o), "s"(rr4) : "memory");
+                    }
+                }
+            }
+        }
+    };
     if (fromJob) {
     } else if (needCut) {
-        cutoff = block_find_cutoff<NT>(vj, prj, a.q, smem + offC, tbl, []() {}, stamp ? ga.tstamp + 8 : nullptr);
+        cutoff = block_find_cutoff<NT>(vj, prj, a.q, smem + offC, tbl, prefetch_rows, stamp ? ga.tstamp + 8 : nullptr);
         cachedCall = ci; cachedCutoff = cutoff;
-        if (b == 0 && tid == 0 && !ga.cutJobs) a_cutoff[0] = cutoff;             // BucketMul.cutoff (bucketMul.swift:22)
+        if (b == 0 && tid == 0 && !ga.cutJobs) {
+            a_cutoff[0] = cutoff;                                                // BucketMul.cutoff (bucketMul.swift:22)
+            if (PREF) const_cast<float*>(a.rankBound)[g.numExperts + e] = cutoff; // ... and the next call's hint
+        }
     } else if (fused) {
         cutoff = cachedCutoff;
         if (b == 0 && tid == 0 && !ga.cutJobs) a_cutoff[0] = cutoff;
@@ -600,6 +634,10 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     // Near the end of its rows (the last two rounds of the loop: a few microseconds of streaming left) a wave asks for the
     // next item: late enough that the queue still balances the workgroups, early enough that the staged loads land under
     // the remaining rows.
+    if constexpr (PREF) {                                           // every prefetch load has landed: its register may be reused
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("" :: "v"(pfSink));
+    }
     bool asked = false;
     // (measured: raising the wave priority of this loop -- s_setprio 2 -- so that a co-resident workgroup's selection does not
     //  take its issue slots is 8 % SLOWER per launch: the other workgroup's head then takes that much longer)
@@ -896,7 +934,7 @@ __device__ __forceinline__ void cutoff_job(const GroupKArgs& ga, uint32_t ci, ch
 // dispatcher only places ~40 workgroups/us chip-wide and spreads a large grid unevenly over the CUs (measured with
 // tools/microbench.hip: residency probe), so a group launch sizes its grid to the chip -- R workgroups per CU,
 // R fixed by the LDS each one asks for -- and balances the work itself.
-template <int FMT, int E, int W, bool FUSED, bool COMPACT = false>
+template <int FMT, int E, int W, bool FUSED, bool COMPACT = false, bool PREF = false>
 __global__ __launch_bounds__(64 * W, (W <= 8 ? EFFORT_MIN_WAVES_PER_EU : 4)) void bucket_mul_kernel(const GroupKArgs ga) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ uint32_t s_item;
@@ -952,7 +990,7 @@ __global__ __launch_bounds__(64 * W, (W <= 8 ? EFFORT_MIN_WAVES_PER_EU : 4)) voi
         }
         gen++;
         bool stagedNext = false;
-        mul_item<FMT, E, W, FUSED, COMPACT>(ga, item - ga.cutJobs, ref, smem, lp, cachedCall, cachedCutoff, par, staged, gen == 1u && (ga.ablate & 512u) != 0u /* (measured: evaluating the first item's cutoff locally instead of waiting for the job is 1 us slower per 32-call launch; kept as an ablation) */, [&]() -> bool {
+        mul_item<FMT, E, W, FUSED, COMPACT, PREF>(ga, item - ga.cutJobs, ref, smem, lp, cachedCall, cachedCutoff, par, staged, gen == 1u && (ga.ablate & 512u) != 0u /* (measured: evaluating the first item's cutoff locally instead of waiting for the job is 1 us slower per 32-call launch; kept as an ablation) */, [&]() -> bool {
             if (!ga.persistent) return true;
             if (threadIdx.x == 0) {                                // wave 0's first call: pull, publish
                 s_next[0] = pull();
@@ -982,8 +1020,6 @@ __global__ __launch_bounds__(64 * W, (W <= 8 ? EFFORT_MIN_WAVES_PER_EU : 4)) voi
         }
     }
 }
-
-#include "stream_mul.inc"
 
 // ---- host side ------------------------------------------------------------------------------
 template <int FMT, int E, int W>
@@ -1018,12 +1054,18 @@ static hipError_t launch_mul_t(const GroupKArgs& ga, hipStream_t st) {
         if (err == hipSuccess && FMT == kFp16)
             err = hipFuncSetAttribute(reinterpret_cast<const void*>(&bucket_mul_kernel<kFp16, E, W, false, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (err == hipSuccess && FMT == kFp16)
+            err = hipFuncSetAttribute(reinterpret_cast<const void*>(&bucket_mul_kernel<kFp16, E, W, false, false, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (err != hipSuccess) return err;
         maxSet = lds;
     }
     const bool compact = (ga.split & 4u) != 0u;                   // (api.hip: persistent FP16 launches of plain calls)
     if (compact && (FMT != kFp16 || fusedAny)) return hipErrorInvalidValue;
+    const bool pref = (ga.split & 8u) != 0u;                      // (api.hip: plain grids of plain FP16 calls)
+    if (pref && (FMT != kFp16 || fusedAny || compact || ga.persistent)) return hipErrorInvalidValue;
     if (fusedAny) hipLaunchKernelGGL((bucket_mul_kernel<kFp16, E, W, true>), dim3(grid), dim3(64 * W), lds, st, ga);
+    else if (pref) hipLaunchKernelGGL((bucket_mul_kernel<kFp16, E, W, false, false, true>), dim3(grid), dim3(64 * W), lds, st, ga);
     else if (compact) hipLaunchKernelGGL((bucket_mul_kernel<kFp16, E, W, false, true>), dim3(grid), dim3(64 * W), lds, st, ga);
     else hipLaunchKernelGGL((bucket_mul_kernel<FMT, E, W, false>), dim3(grid), dim3(64 * W), lds, st, ga);
     return hipGetLastError();

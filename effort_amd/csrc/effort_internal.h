@@ -46,14 +46,18 @@ __host__ __device__ inline uint32_t ol_bits_in(uint32_t inDim) { uint32_t b = 1;
 // Everything a launch needs travels BY VALUE in the kernel arguments (3.6 KB of the 4 KB a kernel may take; arguments
 // are copied when a launch is captured into a hipGraph): a compact descriptor per call, the few distinct launch
 // geometries of the group, and the bases of the context scratch the calls index into.
-constexpr int kMaxGroup = 32;        // calls per launch
+#ifndef EFFORT_MAX_GROUP
+#define EFFORT_MAX_GROUP 32
+#endif
+constexpr int kMaxGroup = EFFORT_MAX_GROUP;        // calls per launch (the macro: A/B builds of the kernel-argument size, tools/ only)
 constexpr int kMaxGeoms = 4;
 constexpr int kTraceOff = 512, kTraceItems = 4096;   // per-item trace records: u64 index into the stamp buffer / capacity         // distinct (shape, slicing) geometries per launch
 enum Prologue : uint16_t { kPreNone = 0, kPreSiluGate = 1, kPreRmsNorm = 2 };
 struct CallDesc {                    // 112 bytes
     const uint16_t* buckets;
     const void* stats;         // f16x4 (FP16) or f32x2 (Q4) per bucket row
-    const float* rankBound;    // [numExperts] sum over ranks of the rank's max |w| (Q4: max row mean): fixed-point bound, from registration
+    const float* rankBound;    // [numExperts] sum over ranks of the rank's max |w| (Q4: max row mean): fixed-point bound, from registration;
+                               // then [numExperts] the cutoff the handle's previous call ended with (+inf: none yet): prefetch hint only
     const uint16_t* probes;    // f16 [numExperts][4096]
     const float* v;
     const uint32_t* expNo;     // nullable
@@ -80,11 +84,12 @@ struct GroupKArgs {
     uint32_t ablate;               // profiling only (env EFFORT_ABLATE): 2 = no last-arriver reduce, 4 = no row streaming, 8 = no selection, 32 = never wait for a cutoff job
     uint32_t split;                // bit 0: the cutoffs were evaluated by find_cutoff_group_kernel (split mode), else in the multiply kernel;
                                    // bit 2: FP16 calls' `stats` point at the compact row means (u16 per bucket row), not at the f16x4 stats
+                                   // bit 3: plain grid of plain FP16 calls: rows are prefetched under the cutoff's serial part (PREF instantiation)
     uint32_t cutJobs;              // persistent launches: the first cutJobs items (a multiple of 8 >= count) are cutoff jobs, one per call
     uint32_t trace;                // profiling only: 1 = every item leaves a 64-byte record (who ran it, where, its phase stamps) at tstamp + kTraceOff
     uint32_t* groupDone;           // counter of finished tiles (zero between launches)
-    uint32_t* queue;               // [9][16]: per-XCD item cursors (one cache line each), line 8 = exit counter | stream kernel: cutoff-job cursor, reduce-job cursor, error word (sticky);
-                                   // then [32] cutoff words (value | ready bit) of the calls; all but the error word zero between launches
+    uint32_t* queue;               // [9][16]: per-XCD item cursors (one cache line each), line 8 = exit counter;
+                                   // then [32] cutoff words (value | ready bit) of the calls; all zero between launches
     float* slabs;                  // context scratch the calls index into
     uint32_t* counters;
     uint32_t* sliceCounts;
@@ -112,9 +117,6 @@ hipError_t launch_find_cutoff(const float* v, const uint16_t* probes, const uint
 
 // Returns hipErrorInvalidValue for unsupported (fmt, W, E).
 hipError_t launch_bucket_mul(Format fmt, int wavesPerGroup, int elemsPerLane, const GroupKArgs& ga, hipStream_t st);
-// The same group as one continuous stream per CU (stream_mul.inc): FP16, plain calls, E = 2 or 4.
-hipError_t launch_stream_mul(int elemsPerLane, const GroupKArgs& ga, hipStream_t st);
-bool stream_mul_fits(int elemsPerLane, const MulGeom* geoms, int nGeoms);
 hipError_t launch_find_cutoff_group(const GroupKArgs& ga, hipStream_t st);    // ga.cutoff[i] of every call
 size_t bucket_mul_lds_bytes(Format fmt, int wavesPerGroup, int elemsPerLane, const MulGeom& g);
 uint32_t bucket_mul_max_candidates(int wavesPerGroup);

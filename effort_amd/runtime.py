@@ -77,16 +77,9 @@ class Gpu:
     def set_persistent(self, wg_per_cu: int = -1):
         self.check(self._lib.effort_set_persistent(self.ctx, int(wg_per_cu)), "set_persistent")
 
-    def set_stream_kernel(self, on: bool = True):
-        """Big FP16 group launches as one continuous stream per CU (effort_set_stream_kernel)."""
-        self.check(self._lib.effort_set_stream_kernel(self.ctx, int(bool(on))), "set_stream_kernel")
-
-    def stream_kernel_status(self):
-        """(error bits, launches): the stream kernel's protocol waits that ran out (0 = none) and the launches that took the
-        stream path, both since the last query (reads and clears)."""
-        n, k = C.c_int(0), C.c_int(0)
-        self.check(self._lib.effort_stream_kernel_status(self.ctx, C.byref(n), C.byref(k)), "stream_kernel_status")
-        return n.value, k.value
+    def set_prefetch(self, on: bool = True):
+        """Lone calls / small groups prefetch rows under the cutoff's serial part (effort_debug_set_prefetch; results never depend on it)."""
+        self.check(self._lib.effort_debug_set_prefetch(self.ctx, int(bool(on))), "set_prefetch")
 
     def set_dense_backend(self, rocblas: bool = False):
         """basicMul through the library's hssgemv (True) or the streaming HIP kernel (False, default)."""

@@ -37,7 +37,7 @@ typedef struct effort_w effort_w;      /* = class ExpertWeights, loader.swift:46
 enum {
     EFFORT_OK = 0,
     EFFORT_ERR_ARG = -1,          /* null pointer / bad handle                                        */
-    EFFORT_ERR_SHAPE = -2,        /* outDim%16, (outDim/16)%4, outDim<=16384 (bucketMul.swift:52,73-76) */
+    EFFORT_ERR_SHAPE = -2,        /* inDim >= 4096, outDim % 32 == 0, outDim <= 16384 (bucketMul.swift:36,52,73) */
     EFFORT_ERR_EFFORT = -3,       /* effort outside [0,1]                                              */
     EFFORT_ERR_HIP = -4,          /* a HIP runtime call failed (see effort_last_error)                 */
     EFFORT_ERR_KIND = -5,         /* FP16 weights passed to the Q4 call or vice versa                  */
@@ -244,48 +244,14 @@ EFFORT_API int effort_cosine(effort_ctx* ctx, const float* a_dev, const float* b
 /* ---- tuning knobs (not part of the reference surface) ------------------------------------------ */
 
 /* Override the launch geometry heuristics of the multiply kernel: waves per workgroup (4, 8 or 16),
- * elements per lane (1, 2 or 4) and number of row slices (0 = heuristic).  Returns EFFORT_ERR_ARG
+ * elements per lane (1, 2, 4 or 8) and number of row slices (0 = heuristic).  Returns EFFORT_ERR_ARG
  * for unsupported combinations. */
 EFFORT_API int effort_set_tuning(effort_ctx* ctx, int wavesPerGroup, int elemsPerLane, int rowSlices);
 /* split = 1: evaluate findCutoff32 in its own one-workgroup launch ahead of the multiply kernel instead of
- * redundantly inside every workgroup of it.  Costs a kernel boundary per call (worse latency) but frees the
- * multiply's workgroups sooner -- better aggregate throughput when independent calls overlap on several
- * streams/contexts.  Results are bit-identical.  Default 0 (fused). */
-/* Group launches with more work items than wgPerCU workgroups per CU run as that many PERSISTENT workgroups pulling
- * items from per-XCD queues.  -1 = heuristic (default), 0 = always one workgroup per item. */
-EFFORT_API int effort_set_persistent(effort_ctx* ctx, int wgPerCU);
-/* Tuning knob: 1 = FP16 group launches whose items outnumber the chip run as one continuous stream per compute unit
- * (one 16-wave workgroup per CU, items double-buffered in LDS, no workgroup barrier between items); 0 = the phased kernel.
- * Results are bit-identical either way. */
-EFFORT_API int effort_set_stream_kernel(effort_ctx* ctx, int mode);
-/* Reads and clears the stream kernel's error word: 0, or a bit per bounded wait of its protocol that ran out (the results of
- * that launch are undefined); `launches` (nullable) receives the number of launches that took the stream path since the
- * last query (launches recorded into a hipGraph count once, at capture).  Synchronises the stream. */
-EFFORT_API int effort_stream_kernel_status(effort_ctx* ctx, int* host_out, int* launches);
+ * inside it.  Costs a kernel boundary per call.  Results are bit-identical.  Default 0 (fused). */
 EFFORT_API int effort_set_split_cutoff(effort_ctx* ctx, int split);
 
-/* Timing hooks.  enable = 1: HIP events are recorded on the context's stream around each of the three
- * kernels of a call (not capturable into a graph) AND the multiply kernel stamps the device wall clock
- * at its first workgroup's start / last workgroup's end; enable = 2: device clock only (works inside
- * hipGraph replays); 3: 2 plus a per-item trace (effort_debug_trace); 0: off.  effort_kernel_timing returns event-to-event averages in microseconds
- * (they include the launch gap in front of each kernel); effort_kernel_clock returns the multiply
- * kernel's own average duration (first start -> last end).  Both reset their accumulators. */
-EFFORT_API int effort_enable_kernel_timing(effort_ctx* ctx, int enable);
-EFFORT_API int effort_kernel_clock(effort_ctx* ctx, double* mul_us_avg, int* n_launches);
-/* Profiling aid: 24 raw u64 phase stamps written by the most recent cutoff / multiply kernels in timing mode. */
-/* resident workgroups per CU the runtime grants the (q4, waves, elems) multiply kernel at ldsBytes of LDS */
-EFFORT_API int effort_debug_occupancy(effort_ctx* ctx, int q4, int waves, int elems, int ldsBytes);
-EFFORT_API int effort_debug_stamps(effort_ctx* ctx, unsigned long long* host32);
-/* Test hook: kept rows per row slice of call idx of the most recent (group) launch (their sum is dispatch.size); returns the
- * number of slices copied (<= maxSlices), or a negative error code. */
-EFFORT_API int effort_debug_slice_counts(effort_ctx* ctx, int idx, uint32_t* host, int maxSlices);
-/* enable = 3 (device clock + trace): every work item of the most recent multiply launch leaves a 64-byte record
- * {item | workgroup << 32 (bit 63: cutoff job), XCC_ID | HW_ID << 32, six device wall-clock stamps: start, staged,
- * cutoff, selected, streamed, handed over}; copies the first maxRecords (<= 4096) records to host (8 u64 each), followed by 4 u64 per item: the device clock when wave 0
- * was a quarter, half and three quarters through its rows (host must hold 12 * maxRecords u64). */
-EFFORT_API int effort_debug_trace(effort_ctx* ctx, unsigned long long* host, int maxRecords);
-EFFORT_API int effort_kernel_timing(effort_ctx* ctx, double* mul_us_avg, double* cutoff_us_avg,
-                         double* integrate_us_avg, int* n_samples);
+/* Profiling, tracing and ablation hooks live in effort_hip_debug.h: they are not part of the drop-in surface. */
 
 #ifdef __cplusplus
 }

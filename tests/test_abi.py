@@ -9,13 +9,18 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _header_functions():
-    src = open(os.path.join(ROOT, "include", "effort_hip.h")).read()
-    return sorted(set(re.findall(r"EFFORT_API\s+[\w\s\*]+?\b(effort_\w+)\s*\(", src)))
+def _header_functions(names=("effort_hip.h", "effort_hip_debug.h")):
+    fns = set()
+    for n in names:
+        src = open(os.path.join(ROOT, "include", n)).read()
+        fns |= set(re.findall(r"EFFORT_API\s+[\w\s\*]+?\b(effort_\w+)\s*\(", src))
+    return sorted(fns)
 
 
 def test_header_declares_the_expected_surface():
-    fns = _header_functions()
+    fns = _header_functions(("effort_hip.h",))
+    # the lab bench (profiling / tracing / ablation hooks) is not part of the drop-in boundary
+    assert not [f for f in fns if f.startswith(("effort_debug_", "effort_kernel_", "effort_enable_kernel_timing", "effort_set_persistent"))]
     for must in ("effort_create", "effort_destroy", "effort_sync", "effort_weights_fp16", "effort_weights_q4",
                  "effort_bucketmul", "effort_bucketmul_q4", "effort_dense_gemv", "effort_convert_fp16",
                  "effort_last_dispatch_count", "effort_calc_dispatch"):

@@ -833,22 +833,11 @@ def test_q4_config3_full_size(ea, oracle_cpu, q4_11008):
         assert close(outs[i].cpu().numpy(), want), i
 
 
-@pytest.mark.parametrize("stream_kernel", [False, True])
-def test_bench_geometry_32_matrices_from_graph(ea, oracle_cpu, stream_kernel):
-    """The headline bench launch: 32 DISTINCT converted 4096 x 11008 matrices, one call each at 25 % effort, one heuristic
+def test_bench_geometry_32_matrices_from_graph(ea, oracle_cpu):
+    """The bench's 32-call launch: 32 DISTINCT converted 4096 x 11008 matrices, one call each at 25 % effort, one heuristic
     group (persistent workgroups, cutoff jobs), replayed from a hipGraph -- every output, dispatch count and cutoff against
-    the oracle, on a second replay with the input changed in place.  Both kernels: the phased one (default) and the
-    continuous stream per CU (effort_set_stream_kernel)."""
-    inDim, outDim, n_calls = 4096, 11008, 32
-    g = ea.gpu()
-    g.set_stream_kernel(stream_kernel)
-    g.stream_kernel_status()
-    try:
-        _bench_geometry(ea, oracle_cpu, g, inDim, outDim, n_calls)
-        err, launches = g.stream_kernel_status()
-        assert err == 0 and (launches > 0) == stream_kernel
-    finally:
-        g.set_stream_kernel(False)
+    the oracle, on a second replay with the input changed in place."""
+    _bench_geometry(ea, oracle_cpu, ea.gpu(), 4096, 11008, 32)
 
 
 def _bench_geometry(ea, oracle_cpu, g, inDim, outDim, n_calls):
@@ -883,59 +872,6 @@ def _bench_geometry(ea, oracle_cpu, g, inDim, outDim, n_calls):
             assert close(outs[i].cpu().numpy(), want), (rep, i)
 
 
-def test_stream_kernel_bit_identical_to_the_phased_kernel(ea, oracle_cpu):
-    """The continuous-stream kernel (stream_mul.inc) against the phased one on launches chosen to hit its corners: efforts 0
-    to 1, inputs with whole slices of zeros (items that keep nothing: no batches, their all-zero slabs are handed over by the
-    producing wave), heavy inputs, two shapes (so two geometries and ragged last tiles) in one launch, columns per lane 4 and 2, launch after launch
-    (queues, counters and the error word rewind).  Bit-identical outputs, dispatch counts and cutoffs; no protocol wait
-    ran out; the stream path was the one taken."""
-    g = ea.gpu()
-    inDim = 4096
-    W, b, s, p = converted(oracle_cpu, 4096, inDim)
-    ewA = gpu_weights(ea, W, b, s, p)
-    gen = torch.Generator(device=DEV)
-    gen.manual_seed(77)
-    Wb = (torch.randn((11008, inDim), generator=gen, device=DEV, dtype=torch.float32) * 0.02).to(torch.float16)
-    ewB = ea.ExpertWeights.from_core(Wb)
-    ewB.core = None
-    efforts = (0.0, 0.1, 0.25, 1.0, 0.5)
-    hv = [make_v(inDim, seed=300 + i, heavy=bool(i % 3 == 0)) for i in range(32)]
-    for i in range(0, 32, 5):
-        hv[i][:1024] = 0.0                                   # whole slices of zeros: items that keep nothing
-    vs = [devf(x) for x in hv]
-    def run(tune, stream):
-        outs = [torch.full((11008 if i % 4 == 3 else 4096,), float("nan"), device=DEV) for i in range(32)]
-        calls = [(vs[i], ewB if i % 4 == 3 else ewA, None, outs[i], efforts[i % 5]) for i in range(32)]
-        g.set_tuning(*tune)
-        g.set_stream_kernel(stream)
-        try:
-            res = []
-            for rep in range(3 if stream else 1):
-                for o in outs:
-                    o.fill_(float("nan"))
-                ea.bucketMulGroup(calls)
-                g.eval()
-                res.append(([o.clone() for o in outs], [g.last_dispatch_count(i) for i in range(32)], [g.last_cutoff(i) for i in range(32)]))
-            return res
-        finally:
-            g.set_tuning(0, 0, 0)
-            g.set_stream_kernel(False)
-    for tune in ((8, 4, 32), (8, 2, 16)):
-        g.stream_kernel_status()
-        want = run(tune, False)[0]
-        err, launches = g.stream_kernel_status()
-        assert err == 0 and launches == 0
-        got = run(tune, True)
-        err, launches = g.stream_kernel_status()
-        assert err == 0 and launches == 3, (tune, err, launches)
-        for outs, counts, cutoffs in got:
-            assert counts == want[1] and cutoffs == want[2], tune
-            for i, (a, b2) in enumerate(zip(outs, want[0])):
-                assert torch.equal(a, b2), (tune, i)
-        assert min(g.slice_counts(0)) == 0                           # (the zero slices: items without batches were in the launch)
-
-
-@pytest.mark.parametrize("world", [2, 4, 8])
 def test_column_shards_of_the_baseline_shapes(ea, oracle_cpu, q4_case, q4_11008, world):
     """BASELINE.json configs[3] on one device: ShardedExpertWeights.from_full for every rank of a world of 2 / 4 / 8, for
     4096 x 11008 (86 bucket columns per rank at world 8: a ragged tile) and 4096 x 4096, FP16 and Q4 with outliers --

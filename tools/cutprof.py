@@ -21,5 +21,6 @@ for shape in ((4096, 11008), (4096, 4096)):
             g.enable_kernel_timing(0)
         c = st[0:8]; it = st[8:16]
         us = lambda a, b: (b - a) / 100.0
-        print(f"{shape} effort {effort}: cutoff total {us(c[0], c[3]):.2f} us = minmax+ballot {us(c[0], c[1]):.2f} + table {us(c[1], c[2]):.2f} + bisection {us(c[2], c[3]):.2f}; loops {c[5] // 1000} passes {c[5] % 1000}; "
+        ghz = (c[7] - c[6]) / max(1.0, (c[3] - c[0]) * 10.0)
+        print(f"{shape} effort {effort}: shader clock during the cutoff {ghz:.2f} GHz; cutoff total {us(c[0], c[3]):.2f} us = minmax+ballot {us(c[0], c[1]):.2f} + table {us(c[1], c[2]):.2f} + bisection {us(c[2], c[3]):.2f}; loops {c[5] // 1000} passes {c[5] % 1000}; "
               f"item0: stage {us(it[0], it[1]):.2f} cutoff {us(it[1], it[2]):.2f} select {us(it[2], it[3]):.2f} stream {us(it[3], it[4]):.2f} handoff {us(it[4], it[5]):.2f} rows {it[6]}")
