@@ -10,11 +10,14 @@ converted matrix (rotation i % 32 exactly like benchmarks/benchmark.swift:206,25
 reads come from HBM, not the 256 MB Infinity Cache), all on the same input vector, each writing its own output
 vector.  Inputs are resident in HBM before the timed region.  The calls of a step are independent (as Wq|Wk|Wv or
 W1|W3 are in the decode loop), so they are issued `--group` at a time through effort_bucketmul_group: ONE kernel
-launch per group.  The K steps of the job are independent too (a serving loop's batches are), so the whole job is
-ONE hipGraph in which step i runs on HIP stream i % S with its own context (scratch) and its own output set: up to
-S = `--streams` launches are in flight, and the head of one (staging, cutoffs, selection: HBM idle) runs under the
-streaming phase of the others.  The host is not in the timed path (the reference's timeIt, helpers/timeit.swift:10-34,
-likewise enqueues everything and waits once).
+launch per group.  The K steps of the job are independent too (a serving loop's batches are): they go, one after the
+other, through ONE context with effort_set_overlap(S) -- the library keeps up to S = `--streams` launches in flight on
+its own lanes, and the head of one (staging, cutoffs, selection: HBM idle) runs under the streaming phase of the
+others.  Every step in flight multiplies its OWN 32 matrices (S x 32 distinct matrices, 11.8 GB: nothing a concurrent
+launch reads can be served from the 256 MB Infinity Cache on another launch's behalf) into its own output set; the
+job is one hipGraph, replayed until the timed region is >= 50 ms; the host is not in the timed path (the reference's
+timeIt, helpers/timeit.swift:10-34, likewise enqueues everything and waits once).  After the timed replays EVERY
+output set the timed graph wrote is checked against the CPU oracle (S x 32 outputs).
 
 value            = effective (dense-equivalent) GB/s = 2*inDim*outDim bytes per call / time per call, whole job
                    over all ranks.
@@ -25,7 +28,11 @@ roofline         = dominant kernel (bucket_mul_kernel: a whole group of calls in
                    ONE launch in flight (launch duration = timed region / launches, which is what `rocprofv3
                    --kernel-trace --stats` reports per launch when kernels do not overlap: profiles/).
 by_group_size    = the step at 1, 2, 3, 4, 8, 16, 32 calls per launch on one stream (1 = the dependent-chain latency).
-by_streams       = the job at 1..4 launches in flight.
+by_streams       = the job at 1..4 launches in flight through one context (effort_set_overlap); `four_contexts` = the same
+                   overlap built by the CALLER from four contexts / streams (round 2's way), `shared_matrices` = every step
+                   in flight on the SAME 32 matrices (round 2's job: what the Infinity Cache could have contributed).
+shard_projection = BASELINE.json configs[3] on one GPU: the per-rank work of a bucket-column split over G = 2 / 4 / 8 GPUs
+                   (32 column shards per launch), kernel-only time, roofline fraction and strong-scaling efficiency.
 cpu_baseline     = the CPU oracle (a port: the reference ships no CPU path) on the host cores, bounded sample.
 decode           = BASELINE.json configs[4]: end-to-end greedy decode of a random-init Mistral-7B-shaped model through
                    effort_amd/decode.py (one hipGraph per token): tokens/s dense vs effort 100 % / 25 %, KL vs dense.
@@ -53,7 +60,7 @@ IN_DIM, OUT_DIM = 4096, 11008
 N_MATS = 32
 SWEEP = [0.10, 0.15, 0.20, 0.25, 0.30, 0.40, 0.50, 0.60, 0.70, 0.80, 0.90, 1.00]
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")   # written from a rocprofv3 --pmc pass (tools/pmc_traffic.py)
+PMC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r03_pmc_traffic.json", "r02_pmc_traffic.json")]   # rocprofv3 --pmc passes folded by tools/pmc_traffic.py
 
 
 def log(*a):
@@ -67,11 +74,17 @@ def algorithmic_bytes(D: int, inDim: int, outDim: int) -> int:
 
 
 def mul_kernel_bytes(D: int, inDim: int, outDim: int) -> int:
-    """What bucket_mul_kernel must move per CALL it serves (a launch serves `group` calls)."""
+    """What bucket_mul_kernel must move per CALL it serves (a launch serves `group` calls): the SURVEY formula."""
     return algorithmic_bytes(D, inDim, outDim)
 
 
-ALIGN_ROWS = True    # (--no-align) bucket rows re-pitched to whole 128-byte lines at registration: effort_weights_align_rows
+def moved_bytes(D: int, inDim: int, outDim: int) -> int:
+    """The same with what a persistent FP16 launch actually stages for the keep test: the 2-byte compact row means
+    instead of the 8-byte stats entries."""
+    return D * (outDim // 16) * 2 + 16 * inDim * 2 + 4096 * 2 + 4 * inDim + 4 * outDim
+
+
+ALIGN_ROWS = True    # (--no-align) the converter writes the bucket rows on whole 128-byte lines (effort_convert_fp16_pitched): no second copy
 
 
 def make_weights(ea, n, inDim, outDim, seed0, dev, keep_core=True, q4=False):
@@ -85,12 +98,10 @@ def make_weights(ea, n, inDim, outDim, seed0, dev, keep_core=True, q4=False):
             ew = ea.ExpertWeights(t["buckets"], t["bucket.stats"], t["probes"], inSize=inDim, outSize=outDim,
                                   outliers=t["outliers"], core=W, q4=True)
         else:
-            ew = ea.ExpertWeights.from_core(W)      # product converter (GPU bucketize)
+            ew = ea.ExpertWeights.from_core(W, aligned=ALIGN_ROWS)      # product converter (GPU bucketize)
         if not keep_core:
             ew.core = None
         ew.handle
-        if ALIGN_ROWS:
-            ew.align_rows()
         ews.append(ew)
     ea.gpu().eval()
     return ews
@@ -138,6 +149,40 @@ class Job:
         for c in self.ctxs:
             c._bind_stream()
         return g
+
+    def last_dispatch_count(self, nsteps, idx):
+        return self.ctxs[(nsteps - 1) % self.S].last_dispatch_count(idx)
+
+
+class LaneJob:
+    """K independent steps as ONE hipGraph through ONE context: the library keeps up to `lanes` launches in flight
+    (effort_set_overlap) and orders each launch after the earlier ones it depends on; step i writes output set i % lanes."""
+
+    def __init__(self, ea, device, lanes=1, tune=(0, 0, 0), ctx=None):
+        self.S = max(1, lanes)
+        self.ctx = ctx if ctx is not None else ea.Gpu(device)
+        self.ctx.set_tuning(*tune)
+        self.ctx.set_overlap(self.S)
+        self.ctxs = [self.ctx]
+
+    def _enqueue(self, step, nsteps):
+        for i in range(nsteps):
+            step(self.ctx, i % self.S)
+        self.ctx.join()                              # the lanes rejoin the (capturing) stream
+
+    def capture(self, step, nsteps):
+        self._enqueue(step, min(nsteps, self.S))     # warm: handles, kernel attributes
+        torch.cuda.synchronize()
+        if hasattr(step, "reset"):
+            step.reset()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            self._enqueue(step, nsteps)
+        self.ctx._bind_stream()
+        return g
+
+    def last_dispatch_count(self, nsteps, idx):
+        return self.ctx.last_dispatch_count(idx)
 
 
 def time_graph(g_timed, g_warm, barrier=None, reps=1):
@@ -208,6 +253,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-decode", action="store_true", help="skip the end-to-end decode section (BASELINE.json configs[4])")
     ap.add_argument("--headline-only", action="store_true", help="only the timed job (for rocprofv3 passes: every bucket_mul_kernel dispatch is then the timed configuration)")
+    ap.add_argument("--headline-shared", action="store_true", help="round 2's job: every step in flight on the SAME 32 matrices")
     ap.add_argument("--no-align", action="store_true", help="stream the converter's rows as they are (2*cols bytes apart) instead of the handle's line-aligned copy")
     ap.add_argument("--tune", default="0,0,0", help="waves,elems,slices of the multiply kernel (0,0,0 = heuristic)")
     args = ap.parse_args()
@@ -239,30 +285,37 @@ def main():
 
     inDim, outDim = IN_DIM, OUT_DIM
     t_setup = time.perf_counter()
-    seed0 = 1234 if world == 1 else 1234 + rank * N_MATS
-    ews = make_weights(ea, N_MATS, inDim, outDim, seed0, dev, keep_core=(rank == 0))
+    # S disjoint sets of 32 matrices: every step in flight multiplies its own (set 0 keeps the dense cores: dense baseline, cos-sim)
+    seed0 = 1234 if world == 1 else 1234 + rank * N_MATS * S
+    n_sets = 1 if args.headline_shared else S
+    ew_sets = [make_weights(ea, N_MATS, inDim, outDim, seed0 + k * N_MATS, dev, keep_core=(rank == 0 and (k == 0 or not args.headline_only))) for k in range(n_sets)]
+    ews = ew_sets[0]
     gen = torch.Generator(device=dev)
     gen.manual_seed(42)
     v = torch.randn(inDim, generator=gen, device=dev, dtype=torch.float32)
     out_sets = [torch.zeros((N_MATS, outDim), device=dev) for _ in range(S)]          # one output set per stream
     outs = [out_sets[0][k] for k in range(N_MATS)]
     torch.cuda.synchronize()
-    log(f"[rank {rank}] setup {time.perf_counter() - t_setup:.1f} s: {N_MATS} matrices {inDim}x{outDim} converted on the GPU")
+    log(f"[rank {rank}] setup {time.perf_counter() - t_setup:.1f} s: {n_sets} x {N_MATS} matrices {inDim}x{outDim} converted on the GPU")
 
     def barrier():
         if dist:
             dist.barrier()
 
-    def mul_step(effort, weights=ews, vec=v, sets=out_sets, group=G):
-        """One step: the group launches of the matrices in `weights`, outputs into set `slot`."""
+    def mul_step(effort, weights=ews, vec=v, sets=out_sets, group=G, wsets=None):
+        """One step: the group launches of the matrices in `weights` (or, `wsets` given, of the slot's own set: step in flight
+        k multiplies wsets[k % len(wsets)]), outputs into set `slot`."""
         def step(ctx, slot):
-            items = [(vec, ew, None, sets[slot][k], effort) for k, ew in enumerate(weights)]
+            ws = wsets[slot % len(wsets)] if wsets else weights
+            items = [(vec, ew, None, sets[slot][k], effort) for k, ew in enumerate(ws)]
             for ch in chunked(items, group):
                 ea.bucketMulGroup(ch, gpu=ctx)
         return step
 
-    job = Job(ea, local, S, tune)
-    one = Job(ea, local, 1, tune) if S > 1 else job
+    # the headline job: ONE context, the library overlaps its launches (effort_set_overlap).  N > 1 keeps round 2's job (four
+    # contexts on four streams) under the all-gather pipeline below.
+    job = Job(ea, local, S, tune) if dist else LaneJob(ea, local, S, tune)
+    one = LaneJob(ea, local, 1, tune, ctx=g)
     launches_per_step = (N_MATS + G - 1) // G
 
     # ---------------- the timed job: K steps at the headline effort --------------------------------
@@ -279,7 +332,8 @@ def main():
             def step(ctx, slot):
                 i = count[0]
                 count[0] += 1
-                items = [(v, ew, None, send[i % send.shape[0]][k], args.effort) for k, ew in enumerate(weights)]
+                ws = weights[slot % len(weights)] if isinstance(weights[0], list) else weights
+                items = [(v, ew, None, send[i % send.shape[0]][k], args.effort) for k, ew in enumerate(ws)]
                 for ch in chunked(items, G):
                     ea.bucketMulGroup(ch, gpu=ctx)
             step.reset = lambda: count.__setitem__(0, 0)
@@ -330,17 +384,22 @@ def main():
                 x = torch.tensor([(time.perf_counter() - t0) / args.steps], device=dev, dtype=torch.float64)
                 dist.all_reduce(x, op=dist.ReduceOp.MAX)
                 return float(x.item())
-        ex = Exchange(ews, outDim)
+        ex = Exchange(ew_sets, outDim)
         ex.timed(False)                                      # (first pass: every graph's first replay uploads it)
         dt_kernel = ex.timed(False)                          # the steps without the exchange (kernel only)
         dt = ex.timed(True)
         D = job.ctxs[0].last_dispatch_count((N_MATS - 1) % G)
         in_flight = min(S, args.steps)
+        reps = 1
     else:
-        g_warm = job.capture(mul_step(args.effort), args.warmup) if args.warmup > 0 else None
-        g_timed = job.capture(mul_step(args.effort), args.steps)
-        D = job.ctxs[(args.steps - 1) % S].last_dispatch_count((N_MATS - 1) % G)
-        dt = time_graph(g_timed, g_warm, barrier) / args.steps
+        head_step = mul_step(args.effort, wsets=ew_sets)
+        g_warm = job.capture(head_step, args.warmup) if args.warmup > 0 else None
+        g_timed = job.capture(head_step, args.steps)
+        D = job.last_dispatch_count(args.steps, (N_MATS - 1) % G)
+        # the K-step graph is replayed until the timed region is >= 50 ms (a 2.5 ms region reads 5 % slow: clocks, caches)
+        est = time_graph(g_timed, g_warm, barrier)
+        reps = max(1, int(0.06 / max(est, 1e-6)) + 1)
+        dt = time_graph(g_timed, g_warm, barrier, reps=reps) / args.steps
         in_flight = min(S, args.steps)
     calls_per_step = N_MATS * world                                  # whole job
     t_call = dt / N_MATS                                             # per-rank time per bucketMul call
@@ -355,18 +414,17 @@ def main():
         "vs_baseline": None, "dtype": "f16", "data": "synthetic",
         "config": {"workload": f"bucketMul {inDim}x{outDim} fp16 buckets, effort {args.effort}, {N_MATS} distinct matrices rotated "
                                f"(one call each per step), fixed-point accumulate (f32 out); {G} independent calls per fused "
-                               f"kernel launch; the job's steps are independent: ONE hipGraph, {in_flight} step(s) in flight "
-                               f"({in_flight} HIP stream(s), one context each)", "effort": args.effort, "matrices_per_step": N_MATS,
+                               f"kernel launch; the job's steps are independent: ONE hipGraph through ONE context, {in_flight} step(s) "
+                               f"in flight (effort_set_overlap), each on its own {N_MATS} matrices", "effort": args.effort, "matrices_per_step": N_MATS,
+                   "distinct_matrices": n_sets * N_MATS,
                    "inDim": inDim, "outDim": outDim, "calls_per_launch": G, "steps_in_flight": in_flight,
                    "bucket_row_pitch_bytes": (outDim // 16 * 2 + 127) // 128 * 128 if ALIGN_ROWS else outDim // 16 * 2,
                    "kernel_geometry(waves,elems,slices)": args.tune if args.tune != "0,0,0" else "heuristic",
                    "partition": "matrices" if world > 1 else "none", "dispatch_rows": D},
         "us_per_call": round(t_call * 1e6, 3),
         "tokens_per_s": round(1.0 / (t_call * 4 * 32), 2),
-        "timed_region_ms": round(dt * args.steps * 1e3, 3),
+        "timed_region_ms": round(dt * args.steps * reps * 1e3, 3), "timed_replays": reps, "timed_steps": args.steps * reps,
     }
-    if dt * args.steps < 0.05:
-        result["timed_region_note"] = "timed region < 50 ms: clocks and caches are still settling, longer runs (--steps 200) read a few % faster"
     if dist:
         result["rccl_ranks"] = dist.get_world_size()
         result["multi_gpu"] = {"partition": "matrices (weak scaling: every rank its own 32 matrices)", "ms_per_step_kernel_only": round(dt_kernel * 1e3, 5),
@@ -396,31 +454,39 @@ def main():
 
     if rank == 0 and world == 1 and not args.headline_only:
         # ---------------- roofline of the dominant kernel, in the timed configuration -----------------
-        traffic = None
-        try:
-            with open(PMC_FILE) as f:
-                pmc = json.load(f)
-            if pmc.get("calls_per_launch") == G and abs(pmc.get("effort", -1) - args.effort) < 1e-9:
-                traffic = pmc["hbm_bytes_per_launch"]
-        except Exception:
-            pmc = None
+        traffic, pmc_src = None, None
+        for pf in PMC_FILES:
+            try:
+                with open(pf) as f:
+                    pmc = json.load(f)
+                if pmc.get("calls_per_launch") == G and abs(pmc.get("effort", -1) - args.effort) < 1e-9:
+                    traffic, pmc_src = pmc["hbm_bytes_per_launch"], os.path.relpath(pf, ROOT)
+                    break
+            except Exception:
+                pass
         t_launch = dt / launches_per_step                # the timed region's share per launch
+        mb = moved_bytes(D, inDim, outDim)
         result["roofline"] = {
             "bound": "hbm", "kernel": "bucket_mul_kernel", "achieved": round(G * kb / t_launch / 1e9, 1), "peak": HBM_PEAK_GBPS,
             "unit": "GB/s", "frac": round(G * kb / t_launch / 1e9 / HBM_PEAK_GBPS, 4), "traffic": traffic,
-            "traffic_source": (f"rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE pass of this command ({os.path.relpath(PMC_FILE, ROOT)}), "
-                               "corrected as MI355X_MICROARCH.md prescribes") if traffic else None,
+            "traffic_source": (f"static: a committed rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE pass of this command on another run ({pmc_src}), "
+                               "corrected as MI355X_MICROARCH.md prescribes; NOT measured in this run") if traffic else None,
             "calls_per_launch": G, "bytes_per_launch": G * kb, "bytes_per_call": kb, "launches_in_flight": in_flight,
+            "bytes_per_call_note": "SURVEY 8d formula (8-byte stats entries); the persistent launch stages 2-byte compact means instead: frac_moved_bytes",
+            "frac_moved_bytes": round(G * mb / t_launch / 1e9 / HBM_PEAK_GBPS, 4),
             "kernel_us": round(t_launch * 1e6, 3),
             "kernel_us_source": ("timed region / launches.  With one launch in flight this is the kernel's duration; with "
                                  f"{in_flight} in flight it is the chip's time per launch (each launch lasts about {in_flight}x as long and "
-                                 "rocprofv3 reports that), so `achieved` is the rate of the CHIP over the timed region; see single_stream"),
+                                 "rocprofv3 reports that), so `achieved` is the rate of the CHIP over the timed region: profiles/r03_span.json "
+                                 "recomputes it from a kernel trace (span = first start .. last end); see single_stream"),
         }
         # the same job with ONE launch in flight: launch duration = timed region / launches (kernels do not overlap)
         if S > 1:
-            g1w = one.capture(mul_step(args.effort), min(args.warmup, 10))
-            g1 = one.capture(mul_step(args.effort), args.steps)
-            dt1 = time_graph(g1, g1w) / args.steps
+            one.S = len(ew_sets)                             # (slots rotate over the weight / output sets; still one launch in flight)
+            g1w = one.capture(mul_step(args.effort, wsets=ew_sets), min(args.warmup, 10))
+            g1 = one.capture(mul_step(args.effort, wsets=ew_sets), max(args.steps, 2 * len(ew_sets)))
+            one.S = 1
+            dt1 = time_graph(g1, g1w, reps=max(1, reps // 2)) / max(args.steps, 2 * len(ew_sets))
             del g1w, g1
         else:
             dt1 = dt
@@ -453,23 +519,34 @@ def main():
             del gn
         result["by_group_size"] = by
         bs = {}
-        for ns in (1, 2, 3, 4):
-            jb = Job(ea, local, ns, tune) if ns not in (1, S) else (one if ns == 1 else job)
-            while len(out_sets) < ns:
-                out_sets.append(torch.zeros((N_MATS, outDim), device=dev))
-            gn = jb.capture(mul_step(args.effort), 48)
-            tn = time_graph(gn, None, reps=2) / 48 / N_MATS
-            bs[str(ns)] = {"us_per_call": round(tn * 1e6, 3), "effective_GBps": round(eff_bytes / tn / 1e9, 1),
-                           "achieved_GBps": round(kb / tn / 1e9, 1), "frac_of_hbm_peak": round(kb / tn / 1e9 / HBM_PEAK_GBPS, 4)}
+
+        def rate(tn):
+            return {"us_per_call": round(tn * 1e6, 3), "us_per_step": round(tn * 1e6 * N_MATS, 2), "effective_GBps": round(eff_bytes / tn / 1e9, 1),
+                    "achieved_GBps": round(kb / tn / 1e9, 1), "frac_of_hbm_peak": round(kb / tn / 1e9 / HBM_PEAK_GBPS, 4)}
+        while len(out_sets) < 4:
+            out_sets.append(torch.zeros((N_MATS, outDim), device=dev))
+        for ns in (1, 2, 3, 4):                              # ONE context, `ns` launches in flight (effort_set_overlap), each step on its own matrices
+            jb = job if ns == S else LaneJob(ea, local, ns, tune)
+            gn = jb.capture(mul_step(args.effort, wsets=ew_sets[:max(1, min(ns, len(ew_sets)))]), 48)
+            bs[str(ns)] = rate(time_graph(gn, None, reps=4) / 48 / N_MATS)
             del gn
         result["by_streams"] = bs
+        result["by_streams_note"] = "one effort_ctx, effort_set_overlap(n): the library keeps n launches in flight; every step in flight on its own 32 matrices"
+        # round 2's job beside it: every step in flight on the SAME 32 matrices, and the overlap built by the caller from four contexts
+        gn = job.capture(mul_step(args.effort), 48)
+        result["shared_matrices"] = rate(time_graph(gn, None, reps=4) / 48 / N_MATS)
+        del gn
+        four_ctx = Job(ea, local, S, tune)
+        gn = four_ctx.capture(mul_step(args.effort, wsets=ew_sets), 48)
+        result["four_contexts"] = rate(time_graph(gn, None, reps=4) / 48 / N_MATS)
+        del gn, four_ctx
         ts = by["1"]["us_per_call"] * 1e-6
         # ---------------- dense baseline (basicMul over the rotating cores) ---------------------------
         dense_sets = [torch.zeros((N_MATS, outDim), device=dev) for _ in range(4)]
         four = Job(ea, local, 4, tune)
 
-        def dense_step(ctx, slot):
-            for k, ew in enumerate(ews):
+        def dense_step(ctx, slot):                               # (every step in flight on its own 32 cores, like the multiply's job)
+            for k, ew in enumerate(ew_sets[slot % len(ew_sets)]):
                 ea.basicMul(v, ew.core, dense_sets[slot][k], gpu=ctx)
         # basicMul (helpers/mps.swift:14-47) twice: through rocBLAS' hssgemv -- the library the north star names -- and
         # through the package's own streaming kernel (csrc/gemv.hip), the default backend of effort_dense_gemv
@@ -487,13 +564,15 @@ def main():
             import numpy as np
             last = N_MATS - 1
             sweep, got_all = [], []
+            slotL = (24 - 1) % S                             # the slot (output set, weight set) of a 24-step graph's last step
+            ewsL = ew_sets[slotL % len(ew_sets)]
             for e in SWEEP:
-                ge = job.capture(mul_step(e), 24)
-                De = job.ctxs[(24 - 1) % S].last_dispatch_count((N_MATS - 1) % G)
+                ge = job.capture(mul_step(e, wsets=ew_sets), 24)
+                De = job.last_dispatch_count(24, (N_MATS - 1) % G)
                 te = time_graph(ge, None, reps=2) / 24 / N_MATS
-                ea.basicMul(v, ews[last].core, dense_out[0])
-                cs = ea.cosineSimilarityTo(out_sets[(24 - 1) % S][last], dense_out[0])
-                got_all.append(out_sets[(24 - 1) % S][last].cpu().numpy().astype(np.float64))
+                ea.basicMul(v, ewsL[last].core, dense_out[0])
+                cs = ea.cosineSimilarityTo(out_sets[slotL][last], dense_out[0])
+                got_all.append(out_sets[slotL][last].cpu().numpy().astype(np.float64))
                 sweep.append({"effort": e, "dispatch_rows": De, "us_per_call": round(te * 1e6, 3),
                               "effective_GBps": round(eff_bytes / te / 1e9, 1),
                               "achieved_GBps": round(algorithmic_bytes(De, inDim, outDim) / te / 1e9, 1),
@@ -506,14 +585,14 @@ def main():
             vh = v * torch.exp(torch.randn(inDim, generator=gen, device=dev, dtype=torch.float32))
             heavy = {}
             for e in (0.25, 0.5):
-                gh = job.capture(mul_step(e, vec=vh), 24)
-                Dh = job.ctxs[(24 - 1) % S].last_dispatch_count((N_MATS - 1) % G)
+                gh = job.capture(mul_step(e, vec=vh, wsets=ew_sets), 24)
+                Dh = job.last_dispatch_count(24, (N_MATS - 1) % G)
                 th = time_graph(gh, None, reps=2) / 24 / N_MATS
-                ea.basicMul(vh, ews[last].core, dense_out[0])
+                ea.basicMul(vh, ewsL[last].core, dense_out[0])
                 heavy[str(e)] = {"dispatch_rows": Dh, "us_per_call": round(th * 1e6, 3),
                                  "achieved_GBps": round(algorithmic_bytes(Dh, inDim, outDim) / th / 1e9, 1),
                                  "frac_of_hbm_peak": round(algorithmic_bytes(Dh, inDim, outDim) / th / 1e9 / HBM_PEAK_GBPS, 4),
-                                 "cos_vs_dense": round(ea.cosineSimilarityTo(out_sets[(24 - 1) % S][last], dense_out[0]), 5)}
+                                 "cos_vs_dense": round(ea.cosineSimilarityTo(out_sets[slotL][last], dense_out[0]), 5)}
                 del gh
             result["heavy_tailed_input"] = heavy
             # one STRUCTURED matrix (effort_amd.decode.structured_matrix) and a state as a norm layer with outlier channels
@@ -543,7 +622,7 @@ def main():
                 jb = one if streams == 1 else job
                 nst = 8 if streams == 1 else 16
                 gx = jb.capture(mul_step(effort, weights=ews_x, vec=vx, sets=sets_x, group=n), nst)
-                Dx = jb.ctxs[(nst - 1) % jb.S].last_dispatch_count((len(ews_x) - 1) % n)
+                Dx = jb.last_dispatch_count(nst, (len(ews_x) - 1) % n)
                 tx = time_graph(gx, None, reps=3) / nst / len(ews_x)
                 del gx
                 if q4:
@@ -575,6 +654,54 @@ def main():
             other["4096x11008 q4 (bucketMulQ4, 2 % outliers)"] = three(q4w, outDim, inDim, 0.25, q4=True)
             del q4w
             result["other_configs"] = other
+            # ---------------- BASELINE.json configs[3] projected on ONE GPU: what a rank of a bucket-column split over G GPUs runs ----
+            # (rank r holds columns [r*C/G, (r+1)*C/G) of every matrix, stats / probes replicated; its kernel-only work
+            #  is a launch of column shards.  Strong scaling: the same matrices on every G; efficiency = t(G=1) / (G * t(G)).)
+            try:
+                from effort_amd.sharded import ShardedExpertWeights
+
+                def shard_times(full, inD, outD, effort, per_launch):
+                    rows = {}
+                    for Gw in (1, 2, 4, 8):
+                        if (outD // 16) % Gw:
+                            continue
+                        sh = full if Gw == 1 else [ShardedExpertWeights.from_full(e, i % Gw, Gw).local for i, e in enumerate(full)]
+                        for x in sh:
+                            x.handle
+                            if ALIGN_ROWS:
+                                x.align_rows()
+                        lo = outD // Gw
+                        vx = v if inD == inDim else torch.randn(inD, generator=gen, device=dev, dtype=torch.float32)
+                        sets_x = [torch.zeros((len(sh), lo), device=dev) for _ in range(S)]
+                        r = {}
+                        for nm, jb, nst in (("1 launch in flight", one, 8), (f"{S} in flight", job, 16)):
+                            gx = jb.capture(mul_step(effort, weights=sh, vec=vx, sets=sets_x, group=per_launch), nst)
+                            Dx = jb.last_dispatch_count(nst, (len(sh) - 1) % per_launch)
+                            tx = time_graph(gx, None, reps=4) / nst            # per step = per rank per step
+                            del gx
+                            ab = len(sh) * algorithmic_bytes(Dx, inD, lo)
+                            r[nm] = {"us_per_step_per_rank": round(tx * 1e6, 2), "frac_of_hbm_peak": round(ab / tx / 1e9 / HBM_PEAK_GBPS, 4)}
+                        r["columns_per_rank"] = outD // 16 // Gw
+                        r["row_pitch_bytes"] = sh[0].align_rows() if ALIGN_ROWS else outD // 16 // Gw * 2
+                        rows[str(Gw)] = r
+                        del sh
+                    for Gw, r in rows.items():
+                        for nm in list(r):
+                            if isinstance(r[nm], dict):
+                                r[nm]["kernel_only_scaling_efficiency"] = round(rows["1"][nm]["us_per_step_per_rank"] / (int(Gw) * r[nm]["us_per_step_per_rank"]), 3)
+                    return rows
+                sp = {"note": "per-rank kernel-only time of a bucket-column split, measured on one GPU: a launch of `calls per launch` column shards "
+                              "(rank i % G of matrix i), 25 % effort; efficiency = t(G=1) / (G * t(G)); the all-gather of the outputs is not in it",
+                      "4096x11008, 32 calls per launch": shard_times(ews, inDim, outDim, 0.25, 32)}
+                sq = make_weights(ea, 16, 4096, 4096, 4321, dev, keep_core=False)
+                sp["4096x4096, 16 calls per launch"] = shard_times(sq, 4096, 4096, 0.25, 16)
+                del sq
+                up = make_weights(ea, 16, 4096, 14336, 7321, dev, keep_core=False)
+                sp["4096x14336, 16 calls per launch"] = shard_times(up, 4096, 14336, 0.25, 16)
+                del up
+                result["shard_projection"] = sp
+            except Exception as ex:
+                result["shard_projection"] = {"error": repr(ex)}
         # ---------------- end-to-end greedy decode (BASELINE.json configs[4]; random-init Mistral-7B shapes) ----------
         if not args.no_decode and not args.no_sweep:
             try:
@@ -629,20 +756,29 @@ def main():
             try:
                 import numpy as np
                 cb = cpu_baseline(ews, v, args.effort, inDim, outDim)
-                g1c = one.capture(mul_step(args.effort), 1)
-                g1c.replay()
+                # EVERY output set the timed graph wrote (its last replay): step k in flight multiplied ew_sets[k] into set k
+                for o in out_sets:
+                    o.fill_(float("nan"))
+                g_timed.replay()                                 # the timed graph itself, once more, into cleared output sets
                 torch.cuda.synchronize()
-                hip = out_sets[0].cpu().numpy()
-                worst, bad = 0.0, 0
-                ref = oracle_outputs(ews, v, args.effort, inDim, outDim, range(N_MATS))
-                for k in range(N_MATS):
-                    want, Do, _ = ref[k]
-                    worst = max(worst, float(np.abs(hip[k] - want).max() / (np.abs(want).max() + 1e-30)))
-                    bad += int(g.last_dispatch_count(k % G) != Do) if G == N_MATS else 0
+                timed_outputs = [o.clone() for o in out_sets[:min(S, args.steps)]]
+                worst, bad, checked = 0.0, 0, 0
+                for k, hip_set in enumerate(timed_outputs):
+                    wk = ew_sets[k % len(ew_sets)]
+                    hip = hip_set.cpu().numpy()
+                    ref = oracle_outputs(wk, v, args.effort, inDim, outDim, range(N_MATS))
+                    for i in range(N_MATS):
+                        want, Do, _ = ref[i]
+                        worst = max(worst, float(np.abs(hip[i] - want).max() / (np.abs(want).max() + 1e-30)))
+                        bad += int(not np.isfinite(hip[i]).all())
+                        checked += 1
+                    if k == (args.steps - 1) % len(timed_outputs) and G == N_MATS:      # the launch whose hooks are still readable: the job's last
+                        for i in range(N_MATS):
+                            bad += int(job.last_dispatch_count(args.steps, i) != ref[i][1])
                 if not args.no_sweep:                        # every sweep point's output against the oracle at that effort
                     sw, gots, last = sweep_check
                     for row, got in zip(sw, gots):
-                        want, Do, _ = oracle_outputs(ews, v, row["effort"], inDim, outDim, [last])[last]
+                        want, Do, _ = oracle_outputs(ewsL, v, row["effort"], inDim, outDim, [last])[last]
                         row["cos_vs_oracle"] = round(float(got @ want.astype(np.float64) / (np.linalg.norm(got) * np.linalg.norm(want) + 1e-300)), 9)
                         row["dispatch_rows_oracle"] = int(Do)
                 try:             # BASELINE.json configs[0]: one 4096x4096 bucketMul at 50 % effort on the CPU path
@@ -652,8 +788,9 @@ def main():
                 except Exception as ex:
                     cb["config0_4096x4096_effort_0.5"] = {"error": repr(ex)}
                 cb["gpu_vs_cpu_max_rel_err"] = worst
-                cb["gpu_vs_cpu_outputs_checked"] = N_MATS
-                cb["gpu_vs_cpu_dispatch_count_mismatches"] = bad
+                cb["gpu_vs_cpu_outputs_checked"] = checked
+                cb["gpu_vs_cpu_outputs_checked_note"] = f"all {len(timed_outputs)} output sets of the timed graph's last replay, each against the oracle on the matrices its step multiplied"
+                cb["gpu_vs_cpu_dispatch_count_or_nan_mismatches"] = bad
                 result["cpu_baseline"] = cb
             except Exception as ex:  # the oracle is optional infrastructure for the bench
                 result["cpu_baseline"] = {"error": repr(ex)}

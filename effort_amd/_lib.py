@@ -38,9 +38,13 @@ _SIGS = {
     "effort_destroy": (None, [_P]),
     "effort_set_stream": (C.c_int, [_P, _P]),
     "effort_sync": (C.c_int, [_P]),
+    "effort_set_overlap": (C.c_int, [_P, C.c_int]),
+    "effort_join": (C.c_int, [_P]),
     "effort_last_error": (C.c_char_p, [_P]),
     "effort_version": (C.c_char_p, []),
     "effort_weights_fp16": (_P, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "effort_weights_fp16_pitched": (_P, [_P, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "effort_aligned_row_pitch": (C.c_int, [C.c_int]),
     "effort_weights_q4": (_P, [_P, _P, _P, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_int]),
     "effort_weights_free": (None, [_P]),
     "effort_weights_refresh": (C.c_int, [_P]),
@@ -57,7 +61,7 @@ _SIGS = {
     "effort_group_cutoff": (C.c_int, [_P, C.c_int, C.POINTER(C.c_float)]),
     "effort_debug_occupancy": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int]),
     "effort_set_persistent": (C.c_int, [_P, C.c_int]),
-    "effort_debug_set_prefetch": (C.c_int, [_P, C.c_int]),
+    "effort_debug_hook_lane": (C.c_int, [_P, C.c_int]),
     "effort_add_rmsnorm_mul": (C.c_int, [_P, _P, _P, _P, _P, C.c_int]),
     "effort_rope_kv": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float]),
     "effort_attention": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int]),
@@ -77,6 +81,7 @@ _SIGS = {
     "effort_last_cutoff": (C.c_int, [_P, C.POINTER(C.c_float)]),
     "effort_calc_dispatch": (C.c_int, [_P, _P, _P, _P, C.c_double, _P, _P]),
     "effort_convert_fp16": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P]),
+    "effort_convert_fp16_pitched": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_int, _P, _P]),
     "effort_cosine": (C.c_int, [_P, _P, _P, C.c_int, C.POINTER(C.c_float)]),
     "effort_set_split_cutoff": (C.c_int, [_P, C.c_int]),
     "effort_set_tuning": (C.c_int, [_P, C.c_int, C.c_int, C.c_int]),

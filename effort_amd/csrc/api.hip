@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "../../include/effort_hip.h"
 #include "../../include/effort_hip_debug.h"
@@ -15,14 +16,34 @@ using namespace effort;
 
 static constexpr size_t kStampBytes = (size_t)(kTraceOff + kTraceItems * 12) * 8;   // phase stamps + per-item trace records
 
-struct effort_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    int numCU = 256;
-    // scratch owned by the context (the reference's singleton state)
+// What ONE multiply launch in flight owns: the reference's singleton scratch (BucketMul.shared: cutoff, dispatch counter,
+// partial tiles) plus the launch machinery's (arrival tickets, per-slice counts, item queues).  A context has one such lane,
+// or -- effort_set_overlap -- up to kMaxLanes of them, each with an internal stream: independent launches then overlap.
+struct Lane {
+    hipStream_t own = nullptr;        // internal stream (overlap mode); with one lane the launches go to the context's stream
+    hipEvent_t done = nullptr;        // recorded after the lane's latest launch
     float* d_cutoff = nullptr;        // BucketMul.cutoff
     uint32_t* d_count = nullptr;      // dispatch.size
     float* d_slabs = nullptr;         // partial tiles (replaces tmpMulVec)
+    uint32_t* d_counters = nullptr;   // per-tile arrival tickets (zero between calls)
+    uint32_t* d_sliceCounts = nullptr;
+    uint32_t* d_queue = nullptr;      // item queues of persistent launches
+    // where each call of the lane's last (group) launch keeps its per-slice counts; slices == 0: dispatch.size is d_count
+    uint32_t lastCalls = 1, lastSliceOff[effort::kMaxGroup] = {0}, lastSlices[effort::kMaxGroup] = {0};
+    // address ranges the launches enqueued since the last join read / write (hazard check of the next launch)
+    struct Range { uintptr_t lo, hi; };
+    std::vector<Range> reads, writes;
+    bool pending = false;
+};
+
+struct effort_ctx {
+    static constexpr int kMaxLanes = 4;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int numCU = 256;
+    Lane lane[kMaxLanes];
+    int nLanes = 1, lastLane = 0, nextLane = 0;
+    hipEvent_t forkEv = nullptr;      // overlap mode: "everything enqueued on the context's stream so far"
     size_t slabBytes = 0;
     uint32_t* d_blockScratch = nullptr;
     uint16_t* d_vhalf = nullptr;      // v.asFloat16() for the dense baseline
@@ -31,13 +52,7 @@ struct effort_ctx {
     uint16_t* d_convVals = nullptr;   // converter scratch (transposed matrix)
     size_t convElems = 0;
     int* d_status = nullptr;
-    uint32_t* d_counters = nullptr;   // per-tile arrival tickets (zero between calls)
-    uint32_t* d_sliceCounts = nullptr;
-    uint32_t* d_queue = nullptr;      // item queues of persistent launches
     int persistent = -1;              // workgroups per CU of group launches: -1 heuristic, 0 plain grid, R > 0 persistent
-    bool prefetch = !(getenv("EFFORT_PREFETCH") && atoi(getenv("EFFORT_PREFETCH")) == 0);   // plain grids prefetch rows under the cutoff's serial part
-    // where each call of the last (group) launch keeps its per-slice counts; slices == 0: dispatch.size is d_count
-    uint32_t lastCalls = 1, lastSliceOff[effort::kMaxGroup] = {0}, lastSlices[effort::kMaxGroup] = {0};
     static constexpr uint32_t kMaxTiles = 1024, kMaxSlices = 4096;
     unsigned long long* d_tstamp = nullptr;   // device-clock stamps of the multiply kernel (timing mode)
     double wallClockKHz = 100000.0;
@@ -63,6 +78,7 @@ struct effort_w {
     const uint16_t* bucketsSrc = nullptr; // the caller's buffer (borrowed)
     uint16_t* aligned = nullptr;          // own copy with rows padded to whole 128-byte lines (effort_weights_align_rows)
     uint32_t rowPitch = 0;                // bytes between rows of `buckets`
+    uint32_t srcPitch = 0;                // ... of `bucketsSrc` (2*cols as the reference lays them out, or what effort_weights_fp16_pitched was given)
     const void* stats = nullptr;
     const uint16_t* probes = nullptr;
     uint32_t inDim = 0, outDim = 0, rowsPerIn = 0, numExperts = 1, cols = 0;
@@ -91,6 +107,25 @@ static int fail(effort_ctx* c, int code, const char* what, hipError_t e = hipSuc
 extern "C" const char* effort_version(void) { return "effort-hip 0.1 (gfx950)"; }
 extern "C" const char* effort_last_error(effort_ctx* c) { return c ? c->err : "null context"; }
 
+static bool lane_alloc(effort_ctx* c, Lane& L) {
+    bool ok = hipMalloc(&L.d_cutoff, 512) == hipSuccess && hipMalloc(&L.d_count, 16) == hipSuccess &&
+              hipMalloc(&L.d_slabs, c->slabBytes) == hipSuccess && hipMalloc(&L.d_counters, effort_ctx::kMaxTiles * 4) == hipSuccess &&
+              hipMalloc(&L.d_sliceCounts, effort_ctx::kMaxSlices * 4) == hipSuccess && hipMalloc(&L.d_queue, 11 * 16 * 4) == hipSuccess;
+    if (!ok) return false;
+    hipMemset(L.d_counters, 0, effort_ctx::kMaxTiles * 4);
+    hipMemset(L.d_sliceCounts, 0, effort_ctx::kMaxSlices * 4);
+    hipMemset(L.d_queue, 0, 11 * 16 * 4);
+    hipMemset(L.d_cutoff, 0, 512);
+    hipMemset(L.d_count, 0, 16);
+    return true;
+}
+static void lane_free(Lane& L) {
+    if (L.own) hipStreamDestroy(L.own);
+    if (L.done) hipEventDestroy(L.done);
+    hipFree(L.d_cutoff); hipFree(L.d_count); hipFree(L.d_slabs); hipFree(L.d_counters); hipFree(L.d_sliceCounts); hipFree(L.d_queue);
+    L = Lane();
+}
+
 extern "C" effort_ctx* effort_create(int device, void* stream) {
     if (hipSetDevice(device) != hipSuccess) return nullptr;
     effort_ctx* c = new (std::nothrow) effort_ctx();
@@ -100,38 +135,76 @@ extern "C" effort_ctx* effort_create(int device, void* stream) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->numCU = prop.multiProcessorCount;
     c->slabBytes = (size_t)64 << 20;
-    bool ok = hipMalloc(&c->d_cutoff, 512) == hipSuccess && hipMalloc(&c->d_count, 16) == hipSuccess &&
-              hipMalloc(&c->d_slabs, c->slabBytes) == hipSuccess && hipMalloc(&c->d_blockScratch, 4096 * 4) == hipSuccess &&
+    bool ok = lane_alloc(c, c->lane[0]) && hipMalloc(&c->d_blockScratch, 4096 * 4) == hipSuccess &&
               hipMalloc(&c->d_cos, 16) == hipSuccess && hipMalloc(&c->d_status, 16) == hipSuccess &&
-              hipMalloc(&c->d_tstamp, kStampBytes) == hipSuccess && hipMalloc(&c->d_counters, effort_ctx::kMaxTiles * 4) == hipSuccess &&
-              hipMalloc(&c->d_sliceCounts, effort_ctx::kMaxSlices * 4) == hipSuccess && hipMalloc(&c->d_queue, 11 * 16 * 4) == hipSuccess;
+              hipMalloc(&c->d_tstamp, kStampBytes) == hipSuccess;
     if (!ok) { effort_destroy(c); return nullptr; }
     int khz = 0;
     if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0) c->wallClockKHz = khz;
     hipMemset(c->d_tstamp, 0, kStampBytes);
-    hipMemset(c->d_counters, 0, effort_ctx::kMaxTiles * 4);
-    hipMemset(c->d_sliceCounts, 0, effort_ctx::kMaxSlices * 4);
-    hipMemset(c->d_queue, 0, 11 * 16 * 4);
     { unsigned long long init[2] = {~0ull, 0ull}; hipMemcpy(c->d_tstamp, init, 16, hipMemcpyHostToDevice); }
-    hipMemset(c->d_cutoff, 0, 512);
-    hipMemset(c->d_count, 0, 16);
     hipMemset(c->d_status, 0, 16);
     return c;
+}
+
+// ---- lanes: independent launches of one context in flight together (effort_set_overlap) -------------------------
+// The stream a launch of lane i goes to.
+static hipStream_t lane_stream(effort_ctx* c, int i) { return c->nLanes > 1 ? c->lane[i].own : c->stream; }
+// The context's stream waits for every lane's launches; from here on the context's stream order covers them.
+static int join_lanes(effort_ctx* c) {
+    if (c->nLanes <= 1) return EFFORT_OK;
+    for (int i = 0; i < c->nLanes; i++) {
+        Lane& L = c->lane[i];
+        if (!L.pending) continue;
+        hipError_t e = hipStreamWaitEvent(c->stream, L.done, 0);
+        if (e != hipSuccess) { snprintf(c->err, sizeof(c->err), "join: %s", hipGetErrorString(e)); return EFFORT_ERR_HIP; }
+        L.pending = false; L.reads.clear(); L.writes.clear();
+    }
+    return EFFORT_OK;
+}
+static bool overlaps(const std::vector<Lane::Range>& a, const std::vector<Lane::Range>& b) {
+    for (const auto& x : a) for (const auto& y : b) if (x.lo < y.hi && y.lo < x.hi) return true;
+    return false;
+}
+
+extern "C" int effort_set_overlap(effort_ctx* c, int lanes) {
+    if (!c || lanes < 1 || lanes > effort_ctx::kMaxLanes) return EFFORT_ERR_ARG;
+    hipSetDevice(c->device);
+    int rc = join_lanes(c);
+    if (rc != EFFORT_OK) return rc;
+    if (lanes > 1) {
+        if (!c->forkEv && hipEventCreateWithFlags(&c->forkEv, hipEventDisableTiming) != hipSuccess) return fail(c, EFFORT_ERR_HIP, "set_overlap: event");
+        for (int i = 0; i < lanes; i++) {
+            Lane& L = c->lane[i];
+            if (!L.d_slabs && !lane_alloc(c, L)) return fail(c, EFFORT_ERR_HIP, "set_overlap: out of device memory for a lane's scratch");
+            if (!L.own && hipStreamCreateWithFlags(&L.own, hipStreamNonBlocking) != hipSuccess) return fail(c, EFFORT_ERR_HIP, "set_overlap: stream");
+            if (!L.done && hipEventCreateWithFlags(&L.done, hipEventDisableTiming) != hipSuccess) return fail(c, EFFORT_ERR_HIP, "set_overlap: event");
+        }
+    }
+    c->nLanes = lanes; c->lastLane = 0; c->nextLane = 0;
+    return EFFORT_OK;
+}
+extern "C" int effort_join(effort_ctx* c) {
+    if (!c) return EFFORT_ERR_ARG;
+    return join_lanes(c);
 }
 
 extern "C" void effort_destroy(effort_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
+    for (int i = 0; i < effort_ctx::kMaxLanes; i++) if (c->lane[i].own) hipStreamSynchronize(c->lane[i].own);
     hipStreamSynchronize(c->stream);
     if (c->blas) rocblas_destroy_handle(c->blas);
     if (c->ev) { for (int i = 0; i < effort_ctx::kMaxSamples * 4; i++) hipEventDestroy(c->ev[i]); delete[] c->ev; }
-    hipFree(c->d_cutoff); hipFree(c->d_count); hipFree(c->d_slabs); hipFree(c->d_blockScratch);
-    hipFree(c->d_vhalf); hipFree(c->d_cos); hipFree(c->d_convVals); hipFree(c->d_status); hipFree(c->d_tstamp); hipFree(c->d_counters); hipFree(c->d_sliceCounts); hipFree(c->d_queue);
+    for (int i = 0; i < effort_ctx::kMaxLanes; i++) lane_free(c->lane[i]);
+    if (c->forkEv) hipEventDestroy(c->forkEv);
+    hipFree(c->d_blockScratch); hipFree(c->d_vhalf); hipFree(c->d_cos); hipFree(c->d_convVals); hipFree(c->d_status); hipFree(c->d_tstamp);
     delete c;
 }
 
 extern "C" int effort_set_stream(effort_ctx* c, void* stream) {
     if (!c) return EFFORT_ERR_ARG;
+    if (reinterpret_cast<hipStream_t>(stream) != c->stream && join_lanes(c) != EFFORT_OK) return EFFORT_ERR_HIP;   // (the old stream carries the join)
     c->stream = reinterpret_cast<hipStream_t>(stream);
     if (c->blas) rocblas_set_stream(c->blas, c->stream);
     return EFFORT_OK;
@@ -139,6 +212,7 @@ extern "C" int effort_set_stream(effort_ctx* c, void* stream) {
 
 extern "C" int effort_sync(effort_ctx* c) {
     if (!c) return EFFORT_ERR_ARG;
+    if (join_lanes(c) != EFFORT_OK) return EFFORT_ERR_HIP;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return EFFORT_OK;
 }
@@ -157,13 +231,12 @@ static int check_shape(uint32_t inDim, uint32_t outDim) {
 // of the largest |w| of that rank (Q4: of the largest row mean).  One pass over the buckets at registration.
 static int register_bound(effort_ctx* c, effort_w* w) {
     // (Re)computed IN PLACE: launches copy these pointers by value, and a captured hipGraph bakes them in, so a refresh must
-    // never move them.  rankBound holds [numExperts] bounds, then [numExperts] cutoff hints (see CallDesc::rankBound).
+    // never move them.
     hipSetDevice(c->device);
     const size_t rows = (size_t)w->numExperts * w->rowsPerIn * w->inDim;
     float* scratch = nullptr;
-    bool ok = (w->rankBound || hipMalloc(&w->rankBound, (size_t)w->numExperts * 8) == hipSuccess) && hipMalloc(&scratch, rows * 4) == hipSuccess;
-    if (ok) ok = launch_rank_bound(w->fmt, w->bucketsSrc, w->stats, w->numExperts, w->rowsPerIn, w->inDim, w->cols, scratch, w->rankBound, c->stream) == hipSuccess;
-    if (ok) ok = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(w->rankBound + w->numExperts), 0x7F800000, w->numExperts, c->stream) == hipSuccess;   // +inf: no hint
+    bool ok = (w->rankBound || hipMalloc(&w->rankBound, (size_t)w->numExperts * 4) == hipSuccess) && hipMalloc(&scratch, rows * 4) == hipSuccess;
+    if (ok) ok = launch_rank_bound(w->fmt, w->bucketsSrc, w->srcPitch / 2u, w->stats, w->numExperts, w->rowsPerIn, w->inDim, w->cols, scratch, w->rankBound, c->stream) == hipSuccess;
     if (ok && w->fmt == kFp16) {
         ok = w->means16 || hipMalloc(&w->means16, rows * 2) == hipSuccess;
         if (ok) ok = launch_compact_means(w->stats, w->means16, (uint32_t)rows, c->stream) == hipSuccess;
@@ -173,20 +246,30 @@ static int register_bound(effort_ctx* c, effort_w* w) {
     return ok ? EFFORT_OK : fail(c, EFFORT_ERR_HIP, "weight registration: rank bound");
 }
 
-extern "C" effort_w* effort_weights_fp16(effort_ctx* c, const void* buckets, const void* stats, const void* probes,
-                                         int inDim, int outDim, int percentLoad, int numExperts) {
+extern "C" int effort_aligned_row_pitch(int outDim) {
+    if (outDim <= 0 || outDim % 16) return EFFORT_ERR_SHAPE;
+    return (outDim / 16 * 2 + 127) / 128 * 128;
+}
+
+extern "C" effort_w* effort_weights_fp16_pitched(effort_ctx* c, const void* buckets, int rowPitchBytes, const void* stats, const void* probes,
+                                                 int inDim, int outDim, int percentLoad, int numExperts) {
     if (!c || !buckets || !stats || !probes) { fail(c, EFFORT_ERR_ARG, "effort_weights_fp16: null argument"); return nullptr; }
+    const int pitch = rowPitchBytes ? rowPitchBytes : (outDim > 0 ? outDim / 16 * 2 : 0);
     if (inDim <= 0 || outDim <= 0 || percentLoad < 1 || percentLoad > 16 || numExperts < 1 || check_shape(inDim, outDim) != EFFORT_OK ||
-        inDim > 65535 || (size_t)numExperts * percentLoad * inDim * (outDim / 16) * 2 > 0xFFFFFFFFull) {
-        fail(c, EFFORT_ERR_SHAPE, "effort_weights_fp16: unsupported shape (or buckets >= 4 GiB)"); return nullptr; }
+        inDim > 65535 || pitch < outDim / 16 * 2 || pitch % 8 || (size_t)numExperts * percentLoad * inDim * pitch > 0xFFFFFFFFull) {
+        fail(c, EFFORT_ERR_SHAPE, "effort_weights_fp16: unsupported shape or row pitch (a multiple of 8 bytes >= 2*cols; buckets < 4 GiB)"); return nullptr; }
     effort_w* w = new (std::nothrow) effort_w();
     if (!w) return nullptr;
     w->ctx = c; w->fmt = kFp16;
     w->buckets = static_cast<const uint16_t*>(buckets); w->stats = stats; w->probes = static_cast<const uint16_t*>(probes);
     w->inDim = inDim; w->outDim = outDim; w->rowsPerIn = percentLoad; w->numExperts = numExperts; w->cols = outDim / 16;
-    w->bucketsSrc = w->buckets; w->rowPitch = w->cols * 2u;
+    w->bucketsSrc = w->buckets; w->rowPitch = w->srcPitch = (uint32_t)pitch;
     if (register_bound(c, w) != EFFORT_OK) { effort_weights_free(w); return nullptr; }
     return w;
+}
+extern "C" effort_w* effort_weights_fp16(effort_ctx* c, const void* buckets, const void* stats, const void* probes,
+                                         int inDim, int outDim, int percentLoad, int numExperts) {
+    return effort_weights_fp16_pitched(c, buckets, 0, stats, probes, inDim, outDim, percentLoad, numExperts);
 }
 
 extern "C" effort_w* effort_weights_q4(effort_ctx* c, const void* buckets, const void* stats, const void* probes,
@@ -200,7 +283,7 @@ extern "C" effort_w* effort_weights_q4(effort_ctx* c, const void* buckets, const
     w->ctx = c; w->fmt = kQ4;
     w->buckets = static_cast<const uint16_t*>(buckets); w->stats = stats; w->probes = static_cast<const uint16_t*>(probes);
     w->inDim = inDim; w->outDim = outDim; w->rowsPerIn = 8; w->numExperts = numExperts; w->cols = outDim / 32;
-    w->bucketsSrc = w->buckets; w->rowPitch = w->cols * 2u;
+    w->bucketsSrc = w->buckets; w->rowPitch = w->srcPitch = w->cols * 2u;
     if (register_bound(c, w) != EFFORT_OK) { effort_weights_free(w); return nullptr; }
     if (outliers && nOutliers > 0) {
         if (outDim > 65536) { fail(c, EFFORT_ERR_SHAPE, "effort_weights_q4: outliers need outDim <= 65536"); effort_weights_free(w); return nullptr; }
@@ -238,7 +321,7 @@ extern "C" effort_w* effort_weights_q4(effort_ctx* c, const void* buckets, const
 // rewritten in place afterwards need effort_weights_refresh (the reference's loader.swift buffers are mutable).
 static int copy_aligned(effort_w* w) {
     const size_t rows = (size_t)w->numExperts * w->rowsPerIn * w->inDim;
-    HIP_TRY(w->ctx, hipMemcpy2DAsync(w->aligned, w->rowPitch, w->bucketsSrc, (size_t)w->cols * 2, (size_t)w->cols * 2, rows, hipMemcpyDeviceToDevice, w->ctx->stream));
+    HIP_TRY(w->ctx, hipMemcpy2DAsync(w->aligned, w->rowPitch, w->bucketsSrc, w->srcPitch, (size_t)w->cols * 2, rows, hipMemcpyDeviceToDevice, w->ctx->stream));
     HIP_TRY(w->ctx, hipStreamSynchronize(w->ctx->stream));
     return EFFORT_OK;
 }
@@ -257,7 +340,7 @@ extern "C" int effort_weights_refresh(effort_w* w) {
 // keep it if the weights are going to change).  No-op when the pitch is line-aligned already.  Results are bit-identical.
 extern "C" int effort_weights_align_rows(effort_w* w) {
     if (!w || !w->ctx) return EFFORT_ERR_ARG;
-    if (w->aligned || (w->cols * 2u) % 128u == 0u) return EFFORT_OK;
+    if (w->aligned || w->rowPitch % 128u == 0u) return EFFORT_OK;        // (already on whole lines: as converted with effort_convert_fp16_pitched, or 2*cols % 128 == 0)
     hipSetDevice(w->ctx->device);
     const uint32_t pitch = (w->cols * 2u + 127u) / 128u * 128u;
     const size_t rows = (size_t)w->numExperts * w->rowsPerIn * w->inDim;
@@ -266,7 +349,7 @@ extern "C" int effort_weights_align_rows(effort_w* w) {
     HIP_TRY(w->ctx, hipMemsetAsync(w->aligned, 0, rows * pitch, w->ctx->stream));
     w->rowPitch = pitch;
     const int rc = copy_aligned(w);
-    if (rc != EFFORT_OK) { hipFree(w->aligned); w->aligned = nullptr; w->rowPitch = w->cols * 2u; return rc; }
+    if (rc != EFFORT_OK) { hipFree(w->aligned); w->aligned = nullptr; w->rowPitch = w->srcPitch; return rc; }
     w->buckets = w->aligned;
     return EFFORT_OK;
 }
@@ -327,11 +410,21 @@ static int pick_elems(const effort_ctx* c, Format fmt, int n, const effort_w* co
         return t;
     };
     const uint32_t numCU = (uint32_t)c->numCU;
+    // how much of its column tiles' lanes a choice keeps busy: a narrow handle -- a column shard of a multi-GPU split, 11008
+    // outputs over 8 ranks = 86 columns -- fills a third of ONE 256-column tile (E = 4: 22 of 64 lanes), two thirds at E = 2
+    auto fill = [&](int E) {
+        double used = 0, have = 0;
+        for (int i = 0; i < n; i++) if (ws[i]) { used += ws[i]->cols; have += (double)((ws[i]->cols + 64 * E - 1) / (64 * E)) * 64 * E; }
+        return have > 0 ? used / have : 1.0;
+    };
+    const double f1 = fill(1), f2 = fill(2), f4 = fill(4), best = f1 > f2 ? (f1 > f4 ? f1 : f4) : (f2 > f4 ? f2 : f4);
     if (n >= 8) {
         const uint32_t i4 = items(4);
-        return ((i4 > numCU / 2 && i4 <= numCU) || i4 >= 3u * numCU) ? 4 : 2;
+        if (((i4 > numCU / 2 && i4 <= numCU) || i4 >= 3u * numCU) && f4 >= 0.8 * best) return 4;
+        return f2 >= 0.8 * best ? 2 : 1;
     }
     const uint32_t i2 = items(2);
+    if (f2 < 0.8 * best) return 1;
     return (i2 * 10u < numCU * 3u / 4u * 6u && items(1) > i2) ? 1 : 2;
 }
 
@@ -398,18 +491,52 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
     const int groupE = pick_elems(c, fmt, n, ws);
     const bool tm = c->timing && c->nSamples < effort_ctx::kMaxSamples;
     hipEvent_t* ev = tm ? c->ev + 4 * c->nSamples : nullptr;
-    if (tm) HIP_TRY(c, hipEventRecord(ev[0], c->stream));
+    // ---- which lane (overlap mode): the launch may run beside the launches in flight on the OTHER lanes unless it reads or
+    // writes what one of them writes, or writes what one of them reads; then it waits for that lane (or simply joins it: a
+    // lane's stream is in order).  Always ordered after everything enqueued on the context's stream before this call.
+    int li = 0;
+    if (c->nLanes > 1 && !c->timing && !c->clock) {
+        std::vector<Lane::Range> rd, wr;
+        auto add = [](std::vector<Lane::Range>& v, const void* p, size_t bytes) { if (p && bytes) v.push_back({(uintptr_t)p, (uintptr_t)p + bytes}); };
+        for (int i = 0; i < n; i++) {
+            add(rd, vs[i], (size_t)ws[i]->inDim * 4);
+            if (expNos && expNos[i]) add(rd, expNos[i], 4);
+            if (vAux && vAux[i]) add(rd, vAux[i], (size_t)ws[i]->inDim * 4);
+            if (resids && resids[i]) add(rd, resids[i], (size_t)ws[i]->outDim * 4);
+            add(wr, outs[i], (size_t)ws[i]->outDim * 4);
+        }
+        int hazard[effort_ctx::kMaxLanes], nh = 0;
+        for (int i = 0; i < c->nLanes; i++) {
+            const Lane& L = c->lane[i];
+            if (L.pending && (overlaps(rd, L.writes) || overlaps(wr, L.writes) || overlaps(wr, L.reads))) hazard[nh++] = i;
+        }
+        li = nh ? hazard[0] : c->nextLane;
+        if (!nh) c->nextLane = (c->nextLane + 1) % c->nLanes;
+        Lane& L = c->lane[li];
+        HIP_TRY(c, hipEventRecord(c->forkEv, c->stream));
+        HIP_TRY(c, hipStreamWaitEvent(L.own, c->forkEv, 0));
+        for (int k = 0; k < nh; k++) if (hazard[k] != li) HIP_TRY(c, hipStreamWaitEvent(L.own, c->lane[hazard[k]].done, 0));
+        if (L.reads.size() + L.writes.size() > 4096) { L.reads.clear(); L.writes.clear(); }     // (cannot happen between joins of a sane caller; stay bounded)
+        L.reads.insert(L.reads.end(), rd.begin(), rd.end());
+        L.writes.insert(L.writes.end(), wr.begin(), wr.end());
+    } else if (c->nLanes > 1) {
+        if (join_lanes(c) != EFFORT_OK) return EFFORT_ERR_HIP;        // timing modes: one launch at a time, on lane 0
+    }
+    Lane& L = c->lane[li];
+    const hipStream_t st = (c->nLanes > 1 && !c->timing && !c->clock) ? L.own : c->stream;
+    c->lastLane = li;
+    if (tm) HIP_TRY(c, hipEventRecord(ev[0], st));
     GroupKArgs ga;
     int W = 0, E = 0;
     uint32_t nGeoms = 0, wg = 0, first = 0;
     size_t slabOff = 0; uint32_t tileOff = 0, sliceOff = 0;
     auto begin = [&](uint32_t firstCall) {
         memset(&ga, 0, sizeof(ga));
-        ga.groupDone = c->d_counters + effort_ctx::kMaxTiles - 1;
-        ga.slabs = c->d_slabs; ga.counters = c->d_counters; ga.sliceCounts = c->d_sliceCounts; ga.cutoff = c->d_cutoff + firstCall;
+        ga.groupDone = L.d_counters + effort_ctx::kMaxTiles - 1;
+        ga.slabs = L.d_slabs; ga.counters = L.d_counters; ga.sliceCounts = L.d_sliceCounts; ga.cutoff = L.d_cutoff + firstCall;
         ga.tstamp = c->clock ? c->d_tstamp : nullptr;
         ga.ablate = ablate; ga.split = c->splitCutoff ? 1u : 0u; ga.trace = (c->clock && c->trace) ? 1u : 0u;
-        ga.numCU = (uint32_t)c->numCU; ga.queue = c->d_queue;
+        ga.numCU = (uint32_t)c->numCU; ga.queue = L.d_queue;
         nGeoms = 0; wg = 0; first = firstCall;
     };
     auto flush = [&]() -> int {                        // one kernel launch for the calls gathered so far
@@ -436,13 +563,8 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
             for (uint32_t i = 0; i < ga.count; i++) ga.call[i].stats = ws[first + i]->means16;
             ga.split |= 4u;
         }
-        // plain grids of plain FP16 calls (lone calls, small groups: latency chains): rows are prefetched into L2 with the handle's
-        // previous cutoff while the exact one is bisected (bucket_mul.hip, PREF)
-        bool pref = fmt == kFp16 && c->prefetch && !ga.persistent && plain && !c->splitCutoff && !ga.trace;
-        for (uint32_t i = 0; pref && i < ga.count; i++) pref = !ga.call[i].resid;
-        if (pref) ga.split |= 8u;
-        if (c->splitCutoff && !(ablate & 1u)) HIP_TRY(c, launch_find_cutoff_group(ga, c->stream));
-        HIP_TRY(c, launch_bucket_mul(fmt, W, E, ga, c->stream));
+        if (c->splitCutoff && !(ablate & 1u)) HIP_TRY(c, launch_find_cutoff_group(ga, st));
+        HIP_TRY(c, launch_bucket_mul(fmt, W, E, ga, st));
         return EFFORT_OK;
     };
     begin(0);
@@ -489,13 +611,14 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
         ga.wgEnd[(uint32_t)i - first] = wg;
         ga.count = (uint32_t)i - first + 1u;
         ga.totalTiles += g.tiles;
-        c->lastSliceOff[i] = sliceOff; c->lastSlices[i] = g.slices;                   // dispatch.size = sum of the per-slice counts
+        L.lastSliceOff[i] = sliceOff; L.lastSlices[i] = g.slices;                   // dispatch.size = sum of the per-slice counts
         slabOff += (slab + 255) / 256 * 256; tileOff += g.tiles; sliceOff += g.slices;
     }
-    c->lastCalls = (uint32_t)n;
+    L.lastCalls = (uint32_t)n;
     int rc = flush();
     if (rc != EFFORT_OK) return rc;
-    if (tm) { HIP_TRY(c, hipEventRecord(ev[1], c->stream)); c->nSamples++; }
+    if (tm) { HIP_TRY(c, hipEventRecord(ev[1], st)); c->nSamples++; }
+    if (st != c->stream) { HIP_TRY(c, hipEventRecord(L.done, st)); L.pending = true; }
     return EFFORT_OK;
 }
 
@@ -523,41 +646,50 @@ extern "C" int effort_calc_dispatch(effort_ctx* c, const effort_w* w, const floa
                                     float* dispatch, uint32_t* count) {
     if (!c || !w || !v || !dispatch) return fail(c, EFFORT_ERR_ARG, "calc_dispatch: null argument");
     if (!(effort >= 0.0 && effort <= 1.0)) return fail(c, EFFORT_ERR_EFFORT, "calc_dispatch: effort outside [0,1]");
+    if (join_lanes(c) != EFFORT_OK) return EFFORT_ERR_HIP;
+    Lane& L = c->lane[0];
+    c->lastLane = 0;
     MulGeom g; int W, E;
     int rc = choose_geom(c, w, 1, pick_elems(c, w->fmt, 1, &w), &g, &W, &E);
     if (rc != EFFORT_OK) return fail(c, rc, "calc_dispatch: geometry");
     const uint32_t q = (uint32_t)(int)((double)(kProbes - 1) * (1.0 - effort));
-    HIP_TRY(c, launch_find_cutoff(v, w->probes, expNo, q, c->d_cutoff, c->d_count, nullptr, c->stream));
-    HIP_TRY(c, launch_calc_dispatch(w->fmt, w->stats, v, expNo, c->d_cutoff, g, dispatch, count, c->d_count, c->d_blockScratch, c->stream));
-    c->lastCalls = 1; c->lastSlices[0] = 0;        // dispatch.size is the scalar written by the scan kernel
+    HIP_TRY(c, launch_find_cutoff(v, w->probes, expNo, q, L.d_cutoff, L.d_count, nullptr, c->stream));
+    HIP_TRY(c, launch_calc_dispatch(w->fmt, w->stats, v, expNo, L.d_cutoff, g, dispatch, count, L.d_count, c->d_blockScratch, c->stream));
+    L.lastCalls = 1; L.lastSlices[0] = 0;        // dispatch.size is the scalar written by the scan kernel
     return EFFORT_OK;
 }
 
 extern "C" int effort_group_dispatch_count(effort_ctx* c, int idx, uint32_t* host_out) {
-    if (!c || !host_out || idx < 0 || (uint32_t)idx >= c->lastCalls) return EFFORT_ERR_ARG;
-    if (c->lastSlices[idx] == 0) {
-        HIP_TRY(c, hipMemcpyAsync(host_out, c->d_count, 4, hipMemcpyDeviceToHost, c->stream));
+    if (!c || !host_out || idx < 0 || (uint32_t)idx >= c->lane[c->lastLane].lastCalls) return EFFORT_ERR_ARG;
+    if (join_lanes(c) != EFFORT_OK) return EFFORT_ERR_HIP;
+    Lane& L = c->lane[c->lastLane];
+    if (L.lastSlices[idx] == 0) {
+        HIP_TRY(c, hipMemcpyAsync(host_out, L.d_count, 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         return EFFORT_OK;
     }
     static thread_local uint32_t h[effort_ctx::kMaxSlices];
-    HIP_TRY(c, hipMemcpyAsync(h, c->d_sliceCounts + c->lastSliceOff[idx], (size_t)c->lastSlices[idx] * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(h, L.d_sliceCounts + L.lastSliceOff[idx], (size_t)L.lastSlices[idx] * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     uint32_t n = 0;
-    for (uint32_t i = 0; i < c->lastSlices[idx]; i++) n += h[i];
+    for (uint32_t i = 0; i < L.lastSlices[idx]; i++) n += h[i];
     *host_out = n;
     return EFFORT_OK;
 }
 extern "C" int effort_debug_slice_counts(effort_ctx* c, int idx, uint32_t* host, int maxSlices) {
-    if (!c || !host || idx < 0 || (uint32_t)idx >= c->lastCalls || maxSlices < 1) return EFFORT_ERR_ARG;
-    const uint32_t n = c->lastSlices[idx] < (uint32_t)maxSlices ? c->lastSlices[idx] : (uint32_t)maxSlices;
-    if (n) HIP_TRY(c, hipMemcpyAsync(host, c->d_sliceCounts + c->lastSliceOff[idx], (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    if (!c || !host || idx < 0 || (uint32_t)idx >= c->lane[c->lastLane].lastCalls || maxSlices < 1) return EFFORT_ERR_ARG;
+    if (join_lanes(c) != EFFORT_OK) return EFFORT_ERR_HIP;
+    Lane& L = c->lane[c->lastLane];
+    const uint32_t n = L.lastSlices[idx] < (uint32_t)maxSlices ? L.lastSlices[idx] : (uint32_t)maxSlices;
+    if (n) HIP_TRY(c, hipMemcpyAsync(host, L.d_sliceCounts + L.lastSliceOff[idx], (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return (int)n;
 }
 extern "C" int effort_group_cutoff(effort_ctx* c, int idx, float* host_out) {
-    if (!c || !host_out || idx < 0 || (uint32_t)idx >= c->lastCalls) return EFFORT_ERR_ARG;
-    HIP_TRY(c, hipMemcpyAsync(host_out, c->d_cutoff + idx, 4, hipMemcpyDeviceToHost, c->stream));
+    if (!c || !host_out || idx < 0 || (uint32_t)idx >= c->lane[c->lastLane].lastCalls) return EFFORT_ERR_ARG;
+    if (join_lanes(c) != EFFORT_OK) return EFFORT_ERR_HIP;
+    Lane& L = c->lane[c->lastLane];
+    HIP_TRY(c, hipMemcpyAsync(host_out, L.d_cutoff + idx, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return EFFORT_OK;
 }
@@ -572,6 +704,7 @@ extern "C" int effort_set_dense_backend(effort_ctx* c, int rocblas) {
 }
 extern "C" int effort_dense_gemv(effort_ctx* c, const void* W, const float* v, float* out, int inDim, int outDim) {
     if (!c || !W || !v || !out || inDim <= 0 || outDim <= 0) return fail(c, EFFORT_ERR_ARG, "dense_gemv: bad argument");
+    if (join_lanes(c) != EFFORT_OK) return EFFORT_ERR_HIP;
     if (inDim % 16) return fail(c, EFFORT_ERR_SHAPE, "dense_gemv: inDim % 16 != 0 (helpers/mps.swift:18)");
     if (!c->denseRocblas && dense_gemv_supported((uint32_t)inDim, (uint32_t)outDim)) {
         HIP_TRY(c, launch_dense_gemv(static_cast<const uint16_t*>(W), v, out, (uint32_t)inDim, (uint32_t)outDim, c->stream));
@@ -599,12 +732,15 @@ extern "C" int effort_dense_gemv(effort_ctx* c, const void* W, const float* v, f
 }
 
 // ---- converter -----------------------------------------------------------------------------------
-extern "C" int effort_convert_fp16(effort_ctx* c, const void* W, int outDim, int inDim, void* buckets, void* stats, void* probes) {
+extern "C" int effort_convert_fp16_pitched(effort_ctx* c, const void* W, int outDim, int inDim, void* buckets, int rowPitchBytes, void* stats, void* probes) {
     if (!c || !W || !buckets || !stats || !probes) return fail(c, EFFORT_ERR_ARG, "convert_fp16: null argument");
+    if (join_lanes(c) != EFFORT_OK) return EFFORT_ERR_HIP;
     // convert.swift:210-215,239 + the 16384-wide limit of the multiply (bucketMul.swift:52)
     if (outDim <= 0 || inDim < kProbes || !(outDim >= kProbes || kProbes % outDim == 0) || outDim > 16384 || inDim > 32000 ||
         outDim % 16 || (outDim / 16) % 4)
         return fail(c, EFFORT_ERR_CONVERT, "convert_fp16: bucketize preconditions violated");
+    const int pitch = rowPitchBytes ? rowPitchBytes : outDim / 16 * 2;
+    if (pitch < outDim / 16 * 2 || pitch % 8) return fail(c, EFFORT_ERR_CONVERT, "convert_fp16: row pitch must be a multiple of 8 bytes >= 2*cols");
     const size_t elems = (size_t)outDim * inDim;
     if (elems > c->convElems) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -612,9 +748,12 @@ extern "C" int effort_convert_fp16(effort_ctx* c, const void* W, int outDim, int
         HIP_TRY(c, hipMalloc(&c->d_convVals, elems * 2));
         c->convElems = elems;
     }
-    HIP_TRY(c, launch_convert_fp16(static_cast<const uint16_t*>(W), outDim, inDim, static_cast<uint16_t*>(buckets),
+    HIP_TRY(c, launch_convert_fp16(static_cast<const uint16_t*>(W), outDim, inDim, static_cast<uint16_t*>(buckets), (uint32_t)pitch / 2u,
                                    static_cast<uint16_t*>(stats), static_cast<uint16_t*>(probes), c->d_convVals, c->d_status, c->stream));
     return EFFORT_OK;
+}
+extern "C" int effort_convert_fp16(effort_ctx* c, const void* W, int outDim, int inDim, void* buckets, void* stats, void* probes) {
+    return effort_convert_fp16_pitched(c, W, outDim, inDim, buckets, 0, stats, probes);
 }
 
 // q4_draft.convert (q4_draft.py:70-322) on the GPU: core2 = W.T, f16 [inDim][outDim].
@@ -625,6 +764,7 @@ extern "C" int64_t effort_q4_outlier_count(int inDim, int outDim, double perc) {
 extern "C" int effort_convert_q4(effort_ctx* c, const void* core2, int inDim, int outDim, double perc, void* buckets, void* stats, void* probes,
                                  void* outliers) {
     if (!c || !core2 || !buckets || !stats || !probes) return fail(c, EFFORT_ERR_ARG, "convert_q4: null argument");
+    if (join_lanes(c) != EFFORT_OK) return EFFORT_ERR_HIP;
     if (inDim <= 0 || outDim <= 0 || outDim % 32 || (int64_t)inDim * outDim >= (1ll << 32) || !(perc >= 0.0 && perc <= 1.0))
         return fail(c, EFFORT_ERR_CONVERT, "convert_q4: outDim % 32 != 0 (q4_draft.py:299), or a matrix of 2^32 elements or more");
     const int64_t cnt = effort_q4_outlier_count(inDim, outDim, perc);
@@ -637,6 +777,7 @@ extern "C" int effort_convert_q4(effort_ctx* c, const void* core2, int inDim, in
 
 extern "C" int effort_cosine(effort_ctx* c, const float* a, const float* b, int n, float* host_out) {
     if (!c || !a || !b || !host_out || n <= 0) return EFFORT_ERR_ARG;
+    if (join_lanes(c) != EFFORT_OK) return EFFORT_ERR_HIP;
     HIP_TRY(c, launch_cosine(a, b, n, c->d_cos, c->stream));
     HIP_TRY(c, hipMemcpyAsync(host_out, c->d_cos, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -646,12 +787,14 @@ extern "C" int effort_cosine(effort_ctx* c, const float* a, const float* b, int 
 // ---- decode-loop glue (runNetwork.swift:68-316; kernels in decode.hip) ---------------------------------------
 extern "C" int effort_add_rmsnorm_mul(effort_ctx* c, float* h, const float* delta, const void* w, float* out, int n) {
     if (!c || !h || !w || !out || n <= 0) return fail(c, EFFORT_ERR_ARG, "add_rmsnorm_mul: bad argument");
+    if (join_lanes(c) != EFFORT_OK) return EFFORT_ERR_HIP;
     HIP_TRY(c, launch_add_rmsnorm_mul(h, delta, static_cast<const uint16_t*>(w), out, (uint32_t)n, c->stream));
     return EFFORT_OK;
 }
 extern "C" int effort_rope_kv(effort_ctx* c, const float* xq, const float* xk, const float* xv, float* qOut, float* kCache,
                               float* vCache, const uint32_t* pos, int numHeads, int numHeadsKV, int headDim, int maxTokens, float ropeBase) {
     if (!c || !xq || !xk || !xv || !qOut || !kCache || !vCache || !pos) return fail(c, EFFORT_ERR_ARG, "rope_kv: null argument");
+    if (join_lanes(c) != EFFORT_OK) return EFFORT_ERR_HIP;
     if (numHeads <= 0 || numHeadsKV <= 0 || numHeads % numHeadsKV || headDim < 2 || headDim > 1024 || headDim % 2 || !(ropeBase > 1.0f) || maxTokens <= 0)
         return fail(c, EFFORT_ERR_SHAPE, "rope_kv: bad head geometry");
     HIP_TRY(c, launch_rope_kv(xq, xk, xv, qOut, kCache, vCache, pos, numHeads, numHeadsKV, headDim, ropeBase, (uint32_t)maxTokens, c->d_status + 1, c->stream));
@@ -660,6 +803,7 @@ extern "C" int effort_rope_kv(effort_ctx* c, const float* xq, const float* xk, c
 extern "C" int effort_attention(effort_ctx* c, const float* q, const float* kCache, const float* vCache, const uint32_t* pos,
                                 float* out, int numHeads, int headDim, int maxTokens) {
     if (!c || !q || !kCache || !vCache || !pos || !out) return fail(c, EFFORT_ERR_ARG, "attention: null argument");
+    if (join_lanes(c) != EFFORT_OK) return EFFORT_ERR_HIP;
     if (numHeads <= 0 || maxTokens <= 0 || maxTokens > 8192 || (headDim != 64 && headDim != 128 && headDim != 256))
         return fail(c, EFFORT_ERR_SHAPE, "attention: headDim 64/128/256, maxTokens <= 8192");
     HIP_TRY(c, launch_attention(q, kCache, vCache, pos, out, numHeads, headDim, maxTokens, c->stream));
@@ -668,6 +812,7 @@ extern "C" int effort_attention(effort_ctx* c, const float* q, const float* kCac
 extern "C" int effort_rope_attention(effort_ctx* c, const float* xq, const float* xk, const float* xv, float* kCache, float* vCache,
                                      const uint32_t* pos, float* out, int numHeads, int numHeadsKV, int headDim, int maxTokens, float ropeBase) {
     if (!c || !xq || !xk || !xv || !kCache || !vCache || !pos || !out) return fail(c, EFFORT_ERR_ARG, "rope_attention: null argument");
+    if (join_lanes(c) != EFFORT_OK) return EFFORT_ERR_HIP;
     if (numHeads <= 0 || numHeadsKV <= 0 || numHeads % numHeadsKV || maxTokens <= 0 || maxTokens > 8192 || !(ropeBase > 1.0f) ||
         (headDim != 64 && headDim != 128 && headDim != 256))
         return fail(c, EFFORT_ERR_SHAPE, "rope_attention: headDim 64/128/256, maxTokens <= 8192");
@@ -676,26 +821,31 @@ extern "C" int effort_rope_attention(effort_ctx* c, const float* xq, const float
 }
 extern "C" int effort_silu_mul(effort_ctx* c, const float* x1, const float* x3, float* out, int n) {
     if (!c || !x1 || !x3 || !out || n <= 0) return fail(c, EFFORT_ERR_ARG, "silu_mul: bad argument");
+    if (join_lanes(c) != EFFORT_OK) return EFFORT_ERR_HIP;
     HIP_TRY(c, launch_silu_mul(x1, x3, out, (uint32_t)n, c->stream));
     return EFFORT_OK;
 }
 extern "C" int effort_fetch_row(effort_ctx* c, const void* emb, const uint32_t* id, float* out, int n) {
     if (!c || !emb || !id || !out || n <= 0) return fail(c, EFFORT_ERR_ARG, "fetch_row: bad argument");
+    if (join_lanes(c) != EFFORT_OK) return EFFORT_ERR_HIP;
     HIP_TRY(c, launch_fetch_row(static_cast<const uint16_t*>(emb), id, out, (uint32_t)n, c->stream));
     return EFFORT_OK;
 }
 extern "C" int effort_top2_softmax(effort_ctx* c, const float* gate, int n, uint32_t* idx2, float* val2) {
     if (!c || !gate || !idx2 || !val2 || n < 1) return fail(c, EFFORT_ERR_ARG, "top2_softmax: bad argument");
+    if (join_lanes(c) != EFFORT_OK) return EFFORT_ERR_HIP;
     HIP_TRY(c, launch_top2_softmax(gate, (uint32_t)n, idx2, val2, c->stream));
     return EFFORT_OK;
 }
 extern "C" int effort_mix2(effort_ctx* c, const float* f0, const float* f1, const float* val2, float* out, int n) {
     if (!c || !f0 || !f1 || !val2 || !out || n <= 0) return fail(c, EFFORT_ERR_ARG, "mix2: bad argument");
+    if (join_lanes(c) != EFFORT_OK) return EFFORT_ERR_HIP;
     HIP_TRY(c, launch_mix2(f0, f1, val2, out, (uint32_t)n, c->stream));
     return EFFORT_OK;
 }
 extern "C" int effort_argmax(effort_ctx* c, const float* logits, int n, uint32_t* idOut, uint32_t* pos, uint32_t* history, int historyLen) {
     if (!c || !logits || !idOut || !pos || n <= 0 || (history && historyLen <= 0)) return fail(c, EFFORT_ERR_ARG, "argmax: bad argument");
+    if (join_lanes(c) != EFFORT_OK) return EFFORT_ERR_HIP;
     HIP_TRY(c, launch_argmax(logits, (uint32_t)n, idOut, pos, history, (uint32_t)(history ? historyLen : 0), c->d_status + 1, c->stream));
     return EFFORT_OK;
 }
@@ -704,6 +854,7 @@ extern "C" int effort_argmax(effort_ctx* c, const float* logits, int n, uint32_t
 // logits (token 0 returned).  Reads and clears the word.
 extern "C" int effort_decode_status(effort_ctx* c, int* host_out) {
     if (!c || !host_out) return EFFORT_ERR_ARG;
+    if (join_lanes(c) != EFFORT_OK) return EFFORT_ERR_HIP;
     HIP_TRY(c, hipMemcpyAsync(host_out, c->d_status + 1, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_status + 1, 0, 4, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -713,6 +864,7 @@ extern "C" int effort_decode_status(effort_ctx* c, int* host_out) {
 // tying with real zeros, convert.metal:40-61: the reference drops those elements silently).  Reads and clears the count.
 extern "C" int effort_convert_status(effort_ctx* c, int* host_out) {
     if (!c || !host_out) return EFFORT_ERR_ARG;
+    if (join_lanes(c) != EFFORT_OK) return EFFORT_ERR_HIP;
     HIP_TRY(c, hipMemcpyAsync(host_out, c->d_status, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_status, 0, 4, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -739,9 +891,9 @@ extern "C" int effort_set_persistent(effort_ctx* c, int wgPerCU) {
     return EFFORT_OK;
 }
 
-extern "C" int effort_debug_set_prefetch(effort_ctx* c, int on) {
-    if (!c) return EFFORT_ERR_ARG;
-    c->prefetch = on != 0;
+extern "C" int effort_debug_hook_lane(effort_ctx* c, int lane) {
+    if (!c || lane < 0 || lane >= c->nLanes) return EFFORT_ERR_ARG;
+    c->lastLane = lane;
     return EFFORT_OK;
 }
 

@@ -230,7 +230,7 @@ __device__ __forceinline__ void stage_issue(const GroupKArgs& ga, const ItemRef&
     const u32x4 rs = make_rsrc(a.stats, (uint32_t)((size_t)g.numExperts * g.expertRows * (compact ? 2u : 8u)));
     const u32x4 rv = make_rsrc(a.v, inDim * 4u);
     const uint32_t ldsM = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(lds_v*)(smem + lp.offM));
-    const uint32_t ldsV = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(lds_v*)(smem + lp.offV[par & 1u]));
+    const uint32_t ldsV = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(lds_v*)(smem + ((par & 1u) ? lp.offV[1] : lp.offV[0])));
     if constexpr (compact) {
         // one dword = the means of candidate slots 2d and 2d+1 (rows j and j+1 of one rank: neighbours in memory; every slice
         // starts on an even row -- the host checks -- so the dword is aligned): half the loads, means[] holds u16 per slot
@@ -267,7 +267,7 @@ __device__ __forceinline__ void stage_issue(const GroupKArgs& ga, const ItemRef&
 // `staged` (per wave): this wave's share of the item's stage loads was issued while the previous item streamed (into vblk
 // buffer `par`).  `prefetch` is polled by every wave near the end of its streaming loop until it returns true: there the
 // caller pulls the next item from the queue (wave 0) and issues the wave's share of its stage loads (into buffer par ^ 1).
-template <int FMT, int E, int W, bool FUSED, bool COMPACT, bool PREF, typename Prefetch>
+template <int FMT, int E, int W, bool FUSED, bool COMPACT, typename Prefetch>
 __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t item, const ItemRef& ref, char* smem, const LdsPlan& lp, uint32_t& cachedCall,
                                          float& cachedCutoff, const uint32_t par, const bool staged, const bool firstItem, Prefetch prefetch) {
     constexpr int NACC = Fmt<FMT>::kAcc;
@@ -304,7 +304,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     const uint32_t offC = __builtin_amdgcn_readfirstlane(lp.offC), offL = __builtin_amdgcn_readfirstlane(lp.offL), offM = __builtin_amdgcn_readfirstlane(lp.offM);
     const uint32_t offA = __builtin_amdgcn_readfirstlane(lp.offA);
     int* acc = reinterpret_cast<int*>(smem + offA);                          // ONE fixed-point tile shared by the W waves
-    float* vblk = reinterpret_cast<float*>(smem + __builtin_amdgcn_readfirstlane(lp.offV[par & 1u]));
+    float* vblk = reinterpret_cast<float*>(smem + __builtin_amdgcn_readfirstlane((par & 1u) ? lp.offV[1] : lp.offV[0]));     // (a select, not lp.offV[par & 1]: a dynamically indexed plan lives in scratch)
     uint32_t* flags = reinterpret_cast<uint32_t*>(smem + offC + 1280);       // [0] last arriver, [2..3] cutoff job verdict, [4] list length
     float* wbound = reinterpret_cast<float*>(smem + offC + 1344);            // [16] per-wave sums of |v_j| over the slice
     uint16_t* list = reinterpret_cast<uint16_t*>(smem + offL);
@@ -318,9 +318,6 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     // ---- A. everything the selection needs lands in LDS (stage_issue): the row means of the candidate slots, the slice of v
     if (!staged) stage_issue<FMT, W, COMPACT>(ga, ref, tid, smem, lp, par);
     const float rankBound = a.rankBound[e];                       // (asked for here: its round trip runs under the staged loads')
-    // PREF (plain grids of lone calls / small groups): the cutoff this handle's previous call ended with, kept beside the
-    // bound; +inf until there was one.  A HINT only: see prefetch_rows below.
-    const float estCut = PREF ? a.rankBound[g.numExperts + e] : 0.0f;
     float vj[VPT]; uint16_t prj[VPT];
     const uint16_t* pr = a.probes + (size_t)e * kProbes;
     const bool fused = (ga.split & 1u) == 0u;                    // uniform
@@ -341,17 +338,34 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     const uint32_t nSlots = FMT == kFp16 ? (g.rowsPerIn << lg) : (nb << 3);
     float normInv = 1.0f;
     if (FUSED && pre == kPreRmsNorm) {
-        float ss = 0.0f;
+        // The sum of squares in EXACTLY the order add_rmsnorm_mul_kernel (decode.hip) sums it -- 1024 threads, thread u adding
+        // x[u], x[u + 1024], ... in that order, a xor butterfly over each 64 of them, the sixteen wave sums in wave order -- so
+        // that the normalised input, hence the cutoff and the row selection, are bit-identical with the unfused path's.  A
+        // thread here stands for R = 1024 / NT of that kernel's threads: u = tid + NT * r.
+        constexpr int R = 1024 / NT;
+        static_assert(R >= 1 && R * NT == 1024 && R * W == 16, "fused rmsNorm: the workgroup must divide add_rmsnorm_mul_kernel's 1024 threads");
+        float part[R];
 #pragma unroll
-        for (int i = 0; i < VPT; i++) ss += rawn[i] * rawn[i];
-        for (uint32_t j = 4096u + tid; j < g.inDim; j += NT) { const float x = a.v[j]; ss += x * x; }
+        for (int r = 0; r < R; r++) part[r] = 0.0f;
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off);
-        if (lane == 0) wbound[wave] = ss;
+        for (int i = 0; i < VPT; i++) part[i % R] += rawn[i] * rawn[i];            // element tid + NT * i = element i / R of virtual thread tid + NT * (i % R)
+        for (uint32_t base = 4096u + (uint32_t)tid; base < g.inDim; base += 1024u) {
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const uint32_t j = base + (uint32_t)(r * NT);
+                if (j < g.inDim) { const float x = a.v[j]; part[r] += x * x; }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) part[r] += __shfl_xor(part[r], off);
+            if (lane == 0) wbound[r * W + wave] = part[r];
+        }
         __syncthreads();
         float tot = 0.0f;
 #pragma unroll
-        for (int w2 = 0; w2 < W; w2++) tot += wbound[w2];
+        for (int w2 = 0; w2 < 16; w2++) tot += wbound[w2];
         normInv = 1.0f / sqrtf(tot / (float)g.inDim + 1e-5f);                  // aux.metal:150
         __syncthreads();                                                         // wbound is reused below
     }
@@ -416,42 +430,11 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
         if (fromJob) { cutoff = __uint_as_float(flags[3]); cachedCall = ci; cachedCutoff = cutoff; }
         else load_cut_inputs();
     }
-    // PREF: while wave 0 runs the serial bisection (1.5-3 us during which this workgroup asks nothing of memory) the other
-    // waves walk the slice's candidate slots with the PREVIOUS call's cutoff for these weights and touch every 128-byte
-    // line of the rows that one would keep: by the time the exact cutoff is known and the rows are streamed (phase D) they
-    // sit in this XCD's L2 instead of HBM.  Nothing is accumulated from these loads -- selection and sums come from the exact
-    // cutoff alone, so results do not depend on the hint; a bad hint costs bandwidth a lone call does not use anyway.
-    uint32_t pfSink = 0;                                          // the one register every prefetch load lands in (kept live until they have)
-    auto prefetch_rows = [&]() {
-        if constexpr (PREF && FMT == kFp16 && !FUSED) {
-            if (wave == 0 || !(estCut < 3.0e38f)) return;         // uniform per wave
-            const u32x4 rr4 = make_rsrc(a.buckets, (uint32_t)min((size_t)0xFFFFFFFFu, (size_t)g.numExperts * g.expertRows * g.rowPitch));
-            const uint32_t lgp = g.sliceLog2, nS = g.rowsPerIn << lgp, maskp = (1u << lgp) - 1u;
-            const uint32_t tileOff = t * (uint32_t)(128 * E), rowB = e * g.expertRows + j0;
-            for (uint32_t c = (uint32_t)(wave - 1) * 64u + (uint32_t)lane; c < nS; c += (uint32_t)(W - 1) * 64u) {
-                const uint32_t rank = c >> lgp, jl = c & maskp;
-                const bool ok = jl < nb;
-                const float ax2 = ok ? fabsf(vblk[jl]) : 0.0f;
-                const uint32_t mr = (COMPACT ? (uint32_t)reinterpret_cast<const uint16_t*>(m32)[c] : (m32[c] >> 16));
-                if (ok && estCut < (kCutoffScale * half_bits_to_float((uint16_t)mr)) * ax2) {
-                    const uint32_t bo = (rowB + rank * g.inDim + jl) * g.rowPitch + tileOff;
-#pragma unroll
-                    for (int k = 0; k <= E; k++) {                // every line a 128*E-byte piece can touch, whatever its alignment
-                        const uint32_t o = bo + (k < E ? (uint32_t)k * 128u : (uint32_t)(128 * E - 4));
-                        asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "+v"(pfSink) : "v"(o), "s"(rr4) : "memory");
-                    }
-                }
-            }
-        }
-    };
     if (fromJob) {
     } else if (needCut) {
-        cutoff = block_find_cutoff<NT>(vj, prj, a.q, smem + offC, tbl, prefetch_rows, stamp ? ga.tstamp + 8 : nullptr);
+        cutoff = block_find_cutoff<NT>(vj, prj, a.q, smem + offC, tbl, []() {}, stamp ? ga.tstamp + 8 : nullptr);
         cachedCall = ci; cachedCutoff = cutoff;
-        if (b == 0 && tid == 0 && !ga.cutJobs) {
-            a_cutoff[0] = cutoff;                                                // BucketMul.cutoff (bucketMul.swift:22)
-            if (PREF) const_cast<float*>(a.rankBound)[g.numExperts + e] = cutoff; // ... and the next call's hint
-        }
+        if (b == 0 && tid == 0 && !ga.cutJobs) a_cutoff[0] = cutoff;             // BucketMul.cutoff (bucketMul.swift:22)
     } else if (fused) {
         cutoff = cachedCutoff;
         if (b == 0 && tid == 0 && !ga.cutJobs) a_cutoff[0] = cutoff;
@@ -485,35 +468,42 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     // lanes of the ballot).  The list order therefore depends on the order in which the waves arrive -- it does not
     // matter: every listed row is added with integer arithmetic (see D), and the reference's own list is appended with an
     // atomic counter in no particular order (bucketMul.metal:71).
-    // (branch-free: all sixteen reads of a thread go out together, rounds past the slice test as "slot does not exist")
     float ax = 0.0f;
     if (FMT == kFp16) { const uint32_t jl = (uint32_t)tid & ((1u << lg) - 1u); ax = jl < nb ? fabsf(vblk[jl]) : 0.0f; }
     const uint32_t slotCap = __builtin_amdgcn_readfirstlane((lp.offV[0] - lp.offM) / 4u) - 1u;      // last dword of the means region
-    uint32_t mraw[kRounds]; float vq[kRounds];
-    if constexpr (COMPACT && FMT == kFp16) {                      // compact means: u16 per slot, kept in the high half as below
-        const uint16_t* m16 = reinterpret_cast<const uint16_t*>(m32);
-#pragma unroll
-        for (int rr = 0; rr < kRounds; rr++) { mraw[rr] = (uint32_t)m16[min((uint32_t)(rr * NT + tid), slotCap)] << 16; vq[rr] = 0.0f; }
-    } else
-#pragma unroll
-    for (int rr = 0; rr < kRounds; rr++) {
-        const uint32_t c = min((uint32_t)(rr * NT + tid), slotCap);
-        mraw[rr] = m32[c];
-        vq[rr] = FMT == kQ4 ? vblk[min(c >> 3, nb - 1u)] : 0.0f;
-    }
+    // (the rounds go in blocks of four, a block's reads issued together; blocks wholly past the slice's slots are skipped with a
+    //  uniform branch: a lone call's slices have 2048 slots -- one block of four rounds with 512 threads -- a 32-call launch's
+    //  8192)
     const bool sel = !(ga.ablate & 8u);
     uint32_t keepMask = 0;                                  // bit r: this thread's slot of round r is kept
     uint32_t before[kRounds];                               // (wave-uniform) survivors of the wave's earlier rounds
     uint32_t wtot = 0;
+    const uint16_t* m16 = reinterpret_cast<const uint16_t*>(m32);
 #pragma unroll
-    for (int rr = 0; rr < kRounds; rr++) {
-        before[rr] = wtot;
-        const uint32_t c = rr * NT + tid;
-        bool k;
-        if (FMT == kFp16) k = (cutoff < (kCutoffScale * half_bits_to_float((uint16_t)(mraw[rr] >> 16))) * ax) & ((c >> lg) < g.rowsPerIn) & sel;
-        else k = (cutoff < (kCutoffScale * __uint_as_float(mraw[rr])) * fabsf(vq[rr])) & (c < nSlots) & sel;
-        keepMask |= k ? (1u << rr) : 0u;
-        wtot += (uint32_t)__popcll(__ballot(k));
+    for (int blk = 0; blk < kRounds / 4; blk++) {
+        if ((uint32_t)(blk * 4 * NT) >= nSlots) {           // uniform
+#pragma unroll
+            for (int u = 0; u < 4; u++) before[blk * 4 + u] = wtot;
+            continue;
+        }
+        uint32_t mraw[4]; float vq[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t c = min((uint32_t)((blk * 4 + u) * NT + tid), slotCap);
+            if constexpr (COMPACT && FMT == kFp16) { mraw[u] = (uint32_t)m16[c] << 16; vq[u] = 0.0f; }      // compact means: u16 per slot, kept in the high half
+            else { mraw[u] = m32[c]; vq[u] = FMT == kQ4 ? vblk[min(c >> 3, nb - 1u)] : 0.0f; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int rr = blk * 4 + u;
+            before[rr] = wtot;
+            const uint32_t c = rr * NT + tid;
+            bool k;
+            if (FMT == kFp16) k = (cutoff < (kCutoffScale * half_bits_to_float((uint16_t)(mraw[u] >> 16))) * ax) & ((c >> lg) < g.rowsPerIn) & sel;
+            else k = (cutoff < (kCutoffScale * __uint_as_float(mraw[u])) * fabsf(vq[u])) & (c < nSlots) & sel;
+            keepMask |= k ? (1u << rr) : 0u;
+            wtot += (uint32_t)__popcll(__ballot(k));
+        }
     }
     uint32_t wbase = 0;
     if (lane == 0) wbase = atomicAdd(&flags[4], wtot);
@@ -634,10 +624,6 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     // Near the end of its rows (the last two rounds of the loop: a few microseconds of streaming left) a wave asks for the
     // next item: late enough that the queue still balances the workgroups, early enough that the staged loads land under
     // the remaining rows.
-    if constexpr (PREF) {                                           // every prefetch load has landed: its register may be reused
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("" :: "v"(pfSink));
-    }
     bool asked = false;
     // (measured: raising the wave priority of this loop -- s_setprio 2 -- so that a co-resident workgroup's selection does not
     //  take its issue slots is 8 % SLOWER per launch: the other workgroup's head then takes that much longer)
@@ -934,7 +920,7 @@ __device__ __forceinline__ void cutoff_job(const GroupKArgs& ga, uint32_t ci, ch
 // dispatcher only places ~40 workgroups/us chip-wide and spreads a large grid unevenly over the CUs (measured with
 // tools/microbench.hip: residency probe), so a group launch sizes its grid to the chip -- R workgroups per CU,
 // R fixed by the LDS each one asks for -- and balances the work itself.
-template <int FMT, int E, int W, bool FUSED, bool COMPACT = false, bool PREF = false>
+template <int FMT, int E, int W, bool FUSED, bool COMPACT = false>
 __global__ __launch_bounds__(64 * W, (W <= 8 ? EFFORT_MIN_WAVES_PER_EU : 4)) void bucket_mul_kernel(const GroupKArgs ga) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ uint32_t s_item;
@@ -990,7 +976,7 @@ __global__ __launch_bounds__(64 * W, (W <= 8 ? EFFORT_MIN_WAVES_PER_EU : 4)) voi
         }
         gen++;
         bool stagedNext = false;
-        mul_item<FMT, E, W, FUSED, COMPACT, PREF>(ga, item - ga.cutJobs, ref, smem, lp, cachedCall, cachedCutoff, par, staged, gen == 1u && (ga.ablate & 512u) != 0u /* (measured: evaluating the first item's cutoff locally instead of waiting for the job is 1 us slower per 32-call launch; kept as an ablation) */, [&]() -> bool {
+        mul_item<FMT, E, W, FUSED, COMPACT>(ga, item - ga.cutJobs, ref, smem, lp, cachedCall, cachedCutoff, par, staged, gen == 1u && (ga.ablate & 512u) != 0u /* (measured: evaluating the first item's cutoff locally instead of waiting for the job is 1 us slower per 32-call launch; kept as an ablation) */, [&]() -> bool {
             if (!ga.persistent) return true;
             if (threadIdx.x == 0) {                                // wave 0's first call: pull, publish
                 s_next[0] = pull();
@@ -1054,18 +1040,12 @@ static hipError_t launch_mul_t(const GroupKArgs& ga, hipStream_t st) {
         if (err == hipSuccess && FMT == kFp16)
             err = hipFuncSetAttribute(reinterpret_cast<const void*>(&bucket_mul_kernel<kFp16, E, W, false, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (err == hipSuccess && FMT == kFp16)
-            err = hipFuncSetAttribute(reinterpret_cast<const void*>(&bucket_mul_kernel<kFp16, E, W, false, false, true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (err != hipSuccess) return err;
         maxSet = lds;
     }
     const bool compact = (ga.split & 4u) != 0u;                   // (api.hip: persistent FP16 launches of plain calls)
     if (compact && (FMT != kFp16 || fusedAny)) return hipErrorInvalidValue;
-    const bool pref = (ga.split & 8u) != 0u;                      // (api.hip: plain grids of plain FP16 calls)
-    if (pref && (FMT != kFp16 || fusedAny || compact || ga.persistent)) return hipErrorInvalidValue;
     if (fusedAny) hipLaunchKernelGGL((bucket_mul_kernel<kFp16, E, W, true>), dim3(grid), dim3(64 * W), lds, st, ga);
-    else if (pref) hipLaunchKernelGGL((bucket_mul_kernel<kFp16, E, W, false, false, true>), dim3(grid), dim3(64 * W), lds, st, ga);
     else if (compact) hipLaunchKernelGGL((bucket_mul_kernel<kFp16, E, W, false, true>), dim3(grid), dim3(64 * W), lds, st, ga);
     else hipLaunchKernelGGL((bucket_mul_kernel<FMT, E, W, false>), dim3(grid), dim3(64 * W), lds, st, ga);
     return hipGetLastError();

@@ -49,7 +49,7 @@ __device__ __forceinline__ uint16_t half_bits_to_ushort(uint16_t h) {       // M
 
 constexpr uint32_t kB = 16;   // bucket size of the FP16 layout (convert.swift:232)
 
-__global__ __launch_bounds__(1024) void sort_bucketize_kernel(const uint16_t* __restrict__ vals, uint16_t* __restrict__ buckets,
+__global__ __launch_bounds__(1024) void sort_bucketize_kernel(const uint16_t* __restrict__ vals, uint16_t* __restrict__ buckets, uint32_t pitchCols,
                                                               uint32_t outDim, uint32_t inDim, uint32_t P, int* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t n = outDim, C = outDim / kB;
@@ -135,16 +135,16 @@ __global__ __launch_bounds__(1024) void sort_bucketize_kernel(const uint16_t* __
     // bucketize (convert.metal:83-100): buckets[(rank*inDim + row)*C + bucket]
     for (uint32_t i = tid; i < n; i += 1024) {
         const uint32_t r = i / C, bkt = i - r * C;
-        buckets[((size_t)r * inDim + row) * C + bkt] = tileOut[i];
+        buckets[((size_t)r * inDim + row) * pitchCols + bkt] = tileOut[i];      // (pitchCols = C as the reference writes it, or padded: whole 128-byte lines)
     }
 }
 
 // makeStats (convert.metal:105-119): f32 sum of |row| in column order, / bCols, stored as half x4
 __global__ __launch_bounds__(256) void make_stats_kernel(const uint16_t* __restrict__ buckets, uint16_t* __restrict__ stats,
-                                                         uint32_t rows, uint32_t C) {
+                                                         uint32_t rows, uint32_t C, uint32_t pitchCols) {
     const uint32_t r = blockIdx.x * 256u + threadIdx.x;
     if (r >= rows) return;
-    const uint2* p = reinterpret_cast<const uint2*>(buckets + (size_t)r * C);   // C % 4 == 0
+    const uint2* p = reinterpret_cast<const uint2*>(buckets + (size_t)r * pitchCols);   // C % 4 == 0, pitchCols % 4 == 0
     float sum = 0.0f;
     for (uint32_t i = 0; i < C / 4; i++) {
         const uint2 w = p[i];
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void make_stats_kernel(const uint16_t* __restr
     reinterpret_cast<uint2*>(stats)[r] = make_uint2((uint32_t)m | ((uint32_t)m << 16), (uint32_t)m | ((uint32_t)m << 16));
 }
 
-hipError_t launch_convert_fp16(const uint16_t* W, uint32_t outDim, uint32_t inDim, uint16_t* buckets,
+hipError_t launch_convert_fp16(const uint16_t* W, uint32_t outDim, uint32_t inDim, uint16_t* buckets, uint32_t pitchCols,
                                uint16_t* stats, uint16_t* probes, uint16_t* scratchVals, int* status, hipStream_t st) {
     const uint32_t rep = outDim >= (uint32_t)kProbes ? 1u : (uint32_t)kProbes / outDim;
     hipLaunchKernelGGL(probes_kernel, dim3((kProbes / rep + 255) / 256), dim3(256), 0, st, W, probes, inDim, rep);
@@ -173,8 +173,8 @@ hipError_t launch_convert_fp16(const uint16_t* W, uint32_t outDim, uint32_t inDi
         if (e != hipSuccess) return e;
         maxSet = lds;
     }
-    hipLaunchKernelGGL(sort_bucketize_kernel, dim3(inDim), dim3(1024), lds, st, scratchVals, buckets, outDim, inDim, P, status);
-    hipLaunchKernelGGL(make_stats_kernel, dim3((inDim * kB + 255) / 256), dim3(256), 0, st, buckets, stats, inDim * kB, C);
+    hipLaunchKernelGGL(sort_bucketize_kernel, dim3(inDim), dim3(1024), lds, st, scratchVals, buckets, pitchCols, outDim, inDim, P, status);
+    hipLaunchKernelGGL(make_stats_kernel, dim3((inDim * kB + 255) / 256), dim3(256), 0, st, buckets, stats, inDim * kB, C, pitchCols);
     return hipGetLastError();
 }
 

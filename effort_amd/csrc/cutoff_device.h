@@ -164,11 +164,35 @@ __device__ __forceinline__ float block_find_cutoff(const float (&vj)[4096 / NT],
             // ---- the bisection proper, one wave, one LDS lookup per round ------------------------------------
             const uint32_t allGE = s_all[0];
             auto count_above = [&](uint32_t p) -> uint32_t {     // branch-free: the lookup is always issued (clamped)
-                const uint32_t c = tbl[min(max(p, base), top) - base];
+                uint32_t c = tbl[min(max(p, base), top) - base];
+                asm volatile("" : "+v"(c));                      // (... really always: hipcc otherwise sinks the read into two exec-masked branches)
                 // below the first cell: everything at or above it (zeros never count); beyond the last: `above`
                 return p < base ? allGE : (p > top ? above : c);
             };
-            while (!done && patHi != patLo + 1u) done = round(count_above(__float_as_uint(newBound) >> 16));
+            // The loop state is kept in VECTOR registers on purpose (the empty asm makes it opaque to hipcc's uniformity
+            // analysis): left to itself the compiler splits every round between SALU and VALU -- v_readfirstlane of the count,
+            // s_cmp / s_cselect for the integers, v_cmp -> vcc -> s_cbranch for the floats -- and each crossing waits out a
+            // pipeline: 390 cycles per round measured (9 rounds 1.5 us, 29 rounds 3.0 us).  All lanes run the same values.
+            {
+                float nb = newBound, lo = minBound, hi = maxBound;
+                uint32_t minC = (uint32_t)minCount, maxC = (uint32_t)maxCount, pLo = patLo, pHi = patHi, nLoops = (uint32_t)loops;
+                asm volatile("" : "+v"(nb), "+v"(lo), "+v"(hi), "+v"(minC), "+v"(maxC), "+v"(pLo), "+v"(pHi), "+v"(nLoops));
+                bool fin = done;
+                while (!fin && pHi != pLo + 1u) {
+                    const uint32_t p = __float_as_uint(nb) >> 16;
+                    const uint32_t cnt = count_above(p);
+                    nLoops += 1u;                                                      // :199-246, as `round` above
+                    const bool below = cnt < effort;
+                    hi = below ? nb : hi; maxC = below ? cnt : maxC; pHi = below ? p : pHi;        // :214-220
+                    lo = below ? lo : nb; minC = below ? minC : cnt; pLo = below ? pLo : p;
+                    const float prev = nb;
+                    nb = (hi + lo) / 2;                                                // :222
+                    int d = (int)maxC - (int)minC; d = d < 0 ? -d : d;
+                    fin = (cnt == effort) | (hi - lo < 0.00001f) | (d < 3) | (nLoops > 100u) | (nb == prev);   // :227-229,236; fixed point
+                }
+                newBound = nb; minBound = lo; maxBound = hi; minCount = (int)minC; maxCount = (int)maxC; patLo = pLo; patHi = pHi;
+                loops = (int)nLoops; done = fin;
+            }
             if (!done) {
                 // tail: bounds in adjacent cells with known counts (below the target at and above X, not below it
                 // under X); those counts differ by >= 3 and neither equals the target, or the loop had exited.

@@ -93,12 +93,12 @@ __global__ void f32_to_f16_kernel(const float* in, uint16_t* out, uint32_t n) {
 }
 // max |w| of every bucket row (position bits included, exactly the value the multiply uses): one wave per row.
 // Run once when a weight handle is registered (first half of launch_rank_bound).
-__global__ __launch_bounds__(256) void row_max_kernel(const uint16_t* __restrict__ buckets, uint32_t rows, uint32_t cols,
+__global__ __launch_bounds__(256) void row_max_kernel(const uint16_t* __restrict__ buckets, uint32_t pitchCols, uint32_t rows, uint32_t cols,
                                                       float* __restrict__ rowMax) {
     const uint32_t row = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
-    const uint16_t* p = buckets + (size_t)row * cols;
+    const uint16_t* p = buckets + (size_t)row * pitchCols;
     float m = 0.0f;
     for (uint32_t c = lane; c < cols; c += 64) m = fmaxf(m, fabsf(half_bits_to_float(p[c])));
 #pragma unroll
@@ -130,10 +130,10 @@ __global__ __launch_bounds__(1024) void rank_bound_kernel(const float* __restric
     if (tid == 0) rankBound[e] = total;
 }
 
-hipError_t launch_rank_bound(Format fmt, const uint16_t* buckets, const void* stats, uint32_t numExperts, uint32_t rowsPerIn,
+hipError_t launch_rank_bound(Format fmt, const uint16_t* buckets, uint32_t pitchCols, const void* stats, uint32_t numExperts, uint32_t rowsPerIn,
                              uint32_t inDim, uint32_t cols, float* rowScratch, float* rankBound, hipStream_t st) {
     const uint32_t rows = numExperts * rowsPerIn * inDim;
-    if (fmt == kFp16) hipLaunchKernelGGL(row_max_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, buckets, rows, cols, rowScratch);
+    if (fmt == kFp16) hipLaunchKernelGGL(row_max_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, buckets, pitchCols, rows, cols, rowScratch);
     hipLaunchKernelGGL(rank_bound_kernel, dim3(numExperts), dim3(1024), 0, st, rowScratch,
                        fmt == kQ4 ? static_cast<const float*>(stats) : nullptr, rowsPerIn, inDim, rankBound);
     return hipGetLastError();

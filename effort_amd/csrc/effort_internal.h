@@ -56,8 +56,7 @@ enum Prologue : uint16_t { kPreNone = 0, kPreSiluGate = 1, kPreRmsNorm = 2 };
 struct CallDesc {                    // 112 bytes
     const uint16_t* buckets;
     const void* stats;         // f16x4 (FP16) or f32x2 (Q4) per bucket row
-    const float* rankBound;    // [numExperts] sum over ranks of the rank's max |w| (Q4: max row mean): fixed-point bound, from registration;
-                               // then [numExperts] the cutoff the handle's previous call ended with (+inf: none yet): prefetch hint only
+    const float* rankBound;    // [numExperts] sum over ranks of the rank's max |w| (Q4: max row mean): fixed-point bound, from registration
     const uint16_t* probes;    // f16 [numExperts][4096]
     const float* v;
     const uint32_t* expNo;     // nullable
@@ -84,7 +83,6 @@ struct GroupKArgs {
     uint32_t ablate;               // profiling only (env EFFORT_ABLATE): 2 = no last-arriver reduce, 4 = no row streaming, 8 = no selection, 32 = never wait for a cutoff job
     uint32_t split;                // bit 0: the cutoffs were evaluated by find_cutoff_group_kernel (split mode), else in the multiply kernel;
                                    // bit 2: FP16 calls' `stats` point at the compact row means (u16 per bucket row), not at the f16x4 stats
-                                   // bit 3: plain grid of plain FP16 calls: rows are prefetched under the cutoff's serial part (PREF instantiation)
     uint32_t cutJobs;              // persistent launches: the first cutJobs items (a multiple of 8 >= count) are cutoff jobs, one per call
     uint32_t trace;                // profiling only: 1 = every item leaves a 64-byte record (who ran it, where, its phase stamps) at tstamp + kTraceOff
     uint32_t* groupDone;           // counter of finished tiles (zero between launches)
@@ -127,14 +125,14 @@ hipError_t launch_calc_dispatch(Format fmt, const void* stats, const float* v, c
                                 const float* cutoff, const MulGeom& g, float* dispatch, uint32_t* count,
                                 uint32_t* ctxCount, uint32_t* blockScratch, hipStream_t st);
 
-hipError_t launch_convert_fp16(const uint16_t* W, uint32_t outDim, uint32_t inDim, uint16_t* buckets,
+hipError_t launch_convert_fp16(const uint16_t* W, uint32_t outDim, uint32_t inDim, uint16_t* buckets, uint32_t pitchCols,
                                uint16_t* stats, uint16_t* probes, uint16_t* scratchVals, int* status, hipStream_t st);
 
 hipError_t launch_convert_q4(const uint16_t* core2, uint32_t inDim, uint32_t outDim, uint32_t cnt, uint16_t* buckets, float* stats, uint16_t* probes,
                              float* outliers, int numCU, hipStream_t st);
 
 hipError_t launch_compact_means(const void* stats_f16x4, uint16_t* means, uint32_t rows, hipStream_t st);
-hipError_t launch_rank_bound(Format fmt, const uint16_t* buckets, const void* stats, uint32_t numExperts, uint32_t rowsPerIn,
+hipError_t launch_rank_bound(Format fmt, const uint16_t* buckets, uint32_t pitchCols, const void* stats, uint32_t numExperts, uint32_t rowsPerIn,
                              uint32_t inDim, uint32_t cols, float* rowScratch, float* rankBound, hipStream_t st);
 // decode-loop glue (decode.hip)
 hipError_t launch_add_rmsnorm_mul(float* h, const float* delta, const uint16_t* w, float* out, uint32_t n, hipStream_t st);

@@ -57,6 +57,21 @@ class Gpu:
         """gpu.eval(): commit + waitUntilCompleted."""
         self.check(self._lib.effort_sync(self.ctx), "gpu.eval")
 
+    def set_overlap(self, lanes: int = 4):
+        """Up to ``lanes`` independent multiply launches of this context in flight at once (effort_set_overlap): each goes to
+        an internal stream with its own scratch, ordered after the context's stream and after earlier multiplies it depends
+        on.  ``join()`` (or ``eval()``, or any other call on the context) makes the stream wait for them -- call it before
+        consuming an output with your own stream work, and before ending a graph capture."""
+        self._bind_stream()
+        self.check(self._lib.effort_set_overlap(self.ctx, int(lanes)), "set_overlap")
+
+    def join(self):
+        self.check(self._lib.effort_join(self.ctx), "join")
+
+    def hook_lane(self, lane: int):
+        """Point last_dispatch_count / last_cutoff / slice_counts at lane ``lane``'s last launch (overlap mode; test hook)."""
+        self.check(self._lib.effort_debug_hook_lane(self.ctx, int(lane)), "hook_lane")
+
     # -- extras ------------------------------------------------------------------------------------
     def set_tuning(self, waves: int = 0, elems: int = 0, slices: int = 0):
         self.check(self._lib.effort_set_tuning(self.ctx, waves, elems, slices), "set_tuning")
@@ -76,10 +91,6 @@ class Gpu:
 
     def set_persistent(self, wg_per_cu: int = -1):
         self.check(self._lib.effort_set_persistent(self.ctx, int(wg_per_cu)), "set_persistent")
-
-    def set_prefetch(self, on: bool = True):
-        """Lone calls / small groups prefetch rows under the cutoff's serial part (effort_debug_set_prefetch; results never depend on it)."""
-        self.check(self._lib.effort_debug_set_prefetch(self.ctx, int(bool(on))), "set_prefetch")
 
     def set_dense_backend(self, rocblas: bool = False):
         """basicMul through the library's hssgemv (True) or the streaming HIP kernel (False, default)."""

@@ -37,7 +37,19 @@ class ExpertWeights:
         cols = self.outSize // 32 if q4 else self.outSize // 16
         rows = self.inSize * self.percentLoad
         # Matrix3D shapes of loader.swift:70,76 (bit-level dtype: 16-bit words / f16x4 or f32x2 stats)
-        self.buckets = buckets.contiguous().view(torch.int16).reshape(self.numExperts, rows, cols)
+        # ``buckets`` may be a view of PITCHED storage -- rows more than ``cols`` words apart, e.g. on whole 128-byte lines as
+        # ``from_core`` / ``bucketize(rowPitch=...)`` write them (effort_weights_fp16_pitched): kept as is, [E, rows, cols]
+        # strided; anything else is made dense like the reference's Matrix3D.
+        b = buckets.view(torch.int16) if buckets.element_size() == 2 else buckets
+        if b.dim() == 2:
+            b = b.unsqueeze(0)
+        if (not q4 and tuple(b.shape) == (self.numExperts, rows, cols) and b.stride(2) == 1 and b.stride(1) > cols
+                and b.stride(1) % 4 == 0 and (self.numExperts == 1 or b.stride(0) == rows * b.stride(1))):
+            self.buckets = b
+            self.rowPitch = b.stride(1) * 2
+        else:
+            self.buckets = buckets.contiguous().view(torch.int16).reshape(self.numExperts, rows, cols)
+            self.rowPitch = cols * 2
         if q4:
             self.stats = stats.contiguous().to(torch.float32).reshape(self.numExperts, rows, 2)
         else:
@@ -63,8 +75,8 @@ class ExpertWeights:
                 h = lib.effort_weights_q4(g.ctx, _ptr(self.buckets), _ptr(self.stats), _ptr(self.probes), _ptr(self.outliers),
                                           n, self.inSize, self.outSize, self.numExperts)
             else:
-                h = lib.effort_weights_fp16(g.ctx, _ptr(self.buckets), _ptr(self.stats), _ptr(self.probes),
-                                            self.inSize, self.outSize, self.percentLoad, self.numExperts)
+                h = lib.effort_weights_fp16_pitched(g.ctx, _ptr(self.buckets), self.rowPitch, _ptr(self.stats), _ptr(self.probes),
+                                                    self.inSize, self.outSize, self.percentLoad, self.numExperts)
             if not h:
                 detail = lib.effort_last_error(g.ctx)
                 raise _lib.EffortError(-2, "ExpertWeights", detail.decode() if detail else "")
@@ -81,11 +93,14 @@ class ExpertWeights:
 
     # -- constructors ------------------------------------------------------------------------------
     @classmethod
-    def from_core(cls, core: torch.Tensor) -> "ExpertWeights":
-        """Dense f16 matrix [outSize, inSize] -> FP16 bundle via the GPU converter (= bucketize())."""
-        from .convert import bucketize
+    def from_core(cls, core: torch.Tensor, aligned: bool = True) -> "ExpertWeights":
+        """Dense f16 matrix [outSize, inSize] -> FP16 bundle via the GPU converter (= bucketize()).  ``aligned`` (default):
+        the converter writes the bucket rows on whole 128-byte lines (same values, rows ``aligned_row_pitch`` bytes apart; the
+        multiply streams them ~10 % faster than the reference's dense rows when HBM is saturated) -- ``buckets`` is then a
+        strided view; ``aligned=False`` gives the reference's dense tensor."""
+        from .convert import aligned_row_pitch, bucketize
         tensors: dict[str, torch.Tensor] = {}
-        bucketize(core, "", tensors, goQ8=False)
+        bucketize(core, "", tensors, goQ8=False, rowPitch=aligned_row_pitch(core.shape[0]) if aligned else 0)
         return cls(tensors["buckets"], tensors["bucket.stats"], tensors["probes"], inSize=core.shape[1],
                    outSize=core.shape[0], core=core)
 
@@ -105,9 +120,9 @@ class ExpertWeights:
                              self.inSize, self.outSize, percentLoad, self.numExperts, core=self.core)
 
     def align_rows(self) -> int:
-        """Give the handle its own copy of the buckets with every row on a 128-byte line (effort_weights_align_rows): the
-        multiply's row pieces then stop straddling lines (+~10 % throughput for 11008 outputs when HBM is saturated), for
-        one more copy of the buckets in device memory.  Returns the row pitch in bytes."""
+        """For bundles held in the reference's dense layout (loaded from a file, ``from_core(aligned=False)``): give the handle
+        its own copy of the buckets with every row on a 128-byte line (effort_weights_align_rows).  No-op for bundles that are
+        aligned already (``from_core`` writes them so).  Call before capturing launches into a graph.  Returns the row pitch."""
         self._gpu.check(_lib.lib().effort_weights_align_rows(self.handle), "ExpertWeights.align_rows")
         return int(_lib.lib().effort_weights_row_pitch(self.handle))
 

@@ -54,6 +54,21 @@ EFFORT_API void effort_destroy(effort_ctx* ctx);
 EFFORT_API int effort_set_stream(effort_ctx* ctx, void* stream);
 /* gpu.eval() -- helpers/gpu.swift:109-119: block until everything enqueued so far has finished. */
 EFFORT_API int effort_sync(effort_ctx* ctx);
+/* Overlap of independent launches (the reference's command queue lets independent kernels overlap too, helpers/gpu.swift:
+ * 135-196).  lanes = 1 (default): every call is enqueued on the context's stream, in order.  lanes = 2..4: the context owns
+ * that many internal streams, each with its own scratch, and every effort_bucketmul* call goes to one of them, ordered
+ *   - after everything enqueued on the context's stream BEFORE the call, and
+ *   - after earlier multiplies of this context whose outputs it reads or overwrites, or whose inputs it overwrites (address
+ *     ranges of v / expNo / aux / resid / out are compared);
+ * otherwise it runs beside the multiplies still in flight: the head of one launch (staging, cutoffs, selection: HBM idle)
+ * hides under the streaming of the others (one 32-call launch after another: 0.57 -> 0.75 of the HBM roofline).  Results
+ * are bit-identical.  The multiplies become visible to the context's stream at effort_join (enqueues waits, returns at
+ * once), and implicitly at effort_sync, at any other effort_* call on the context and at the test hooks.  A caller who
+ * enqueues its OWN work on the stream to consume an output calls effort_join first; inside a hipGraph capture call
+ * effort_join before ending the capture (the lanes fork from and must rejoin the capturing stream).
+ * Costs 64 MiB of scratch per extra lane. */
+EFFORT_API int effort_set_overlap(effort_ctx* ctx, int lanes);
+EFFORT_API int effort_join(effort_ctx* ctx);
 EFFORT_API const char* effort_last_error(effort_ctx* ctx);
 EFFORT_API const char* effort_version(void);
 
@@ -71,6 +86,15 @@ EFFORT_API const char* effort_version(void);
 EFFORT_API effort_w* effort_weights_fp16(effort_ctx* ctx, const void* buckets_dev, const void* stats_dev,
                               const void* probes_dev, int inDim, int outDim, int percentLoad,
                               int numExperts);
+
+/* The same with bucket rows `rowPitchBytes` apart (0 = 2*outDim/16, the reference's dense layout; a multiple of 8 >= that).
+ * The reference's rows are 2*cols bytes apart (1376 for 11008 outputs): the 512-byte row pieces the multiply streams then
+ * straddle 128-byte lines and HBM delivers 5.4-5.6 TB/s where line-aligned rows reach 6.1-6.9.  A loader that places the rows
+ * effort_aligned_row_pitch(outDim) bytes apart (effort_convert_fp16_pitched writes them so) gets the fast stream with no
+ * second copy of the buckets (+2.3 % bytes for 11008 outputs).  Results are bit-identical for any pitch. */
+EFFORT_API effort_w* effort_weights_fp16_pitched(effort_ctx* ctx, const void* buckets_dev, int rowPitchBytes, const void* stats_dev,
+                                      const void* probes_dev, int inDim, int outDim, int percentLoad, int numExperts);
+EFFORT_API int effort_aligned_row_pitch(int outDim);
 
 /* Q4 bundle (layout written by q4_draft.py:70-322; loaded by loader.swift:70,98,124):
  *   buckets  u16 [numExperts][inDim*8][outDim/32]   4 nibbles per word, nibble = sign<<3 | pos,
@@ -96,10 +120,11 @@ EFFORT_API void effort_weights_free(effort_w* w);
 EFFORT_API int effort_weights_refresh(effort_w* w);
 /* Row pitch.  The converter's bucket rows are 2*cols bytes apart (1376 for 11008 outputs), so the row pieces the multiply
  * streams straddle 128-byte lines and HBM delivers 5.4-5.6 TB/s instead of 6.1-6.9 (measured on line-aligned shapes).
- * effort_weights_align_rows gives the handle its OWN device copy of the buckets with every row on a 128-byte boundary
- * (+2.3 % bytes for 11008 outputs) and reads that from then on: bit-identical results, ~10 % more throughput when several
- * launches keep HBM saturated.  The caller's buffer is no longer read by multiplies (it may be freed; keep it if
- * effort_weights_refresh will be needed).  No-op if the pitch is aligned already.  effort_weights_row_pitch: bytes. */
+ * effort_weights_align_rows gives a handle registered on the dense layout its OWN device copy of the buckets with every row
+ * on a 128-byte boundary and reads that from then on (bit-identical results; the caller's buffer is no longer read by
+ * multiplies and may be freed -- keep it if effort_weights_refresh will be needed).  Call it BEFORE capturing launches of
+ * the handle into a hipGraph (a captured launch keeps the pointers it was given).  No-op if the pitch is aligned already
+ * (buckets converted or loaded with effort_aligned_row_pitch: no second copy).  effort_weights_row_pitch: bytes. */
 EFFORT_API int effort_weights_align_rows(effort_w* w);
 EFFORT_API int effort_weights_row_pitch(const effort_w* w);
 EFFORT_API int effort_weights_get_bound(effort_w* w, float* host_out);
@@ -222,6 +247,9 @@ EFFORT_API int effort_decode_status(effort_ctx* ctx, int* host_out);
  * percentLoad 16, one expert.  Runs on the GPU (all device pointers), enqueued on the stream. */
 EFFORT_API int effort_convert_fp16(effort_ctx* ctx, const void* W_f16_dev, int outDim, int inDim,
                         void* buckets_dev, void* stats_dev, void* probes_dev);
+/* The same, writing bucket rows `rowPitchBytes` apart (see effort_weights_fp16_pitched; the padding is left untouched). */
+EFFORT_API int effort_convert_fp16_pitched(effort_ctx* ctx, const void* W_f16_dev, int outDim, int inDim,
+                                void* buckets_dev, int rowPitchBytes, void* stats_dev, void* probes_dev);
 /* Elements the last effort_convert_fp16 calls could not place: the reference's preBucketize (convert.metal:40-61) drops an
  * element whose bucket is already full, which happens when zero padding of a non-power-of-two row ties with real zeros;
  * the converter reproduces that and counts the drops here.  Reads and clears the count (0 = every element was placed). */

@@ -15,9 +15,10 @@ extern "C" {
 /* Group launches with more work items than wgPerCU workgroups per CU run as that many PERSISTENT workgroups pulling
  * items from per-XCD queues.  -1 = heuristic (default), 0 = always one workgroup per item. */
 EFFORT_API int effort_set_persistent(effort_ctx* ctx, int wgPerCU);
-/* Lone calls and small groups (plain grids) prefetch the rows the handle's previous cutoff would keep into L2 while the
- * exact cutoff is bisected; results never depend on it.  1 = on (default; env EFFORT_PREFETCH=0 turns it off), 0 = off. */
-EFFORT_API int effort_debug_set_prefetch(effort_ctx* ctx, int on);
+
+/* Overlap mode (effort_set_overlap): the hooks effort_group_dispatch_count / effort_group_cutoff / effort_debug_slice_counts
+ * read the lane the most recent launch went to; this points them at another lane's last launch (0 .. lanes-1). */
+EFFORT_API int effort_debug_hook_lane(effort_ctx* ctx, int lane);
 
 /* Timing hooks.  enable = 1: HIP events are recorded on the context's stream around each launch (not capturable into a
  * graph) AND the multiply kernel stamps the device wall clock at its first workgroup's start / last workgroup's end;

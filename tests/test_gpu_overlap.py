@@ -1,0 +1,214 @@
+"""GPU tests of the features round 3 added around the multiply: launches of ONE context in flight together
+(effort_set_overlap), the pitched bucket layout, weights refreshed under a captured graph, and the bench's timed
+configuration as a whole.  Through the C ABI, against the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from tests.test_gpu_parity import DEV, close, converted, dev16, devf, ea, gpu_weights  # noqa: F401  (ea: module fixture)
+from tests.util import make_v
+
+pytestmark = pytest.mark.gpu
+
+
+def _host(ew):
+    """Oracle inputs of a bundle: dense uint16 arrays (the buckets may be a pitched view)."""
+    return (ew.buckets[0].contiguous().cpu().numpy().view(np.uint16), ew.stats[0].cpu().numpy().view(np.uint16),
+            ew.probes[0].cpu().numpy().view(np.uint16))
+
+
+def test_pitched_layout_is_bit_identical(ea, oracle_cpu):
+    """from_core(aligned=True) has the converter write the bucket rows on whole 128-byte lines (effort_convert_fp16_pitched +
+    effort_weights_fp16_pitched: 1376 -> 1408 bytes for 11008 outputs, no second copy): same layout values, same stats /
+    probes, and bit-identical products, lone and in a 32-call persistent launch (compact means, E = 4)."""
+    outDim, inDim = 11008, 4096
+    gen = torch.Generator(device=DEV)
+    gen.manual_seed(77)
+    W = (torch.randn((outDim, inDim), generator=gen, device=DEV, dtype=torch.float32) * 0.02).to(torch.float16)
+    dense, pitched = ea.ExpertWeights.from_core(W, aligned=False), ea.ExpertWeights.from_core(W, aligned=True)
+    lib = ea.lib()
+    assert pitched.rowPitch == 1408 and dense.rowPitch == 1376
+    assert lib.effort_weights_row_pitch(pitched.handle) == 1408 and lib.effort_aligned_row_pitch(outDim) == 1408
+    assert pitched.align_rows() == 1408                                       # nothing to do: no second copy
+    assert torch.equal(dense.buckets, pitched.buckets) and torch.equal(dense.stats, pitched.stats) and torch.equal(dense.probes, pitched.probes)
+    b, s, p = _host(pitched)
+    g = ea.gpu()
+    v = make_v(inDim, seed=5, heavy=True)
+    vd = devf(v)
+    for effort in (0.1, 0.25, 1.0):
+        o1, o2 = torch.zeros(outDim, device=DEV), torch.zeros(outDim, device=DEV)
+        ea.bucketMul(vd, dense, None, o1, effort)
+        g.eval()
+        n1, c1 = g.last_dispatch_count(), g.last_cutoff()
+        ea.bucketMul(vd, pitched, None, o2, effort)
+        g.eval()
+        assert (g.last_dispatch_count(), g.last_cutoff()) == (n1, c1) and torch.equal(o1, o2), effort
+    want, n, cutoff = oracle_cpu.bucket_mul(v, b, s, p, inDim, outDim, 0.25)
+    outs = [torch.full((outDim,), float("nan"), device=DEV) for _ in range(32)]
+    ea.bucketMulGroup([(vd, pitched if i & 1 else dense, None, outs[i], 0.25) for i in range(32)])
+    g.eval()
+    for i in range(32):
+        assert g.last_dispatch_count(i) == n and g.last_cutoff(i) == cutoff and torch.equal(outs[i], outs[0]) and close(outs[i].cpu().numpy(), want), i
+    # a pitch the library did not choose (a multiple of 8 bytes >= 2 * cols), and a bad one
+    from effort_amd.convert import bucketize
+    t = {}
+    bucketize(W, "", t, rowPitch=1376 + 40)
+    odd = ea.ExpertWeights(t["buckets"], t["bucket.stats"], t["probes"], inSize=inDim, outSize=outDim)
+    assert odd.rowPitch == 1416
+    o3, o4 = torch.zeros(outDim, device=DEV), torch.zeros(outDim, device=DEV)
+    ea.bucketMul(vd, odd, None, o3, 0.25)
+    ea.bucketMul(vd, dense, None, o4, 0.25)
+    g.eval()
+    assert torch.equal(o3, o4) and close(o3.cpu().numpy(), want) and g.last_dispatch_count() == n
+    with pytest.raises(ValueError):
+        bucketize(W, "", {}, rowPitch=1380)
+
+
+def test_refresh_keeps_captured_graphs_valid(ea, oracle_cpu):
+    """A launch copies the handle's pointers by value and a captured hipGraph bakes them in: effort_weights_refresh recomputes
+    the bound and the compact means IN PLACE, so a graph captured before the refresh replays on the rewritten weights with
+    the new bound (lone call: 8-byte stats path; 32-call persistent launch: compact means)."""
+    outDim, inDim = 1024, 4096
+    W, b, s, p = converted(oracle_cpu, outDim, inDim)
+    ew = gpu_weights(ea, W, b, s, p)
+    g = ea.gpu()
+    v = make_v(inDim, seed=8)
+    vd = devf(v)
+    lone = torch.zeros(outDim, device=DEV)
+    many = [torch.zeros(outDim, device=DEV) for _ in range(32)]
+
+    def enqueue():
+        ea.bucketMul(vd, ew, None, lone, 0.5)
+        g.set_tuning(8, 1, 64)                           # 64 slices per call: a persistent launch with cutoff jobs and compact means
+        ea.bucketMulGroup([(vd, ew, None, o, 0.5) for o in many])
+        g.set_tuning(0, 0, 0)
+    try:
+        enqueue()
+        g.eval()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            enqueue()
+        g._bind_stream()
+        W2 = (W.astype(np.float32) * 16).astype(np.float16)           # exact scaling: same order, same positions, 16x the bound
+        b2, s2, p2, _ = oracle_cpu.convert_fp16(W2)
+        ew.buckets.copy_(dev16(b2).reshape(ew.buckets.shape))
+        ew.stats.copy_(dev16(s2).reshape(ew.stats.shape))
+        ew.probes.copy_(dev16(p2).reshape(ew.probes.shape))
+        ew.refresh()
+        lone.fill_(float("nan"))
+        for o in many:
+            o.fill_(float("nan"))
+        graph.replay()
+        g.eval()
+        want, n, cutoff = oracle_cpu.bucket_mul(v, b2, s2, p2, inDim, outDim, 0.5)
+        assert close(lone.cpu().numpy(), want)
+        for i in (0, 7, 31):
+            assert g.last_dispatch_count(i) == n and g.last_cutoff(i) == cutoff and close(many[i].cpu().numpy(), want), i
+    finally:
+        g.set_tuning(0, 0, 0)
+
+
+def test_overlap_orders_dependent_launches(ea, oracle_cpu):
+    """effort_set_overlap: launches of ONE context go to internal lanes.  Independent ones may overlap; one that reads an
+    earlier launch's output (RAW), overwrites it (WAW) or overwrites its input (WAR) is ordered after it.  A chain mixing all
+    three, eager and replayed from a hipGraph, gives the bits of the same chain on a single lane."""
+    inDim = outDim = 4096
+    W, b, s, p = converted(oracle_cpu, outDim, inDim)
+    W2, b2, s2, p2 = converted(oracle_cpu, outDim, inDim, seed=99)
+    ewA, ewB = gpu_weights(ea, W, b, s, p), gpu_weights(ea, W2, b2, s2, p2)
+    ctx = ea.Gpu(0)
+    v0 = devf(make_v(inDim, seed=3, heavy=True))
+    bufs = {k: torch.zeros(inDim, device=DEV) for k in "vxyzw"}
+
+    def chain():
+        bufs["v"].copy_(v0)
+        ea.bucketMul(bufs["v"], ewA, None, bufs["x"], 0.25, gpu=ctx)        # x = A v
+        ea.bucketMul(bufs["v"], ewB, None, bufs["y"], 0.5, gpu=ctx)         # y = B v          (independent of the first: may overlap)
+        ea.bucketMul(bufs["x"], ewB, None, bufs["z"], 0.25, gpu=ctx)        # z = B x          (RAW on x)
+        ea.bucketMul(bufs["y"], ewA, None, bufs["v"], 0.25, gpu=ctx)        # v = A y          (WAR on v: launches 1, 2 read it; RAW on y)
+        ea.bucketMul(bufs["z"], ewA, None, bufs["x"], 0.5, gpu=ctx)         # x = A z          (WAW on x, WAR vs launch 3; RAW on z)
+        ea.bucketMulGroup([(bufs["v"], ewA, None, bufs["w"], 0.25), (bufs["x"], ewB, None, bufs["y"], 0.25)], gpu=ctx)   # RAW on v and x, WAW on y
+        ctx.join()
+    res = {}
+    for lanes in (1, 4):
+        ctx.set_overlap(lanes)
+        for k in bufs:
+            bufs[k].zero_()
+        chain()
+        ctx.eval()
+        res[lanes] = {k: t.clone() for k, t in bufs.items()}
+    for k in bufs:
+        assert torch.equal(res[1][k], res[4][k]), k
+    # the same from a graph (the lanes fork from and rejoin the capturing stream), twice
+    ctx.set_overlap(4)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+        chain()
+    ctx._bind_stream()
+    for _ in range(2):
+        for k in "xyzw":
+            bufs[k].fill_(float("nan"))
+        graph.replay()
+        ctx.eval()
+        for k in bufs:
+            assert torch.equal(res[1][k], bufs[k]), k
+    # and against the oracle: the first link
+    want, n, cutoff = oracle_cpu.bucket_mul(v0.cpu().numpy(), b2, s2, p2, inDim, outDim, 0.5)
+    ctx.set_overlap(1)
+    y = torch.zeros(outDim, device=DEV)
+    ea.bucketMul(v0, ewB, None, y, 0.5, gpu=ctx)
+    ctx.eval()
+    assert close(y.cpu().numpy(), want) and ctx.last_dispatch_count() == n
+    ctx.close()
+
+
+def test_timed_configuration_as_a_whole(ea, oracle_cpu):
+    """bench.py's timed job, as a whole: 4096 x 11008 matrices converted on line-aligned rows (pitch 1408), 32 calls per
+    launch at 25 % effort on the heuristic geometry (persistent workgroups, cutoff jobs, COMPACT means, E = 4), ONE context
+    with four launches in flight (effort_set_overlap), eight steps in one hipGraph, every step its own input vector and
+    output set, the steps in flight on DISJOINT matrix sets -- every output of every step against the oracle, and the
+    dispatch counts and cutoffs of each lane's last launch."""
+    inDim, outDim, n_calls, lanes, steps, n_sets = 4096, 11008, 32, 4, 8, 2
+    gen = torch.Generator(device=DEV)
+    sets, host = [], []
+    for k in range(n_sets * n_calls):
+        gen.manual_seed(7000 + k)
+        W = (torch.randn((outDim, inDim), generator=gen, device=DEV, dtype=torch.float32) * 0.02).to(torch.float16)
+        ew = ea.ExpertWeights.from_core(W)                                    # aligned rows: what bench.make_weights does
+        ew.core = None
+        assert ew.rowPitch == 1408
+        host.append(_host(ew))
+        if k % n_calls == 0:
+            sets.append([])
+        sets[-1].append(ew)
+    ctx = ea.Gpu(0)
+    ctx.set_overlap(lanes)
+    vs = [torch.zeros(inDim, device=DEV) for _ in range(steps)]
+    outs = [[torch.zeros(outDim, device=DEV) for _ in range(n_calls)] for _ in range(steps)]
+
+    def enqueue():
+        for i in range(steps):
+            ea.bucketMulGroup([(vs[i], sets[i % n_sets][k], None, outs[i][k], 0.25) for k in range(n_calls)], gpu=ctx)
+        ctx.join()
+    enqueue()
+    ctx.eval()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+        enqueue()
+    ctx._bind_stream()
+    hv = [make_v(inDim, seed=500 + i, heavy=bool(i & 1)) for i in range(steps)]
+    for i in range(steps):
+        vs[i].copy_(devf(hv[i]))
+        for o in outs[i]:
+            o.fill_(float("nan"))
+    graph.replay()
+    graph.replay()
+    ctx.eval()
+    for i in range(steps):
+        for k in range(n_calls):
+            want, n, cutoff = oracle_cpu.bucket_mul(hv[i], *host[(i % n_sets) * n_calls + k], inDim, outDim, 0.25)
+            assert close(outs[i][k].cpu().numpy(), want), (i, k)
+            if i >= steps - lanes:                                            # lane i % lanes ran step i last: its hooks are readable
+                ctx.hook_lane(i % lanes)
+                assert ctx.last_dispatch_count(k) == n and ctx.last_cutoff(k) == cutoff, (i, k)
+    ctx.close()

@@ -742,19 +742,31 @@ def test_fused_prologues_and_residual(ea, oracle_cpu):
     g.eval()
     assert g.last_dispatch_count() == n0 and g.last_cutoff() == c0
     assert torch.equal(fused, resid + plain)
-    # --- rmsNorm: materialised by effort_add_rmsnorm_mul (its own summation order: same selection, outputs to rounding)
+    # --- rmsNorm: materialised by effort_add_rmsnorm_mul; the fused prologue sums the squares in that kernel's order, so the
+    #     input -- hence cutoff, selection and product -- is the same to the bit
     hn = torch.zeros(inDim, device=DEV)
     hc = hvec.clone()
     g.check(lib.effort_add_rmsnorm_mul(g.ctx, P(hc), None, P(wn), P(hn), inDim), "rmsnorm")
     plain2 = torch.zeros(outDim, device=DEV)
     ea.bucketMul(hn, ew, None, plain2, 0.5)
     g.eval()
-    n1 = g.last_dispatch_count()
+    n1, c1 = g.last_dispatch_count(), g.last_cutoff()
+    want2, n2_or, c2_or = oracle_cpu.bucket_mul(hn.cpu().numpy(), b, s, p, inDim, outDim, 0.5)
+    assert n1 == n2_or and c1 == c2_or
     fused2 = torch.zeros(outDim, device=DEV)
     ea.bucketMulGroup([(hvec, ew, None, fused2, 0.5, {"norm": wn}), (x1, ew, None, plain, 0.3)])   # mixed with a plain call
     g.eval()
-    assert abs(g.last_dispatch_count(0) - n1) <= 2                       # an input 1 ulp apart may flip a row at the threshold
-    assert close(fused2.cpu().numpy(), plain2.cpu().numpy())
+    assert g.last_dispatch_count(0) == n1 and g.last_cutoff(0) == c1     # exact: same input bits
+    assert torch.equal(fused2, plain2)
+    for tune in ((4, 2, 0), (16, 1, 0), (2, 4, 0)):                       # 256 / 1024 / 128 threads standing for that kernel's 1024
+        g.set_tuning(*tune)
+        try:
+            f3 = torch.zeros(outDim, device=DEV)
+            ea.bucketMulGroup([(hvec, ew, None, f3, 0.5, {"norm": wn})])
+            g.eval()
+            assert g.last_dispatch_count(0) == n1 and g.last_cutoff(0) == c1 and close(f3.cpu().numpy(), want2), tune
+        finally:
+            g.set_tuning(0, 0, 0)
     want1, n1_or, c1_or = oracle_cpu.bucket_mul(x1.cpu().numpy(), b, s, p, inDim, outDim, 0.3)     # the plain call sharing the launch
     assert g.last_dispatch_count(1) == n1_or and g.last_cutoff(1) == c1_or and close(plain.cpu().numpy(), want1)
     with pytest.raises(ValueError):
@@ -872,24 +884,27 @@ def _bench_geometry(ea, oracle_cpu, g, inDim, outDim, n_calls):
             assert close(outs[i].cpu().numpy(), want), (rep, i)
 
 
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_column_shards_of_the_baseline_shapes(ea, oracle_cpu, q4_case, q4_11008, world):
     """BASELINE.json configs[3] on one device: ShardedExpertWeights.from_full for every rank of a world of 2 / 4 / 8, for
-    4096 x 11008 (86 bucket columns per rank at world 8: a ragged tile) and 4096 x 4096, FP16 and Q4 with outliers --
+    4096 x 11008 (86 bucket columns per rank at world 8: a ragged tile), 4096 x 4096, 4096 x 1024 (Wk / Wv: 8 columns per rank
+    at world 8) and 14336 x 4096 (W2), FP16, and Q4 with outliers --
     every rank's dispatch count and cutoff are the full call's, and the concatenated outputs are the full product."""
     from effort_amd.sharded import ShardedExpertWeights
     g = ea.gpu()
     cases = []
-    for outDim in (11008, 4096):
-        W, b, s, p = converted(oracle_cpu, outDim, 4096)
-        cases.append(("fp16", outDim, gpu_weights(ea, W, b, s, p), lambda v, e, b=b, s=s, p=p, outDim=outDim: oracle_cpu.bucket_mul(v, b, s, p, 4096, outDim, e)))
+    for outDim, inD in ((11008, 4096), (4096, 4096), (1024, 4096), (4096, 14336)):          # W1/W3-like, Wq/Wo, Wk/Wv (8 columns per rank at world 8), W2
+        W, b, s, p = converted(oracle_cpu, outDim, inD)
+        cases.append(("fp16", outDim, gpu_weights(ea, W, b, s, p), lambda v, e, b=b, s=s, p=p, outDim=outDim, inD=inD: oracle_cpu.bucket_mul(v, b, s, p, inD, outDim, e)))
     for (W, L, inDim, outDim) in (q4_11008, q4_case):
         ew = ea.ExpertWeights(dev16(L["buckets"]), devf(L["bucket.stats"]), dev16(L["probes"]), inSize=inDim, outSize=outDim,
                               outliers=devf(L["outliers"]), q4=True)
         cases.append(("q4", outDim, ew, lambda v, e, L=L, inDim=inDim, outDim=outDim: oracle_cpu.bucket_mul_q4(
             v, L["buckets"], L["bucket.stats"], L["probes"], L["outliers"], inDim, outDim, e)))
-    v = make_v(4096, seed=91, heavy=True)
-    vd = devf(v)
+    vin = {4096: make_v(4096, seed=91, heavy=True), 14336: make_v(14336, seed=92, heavy=True)}
+    vdev = {k: devf(x) for k, x in vin.items()}
     for kind, outDim, full, oracle in cases:
+        v, vd = vin[full.inSize], vdev[full.inSize]
         want, n, cutoff = oracle(v, 0.5)
         parts = []
         for r in range(world):
@@ -903,7 +918,8 @@ def test_column_shards_of_the_baseline_shapes(ea, oracle_cpu, q4_case, q4_11008,
         assert close(np.concatenate(parts), want), (kind, outDim, world)
     # the shards of several matrices sharing v go out as ONE grouped launch per rank (shardedExpertMulGroup's default multiply)
     from effort_amd.sharded import _default_mul_group
-    fp = [c for c in cases if c[0] == "fp16"]
+    fp = [c for c in cases if c[0] == "fp16" and c[2].inSize == 4096]
+    v, vd = vin[4096], vdev[4096]
     for r in (0, world - 1):
         shs = [ShardedExpertWeights.from_full(c[2], r, world) for c in fp]
         outs = [torch.full((sh.localOut,), float("nan"), device=DEV) for sh in shs]

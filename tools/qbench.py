@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--tag", default="")
     ap.add_argument("--streams", type=int, default=1, help="spread the launches of a step round-robin over K streams / contexts")
     ap.add_argument("--steps-per-graph", type=int, default=1, help="steps captured into one graph")
+    ap.add_argument("--overlap", type=int, default=1, help="K > 1: ONE context with effort_set_overlap(K); the steps of a graph write K rotating output sets")
     ap.add_argument("--split", type=int, default=0, help="1: the cutoffs in a kernel of their own before the multiply (the device-clock span then covers the multiply alone)")
     args = ap.parse_args()
     inDim, outDim = (int(x) for x in args.shape.split("x"))
@@ -40,6 +41,9 @@ def main():
     gen.manual_seed(42)
     v = torch.randn(inDim, generator=gen, device=dev)
     outs = [torch.zeros(outDim, device=dev) for _ in ews]
+    osets = [[torch.zeros(outDim, device=dev) for _ in ews] for _ in range(max(1, args.overlap))]
+    if args.overlap > 1:
+        g.set_overlap(args.overlap)
     items = list(zip(ews, outs))
     chunks = [items[i:i + args.group] for i in range(0, len(items), args.group)]
     for rep in range(args.reps):
@@ -59,7 +63,11 @@ def main():
 
             def run():
                 for rep_ in range(args.steps_per_graph):
-                    if K == 1:
+                    if args.overlap > 1:
+                        oo = osets[rep_ % args.overlap]
+                        for c0 in range(0, len(ews), args.group):
+                            ea.bucketMulGroup([(v, ews[k], None, oo[k], args.effort) for k in range(c0, min(len(ews), c0 + args.group))])
+                    elif K == 1:
                         for ch in chunks:
                             ea.bucketMulGroup([(v, ew, None, o, args.effort) for ew, o in ch])
                     else:                                # step `rep_` of the graph goes to stream rep_ % K (own context: own scratch)
@@ -73,6 +81,8 @@ def main():
                 if K > 1:
                     for st in main.sts:
                         torch.cuda.current_stream().wait_stream(st)
+                if args.overlap > 1:
+                    g.join()
 
             def timed(n):
                 run()
