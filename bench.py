@@ -526,6 +526,7 @@ def main():
         while len(out_sets) < 4:
             out_sets.append(torch.zeros((N_MATS, outDim), device=dev))
         for ns in (1, 2, 3, 4):                              # ONE context, `ns` launches in flight (effort_set_overlap), each step on its own matrices
+            log(f"by_streams: {ns} lane(s)")
             jb = job if ns == S else LaneJob(ea, local, ns, tune)
             gn = jb.capture(mul_step(args.effort, wsets=ew_sets[:max(1, min(ns, len(ew_sets)))]), 48)
             bs[str(ns)] = rate(time_graph(gn, None, reps=4) / 48 / N_MATS)

@@ -5,6 +5,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -119,9 +120,31 @@ static bool lane_alloc(effort_ctx* c, Lane& L) {
     hipMemset(L.d_count, 0, 16);
     return true;
 }
+// The lanes' streams and events are POOLED per process and never destroyed: a stream or event that took part in a hipGraph
+// capture and is destroyed while other captured graphs are alive crashes a later hipGraphLaunch inside the runtime (ROCm 7.2:
+// segfault in hipGraphLaunch after a multi-lane context was destroyed; tools/lane_crash.py reproduces it).  A context returns
+// them to the pool; the next one takes them from there.
+static std::mutex g_poolMutex;
+static std::vector<hipStream_t> g_streamPool;
+static std::vector<hipEvent_t> g_eventPool;
+static hipStream_t pool_stream() {
+    std::lock_guard<std::mutex> lk(g_poolMutex);
+    if (!g_streamPool.empty()) { hipStream_t s = g_streamPool.back(); g_streamPool.pop_back(); return s; }
+    hipStream_t s = nullptr;
+    return hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess ? s : nullptr;
+}
+static hipEvent_t pool_event() {
+    std::lock_guard<std::mutex> lk(g_poolMutex);
+    if (!g_eventPool.empty()) { hipEvent_t e = g_eventPool.back(); g_eventPool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    return hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess ? e : nullptr;
+}
+static void pool_put(hipStream_t s) { if (s) { std::lock_guard<std::mutex> lk(g_poolMutex); g_streamPool.push_back(s); } }
+static void pool_put(hipEvent_t e) { if (e) { std::lock_guard<std::mutex> lk(g_poolMutex); g_eventPool.push_back(e); } }
+
 static void lane_free(Lane& L) {
-    if (L.own) hipStreamDestroy(L.own);
-    if (L.done) hipEventDestroy(L.done);
+    pool_put(L.own);
+    pool_put(L.done);
     hipFree(L.d_cutoff); hipFree(L.d_count); hipFree(L.d_slabs); hipFree(L.d_counters); hipFree(L.d_sliceCounts); hipFree(L.d_queue);
     L = Lane();
 }
@@ -173,12 +196,12 @@ extern "C" int effort_set_overlap(effort_ctx* c, int lanes) {
     int rc = join_lanes(c);
     if (rc != EFFORT_OK) return rc;
     if (lanes > 1) {
-        if (!c->forkEv && hipEventCreateWithFlags(&c->forkEv, hipEventDisableTiming) != hipSuccess) return fail(c, EFFORT_ERR_HIP, "set_overlap: event");
+        if (!c->forkEv && !(c->forkEv = pool_event())) return fail(c, EFFORT_ERR_HIP, "set_overlap: event");
         for (int i = 0; i < lanes; i++) {
             Lane& L = c->lane[i];
             if (!L.d_slabs && !lane_alloc(c, L)) return fail(c, EFFORT_ERR_HIP, "set_overlap: out of device memory for a lane's scratch");
-            if (!L.own && hipStreamCreateWithFlags(&L.own, hipStreamNonBlocking) != hipSuccess) return fail(c, EFFORT_ERR_HIP, "set_overlap: stream");
-            if (!L.done && hipEventCreateWithFlags(&L.done, hipEventDisableTiming) != hipSuccess) return fail(c, EFFORT_ERR_HIP, "set_overlap: event");
+            if (!L.own && !(L.own = pool_stream())) return fail(c, EFFORT_ERR_HIP, "set_overlap: stream");
+            if (!L.done && !(L.done = pool_event())) return fail(c, EFFORT_ERR_HIP, "set_overlap: event");
         }
     }
     c->nLanes = lanes; c->lastLane = 0; c->nextLane = 0;
@@ -197,7 +220,7 @@ extern "C" void effort_destroy(effort_ctx* c) {
     if (c->blas) rocblas_destroy_handle(c->blas);
     if (c->ev) { for (int i = 0; i < effort_ctx::kMaxSamples * 4; i++) hipEventDestroy(c->ev[i]); delete[] c->ev; }
     for (int i = 0; i < effort_ctx::kMaxLanes; i++) lane_free(c->lane[i]);
-    if (c->forkEv) hipEventDestroy(c->forkEv);
+    pool_put(c->forkEv);
     hipFree(c->d_blockScratch); hipFree(c->d_vhalf); hipFree(c->d_cos); hipFree(c->d_convVals); hipFree(c->d_status); hipFree(c->d_tstamp);
     delete c;
 }
@@ -256,8 +279,8 @@ extern "C" effort_w* effort_weights_fp16_pitched(effort_ctx* c, const void* buck
     if (!c || !buckets || !stats || !probes) { fail(c, EFFORT_ERR_ARG, "effort_weights_fp16: null argument"); return nullptr; }
     const int pitch = rowPitchBytes ? rowPitchBytes : (outDim > 0 ? outDim / 16 * 2 : 0);
     if (inDim <= 0 || outDim <= 0 || percentLoad < 1 || percentLoad > 16 || numExperts < 1 || check_shape(inDim, outDim) != EFFORT_OK ||
-        inDim > 65535 || pitch < outDim / 16 * 2 || pitch % 8 || (size_t)numExperts * percentLoad * inDim * pitch > 0xFFFFFFFFull) {
-        fail(c, EFFORT_ERR_SHAPE, "effort_weights_fp16: unsupported shape or row pitch (a multiple of 8 bytes >= 2*cols; buckets < 4 GiB)"); return nullptr; }
+        inDim > 65535 || pitch < outDim / 16 * 2 || pitch % 4 || (size_t)numExperts * percentLoad * inDim * pitch > 0xFFFFFFFFull) {
+        fail(c, EFFORT_ERR_SHAPE, "effort_weights_fp16: unsupported shape or row pitch (a multiple of 4 bytes >= 2*cols; buckets < 4 GiB)"); return nullptr; }
     effort_w* w = new (std::nothrow) effort_w();
     if (!w) return nullptr;
     w->ctx = c; w->fmt = kFp16;
@@ -740,7 +763,7 @@ extern "C" int effort_convert_fp16_pitched(effort_ctx* c, const void* W, int out
         outDim % 16 || (outDim / 16) % 4)
         return fail(c, EFFORT_ERR_CONVERT, "convert_fp16: bucketize preconditions violated");
     const int pitch = rowPitchBytes ? rowPitchBytes : outDim / 16 * 2;
-    if (pitch < outDim / 16 * 2 || pitch % 8) return fail(c, EFFORT_ERR_CONVERT, "convert_fp16: row pitch must be a multiple of 8 bytes >= 2*cols");
+    if (pitch < outDim / 16 * 2 || pitch % 8) return fail(c, EFFORT_ERR_CONVERT, "convert_fp16: row pitch must be a multiple of 8 bytes >= 2*cols");   // (the stats pass reads 8 bytes at a time)
     const size_t elems = (size_t)outDim * inDim;
     if (elems > c->convElems) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));

@@ -87,7 +87,7 @@ EFFORT_API effort_w* effort_weights_fp16(effort_ctx* ctx, const void* buckets_de
                               const void* probes_dev, int inDim, int outDim, int percentLoad,
                               int numExperts);
 
-/* The same with bucket rows `rowPitchBytes` apart (0 = 2*outDim/16, the reference's dense layout; a multiple of 8 >= that).
+/* The same with bucket rows `rowPitchBytes` apart (0 = 2*outDim/16, the reference's dense layout; a multiple of 4 >= that).
  * The reference's rows are 2*cols bytes apart (1376 for 11008 outputs): the 512-byte row pieces the multiply streams then
  * straddle 128-byte lines and HBM delivers 5.4-5.6 TB/s where line-aligned rows reach 6.1-6.9.  A loader that places the rows
  * effort_aligned_row_pitch(outDim) bytes apart (effort_convert_fp16_pitched writes them so) gets the fast stream with no

@@ -758,6 +758,8 @@ def test_fused_prologues_and_residual(ea, oracle_cpu):
     g.eval()
     assert g.last_dispatch_count(0) == n1 and g.last_cutoff(0) == c1     # exact: same input bits
     assert torch.equal(fused2, plain2)
+    want1, n1_or, c1_or = oracle_cpu.bucket_mul(x1.cpu().numpy(), b, s, p, inDim, outDim, 0.3)     # the plain call sharing the launch
+    assert g.last_dispatch_count(1) == n1_or and g.last_cutoff(1) == c1_or and close(plain.cpu().numpy(), want1)
     for tune in ((4, 2, 0), (16, 1, 0), (2, 4, 0)):                       # 256 / 1024 / 128 threads standing for that kernel's 1024
         g.set_tuning(*tune)
         try:
@@ -767,8 +769,6 @@ def test_fused_prologues_and_residual(ea, oracle_cpu):
             assert g.last_dispatch_count(0) == n1 and g.last_cutoff(0) == c1 and close(f3.cpu().numpy(), want2), tune
         finally:
             g.set_tuning(0, 0, 0)
-    want1, n1_or, c1_or = oracle_cpu.bucket_mul(x1.cpu().numpy(), b, s, p, inDim, outDim, 0.3)     # the plain call sharing the launch
-    assert g.last_dispatch_count(1) == n1_or and g.last_cutoff(1) == c1_or and close(plain.cpu().numpy(), want1)
     with pytest.raises(ValueError):
         ea.bucketMulGroup([(x1, ew, None, fused, 0.3, {"gate": x3, "norm": wn})])
 
