@@ -421,7 +421,7 @@ def main():
                    "bucket_row_pitch_bytes": (outDim // 16 * 2 + 127) // 128 * 128 if ALIGN_ROWS else outDim // 16 * 2,
                    "kernel_geometry(waves,elems,slices)": args.tune if args.tune != "0,0,0" else "heuristic",
                    "partition": "matrices" if world > 1 else "none", "dispatch_rows": D},
-        "us_per_call": round(t_call * 1e6, 3),
+        "bytes_per_launch": G * kb, "us_per_call": round(t_call * 1e6, 3),
         "tokens_per_s": round(1.0 / (t_call * 4 * 32), 2),
         "timed_region_ms": round(dt * args.steps * reps * 1e3, 3), "timed_replays": reps, "timed_steps": args.steps * reps,
     }
@@ -763,7 +763,7 @@ def main():
                 g_timed.replay()                                 # the timed graph itself, once more, into cleared output sets
                 torch.cuda.synchronize()
                 timed_outputs = [o.clone() for o in out_sets[:min(S, args.steps)]]
-                worst, bad, checked = 0.0, 0, 0
+                worst, bad, checked, counts_checked, refs_by_set = 0.0, 0, 0, 0, {}
                 for k, hip_set in enumerate(timed_outputs):
                     wk = ew_sets[k % len(ew_sets)]
                     hip = hip_set.cpu().numpy()
@@ -773,9 +773,16 @@ def main():
                         worst = max(worst, float(np.abs(hip[i] - want).max() / (np.abs(want).max() + 1e-30)))
                         bad += int(not np.isfinite(hip[i]).all())
                         checked += 1
-                    if k == (args.steps - 1) % len(timed_outputs) and G == N_MATS:      # the launch whose hooks are still readable: the job's last
+                    refs_by_set[k] = ref
+                # dispatch counts (the reference's dispatch.size hook): one more step per lane, eagerly, then every lane's hooks
+                if G == N_MATS and isinstance(job, LaneJob):
+                    job._enqueue(head_step, len(timed_outputs))
+                    torch.cuda.synchronize()
+                    for k in range(len(timed_outputs)):
+                        job.ctx.hook_lane(k)
                         for i in range(N_MATS):
-                            bad += int(job.last_dispatch_count(args.steps, i) != ref[i][1])
+                            bad += int(job.ctx.last_dispatch_count(i) != refs_by_set[k][i][1])
+                            counts_checked += 1
                 if not args.no_sweep:                        # every sweep point's output against the oracle at that effort
                     sw, gots, last = sweep_check
                     for row, got in zip(sw, gots):
@@ -791,6 +798,7 @@ def main():
                 cb["gpu_vs_cpu_max_rel_err"] = worst
                 cb["gpu_vs_cpu_outputs_checked"] = checked
                 cb["gpu_vs_cpu_outputs_checked_note"] = f"all {len(timed_outputs)} output sets of the timed graph's last replay, each against the oracle on the matrices its step multiplied"
+                cb["gpu_vs_cpu_dispatch_counts_checked"] = counts_checked
                 cb["gpu_vs_cpu_dispatch_count_or_nan_mismatches"] = bad
                 result["cpu_baseline"] = cb
             except Exception as ex:  # the oracle is optional infrastructure for the bench

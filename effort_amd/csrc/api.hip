@@ -407,12 +407,18 @@ static bool supported(int W, int E) {
 // (tools/tune.py, 4096x4096 .. 14336x4096, 10-100 % effort): a workgroup's life is mostly fixed-latency steps (staging,
 // cutoff, selection, hand-off), so FEWER, fatter items win even when they leave CUs idle -- about 3/4 of an item per CU
 // for small groups, with slices between 128 and 512 input rows; from 8 calls on, the fattest slices (512 rows).
-static uint32_t pick_slices(const effort_ctx* c, const effort_w* w, int groupSize, int E) {
+static uint32_t pick_slices(const effort_ctx* c, const effort_w* w, int groupSize, int E, uint32_t groupTiles = 0) {
     const uint32_t tiles = (w->cols + 64 * E - 1) / (64 * E);
     const uint32_t lo = ((w->inDim + 511) / 512 + 7) / 8 * 8, hi = ((w->inDim + 127) / 128 + 7) / 8 * 8;
     if (groupSize >= 8) return lo;
-    const uint32_t target = (uint32_t)c->numCU * 3u / 4u;
-    uint32_t S = (target / ((uint32_t)groupSize * tiles) + 4u) / 8u * 8u;       // nearest multiple of 8
+    // (64-column tiles -- narrow matrices, see pick_elems -- are worked best at one item per CU: measured, 14336 -> 4096 lone, 64 slices
+    //  26.9 us against 29.2 at 48)
+    const bool fullTarget = E == 1 && !(getenv("EFFORT_X_FULL") && atoi(getenv("EFFORT_X_FULL")) == 0);
+    const uint32_t target = fullTarget ? (uint32_t)c->numCU : (uint32_t)c->numCU * 3u / 4u;
+    // the launch's items come from ALL its calls: with the column tiles of the whole group known (Wq | Wk | Wv: 4 + 1 + 1 at
+    // E = 1) every call takes target / tiles slices; without, the calls are taken as equals
+    const uint32_t allTiles = (groupTiles && !(getenv("EFFORT_X_GT") && atoi(getenv("EFFORT_X_GT")) == 0)) ? groupTiles : (uint32_t)groupSize * tiles;
+    uint32_t S = (target / allTiles + 4u) / 8u * 8u;       // nearest multiple of 8
     if (S < lo) S = lo;
     if (S > hi) S = hi;
     return S;
@@ -427,9 +433,15 @@ static int pick_elems(const effort_ctx* c, Format fmt, int n, const effort_w* co
     if (c->tuneE) return c->tuneE;
     if (fmt != kFp16) return n >= 8 ? 2 : 1;        // measured, 4096x11008 Q4: 32 calls 5.3 vs 6.4 us/call, 8 calls 8.3 vs 8.3, 2 calls 20.8 vs 18.8
     if (c->tuneS) return 2;
+    auto group_tiles = [&](int E) {
+        uint32_t t = 0;
+        for (int i = 0; i < n; i++) if (ws[i]) t += (ws[i]->cols + 64 * E - 1) / (64 * E);
+        return t;
+    };
     auto items = [&](int E) {
         uint32_t t = 0;
-        for (int i = 0; i < n; i++) if (ws[i]) t += (ws[i]->cols + 64 * E - 1) / (64 * E) * pick_slices(c, ws[i], n, E);
+        const uint32_t gt = group_tiles(E);
+        for (int i = 0; i < n; i++) if (ws[i]) t += (ws[i]->cols + 64 * E - 1) / (64 * E) * pick_slices(c, ws[i], n, E, gt);
         return t;
     };
     const uint32_t numCU = (uint32_t)c->numCU;
@@ -448,10 +460,15 @@ static int pick_elems(const effort_ctx* c, Format fmt, int n, const effort_w* co
     }
     const uint32_t i2 = items(2);
     if (f2 < 0.8 * best) return 1;
+    // narrow matrices (<= 256 bucket columns: 4096 outputs) in small groups: 64-column tiles -- more tiles, each reduced by its
+    // own last arriver (measured, us per launch at 25 %: Wq|Wk|Wv 21.2 vs 23.8, 14336 -> 4096 lone 26.6-27.5 vs 29.7)
+    bool narrow = true;
+    for (int i = 0; i < n; i++) narrow = narrow && (!ws[i] || ws[i]->cols <= 256u);
+    if (narrow && f1 >= 0.8 * best && !(getenv("EFFORT_X_NARROW") && atoi(getenv("EFFORT_X_NARROW")) == 0)) return 1;   // (X knobs: A/B of the heuristics, tools only)
     return (i2 * 10u < numCU * 3u / 4u * 6u && items(1) > i2) ? 1 : 2;
 }
 
-static int choose_geom(const effort_ctx* c, const effort_w* w, int groupSize, int E, MulGeom* g, int* Wout, int* Eout, uint32_t sliceMult = 1) {
+static int choose_geom(const effort_ctx* c, const effort_w* w, int groupSize, int E, MulGeom* g, int* Wout, int* Eout, uint32_t sliceMult = 1, uint32_t groupTiles = 0) {
     const int W = c->tuneW ? c->tuneW : 8;                 // 8 waves per workgroup
     if (!supported(W, E)) return EFFORT_ERR_ARG;
     const uint32_t nacc = w->fmt == kFp16 ? 16 : 32;
@@ -464,7 +481,7 @@ static int choose_geom(const effort_ctx* c, const effort_w* w, int groupSize, in
     uint32_t S;
     if (c->tuneS) S = c->tuneS;                            // any count: the item grid is padded to a multiple of 8 slices
     else {
-        const uint32_t want = pick_slices(c, w, groupSize, E) * sliceMult;
+        const uint32_t want = pick_slices(c, w, groupSize, E, groupTiles) * sliceMult;
         const uint32_t cap = (c->numCU * 2u) / g->tiles / 8 * 8;              // one round of workgroups
         S = cap < want ? cap : want;
     }
@@ -590,6 +607,8 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
         HIP_TRY(c, launch_bucket_mul(fmt, W, E, ga, st));
         return EFFORT_OK;
     };
+    uint32_t groupTiles = 0;
+    for (int i = 0; i < n; i++) groupTiles += (ws[i]->cols + 64 * groupE - 1) / (64 * groupE);
     begin(0);
     for (int i = 0; i < n; i++) {
         const effort_w* w = ws[i];
@@ -606,7 +625,7 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
             if (i >= n - tc) mult = (uint32_t)tailMult;
             if (tailMult >= 4 && i >= n - tc && i < n - tc / 2) mult = (uint32_t)tailMult / 2;      // two steps: ... x2 x2 x4 x4
         }
-        int rc = choose_geom(c, w, n, groupE, &g, &Wi, &Ei, mult);
+        int rc = choose_geom(c, w, n, groupE, &g, &Wi, &Ei, mult, groupTiles);
         if (rc != EFFORT_OK) return fail(c, rc, "bucketmul: no launch geometry for this shape/tuning");
         if (i == 0) { W = Wi; E = Ei; }
         else if (Wi != W || Ei != E) return fail(c, EFFORT_ERR_SHAPE, "bucketmul: the calls of a group must agree on the kernel variant");
@@ -791,6 +810,7 @@ extern "C" int effort_convert_q4(effort_ctx* c, const void* core2, int inDim, in
     if (inDim <= 0 || outDim <= 0 || outDim % 32 || (int64_t)inDim * outDim >= (1ll << 32) || !(perc >= 0.0 && perc <= 1.0))
         return fail(c, EFFORT_ERR_CONVERT, "convert_q4: outDim % 32 != 0 (q4_draft.py:299), or a matrix of 2^32 elements or more");
     const int64_t cnt = effort_q4_outlier_count(inDim, outDim, perc);
+    if (cnt >= (1ll << 31)) return fail(c, EFFORT_ERR_CONVERT, "convert_q4: 2^31 outliers or more (the candidate sort counts in int)");
     if (cnt > 0 && !outliers) return fail(c, EFFORT_ERR_ARG, "convert_q4: outliers buffer missing");
     hipSetDevice(c->device);
     HIP_TRY(c, launch_convert_q4(static_cast<const uint16_t*>(core2), (uint32_t)inDim, (uint32_t)outDim, (uint32_t)cnt, static_cast<uint16_t*>(buckets),

@@ -719,30 +719,76 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
             // 27.3 / 5.52 / 3.28; this 27.3 / 5.51 / 3.27 -- half the outlier bytes at the same speed: the Q4 multiply is
             // bound by its LDS atomics (four per 16-bit word of a bucket row), not by HBM.)
             const uint32_t parts = (nB && nB < (uint32_t)W) ? (uint32_t)W / nB : 1u;
-            for (uint32_t q = (uint32_t)wave; q < nB * parts; q += W) {
-                const uint32_t bq = q / parts, part = q % parts;
-                const uint32_t kB0 = __builtin_amdgcn_readfirstlane(sPtr[bq]), kE0 = __builtin_amdgcn_readfirstlane(sPtr[bq + 1u]);
-                const uint32_t chunk = align_up((kE0 - kB0 + parts - 1u) / parts, 64u);
-                const uint32_t kB = min(kE0, kB0 + part * chunk), kE = min(kE0, kB + chunk);
-                const uint32_t outBase = ((bFirst + bq) << bsLog) - oBeg;
-                for (uint32_t k0 = kB; k0 < kE; k0 += 64u * kOlBatch) {
-                    uint32_t ent[kOlBatch];
-#pragma unroll
-                    for (int u = 0; u < kOlBatch; u++) ent[u] = ol.entry[min(k0 + u * 64u + (uint32_t)lane, kE - 1u)];   // clamped, branch-free: the batch in flight
-#pragma unroll
-                    for (int u = 0; u < kOlBatch; u++) {
-                        const uint32_t in = ent[u] & inMask, o = outBase + ((ent[u] & 0xFFFFu) >> bitsIn);
-                        const float x = vLds ? vfull[in] : a.v[in];
-                        // two-level fixed point: the bound can sit far above the sums (one huge input), so the rounding
-                        // remainder of every product -- exact in f32 -- is summed too, 2^12 times finer (|ql| <= 2^11: an
-                        // output may have 2^19 entries before that sum could leave int32; registration refuses more)
-                        const float cs = (x * half_bits_to_float((uint16_t)(ent[u] >> 16))) * olScale;
-                        const int qh = __float2int_rn(cs);
-                        const int ql = __float2int_rn((cs - (float)qh) * 4096.0f);
-                        if (k0 + u * 64u + (uint32_t)lane < kE) { atomicAdd(&olacc[o], qh); atomicAdd(&ollo[o], ql); }
-                    }
+            // The wave's work, flattened into UNITS of up to 64 * kOlBatch entries of one (part of a) block, and software-pipelined:
+            // the entries of the next unit are asked for before the current one's are added.  (Measured before: a unit's loads
+            // are a full memory round trip each, ~2.5 us, and a wave had eight of them in a row -- 28 of the 87 us of a 16-call
+            // launch went here, at 2 TB/s.)
+            uint32_t q = (uint32_t)wave, kPos = 0, kEnd = 0, oB = 0;
+            auto advance = [&]() -> bool {                       // (uniform) moves to the wave's next non-empty unit
+                for (;;) {
+                    if (kPos < kEnd) return true;
+                    if (q >= nB * parts) return false;
+                    const uint32_t bq = q / parts, part = q % parts;
+                    const uint32_t kB0 = __builtin_amdgcn_readfirstlane(sPtr[bq]), kE0 = __builtin_amdgcn_readfirstlane(sPtr[bq + 1u]);
+                    const uint32_t chunk = align_up((kE0 - kB0 + parts - 1u) / parts, 64u);
+                    kPos = min(kE0, kB0 + part * chunk); kEnd = min(kE0, kPos + chunk);
+                    oB = ((bFirst + bq) << bsLog) - oBeg;
+                    q += W;
                 }
-            }
+            };
+            struct Unit { uint32_t k0, kE, outBase; };
+            auto fetch = [&](uint32_t (&ent)[kOlBatch], Unit& un) {  // the unit at the cursor: its entries asked for (clamped, branch-free), the cursor moved on
+                un.k0 = kPos; un.kE = kEnd; un.outBase = oB;
+#pragma unroll
+                for (int u = 0; u < kOlBatch; u++) ent[u] = ol.entry[min(un.k0 + u * 64u + (uint32_t)lane, un.kE - 1u)];
+                kPos = min(kEnd, kPos + 64u * kOlBatch);
+            };
+            // (Measured and dropped: units whose entries sit regularly on their block's outputs -- lane l on output l % 16, four
+            //  fifths of them -- summed in registers and folded with shuffles, two conflict-free atomics per unit instead of 32
+            //  four-way conflicted ones: 94.8 against 85.1 us per 16-call launch.  The phase is bound by its VALU work per entry,
+            //  not by the LDS atomics.)
+            // v is gathered from its LDS copy (inDim <= 16384) or from memory -- two instantiations of the loop, NOT one loop
+            // reading through `vLds ? vfull : a.v`: hipcc turns that select into a generic pointer and every gather into a FLAT
+            // load followed by s_waitcnt vmcnt(0) lgkmcnt(0) -- one gather at a time, ~430 cycles each, and the wait drains the
+            // next unit's prefetch as well (that was 26 of the 87 us of a 16-call launch).
+            using lds_f = __attribute__((address_space(3))) float;
+            const lds_f* const vfullL = (const lds_f*)(size_t)(uint32_t)(size_t)(__attribute__((address_space(3))) void*)vfull;
+            auto add = [&](auto fromLds, const uint32_t (&ent)[kOlBatch], const Unit& un) {
+                float x[kOlBatch];
+#pragma unroll
+                for (int u = 0; u < kOlBatch; u++) {                              // all the gathers of the unit go out together
+                    const uint32_t in = ent[u] & inMask;
+                    if constexpr (decltype(fromLds)::value) x[u] = vfullL[in]; else x[u] = a.v[in];
+                }
+#pragma unroll
+                for (int u = 0; u < kOlBatch; u++) {
+                    const uint32_t o = un.outBase + ((ent[u] & 0xFFFFu) >> bitsIn);
+                    // two-level fixed point: the bound can sit far above the sums (one huge input), so the rounding
+                    // remainder of every product -- exact in f32 -- is summed too, 2^12 times finer (|ql| <= 2^11: an
+                    // output may have 2^19 entries before that sum could leave int32; registration refuses more)
+                    const float cs = (x[u] * half_bits_to_float((uint16_t)(ent[u] >> 16))) * olScale;
+                    const int qh = __float2int_rn(cs);
+                    const int ql = __float2int_rn((cs - (float)qh) * 4096.0f);
+                    if (un.k0 + u * 64u + (uint32_t)lane < un.kE) { atomicAdd(&olacc[o], qh); atomicAdd(&ollo[o], ql); }
+                }
+            };
+            auto run_units = [&](auto fromLds) {
+                if (!advance()) return;
+                uint32_t entA[kOlBatch], entB[kOlBatch];
+                Unit ua, ub;
+                fetch(entA, ua);
+                for (;;) {
+                    bool more = advance();
+                    if (more) fetch(entB, ub);
+                    add(fromLds, entA, ua);
+                    if (!more) break;
+                    more = advance();
+                    if (more) fetch(entA, ua);
+                    add(fromLds, entB, ub);
+                    if (!more) break;
+                }
+            };
+            if (vLds) run_units(std::true_type{}); else run_units(std::false_type{});
             __syncthreads();
         }
     }
@@ -924,7 +970,8 @@ template <int FMT, int E, int W, bool FUSED, bool COMPACT = false>
 __global__ __launch_bounds__(64 * W, (W <= 8 ? EFFORT_MIN_WAVES_PER_EU : 4)) void bucket_mul_kernel(const GroupKArgs ga) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ uint32_t s_item;
-    __shared__ uint32_t s_next[2];                         // the item after the current one, and the generation (item count) it was pulled in
+    __shared__ unsigned long long s_next;                  // the item after the current one | the generation (item count) it was pulled in << 32: ONE word,
+                                                           // so that a wave polling mid-loop can never pair a new generation with a stale item
     const uint32_t total = ga.wgEnd[ga.count - 1] + ga.cutJobs;
     uint32_t cachedCall = 0xFFFFFFFFu; float cachedCutoff = 0.0f;
     const uint32_t x = blockIdx.x & 7u;                    // block b sits on XCD b%8; item i wants XCD i%8
@@ -961,7 +1008,7 @@ __global__ __launch_bounds__(64 * W, (W <= 8 ? EFFORT_MIN_WAVES_PER_EU : 4)) voi
     uint32_t par = 0;                                      // vblk buffer of the current item
     bool staged = false;                                   // (per wave) its share of the item's stage loads is already in flight / landed
     uint32_t gen = 0;                                      // items this workgroup has worked
-    if (threadIdx.x == 0) s_next[1] = 0u;
+    if (threadIdx.x == 0) __hip_atomic_store(&s_next, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     uint32_t item = ga.persistent ? pull_sync() : blockIdx.x;
     while (item < total) {
         if (item < ga.cutJobs) {                           // uniform: a cutoff job (the queues hand these out first)
@@ -978,12 +1025,11 @@ __global__ __launch_bounds__(64 * W, (W <= 8 ? EFFORT_MIN_WAVES_PER_EU : 4)) voi
         bool stagedNext = false;
         mul_item<FMT, E, W, FUSED, COMPACT>(ga, item - ga.cutJobs, ref, smem, lp, cachedCall, cachedCutoff, par, staged, gen == 1u && (ga.ablate & 512u) != 0u /* (measured: evaluating the first item's cutoff locally instead of waiting for the job is 1 us slower per 32-call launch; kept as an ablation) */, [&]() -> bool {
             if (!ga.persistent) return true;
-            if (threadIdx.x == 0) {                                // wave 0's first call: pull, publish
-                s_next[0] = pull();
-                s_next[1] = gen;
-            }
-            if (__builtin_amdgcn_readfirstlane(s_next[1]) != gen) return false;   // no answer yet
-            const uint32_t next = __builtin_amdgcn_readfirstlane(s_next[0]);
+            if (threadIdx.x == 0)                                  // wave 0's first call: pull, publish (item and generation in one store)
+                __hip_atomic_store(&s_next, ((unsigned long long)gen << 32) | (unsigned long long)pull(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const unsigned long long nx = __hip_atomic_load(&s_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (__builtin_amdgcn_readfirstlane((uint32_t)(nx >> 32)) != gen) return false;   // no answer yet
+            const uint32_t next = __builtin_amdgcn_readfirstlane((uint32_t)nx);
             ItemRef nref;
             if (kPipe && !(ga.ablate & 128u) && next >= ga.cutJobs && next < total && locate_item(ga, next - ga.cutJobs, nref)) {
                 int tid0 = threadIdx.x;
@@ -994,7 +1040,7 @@ __global__ __launch_bounds__(64 * W, (W <= 8 ? EFFORT_MIN_WAVES_PER_EU : 4)) voi
             return true;
         });
         // (mul_item's barriers lie between wave 0's publication and this read)
-        item = ga.persistent ? __builtin_amdgcn_readfirstlane(s_next[0]) : total;
+        item = ga.persistent ? __builtin_amdgcn_readfirstlane((uint32_t)__hip_atomic_load(&s_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) : total;
         staged = stagedNext;
         par ^= 1u;
     }

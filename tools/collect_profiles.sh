@@ -1,27 +1,45 @@
 #!/bin/bash
 # Regenerates everything under profiles/ on a GPU box (run from the repo root through gpurun; outputs land in gpurun_out/).
-#   gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh'   then copy gpurun_out/${ROUND}_* into profiles/
+#   gpurun --timeout 2400 -- 'ROUND=r03 bash tools/collect_profiles.sh'   then copy gpurun_out/${ROUND}_* into profiles/
 set -u
-R=${ROUND:-r02}
+R=${ROUND:-r03}
 O=gpurun_out
 mkdir -p $O
 export TMPDIR=/tmp
-rm -rf $O/prof_bench $O/prof_bench1 $O/prof_dec $O/pmc_fetch $O/pmc_write
-# HBM-side traffic of the timed configuration (separate --pmc passes, kernel-trace only: MI355X_MICROARCH.md)
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python bench.py --steps 48 --warmup 8 --headline-only > $O/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python bench.py --steps 48 --warmup 8 --headline-only > $O/pmc_write.log 2>&1
-python tools/pmc_traffic.py --fetch $O/pmc_fetch --write $O/pmc_write --group 32 --effort 0.25 --out $O/${R}_pmc_traffic.json
-cp $O/${R}_pmc_traffic.json profiles/${R}_pmc_traffic.json          # bench.py reads it back as roofline.traffic
-# kernel durations: the timed job (4 launches in flight: each launch lasts ~4x the chip's time per launch) ...
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -- python bench.py --steps 200 --warmup 50 --headline-only > $O/prof_bench.log 2>&1
+H="python bench.py --steps 96 --warmup 16 --headline-only"
+rm -rf $O/prof_*
+# 1. kernel trace of the timed job (4 launches in flight through one context, every step on its own 32 matrices): per-kernel
+#    stats AND the span fold (first start -> last end of the back-to-back launches: what the chip did per launch)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -- $H > $O/prof_bench.json 2> $O/prof_bench.log
 cp "$(ls -t $O/prof_bench/*/*kernel_stats.csv | head -1)" $O/${R}_rocprofv3_kernel_stats_bench.csv
-# ... and the same job with ONE launch in flight (kernels do not overlap: the launch duration of roofline.single_stream)
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench1 -- python bench.py --steps 200 --warmup 50 --headline-only --streams 1 > $O/prof_bench1.log 2>&1
+BPL=$(python -c "import json;print(json.loads(open('$O/prof_bench.json').read().strip().split('\n')[-1])['bytes_per_launch'])")
+python tools/span.py --trace $O/prof_bench --bytes-per-launch $BPL --out $O/${R}_span.json --label "bench.py headline: 4 launches in flight (effort_set_overlap), 4 x 32 disjoint matrices"
+# 2. the same with ONE launch in flight: kernels do not overlap, the stats' average duration is the launch duration
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench1 -- $H --streams 1 > $O/prof_bench1.json 2> $O/prof_bench1.log
 cp "$(ls -t $O/prof_bench1/*/*kernel_stats.csv | head -1)" $O/${R}_rocprofv3_kernel_stats_bench_single_stream.csv
-python bench.py > $O/${R}_bench.json 2> $O/bench.log
-tail -c 600 $O/${R}_bench.json
+python tools/span.py --trace $O/prof_bench1 --bytes-per-launch $BPL --out $O/${R}_span_single_stream.json --label "one launch in flight"
+# 3. round 2's job (every step in flight on the SAME 32 matrices) for the comparison
+rocprofv3 --kernel-trace --output-format csv -d $O/prof_shared -- $H --headline-shared > $O/prof_shared.json 2> $O/prof_shared.log
+python tools/span.py --trace $O/prof_shared --bytes-per-launch $BPL --out $O/${R}_span_shared_matrices.json --label "4 launches in flight on the SAME 32 matrices (round 2's job)"
+# 4. HBM-side traffic and L2 hit / miss counters (separate --pmc passes, kernel-trace only: MI355X_MICROARCH.md)
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/prof_fetch -- $H > /dev/null 2> $O/pmc_fetch.log
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/prof_write -- $H > /dev/null 2> $O/pmc_write.log
+python tools/pmc_traffic.py --fetch $O/prof_fetch --write $O/prof_write --group 32 --effort 0.25 --out $O/${R}_pmc_traffic.json
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $O/prof_tcc25 -- $H > /dev/null 2> $O/pmc_tcc25.log
+python tools/pmc_cache.py --dir $O/prof_tcc25 --out $O/${R}_pmc_tcc_effort25.json --label "effort 0.25, 4 in flight, disjoint matrices"
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $O/prof_tcc10 -- $H --effort 0.1 > /dev/null 2> $O/pmc_tcc10.log
+python tools/pmc_cache.py --dir $O/prof_tcc10 --out $O/${R}_pmc_tcc_effort10.json --label "effort 0.10, 4 in flight, disjoint matrices"
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $O/prof_tcc25s -- $H --headline-shared > /dev/null 2> $O/pmc_tcc25s.log
+python tools/pmc_cache.py --dir $O/prof_tcc25s --out $O/${R}_pmc_tcc_effort25_shared_matrices.json --label "effort 0.25, 4 in flight on the SAME 32 matrices"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/prof_fetchs -- $H --headline-shared > /dev/null 2> $O/pmc_fetchs.log
+python tools/pmc_traffic.py --fetch $O/prof_fetchs --group 32 --effort 0.25 --out $O/${R}_pmc_traffic_shared_matrices.json
+rm -rf $O/prof_bench $O/prof_bench1 $O/prof_shared $O/prof_fetch $O/prof_write $O/prof_tcc25 $O/prof_tcc10 $O/prof_tcc25s $O/prof_fetchs
+# 5. the bench line as the driver runs it, and at the default length
+python bench.py --steps 20 --warmup 5 > $O/${R}_bench_driver_style.json 2> $O/bench_driver_style.log
+tail -c 400 $O/${R}_bench_driver_style.json
+# 6. decode loop: tokens/s and per-kernel summary
 python tools/decode_bench.py --tokens 64 > $O/${R}_decode_bench.json 2> $O/decode.log
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_dec -- python tools/decode_bench.py --tokens 64 --efforts 0.25 > $O/prof_dec.log 2>&1
 cp "$(ls -t $O/prof_dec/*/*kernel_stats.csv | head -1)" $O/${R}_rocprofv3_kernel_stats_decode.csv
-rm -rf $O/prof_bench $O/prof_bench1 $O/prof_dec $O/pmc_fetch $O/pmc_write
-ls -la $O
+rm -rf $O/prof_dec
+ls -la $O | grep ${R}_

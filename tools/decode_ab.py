@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--tokens", type=int, default=48)
     ap.add_argument("--efforts", default="0.25,1.0")
     ap.add_argument("--fused-glue", type=int, default=0)
+    ap.add_argument("--split", type=int, default=0, help="also time every knob set with the cutoffs in a kernel of their own")
     a = ap.parse_args()
     torch.cuda.set_device(0)
     model = Model.random(MistralConfig(numLayers=a.layers), seed=1)
@@ -30,13 +31,18 @@ def main():
     dec.g.set_dense_backend(False)
     _, dt_d, _ = dec.run(prompt, a.tokens, dense=True)
     out["dense_hip_kernel_tokens_per_s"] = round(1 / dt_d, 1)
+    knobs = [{}, {"EFFORT_X_NARROW": "0"}, {"EFFORT_X_FULL": "0"}, {"EFFORT_X_GT": "0"}, {"EFFORT_X_NARROW": "0", "EFFORT_X_GT": "0"}, {}]
     for e in (float(x) for x in a.efforts.split(",")):
-        for pf in (0, 1, 0, 1):
-            if hasattr(dec.g, "set_prefetch"):
-                dec.g.set_prefetch(bool(pf))
-            dec._graphs.clear()
-            _, dt_e, _ = dec.run(prompt, a.tokens, effort=e)
-            out.setdefault(f"effort {e}", []).append({"prefetch": pf, "tokens_per_s": round(1 / dt_e, 1), "vs_dense": round(dt_d / dt_e, 3)})
+        for kn in knobs:
+            for k in ("EFFORT_X_NARROW", "EFFORT_X_FULL", "EFFORT_X_GT"):
+                os.environ.pop(k, None)
+            os.environ.update(kn)
+            for split in ((0, 1) if a.split else (0,)):
+                dec.g.set_split_cutoff(bool(split))
+                dec._graphs.clear()
+                _, dt_e, _ = dec.run(prompt, a.tokens, effort=e)
+                out.setdefault(f"effort {e}", []).append({"knobs": kn, "split_cutoff": split, "tokens_per_s": round(1 / dt_e, 1), "vs_dense": round(dt_d / dt_e, 3)})
+        dec.g.set_split_cutoff(False)
     print(json.dumps(out))
 
 

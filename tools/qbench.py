@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--streams", type=int, default=1, help="spread the launches of a step round-robin over K streams / contexts")
     ap.add_argument("--steps-per-graph", type=int, default=1, help="steps captured into one graph")
     ap.add_argument("--overlap", type=int, default=1, help="K > 1: ONE context with effort_set_overlap(K); the steps of a graph write K rotating output sets")
+    ap.add_argument("--no-outliers", type=int, default=0, help="Q4: register the bundles without their outlier tables")
     ap.add_argument("--split", type=int, default=0, help="1: the cutoffs in a kernel of their own before the multiply (the device-clock span then covers the multiply alone)")
     args = ap.parse_args()
     inDim, outDim = (int(x) for x in args.shape.split("x"))
@@ -37,6 +38,10 @@ def main():
     dev = torch.device("cuda", 0)
     g = ea.gpu(0)
     ews = make_weights(ea, args.mats, inDim, outDim, 1234, dev, keep_core=False, q4=bool(args.q4))
+    if args.q4 and args.no_outliers:
+        ews = [ea.ExpertWeights(e.buckets, e.stats, e.probes, inSize=inDim, outSize=outDim, q4=True) for e in ews]
+        for e in ews:
+            e.handle
     gen = torch.Generator(device=dev)
     gen.manual_seed(42)
     v = torch.randn(inDim, generator=gen, device=dev)
