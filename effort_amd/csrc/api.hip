@@ -399,8 +399,8 @@ extern "C" void effort_weights_free(effort_w* w) {
 // ---- launch geometry ----------------------------------------------------------------------------
 static bool supported(int W, int E) {
     // must match EFFORT_GEOMS in bucket_mul.hip
-    return (W == 16 && (E == 1 || E == 2 || E == 4 || E == 8)) || (W == 8 && (E == 1 || E == 2 || E == 4 || E == 8)) ||
-           (W == 4 && (E == 1 || E == 2 || E == 4 || E == 8)) || (W == 2 && (E == 4 || E == 8));
+    return (W == 16 && (E == 1 || E == 2 || E == 4)) || (W == 8 && (E == 1 || E == 2 || E == 4)) ||
+           (W == 4 && (E == 1 || E == 2 || E == 4)) || (W == 2 && E == 4);
 }
 
 // Row slices per call when the launch carries `groupSize` calls and a lane owns E columns.  Measured on MI355X
@@ -413,11 +413,10 @@ static uint32_t pick_slices(const effort_ctx* c, const effort_w* w, int groupSiz
     if (groupSize >= 8) return lo;
     // (64-column tiles -- narrow matrices, see pick_elems -- are worked best at one item per CU: measured, 14336 -> 4096 lone, 64 slices
     //  26.9 us against 29.2 at 48)
-    const bool fullTarget = E == 1 && !(getenv("EFFORT_X_FULL") && atoi(getenv("EFFORT_X_FULL")) == 0);
-    const uint32_t target = fullTarget ? (uint32_t)c->numCU : (uint32_t)c->numCU * 3u / 4u;
+    const uint32_t target = E == 1 ? (uint32_t)c->numCU : (uint32_t)c->numCU * 3u / 4u;
     // the launch's items come from ALL its calls: with the column tiles of the whole group known (Wq | Wk | Wv: 4 + 1 + 1 at
     // E = 1) every call takes target / tiles slices; without, the calls are taken as equals
-    const uint32_t allTiles = (groupTiles && !(getenv("EFFORT_X_GT") && atoi(getenv("EFFORT_X_GT")) == 0)) ? groupTiles : (uint32_t)groupSize * tiles;
+    const uint32_t allTiles = groupTiles ? groupTiles : (uint32_t)groupSize * tiles;
     uint32_t S = (target / allTiles + 4u) / 8u * 8u;       // nearest multiple of 8
     if (S < lo) S = lo;
     if (S > hi) S = hi;
@@ -464,7 +463,7 @@ static int pick_elems(const effort_ctx* c, Format fmt, int n, const effort_w* co
     // own last arriver (measured, us per launch at 25 %: Wq|Wk|Wv 21.2 vs 23.8, 14336 -> 4096 lone 26.6-27.5 vs 29.7)
     bool narrow = true;
     for (int i = 0; i < n; i++) narrow = narrow && (!ws[i] || ws[i]->cols <= 256u);
-    if (narrow && f1 >= 0.8 * best && !(getenv("EFFORT_X_NARROW") && atoi(getenv("EFFORT_X_NARROW")) == 0)) return 1;   // (X knobs: A/B of the heuristics, tools only)
+    if (narrow && f1 >= 0.8 * best) return 1;
     return (i2 * 10u < numCU * 3u / 4u * 6u && items(1) > i2) ? 1 : 2;
 }
 

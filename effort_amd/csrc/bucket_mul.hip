@@ -111,15 +111,6 @@ template <> struct Piece<4> {
     __device__ __forceinline__ uint32_t word(int j) const { return (w[j >> 1] >> (16 * (j & 1))) & 0xFFFFu; }
     __device__ __forceinline__ uint32_t dword(int j) const { return w[j >> 1]; }
 };
-template <> struct Piece<8> {
-    uint32_t w[4];
-    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
-        auto t = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, kRowAux); w[0] = t[0]; w[1] = t[1]; w[2] = t[2]; w[3] = t[3];
-    }
-    __device__ __forceinline__ uint32_t word(int j) const { return (w[j >> 1] >> (16 * (j & 1))) & 0xFFFFu; }
-    __device__ __forceinline__ uint32_t dword(int j) const { return w[j >> 1]; }
-};
-
 __host__ __device__ inline uint32_t align_up(uint32_t x, uint32_t a) { return (x + a - 1) / a * a; }
 
 // Q4 outliers: an item adds the outliers of 1/slices of its tile's outputs to its slab (phase O below).
@@ -573,7 +564,9 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     // The LDS byte address is built with v_bfe_u32 + v_lshl_add_u32 (hipcc otherwise spends three VALU ops on it).
     using lds_i = __attribute__((address_space(3))) int;
     const uint32_t accB = (uint32_t)(size_t)(lds_i*)(acc + lane);
-    constexpr int kShift = (E == 1 ? 8 : E == 2 ? 9 : E == 4 ? 10 : 11);      // log2(E * 64 lanes * 4 bytes)
+    constexpr int kShift = (E == 1 ? 8 : E == 2 ? 9 : 10);      // log2(E * 64 lanes * 4 bytes)
+    // (Measured and dropped: E = 6 -- 12-byte pieces, 384-column tiles, so that the 688 columns of 11008 outputs make TWO tiles and a
+    //  32-call launch exactly one item per persistent workgroup -- 169 against 158 us per launch; E = 8: 204-218 against 183.)
     auto row = [&](const Piece<E>& pc, float dd) {
         if (FMT == kFp16) {
             // bucketMul.metal:100-106: v = d.x*float(w) with the position bits left in w; acc[pos] += v
@@ -1097,7 +1090,7 @@ static hipError_t launch_mul_t(const GroupKArgs& ga, hipStream_t st) {
     return hipGetLastError();
 }
 
-#define EFFORT_GEOMS(X) X(16, 1) X(16, 2) X(16, 4) X(16, 8) X(8, 1) X(8, 2) X(8, 4) X(8, 8) X(4, 1) X(4, 2) X(4, 4) X(4, 8) X(2, 4) X(2, 8)
+#define EFFORT_GEOMS(X) X(16, 1) X(16, 2) X(16, 4) X(8, 1) X(8, 2) X(8, 4) X(4, 1) X(4, 2) X(4, 4) X(2, 4)
 
 template <int FMT>
 static hipError_t launch_mul_fmt(int W, int E, const GroupKArgs& a, hipStream_t st) {

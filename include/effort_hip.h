@@ -272,7 +272,7 @@ EFFORT_API int effort_cosine(effort_ctx* ctx, const float* a_dev, const float* b
 /* ---- tuning knobs (not part of the reference surface) ------------------------------------------ */
 
 /* Override the launch geometry heuristics of the multiply kernel: waves per workgroup (4, 8 or 16),
- * elements per lane (1, 2, 4 or 8) and number of row slices (0 = heuristic).  Returns EFFORT_ERR_ARG
+ * elements per lane (1, 2 or 4) and number of row slices (0 = heuristic).  Returns EFFORT_ERR_ARG
  * for unsupported combinations. */
 EFFORT_API int effort_set_tuning(effort_ctx* ctx, int wavesPerGroup, int elemsPerLane, int rowSlices);
 /* split = 1: evaluate findCutoff32 in its own one-workgroup launch ahead of the multiply kernel instead of

@@ -1,0 +1,129 @@
+// rowbench -- what HBM delivers for bucketMul's ACCESS PATTERN, without any of its arithmetic (tools only):
+// 32 matrices of 65536 bucket rows, 1408 bytes apart (4096 x 11008 at the line-aligned pitch), a quarter of the rows kept
+// (rank-major rows r = rank * 4096 + j; a row is kept when |v_j| clears a threshold that grows with the rank: the structure
+// of a real selection -- inputs with large |v| keep many ranks -- not a Bernoulli mask).  512 persistent workgroups of 8
+// waves pull items from a queue and read their kept rows with 16 loads in flight per lane:
+//   mode 0  an item = (matrix, slice of 512 inputs, column tile): the 512-byte piece of every kept row   [the kernel's E = 4 tiles]
+//   mode 1  an item = (matrix, slice of 256 inputs): whole rows, 1376 bytes                               [full-row items]
+//   mode 2  like 0 with 768 + 608-byte pieces (two tiles)                                                 [E = 6]
+//   mode 3  every row of the slice, whole (dense streaming of the same buffers: the ceiling)
+// Prints TB/s of bytes actually requested.    hipcc --offload-arch=gfx950 -O3 -o build/rowbench tools/rowbench.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include <vector>
+#include <random>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+constexpr uint32_t kIn = 4096, kRanks = 16, kRowsPerMat = kIn * kRanks, kPitch = 1408, kRowBytes = 1376, kMats = 32;
+
+struct Item { uint32_t first, count, off, bytes; };       // rows list[first .. first+count), byte window [off, off+bytes) of each row
+
+// One row window per wave-load where it fits: 8 bytes per lane for 512-byte pieces (the kernel's dwordx2 loads), 12 for 768, and a
+// whole 1376-byte row as a 16-byte load (1024 bytes) plus an 8-byte load of its last 352 bytes (44 lanes).  16 rows in flight per wave.
+template <int MODE>
+__global__ __launch_bounds__(512, 4) void read_kernel(const char* __restrict__ base, const uint32_t* __restrict__ list, const Item* __restrict__ items,
+                                                       uint32_t nItems, uint32_t* __restrict__ queue, uint32_t* __restrict__ sink) {
+    __shared__ uint32_t s_item;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t acc = 0;
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    typedef uint32_t u3 __attribute__((ext_vector_type(3)));
+    typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+    for (;;) {
+        if (threadIdx.x == 0) s_item = atomicAdd(queue, 1u);
+        __syncthreads();
+        const uint32_t it = s_item;
+        __syncthreads();
+        if (it >= nItems) break;
+        const Item I = items[it];
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, -1, 0x00020000);
+        constexpr int R = 16;
+        for (uint32_t r0 = wave * R; r0 < I.count; r0 += 8u * R) {
+            uint32_t rows[R];
+#pragma unroll
+            for (int u = 0; u < R; u++) rows[u] = list[I.first + min(r0 + (uint32_t)u, I.count - 1u)] * kPitch;
+            if constexpr (MODE == 0) {
+                const uint32_t o = I.off + min((uint32_t)lane * 8u, I.bytes - 8u);
+                u2 x[R];
+#pragma unroll
+                for (int u = 0; u < R; u++) x[u] = __builtin_amdgcn_raw_buffer_load_b64(rs, o, __builtin_amdgcn_readfirstlane(rows[u]), 0);
+#pragma unroll
+                for (int u = 0; u < R; u++) acc ^= x[u][0] ^ x[u][1];
+            } else if constexpr (MODE == 2) {
+                const uint32_t o = I.off + min((uint32_t)lane * 12u, I.bytes - 12u);
+                u3 x[R];
+#pragma unroll
+                for (int u = 0; u < R; u++) x[u] = __builtin_amdgcn_raw_buffer_load_b96(rs, o, __builtin_amdgcn_readfirstlane(rows[u]), 0);
+#pragma unroll
+                for (int u = 0; u < R; u++) acc ^= x[u][0] ^ x[u][1] ^ x[u][2];
+            } else {
+                const uint32_t o = (uint32_t)lane * 16u, o2 = 1024u + min((uint32_t)lane, 43u) * 8u;
+                u4 x[R / 2]; u2 y[R / 2];
+#pragma unroll
+                for (int h = 0; h < 2; h++) {                                    // (two halves of 8 rows: 2 x 8 x 6 registers)
+#pragma unroll
+                    for (int u = 0; u < R / 2; u++) {
+                        x[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, o, __builtin_amdgcn_readfirstlane(rows[h * (R / 2) + u]), 0);
+                        y[u] = __builtin_amdgcn_raw_buffer_load_b64(rs, o2, __builtin_amdgcn_readfirstlane(rows[h * (R / 2) + u]), 0);
+                    }
+#pragma unroll
+                    for (int u = 0; u < R / 2; u++) acc ^= x[u][0] ^ x[u][1] ^ x[u][2] ^ x[u][3] ^ y[u][0] ^ y[u][1];
+                }
+            }
+        }
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+
+int main(int argc, char** argv) {
+    const size_t bytes = (size_t)kMats * kRowsPerMat * kPitch;
+    char* d_base; CK(hipMalloc(&d_base, bytes)); CK(hipMemset(d_base, 1, bytes));
+    std::mt19937 rng(1);
+    std::normal_distribution<float> nd;
+    for (int mode = 0; mode < 4; mode++) {
+        std::vector<uint32_t> list; std::vector<Item> items;
+        size_t want = 0;
+        for (uint32_t m = 0; m < kMats; m++) {
+            std::vector<float> av(kIn);
+            for (auto& x : av) x = fabsf(nd(rng));
+            const uint32_t sliceIn = mode == 1 || mode == 3 ? 256u : 512u;
+            for (uint32_t s0 = 0; s0 < kIn; s0 += sliceIn) {
+                const uint32_t first = (uint32_t)list.size();
+                for (uint32_t rank = 0; rank < kRanks; rank++)
+                    for (uint32_t j = s0; j < s0 + sliceIn; j++) {
+                        // threshold per rank: P(|N| > t) from 0.95 at rank 0 falling to ~0.001 at rank 15; averages ~0.25
+                        const float t = 0.06f + 0.22f * (float)rank * (1.0f + 0.035f * (float)rank);
+                        if (mode == 3 || av[j] > t) list.push_back(m * kRowsPerMat + rank * kIn + j);
+                    }
+                const uint32_t count = (uint32_t)list.size() - first;
+                if (!count) continue;
+                if (mode == 0) for (uint32_t t = 0; t < 3; t++) { const uint32_t b = t < 2 ? 512u : kRowBytes - 1024u; items.push_back({first, count, t * 512u, b}); want += (size_t)count * b; }
+                else if (mode == 2) for (uint32_t t = 0; t < 2; t++) { const uint32_t b = t < 1 ? 768u : kRowBytes - 768u; items.push_back({first, count, t * 768u, b}); want += (size_t)count * b; }
+                else { items.push_back({first, count, 0u, kRowBytes}); want += (size_t)count * kRowBytes; }
+            }
+        }
+        uint32_t *d_list, *d_queue, *d_sink; Item* d_items;
+        CK(hipMalloc(&d_list, list.size() * 4)); CK(hipMemcpy(d_list, list.data(), list.size() * 4, hipMemcpyHostToDevice));
+        CK(hipMalloc(&d_items, items.size() * sizeof(Item))); CK(hipMemcpy(d_items, items.data(), items.size() * sizeof(Item), hipMemcpyHostToDevice));
+        CK(hipMalloc(&d_queue, 4)); CK(hipMalloc(&d_sink, 4));
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        float best = 1e9f;
+        for (int rep = 0; rep < 6; rep++) {
+            CK(hipMemset(d_queue, 0, 4));
+            CK(hipEventRecord(e0));
+            if (mode == 0) hipLaunchKernelGGL(read_kernel<0>, dim3(512), dim3(512), 0, 0, d_base, d_list, d_items, (uint32_t)items.size(), d_queue, d_sink);
+            else if (mode == 2) hipLaunchKernelGGL(read_kernel<2>, dim3(512), dim3(512), 0, 0, d_base, d_list, d_items, (uint32_t)items.size(), d_queue, d_sink);
+            else hipLaunchKernelGGL(read_kernel<1>, dim3(512), dim3(512), 0, 0, d_base, d_list, d_items, (uint32_t)items.size(), d_queue, d_sink);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            if (rep) best = fminf(best, ms);
+        }
+        const char* names[4] = {"512-byte pieces (3 tiles), 512-input slices", "whole rows, 256-input slices", "768/608-byte pieces (2 tiles), 512-input slices", "dense: every row, whole"};
+        printf("mode %d  %-52s items %6zu  rows kept %.3f  %7.1f MB  %8.1f us  %.2f TB/s\n", mode, names[mode], items.size(),
+               mode == 3 ? 1.0 : (double)list.size() / ((double)kMats * kRowsPerMat) / (mode == 1 ? 1.0 : 1.0), want / 1e6, best * 1e3, want / (best * 1e-3) / 1e12);
+        CK(hipFree(d_list)); CK(hipFree(d_items)); CK(hipFree(d_queue)); CK(hipFree(d_sink));
+    }
+    return 0;
+}

@@ -22,7 +22,7 @@ def main():
     ap.add_argument("--trace", required=True)
     ap.add_argument("--bytes-per-launch", type=float, required=True)
     ap.add_argument("--kernel", default="bucket_mul_kernel")
-    ap.add_argument("--gap-us", type=float, default=300.0)
+    ap.add_argument("--gap-us", type=float, default=2000.0)
     ap.add_argument("--min-launches", type=int, default=100)
     ap.add_argument("--peak-gbps", type=float, default=8000.0)
     ap.add_argument("--out", required=True)
