@@ -161,7 +161,11 @@ class Decoder:
         # rmsNorm, silu and the residual adds folded into the multiplies (effort_bucketmul_group_fused): 5 launches per layer
         # instead of 8.  Dense-FFN models only; the dense baseline keeps the separate glue kernels.  Off by default: measured
         # 4.45 vs 4.39 ms/token -- the folded work sits on every workgroup's critical path and costs what the launches saved.
-        self.fused_glue = bool(fused_glue) and all(L.ffnGate is None for L in model.layers)
+        # fused_glue may also name WHICH steps fold into the multiplies: any of "norm" (rmsNorm into wq|wk|wv and w1|w3), "gate"
+        # (silu into w2), "resid" (the residual adds after wo and w2); True = all three
+        parts = ("norm", "gate", "resid") if fused_glue is True else tuple(fused_glue or ())
+        self.fuse = frozenset(parts) if all(L.ffnGate is None for L in model.layers) else frozenset()
+        self.fused_glue = bool(self.fuse)
         self.model, self.maxTokens = model, int(maxTokens)
         dev = model.norm.device
         self.g = _gpu(dev.index)
@@ -202,18 +206,46 @@ class Decoder:
         ck(lib.effort_fetch_row(g.ctx, _p(m.tokEmbeddings), _p(self.tokId), _p(self.h), cfg.stateDim), "fetch_row")
         delta = None
         if self.fused_glue and not dense:
+            fn, fg, fr = "norm" in self.fuse, "gate" in self.fuse, "resid" in self.fuse
             for n, L in enumerate(m.layers):
-                bucketMulGroup([(self.h, L.wq, None, self.xq_temp, effort, {"norm": L.attnNorm}),            # :121-134
-                                (self.h, L.wk, None, self.xk_temp, effort, {"norm": L.attnNorm}),
-                                (self.h, L.wv, None, self.xv_temp, effort, {"norm": L.attnNorm})])
+                if fn and delta is None:                       # (a pending residual add needs the glue kernel: "norm" folds fully only with "resid")   :121-134
+                    bucketMulGroup([(self.h, L.wq, None, self.xq_temp, effort, {"norm": L.attnNorm}),
+                                    (self.h, L.wk, None, self.xk_temp, effort, {"norm": L.attnNorm}),
+                                    (self.h, L.wv, None, self.xv_temp, effort, {"norm": L.attnNorm})])
+                else:
+                    ck(lib.effort_add_rmsnorm_mul(g.ctx, _p(self.h), _p(delta), _p(L.attnNorm), _p(self.h_norm), cfg.stateDim), "rmsnorm")
+                    delta = None
+                    muls(self.h_norm, [(L.wq, self.xq_temp), (L.wk, self.xk_temp), (L.wv, self.xv_temp)])
                 ck(lib.effort_rope_attention(g.ctx, _p(self.xq_temp), _p(self.xk_temp), _p(self.xv_temp), _p(self.kCache[n]), _p(self.vCache[n]),
                                              _p(self.pos), _p(self.attnOutput), cfg.numHeads, cfg.numHeadsKV, cfg.headDim, self.maxTokens,
                                              C.c_float(cfg.ropeBase)), "rope_attention")
-                bucketMulGroup([(self.attnOutput, L.wo, None, self.h, effort, {"resid": self.h})])             # :170-172, h += wo(attn)
-                bucketMulGroup([(self.h, L.w1, None, self.x1, effort, {"norm": L.ffnNorm}),                  # :173-179
-                                (self.h, L.w3, None, self.x3, effort, {"norm": L.ffnNorm})])
-                bucketMulGroup([(self.x1, L.w2, None, self.h, effort, {"gate": self.x3, "resid": self.h})])    # :181-183, h += w2(silu)
-            ck(lib.effort_add_rmsnorm_mul(g.ctx, _p(self.h), None, _p(m.norm), _p(self.outNormed), cfg.stateDim), "rmsnorm")
+                if fr:
+                    bucketMulGroup([(self.attnOutput, L.wo, None, self.h, effort, {"resid": self.h})])         # :170-172, h += wo(attn)
+                    d2 = None
+                else:
+                    muls(self.attnOutput, [(L.wo, self.attnFfnOut)])
+                    d2 = self.attnFfnOut
+                if fn and d2 is None:
+                    bucketMulGroup([(self.h, L.w1, None, self.x1, effort, {"norm": L.ffnNorm}),              # :173-179
+                                    (self.h, L.w3, None, self.x3, effort, {"norm": L.ffnNorm})])
+                else:
+                    ck(lib.effort_add_rmsnorm_mul(g.ctx, _p(self.h), _p(d2), _p(L.ffnNorm), _p(self.fxn), cfg.stateDim), "rmsnorm")
+                    muls(self.fxn, [(L.w1, self.x1), (L.w3, self.x3)])
+                if fg:
+                    src, extra = self.x1, {"gate": self.x3}
+                else:
+                    ck(lib.effort_silu_mul(g.ctx, _p(self.x1), _p(self.x3), _p(self.x2), cfg.hiddenDim), "silu")
+                    src, extra = self.x2, {}
+                if fr:
+                    bucketMulGroup([(src, L.w2, None, self.h, effort, dict(extra, resid=self.h))])            # :181-183, h += w2(silu)
+                    delta = None
+                else:
+                    if extra:
+                        bucketMulGroup([(src, L.w2, None, self.ffnOut, effort, extra)])
+                    else:
+                        muls(src, [(L.w2, self.ffnOut)])
+                    delta = self.ffnOut
+            ck(lib.effort_add_rmsnorm_mul(g.ctx, _p(self.h), _p(delta), _p(m.norm), _p(self.outNormed), cfg.stateDim), "rmsnorm")
             basicMul(self.outNormed, m.output, self.logits)                                           # :222
             ck(lib.effort_argmax(g.ctx, _p(self.logits), cfg.vocab, _p(self.tokId), _p(self.pos), _p(self.history), int(self.history.numel())), "argmax")
             return

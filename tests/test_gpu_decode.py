@@ -194,3 +194,42 @@ def test_steps_past_the_cache_write_nothing_and_are_reported(small_model, fused_
     dec.g.check(_lib.lib().effort_argmax(dec.g.ctx, p(dec.logits), small_model.cfg.vocab, p(dec.tokId), p(dec.pos), p(dec.history), 4), "argmax")
     dec.g.eval()
     assert int(dec.tokId.item()) == 0 and dec.status() == 2
+
+
+def test_in_graph_multiplies_match_the_oracle(small_model, oracle_cpu):
+    """The effort path of the decode loop against the CPU oracle, multiply by multiply: after a replayed token step the
+    decoder's buffers hold the LAST layer's inputs and outputs -- h_norm -> xq|xk|xv (the grouped launch), attnOutput -> wo,
+    fxn -> x1|x3, x2 -> w2 -- and every one of those seven in-graph multiplies must be the oracle's bucketMul of the GPU's
+    own input vector (same cutoff and rows, or the outputs would be far apart; products within the multiply's tolerance).
+    Then the same with rmsNorm folded into the launches (fused_glue): the fused launch's input is what the glue kernel
+    writes, bit for bit, so the oracle is fed that."""
+    import numpy as np
+
+    from effort_amd.decode import Decoder
+    from tests.test_gpu_parity import close
+    cfg, L = small_model.cfg, small_model.layers[-1]
+
+    def host(ew):
+        return (ew.buckets[0].contiguous().cpu().numpy().view(np.uint16), ew.stats[0].cpu().numpy().view(np.uint16),
+                ew.probes[0].cpu().numpy().view(np.uint16))
+
+    def check(ew, vin, out, effort, what):
+        want, n, cutoff = oracle_cpu.bucket_mul(vin.cpu().numpy(), *host(ew), ew.inSize, ew.outSize, effort)
+        assert close(out.cpu().numpy(), want), what
+        return n
+    for effort in (0.25, 0.6):
+        dec = Decoder(small_model, maxTokens=16)
+        dec.run([3, 77, 130, 9], 4, effort=effort, forced=True)                  # four replayed steps; the buffers hold the last one
+        check(L.wq, dec.h_norm, dec.xq_temp, effort, "wq")
+        check(L.wk, dec.h_norm, dec.xk_temp, effort, "wk")
+        check(L.wv, dec.h_norm, dec.xv_temp, effort, "wv")
+        check(L.wo, dec.attnOutput, dec.attnFfnOut, effort, "wo")
+        check(L.w1, dec.fxn, dec.x1, effort, "w1")
+        check(L.w3, dec.fxn, dec.x3, effort, "w3")
+        n2 = check(L.w2, dec.x2, dec.ffnOut, effort, "w2")
+        assert dec.g.last_dispatch_count() == n2                                 # the last multiply launch of the step: exact row count
+        # rmsNorm and the residual adds folded into the launches: the same single f32 add per element and the glue kernel's own
+        # summation order, so the fused launches see the same input bits
+        fus = Decoder(small_model, maxTokens=16, fused_glue=("norm", "resid"))
+        fus.run([3, 77, 130, 9], 4, effort=effort, forced=True)
+        assert torch.equal(fus.x1, dec.x1) and torch.equal(fus.x3, dec.x3) and torch.equal(fus.logits, dec.logits)   # same input bits, same everything

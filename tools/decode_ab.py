@@ -20,18 +20,19 @@ def main():
     ap.add_argument("--layers", type=int, default=32)
     ap.add_argument("--tokens", type=int, default=48)
     ap.add_argument("--efforts", default="0.25,1.0")
-    ap.add_argument("--fused-glue", type=int, default=0)
+    ap.add_argument("--fused-glue", default="", help="comma list of norm,gate,resid (or 1 = all) folded into the multiplies")
     ap.add_argument("--split", type=int, default=0, help="also time every knob set with the cutoffs in a kernel of their own")
     a = ap.parse_args()
     torch.cuda.set_device(0)
     model = Model.random(MistralConfig(numLayers=a.layers), seed=1)
-    dec = Decoder(model, maxTokens=max(64, a.tokens + 8), fused_glue=bool(a.fused_glue))
+    fg = True if a.fused_glue == "1" else tuple(x for x in a.fused_glue.split(",") if x)
+    dec = Decoder(model, maxTokens=max(64, a.tokens + 8), fused_glue=fg)
     prompt = [1, 733, 16289, 28793, 22557]
     out = {}
     dec.g.set_dense_backend(False)
     _, dt_d, _ = dec.run(prompt, a.tokens, dense=True)
     out["dense_hip_kernel_tokens_per_s"] = round(1 / dt_d, 1)
-    knobs = [{}, {"EFFORT_X_NARROW": "0"}, {"EFFORT_X_FULL": "0"}, {"EFFORT_X_GT": "0"}, {"EFFORT_X_NARROW": "0", "EFFORT_X_GT": "0"}, {}]
+    knobs = [{}, {}]
     for e in (float(x) for x in a.efforts.split(",")):
         for kn in knobs:
             for k in ("EFFORT_X_NARROW", "EFFORT_X_FULL", "EFFORT_X_GT"):
