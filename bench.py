@@ -218,8 +218,15 @@ def cpu_baseline(ews, v, effort, inDim, outDim, budget_s=10.0, nmat=4):
         np.save(os.path.join(d, "v.npy"), v.cpu().numpy())
         best = None
         logical = os.cpu_count() or 1
-        for threads in sorted({logical, max(1, logical // 2), min(logical, 64)}, reverse=True):      # SMT siblings rarely help a streaming loop
-            env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_WAIT_POLICY="active", OMP_PROC_BIND="spread", OMP_PLACES="cores", GOMP_SPINCOUNT="100000000")
+        quota = logical                                   # the container's CPU quota (cgroup v2 cpu.max = "<quota> <period>"): threads beyond it are throttled
+        try:
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+            if q != "max":
+                quota = max(1, min(logical, int(q) // int(per)))
+        except Exception:
+            pass
+        for threads in sorted({quota, max(1, quota // 2), min(logical, 2 * quota)}, reverse=True):
+            env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_WAIT_POLICY="active", OMP_PROC_BIND="close", OMP_PLACES="cores", GOMP_SPINCOUNT="100000000")
             out = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_bench.py"), d, str(inDim), str(outDim), str(effort),
                                   str(budget_s / 3), str(nmat)], env=env, capture_output=True, text=True, timeout=120 + 4 * budget_s)
             r = json.loads(out.stdout.strip().split("\n")[-1])
@@ -229,11 +236,12 @@ def cpu_baseline(ews, v, effort, inDim, outDim, budget_s=10.0, nmat=4):
         dt, n = best["seconds_per_call"], best["calls"]
     finally:
         shutil.rmtree(d, ignore_errors=True)
-    return {"value": round(2 * inDim * outDim / dt / 1e9, 3), "unit": "GB/s", "cores": best["threads"], "host_logical_cpus": logical,
+    return {"value": round(2 * inDim * outDim / dt / 1e9, 3), "unit": "GB/s", "cores": best["threads"], "host_logical_cpus": logical, "container_cpu_quota": quota,
             "kind": "port", "us_per_call": round(dt * 1e6, 1),
             "sample": f"{n} bucketMul calls at effort {effort} over {nmat} of the converted {inDim}x{outDim} matrices (the CPU port: bucket rows "
                       f"streamed by (group, column block) tasks, OpenMP, {best['threads']} bound spinning threads: the fastest of "
-                      f"{logical} / {max(1, logical // 2)} / {min(logical, 64)} threads), {budget_s / 3:.0f} s each"}
+                      f"{quota} / {max(1, quota // 2)} / {min(logical, 2 * quota)}; the container may use {quota} of the host's {logical} logical CPUs), "
+                      f"{budget_s / 3:.0f} s each"}
 
 
 def oracle_outputs(ews, v, effort, inDim, outDim, idxs):
@@ -630,92 +638,110 @@ def main():
                 result["sweep_structured"] = {"error": repr(ex)}
         # ---------------- the other shapes / formats BASELINE.json names ------------------------------------
         if not args.no_sweep:
-            def quick(ews_x, outDim_x, inDim_x, effort, n, streams, q4=False):
+            def make_sets(n, inDim_x, outDim_x, seed, q4=False):
+                """S disjoint sets of n matrices: every step in flight multiplies its own (nothing served from the Infinity Cache on
+                another launch's behalf)."""
+                return [make_weights(ea, n, inDim_x, outDim_x, seed + 100 * k, dev, keep_core=False, q4=q4) for k in range(S)]
+
+            def quick(sets_w, outDim_x, inDim_x, effort, n, streams, q4=False):
                 vx = v if inDim_x == inDim else torch.randn(inDim_x, generator=gen, device=dev, dtype=torch.float32)
-                sets_x = [torch.zeros((len(ews_x), outDim_x), device=dev) for _ in range(streams)]
+                nm = len(sets_w[0])
+                sets_x = [torch.zeros((nm, outDim_x), device=dev) for _ in range(max(streams, len(sets_w)))]
                 jb = one if streams == 1 else job
                 nst = 8 if streams == 1 else 16
-                gx = jb.capture(mul_step(effort, weights=ews_x, vec=vx, sets=sets_x, group=n), nst)
-                Dx = jb.last_dispatch_count(nst, (len(ews_x) - 1) % n)
-                tx = time_graph(gx, None, reps=3) / nst / len(ews_x)
+                if streams == 1:
+                    one.S = len(sets_w)                  # (one launch in flight, rotating through the sets)
+                try:
+                    gx = jb.capture(mul_step(effort, vec=vx, sets=sets_x, group=n, wsets=sets_w), nst)
+                finally:
+                    one.S = 1
+                Dx = jb.last_dispatch_count(nst, (nm - 1) % n)
+                tx = time_graph(gx, None, reps=3) / nst / nm
                 del gx
                 if q4:
-                    nol = ews_x[0].outliers.shape[0]
+                    nol = sets_w[0][0].outliers.shape[0]
                     ab = Dx * (outDim_x // 32) * 2 + 8 * inDim_x * 8 + 4096 * 2 + 4 * inDim_x + 4 * outDim_x + 16 * nol
                 else:
                     ab = algorithmic_bytes(Dx, inDim_x, outDim_x)
                 r = {"us_per_call": round(tx * 1e6, 3), "dispatch_rows": Dx, "effective_GBps": round(2 * inDim_x * outDim_x / tx / 1e9, 1),
                      "achieved_GBps": round(ab / tx / 1e9, 1), "frac_of_hbm_peak": round(ab / tx / 1e9 / HBM_PEAK_GBPS, 4)}
-                if q4:       # SURVEY 8d prices an outlier at the reference's 16 bytes; the registered index holds 4
+                if q4:       # SURVEY 8d prices an outlier at the reference's 16 bytes; the registered index holds 4: the bytes actually moved
                     r["achieved_GBps_4B_outliers"] = round((ab - 12 * nol) / tx / 1e9, 1)
+                    r["frac_of_hbm_peak_4B_outliers"] = round((ab - 12 * nol) / tx / 1e9 / HBM_PEAK_GBPS, 4)
                 return r
 
-            def three(ews_x, outDim_x, inDim_x, effort, q4=False):
-                return {f"effort {effort}, 1 per launch": quick(ews_x, outDim_x, inDim_x, effort, 1, 1, q4),
-                        f"effort {effort}, 16 per launch": quick(ews_x, outDim_x, inDim_x, effort, 16, 1, q4),
-                        f"effort {effort}, 16 per launch, {S} in flight": quick(ews_x, outDim_x, inDim_x, effort, 16, S, q4)}
-            other = {}
-            sq = make_weights(ea, 16, 4096, 4096, 4321, dev, keep_core=False)
-            other["4096x4096 fp16"] = {**three(sq, 4096, 4096, 0.5), **three(sq, 4096, 4096, 0.25)}
-            del sq
-            up = make_weights(ea, 16, 4096, 14336, 7321, dev, keep_core=False)       # W1/W3 of Mistral's FFN: 4096 -> 14336, the shape benchmarks/benchmark.swift:251-257 times
-            other["4096x14336 fp16 (the reference's timed shape)"] = three(up, 14336, 4096, 0.25)
-            del up
-            dn = make_weights(ea, 16, 14336, 4096, 5321, dev, keep_core=False)       # W2 of the FFN: 14336 -> 4096
-            other["14336x4096 fp16"] = three(dn, 4096, 14336, 0.25)
-            del dn
-            q4w = make_weights(ea, 16, inDim, outDim, 6321, dev, keep_core=False, q4=True)
-            other["4096x11008 q4 (bucketMulQ4, 2 % outliers)"] = three(q4w, outDim, inDim, 0.25, q4=True)
-            del q4w
-            result["other_configs"] = other
-            # ---------------- BASELINE.json configs[3] projected on ONE GPU: what a rank of a bucket-column split over G GPUs runs ----
-            # (rank r holds columns [r*C/G, (r+1)*C/G) of every matrix, stats / probes replicated; its kernel-only work
-            #  is a launch of column shards.  Strong scaling: the same matrices on every G; efficiency = t(G=1) / (G * t(G)).)
-            try:
-                from effort_amd.sharded import ShardedExpertWeights
+            def three(sets_w, outDim_x, inDim_x, effort, q4=False):
+                return {f"effort {effort}, 1 per launch": quick(sets_w, outDim_x, inDim_x, effort, 1, 1, q4),
+                        f"effort {effort}, 16 per launch": quick(sets_w, outDim_x, inDim_x, effort, 16, 1, q4),
+                        f"effort {effort}, 16 per launch, {S} in flight": quick(sets_w, outDim_x, inDim_x, effort, 16, S, q4)}
+            from effort_amd.sharded import ShardedExpertWeights
 
-                def shard_times(full, inD, outD, effort, per_launch):
-                    rows = {}
-                    for Gw in (1, 2, 4, 8):
-                        if (outD // 16) % Gw:
-                            continue
-                        sh = full if Gw == 1 else [ShardedExpertWeights.from_full(e, i % Gw, Gw).local for i, e in enumerate(full)]
-                        for x in sh:
+            def shard_times(full_sets, inD, outD, effort, per_launch):
+                """Per-rank kernel-only time of a bucket-column split over G GPUs, on this one: a launch = the rank's column shards
+                of `per_launch` matrices (rank i % G of matrix i); the steps in flight work disjoint matrix sets."""
+                rows = {}
+                for Gw in (1, 2, 4, 8):
+                    if (outD // 16) % Gw or (outD // Gw) % 32:
+                        continue
+                    sh_sets = full_sets if Gw == 1 else [[ShardedExpertWeights.from_full(e, i % Gw, Gw).local for i, e in enumerate(fs)] for fs in full_sets]
+                    for fs in sh_sets:
+                        for x in fs:
                             x.handle
                             if ALIGN_ROWS:
                                 x.align_rows()
-                        lo = outD // Gw
-                        vx = v if inD == inDim else torch.randn(inD, generator=gen, device=dev, dtype=torch.float32)
-                        sets_x = [torch.zeros((len(sh), lo), device=dev) for _ in range(S)]
-                        r = {}
-                        for nm, jb, nst in (("1 launch in flight", one, 8), (f"{S} in flight", job, 16)):
-                            gx = jb.capture(mul_step(effort, weights=sh, vec=vx, sets=sets_x, group=per_launch), nst)
-                            Dx = jb.last_dispatch_count(nst, (len(sh) - 1) % per_launch)
-                            tx = time_graph(gx, None, reps=4) / nst            # per step = per rank per step
-                            del gx
-                            ab = len(sh) * algorithmic_bytes(Dx, inD, lo)
-                            r[nm] = {"us_per_step_per_rank": round(tx * 1e6, 2), "frac_of_hbm_peak": round(ab / tx / 1e9 / HBM_PEAK_GBPS, 4)}
-                        r["columns_per_rank"] = outD // 16 // Gw
-                        r["row_pitch_bytes"] = sh[0].align_rows() if ALIGN_ROWS else outD // 16 // Gw * 2
-                        rows[str(Gw)] = r
-                        del sh
-                    for Gw, r in rows.items():
-                        for nm in list(r):
-                            if isinstance(r[nm], dict):
-                                r[nm]["kernel_only_scaling_efficiency"] = round(rows["1"][nm]["us_per_step_per_rank"] / (int(Gw) * r[nm]["us_per_step_per_rank"]), 3)
-                    return rows
-                sp = {"note": "per-rank kernel-only time of a bucket-column split, measured on one GPU: a launch of `calls per launch` column shards "
-                              "(rank i % G of matrix i), 25 % effort; efficiency = t(G=1) / (G * t(G)); the all-gather of the outputs is not in it",
-                      "4096x11008, 32 calls per launch": shard_times(ews, inDim, outDim, 0.25, 32)}
-                sq = make_weights(ea, 16, 4096, 4096, 4321, dev, keep_core=False)
-                sp["4096x4096, 16 calls per launch"] = shard_times(sq, 4096, 4096, 0.25, 16)
-                del sq
-                up = make_weights(ea, 16, 4096, 14336, 7321, dev, keep_core=False)
-                sp["4096x14336, 16 calls per launch"] = shard_times(up, 4096, 14336, 0.25, 16)
-                del up
-                result["shard_projection"] = sp
+                    lo = outD // Gw
+                    vx = v if inD == inDim else torch.randn(inD, generator=gen, device=dev, dtype=torch.float32)
+                    nm = len(sh_sets[0])
+                    sets_x = [torch.zeros((nm, lo), device=dev) for _ in range(max(S, len(sh_sets)))]
+                    r = {}
+                    for nm_, jb, nst in (("1 launch in flight", one, 8), (f"{S} in flight", job, 16)):
+                        if jb is one:
+                            one.S = len(sh_sets)
+                        try:
+                            gx = jb.capture(mul_step(effort, vec=vx, sets=sets_x, group=per_launch, wsets=sh_sets), nst)
+                        finally:
+                            one.S = 1
+                        Dx = jb.last_dispatch_count(nst, (nm - 1) % per_launch)
+                        tx = time_graph(gx, None, reps=4) / nst            # per step = per rank per step
+                        del gx
+                        ab = nm * algorithmic_bytes(Dx, inD, lo)
+                        r[nm_] = {"us_per_step_per_rank": round(tx * 1e6, 2), "frac_of_hbm_peak": round(ab / tx / 1e9 / HBM_PEAK_GBPS, 4)}
+                    r["columns_per_rank"] = outD // 16 // Gw
+                    r["row_pitch_bytes"] = sh_sets[0][0].align_rows() if ALIGN_ROWS else outD // 16 // Gw * 2
+                    rows[str(Gw)] = r
+                    del sh_sets
+                for Gw, r in rows.items():
+                    for k2 in list(r):
+                        if isinstance(r[k2], dict):
+                            r[k2]["kernel_only_scaling_efficiency"] = round(rows["1"][k2]["us_per_step_per_rank"] / (int(Gw) * r[k2]["us_per_step_per_rank"]), 3)
+                return rows
+            other = {}
+            # BASELINE.json configs[3] projected on ONE GPU (SURVEY 8e: rank r holds columns [r*C/G, (r+1)*C/G) of every matrix, stats /
+            # probes replicated; its kernel-only work is a launch of column shards.  Strong scaling: efficiency = t(G=1) / (G * t(G)))
+            sp = {"note": "per-rank kernel-only time of a bucket-column split, measured on one GPU: a launch of `calls per launch` column shards "
+                          "(rank i % G of matrix i), 25 % effort, the steps in flight on disjoint matrix sets; efficiency = t(G=1) / (G * t(G)); "
+                          "the all-gather of the outputs is not in it"}
+            try:
+                sp["4096x11008, 32 calls per launch"] = shard_times(ew_sets, inDim, outDim, 0.25, 32)
             except Exception as ex:
-                result["shard_projection"] = {"error": repr(ex)}
+                sp["4096x11008, 32 calls per launch"] = {"error": repr(ex)}
+            for name, (iD, oD, seed, efforts) in {"4096x4096 fp16": (4096, 4096, 4321, (0.5, 0.25)),
+                                                   "4096x14336 fp16 (the reference's timed shape)": (4096, 14336, 7321, (0.25,)),
+                                                   "14336x4096 fp16": (14336, 4096, 5321, (0.25,))}.items():
+                sets_w = make_sets(16, iD, oD, seed)
+                other[name] = {}
+                for e in efforts:
+                    other[name].update(three(sets_w, oD, iD, e))
+                try:
+                    sp[f"{iD}x{oD}, 16 calls per launch"] = shard_times(sets_w, iD, oD, 0.25, 16)
+                except Exception as ex:
+                    sp[f"{iD}x{oD}, 16 calls per launch"] = {"error": repr(ex)}
+                del sets_w
+            q4w = make_sets(16, inDim, outDim, 6321, q4=True)
+            other["4096x11008 q4 (bucketMulQ4, 2 % outliers)"] = three(q4w, outDim, inDim, 0.25, q4=True)
+            del q4w
+            result["other_configs"] = other
+            result["shard_projection"] = sp
         # ---------------- end-to-end greedy decode (BASELINE.json configs[4]; random-init Mistral-7B shapes) ----------
         if not args.no_decode and not args.no_sweep:
             try:
