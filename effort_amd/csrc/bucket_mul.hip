@@ -393,8 +393,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
             bound += fabsf(x);
         }
     }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) bound += __shfl_xor(bound, off);
+    bound = wave_sum_f32(bound);                                  // (only the exponent of the slice's bound matters: any order)
     if (lane == 0) wbound[wave] = bound;
     if (tid == 0) { flags[4] = 0u; flags[5] = 0u; }               // the list is empty, none of it handed out
     if (stamp) ga.tstamp[17] = wall_clock64();
@@ -519,7 +518,9 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     const bool colOK = col < g.cols;                               // a piece past the last column is skipped whole
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint16_t*>(a.buckets), 0, (int)min((size_t)0xFFFFFFFFu, (size_t)g.numExperts * g.expertRows * g.rowPitch), 0x00020000);
-    const uint32_t voff = (colOK ? col : 0u) * 2u;                 // lanes past the last column re-read column 0
+    // lanes past the last column re-read the row's LAST piece -- the line their neighbours are fetching anyway.  (They used to
+    // re-read column 0: one more 128-byte line per kept row for the ragged last tile, 68 MB of a 32-call launch's 824.)
+    const uint32_t voff = (colOK ? col : (g.cols - 1u) / (uint32_t)E * (uint32_t)E) * 2u;
     const uint32_t nU = (ga.ablate & 4u) ? 0u : __builtin_amdgcn_readfirstlane(n);   // n is workgroup-uniform; keep it in an SGPR
     // The waves of a workgroup do NOT run at one speed (the older wave wins the arbitration for issue slots and the memory
     // pipeline: measured, wave 0 gets through a static share of the rows 2-3x sooner than the last wave and then idles at
@@ -694,8 +695,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
             }
             for (uint32_t i = tid; i < olPer; i += NT) { olacc[i] = 0; ollo[i] = 0; }
             float* const wmax = reinterpret_cast<float*>(smem + offC + 1408);              // [W] per-wave max of the block bounds
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) { vm = fmaxf(vm, __shfl_xor(vm, off)); olBound = fmaxf(olBound, __shfl_xor(olBound, off)); }
+            vm = __uint_as_float(wave_max_u32(__float_as_uint(vm))); olBound = __uint_as_float(wave_max_u32(__float_as_uint(olBound)));   // (non-negative floats order like their bit patterns)
             if (lane == 0) { wbound[wave] = vm; wmax[wave] = olBound; }                    // (the slice bounds are dead by now)
             __syncthreads();
             vm = 0.0f; olBound = 0.0f;

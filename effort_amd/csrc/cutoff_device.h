@@ -69,12 +69,7 @@ __device__ __forceinline__ float block_find_cutoff(const float (&vj)[4096 / NT],
         pmax = max(pmax, vp[k]);
         pminnz = min(pminnz, vp[k] ? vp[k] : 0xFFFFu);
     }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        pmin = min(pmin, (uint32_t)__shfl_xor((int)pmin, off));
-        pmax = max(pmax, (uint32_t)__shfl_xor((int)pmax, off));
-        pminnz = min(pminnz, (uint32_t)__shfl_xor((int)pminnz, off));
-    }
+    pmin = wave_min_u32(pmin); pmax = wave_max_u32(pmax); pminnz = wave_min_u32(pminnz);      // (DPP: no LDS round trips)
     if (lane == 0) { atomicMin(&s_mm[0], pmin); atomicMax(&s_mm[1], pmax); atomicMin(&s_mm[2], pminnz); }
     __syncthreads();
     const uint32_t pminAll = s_mm[0], pmaxAll = s_mm[1];
@@ -142,13 +137,10 @@ __device__ __forceinline__ float block_find_cutoff(const float (&vj)[4096 / NT],
         uint32_t mine = 0;
 #pragma unroll
         for (uint32_t i = 0; i < BPT; i++) mine += h[i];
-        uint32_t suf = mine;                             // inclusive suffix sum over the lanes of this wave
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t o = __shfl_down(suf, off);
-            suf += (lane + off < 64) ? o : 0u;
-        }
-        if (lane == 0) s_tot[wave] = suf;                // wave total
+        // inclusive suffix sum over the lanes of this wave = wave total - inclusive prefix + own (integers: exact)
+        const uint32_t pre = wave_prefix_sum_u32(mine), wtotal = (uint32_t)__builtin_amdgcn_readlane((int)pre, 63);
+        const uint32_t suf = wtotal - pre + mine;
+        if (lane == 0) s_tot[wave] = wtotal;             // wave total
         __syncthreads();
         uint32_t running = above + suf - mine;           // values in cells owned by later lanes / waves, or beyond top
 #pragma unroll

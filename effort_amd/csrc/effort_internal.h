@@ -107,6 +107,36 @@ __device__ __forceinline__ float bf16_round(float f) {
     return __uint_as_float(u & 0xFFFF0000u);
 }
 
+// ---- wave64 reductions and scans on DPP ------------------------------------------------------
+// __shfl_xor / __shfl_down compile to ds_bpermute_b32 on gfx950: an LDS round trip per step, six dependent ones per reduction
+// (~400 cycles).  row_shr:1/2/4/8 + row_bcast:15/31 fold into the VALU instruction itself (v_add_u32_dpp ...): six
+// instructions, the inclusive scan in every lane and the total in lane 63.
+#define EFFORT_DPP_SCAN(v, OP, IDENT)                                                                 \
+    v = OP(v, __builtin_amdgcn_update_dpp(IDENT, v, 0x111, 0xf, 0xf, false)); /* row_shr:1 */         \
+    v = OP(v, __builtin_amdgcn_update_dpp(IDENT, v, 0x112, 0xf, 0xf, false)); /* row_shr:2 */         \
+    v = OP(v, __builtin_amdgcn_update_dpp(IDENT, v, 0x114, 0xf, 0xf, false)); /* row_shr:4 */         \
+    v = OP(v, __builtin_amdgcn_update_dpp(IDENT, v, 0x118, 0xf, 0xf, false)); /* row_shr:8 */         \
+    v = OP(v, __builtin_amdgcn_update_dpp(IDENT, v, 0x142, 0xa, 0xf, false)); /* row_bcast:15 */      \
+    v = OP(v, __builtin_amdgcn_update_dpp(IDENT, v, 0x143, 0xc, 0xf, false)); /* row_bcast:31 */
+__device__ __forceinline__ int dpp_op_add(int a, int b) { return a + b; }
+__device__ __forceinline__ int dpp_op_umin(int a, int b) { return (int)min((uint32_t)a, (uint32_t)b); }
+__device__ __forceinline__ int dpp_op_umax(int a, int b) { return (int)max((uint32_t)a, (uint32_t)b); }
+// inclusive prefix sum over the wave's lanes (lane i: v_0 + ... + v_i)
+__device__ __forceinline__ uint32_t wave_prefix_sum_u32(uint32_t x) { int v = (int)x; EFFORT_DPP_SCAN(v, dpp_op_add, 0) return (uint32_t)v; }
+// the wave's total / minimum / maximum, uniform
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t x) { int v = (int)x; EFFORT_DPP_SCAN(v, dpp_op_add, 0) return (uint32_t)__builtin_amdgcn_readlane(v, 63); }
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t x) { int v = (int)x; EFFORT_DPP_SCAN(v, dpp_op_umin, -1) return (uint32_t)__builtin_amdgcn_readlane(v, 63); }
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t x) { int v = (int)x; EFFORT_DPP_SCAN(v, dpp_op_umax, 0) return (uint32_t)__builtin_amdgcn_readlane(v, 63); }
+// (f32 sum: the additions run in scan order -- lanes 0..15 left to right within a row, then the rows -- not in the xor
+//  butterfly's; use only where the order is free, i.e. not for the rmsNorm sums the glue kernel and the fused prologue share)
+__device__ __forceinline__ float wave_sum_f32(float x) {
+    int v = __float_as_int(x);
+#define EFFORT_FADD_(a, b) __float_as_int(__int_as_float(a) + __int_as_float(b))
+    EFFORT_DPP_SCAN(v, EFFORT_FADD_, 0)
+#undef EFFORT_FADD_
+    return __int_as_float(__builtin_amdgcn_readlane(v, 63));
+}
+
 // ---- launchers (one per translation unit) ---------------------------------------------------
 bool dense_gemv_supported(uint32_t inDim, uint32_t outDim);
 hipError_t launch_dense_gemv(const uint16_t* W_f16, const float* v, float* out, uint32_t inDim, uint32_t outDim, hipStream_t st);
