@@ -330,7 +330,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     float normInv = 1.0f;
     if (FUSED && pre == kPreRmsNorm) {
         // The sum of squares in EXACTLY the order add_rmsnorm_mul_kernel (decode.hip) sums it -- 1024 threads, thread u adding
-        // x[u], x[u + 1024], ... in that order, a xor butterfly over each 64 of them, the sixteen wave sums in wave order -- so
+        // x[u], x[u + 1024], ... in that order, a DPP scan-order sum over each 64 of them (wave_sum_f32), the sixteen wave sums in wave order -- so
         // that the normalised input, hence the cutoff and the row selection, are bit-identical with the unfused path's.  A
         // thread here stands for R = 1024 / NT of that kernel's threads: u = tid + NT * r.
         constexpr int R = 1024 / NT;
@@ -349,8 +349,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
         }
 #pragma unroll
         for (int r = 0; r < R; r++) {
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) part[r] += __shfl_xor(part[r], off);
+            part[r] = wave_sum_f32(part[r]);                                   // (the glue kernel's block_sum: same DPP order)
             if (lane == 0) wbound[r * W + wave] = part[r];
         }
         __syncthreads();

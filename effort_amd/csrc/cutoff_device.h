@@ -26,7 +26,7 @@
 namespace effort {
 
 constexpr uint32_t kCutoffBinsPerThread = 8;
-constexpr uint32_t kCutoffLdsBytes = 256;     // small scratch: count slots, min/max, scan totals, result
+constexpr uint32_t kCutoffLdsBytes = 512;     // small scratch: count slots, per-wave min/max, scan totals, result
 __host__ __device__ constexpr uint32_t cutoff_table_bytes(int NT) { return (uint32_t)NT * kCutoffBinsPerThread * 4u; }
 
 // NT threads (multiple of 64, <= 1024, dividing 4096); lds = kCutoffLdsBytes of scratch; tbl =
@@ -43,7 +43,7 @@ __device__ __forceinline__ float block_find_cutoff(const float (&vj)[4096 / NT],
     constexpr int NW = NT / 64;
     constexpr uint32_t BPT = kCutoffBinsPerThread, CAP = (uint32_t)NT * BPT;
     uint32_t* s_cnt = reinterpret_cast<uint32_t*>(lds);            // [4] rotating count slots (ballot passes)
-    uint32_t* s_mm = reinterpret_cast<uint32_t*>(lds) + 4;         // [0] min pattern, [1] max pattern, [2] min NONZERO pattern
+    uint32_t* s_wm = reinterpret_cast<uint32_t*>(lds) + 32;        // [NW][3] per wave: min pattern, max pattern, min NONZERO pattern
     uint32_t* s_tot = reinterpret_cast<uint32_t*>(lds) + 8;        // [16] wave totals of the scan
     float* s_res = reinterpret_cast<float*>(lds) + 24;             // [0] result
     uint32_t* s_all = reinterpret_cast<uint32_t*>(lds) + 25;       // [0] values at or above the table's first cell
@@ -54,8 +54,6 @@ __device__ __forceinline__ float block_find_cutoff(const float (&vj)[4096 / NT],
     if (dbg && tid == 0) { dbg[0] = wall_clock64(); dbg[6] = clock64(); }
 
     if (tid < 4) s_cnt[tid] = 0;
-    if (tid == 0) { s_mm[0] = 0xFFFFFFFFu; s_mm[1] = 0; s_mm[2] = 0xFFFFFFFFu; }
-    __syncthreads();
     // the 4096 values bf16(|(1e5*v[j]) * bf16(probe[j])|), products evaluated left to right (:160), kept as
     // their 16-bit patterns
     uint32_t vp[VPT];
@@ -69,14 +67,23 @@ __device__ __forceinline__ float block_find_cutoff(const float (&vj)[4096 / NT],
         pmax = max(pmax, vp[k]);
         pminnz = min(pminnz, vp[k] ? vp[k] : 0xFFFFu);
     }
-    pmin = wave_min_u32(pmin); pmax = wave_max_u32(pmax); pminnz = wave_min_u32(pminnz);      // (DPP: no LDS round trips)
-    if (lane == 0) { atomicMin(&s_mm[0], pmin); atomicMax(&s_mm[1], pmax); atomicMin(&s_mm[2], pminnz); }
+    // wave results on DPP (no LDS round trips), one slot per wave; the count table is zeroed under the same barrier (its
+    // region is free on entry): ONE barrier where there were three
+    pmin = wave_min_u32(pmin); pmax = wave_max_u32(pmax); pminnz = wave_min_u32(pminnz);
+    if (lane == 0) { s_wm[wave * 3 + 0] = pmin; s_wm[wave * 3 + 1] = pmax; s_wm[wave * 3 + 2] = pminnz; }
+    {
+        uint4* z4 = reinterpret_cast<uint4*>(tbl + tid * BPT);
+        z4[0] = make_uint4(0, 0, 0, 0); z4[1] = make_uint4(0, 0, 0, 0);
+    }
     __syncthreads();
-    const uint32_t pminAll = s_mm[0], pmaxAll = s_mm[1];
+    uint32_t mmin = 0xFFFFFFFFu, mmax = 0u, mnz = 0xFFFFFFFFu;
+#pragma unroll
+    for (int w2 = 0; w2 < NW; w2++) { mmin = min(mmin, s_wm[w2 * 3 + 0]); mmax = max(mmax, s_wm[w2 * 3 + 1]); mnz = min(mnz, s_wm[w2 * 3 + 2]); }
+    const uint32_t pminAll = mmin, pmaxAll = mmax;
     // Exact zeros (a zero input, or a probe zeroed as a Q4 outlier) exceed no threshold, so the count table only has
     // to start at the smallest NONZERO value: below it every count is the same.  (Without this, zeros make the value
     // range span every bf16 cell down to 0 and the bracket never fits the table: ~100 ballot rounds at effort 1.)
-    const uint32_t pminNZ = min(s_mm[2], pmaxAll);
+    const uint32_t pminNZ = min(mnz, pmaxAll);
     // The reference starts each thread's min at 999 / max at -999, clamps per simdgroup and stores the
     // simdgroup results as bfloat (999 -> 1000) before the cross-simdgroup reduction (:155-190).  All values
     // are non-negative bf16 numbers, so the net effect is minBound = min(globalMin, 1000), maxBound = globalMax.
@@ -126,9 +133,7 @@ __device__ __forceinline__ float block_find_cutoff(const float (&vj)[4096 / NT],
         // ---- table over the cells [base, top]: suffix[i] = #{values with pattern > base + i} ---------------
         const uint32_t base = lowCell(), top = topCell();
         const uint32_t above = (patHi != kNoHi) ? (uint32_t)maxCount : 0u;     // values beyond the top cell
-        uint4* t4 = reinterpret_cast<uint4*>(tbl + tid * BPT);
-        t4[0] = make_uint4(0, 0, 0, 0); t4[1] = make_uint4(0, 0, 0, 0);
-        __syncthreads();
+        uint4* t4 = reinterpret_cast<uint4*>(tbl + tid * BPT);      // (zeroed on entry)
 #pragma unroll
         for (int k = 0; k < VPT; k++) if (vp[k] >= base && vp[k] <= top) atomicAdd(&tbl[vp[k] - base], 1u);
         __syncthreads();

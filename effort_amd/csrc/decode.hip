@@ -15,8 +15,7 @@ namespace effort {
 
 __device__ __forceinline__ float block_sum(float x, float* red /* [17] */) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off);
+    x = wave_sum_f32(x);                              // (DPP scan order; the multiply's fused rmsNorm prologue sums the same way)
     __syncthreads();                                  // red may still be read from a previous call
     if (lane == 0) red[wave] = x;
     __syncthreads();
@@ -27,8 +26,7 @@ __device__ __forceinline__ float block_sum(float x, float* red /* [17] */) {
 
 __device__ __forceinline__ float block_max(float x, float* red) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) x = fmaxf(x, __shfl_xor(x, off));
+    x = wave_max_f32(x);
     __syncthreads();
     if (lane == 0) red[wave] = x;
     __syncthreads();
@@ -202,8 +200,13 @@ __global__ __launch_bounds__(256) void rope_attention_kernel(const float* __rest
                 dot = q8[0] * ka[u].x + q8[1] * ka[u].y + q8[2] * ka[u].z + q8[3] * ka[u].w +
                       q8[4] * kb[u].x + q8[5] * kb[u].y + q8[6] * kb[u].z + q8[7] * kb[u].w;
             }
-            for (uint32_t off = lpt / 2u; off >= 1u; off >>= 1) dot += __shfl_xor(dot, (int)off);
-            if (sub == 0 && t < nTok) sc[t] = dot * scale;
+            if (lpt == 16u) {                                                  // (uniform) headDim 128: a token's 16 lanes are one DPP row -- no LDS round trips
+                dot = row16_sum_f32(dot);                                      // the row's total sits in its lane 15
+                if (sub == 15u && t < nTok) sc[t] = dot * scale;
+            } else {
+                for (uint32_t off = lpt / 2u; off >= 1u; off >>= 1) dot += __shfl_xor(dot, (int)off);
+                if (sub == 0 && t < nTok) sc[t] = dot * scale;
+            }
         }
     }
     __syncthreads();

@@ -137,6 +137,26 @@ __device__ __forceinline__ float wave_sum_f32(float x) {
     return __int_as_float(__builtin_amdgcn_readlane(v, 63));
 }
 
+// maximum of any floats (v_max_f32 on DPP), uniform
+__device__ __forceinline__ float wave_max_f32(float x) {
+    int v = __float_as_int(x);
+#define EFFORT_FMAX_(a, b) __float_as_int(fmaxf(__int_as_float(a), __int_as_float(b)))
+    EFFORT_DPP_SCAN(v, EFFORT_FMAX_, (int)0xFF800000)      /* -inf */
+#undef EFFORT_FMAX_
+    return __int_as_float(__builtin_amdgcn_readlane(v, 63));
+}
+// sum over each row of 16 lanes; the row's total lands in its lane 15 (row_shr only: rows do not mix)
+__device__ __forceinline__ float row16_sum_f32(float x) {
+    int v = __float_as_int(x);
+#define EFFORT_FADD_(a, b) __float_as_int(__int_as_float(a) + __int_as_float(b))
+    v = EFFORT_FADD_(v, __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false));
+    v = EFFORT_FADD_(v, __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false));
+    v = EFFORT_FADD_(v, __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false));
+    v = EFFORT_FADD_(v, __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false));
+#undef EFFORT_FADD_
+    return __int_as_float(v);
+}
+
 // ---- launchers (one per translation unit) ---------------------------------------------------
 bool dense_gemv_supported(uint32_t inDim, uint32_t outDim);
 hipError_t launch_dense_gemv(const uint16_t* W_f16, const float* v, float* out, uint32_t inDim, uint32_t outDim, hipStream_t st);
