@@ -24,6 +24,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
+#include <omp.h>
 
 #define EO_API __attribute__((visibility("default")))
 
@@ -360,15 +361,24 @@ EO_API void eo_bucket_mul(const uint16_t* weights, const float* dispatch, uint32
      * block adds its product: per thread (x, y) of the reference that is the same sequence of additions, r ascending, so
      * the sums are bit-identical with the literal loop nest -- but a bucket row is read as a contiguous piece instead of one
      * half per 64-byte line (the column-wise walk ran at 1.8 GB/s on 256 cores). */
-    enum { XB = 32 };
-    uint32_t per = dispatchSize / groups, nblk = (cols + XB - 1) / XB;
+    /* column blocks as wide as the thread count allows (about four tasks per thread): a block is a contiguous run of each row,
+     * and narrow blocks turn the walk into one cache line per row again once the matrices stop fitting the last-level cache */
+    enum { XBMAX = 1024 };
+    int threads = omp_get_max_threads();
+    uint32_t want = (uint32_t)((4 * threads + (int)groups - 1) / (int)groups);
+    uint32_t nblk = want < 1 ? 1 : want;
+    if (nblk > (cols + 31) / 32) nblk = (cols + 31) / 32;
+    uint32_t XB = (cols + nblk - 1) / nblk;
+    if (XB > XBMAX) { XB = XBMAX; }
+    nblk = (cols + XB - 1) / XB;
+    uint32_t per = dispatchSize / groups;
     h2f_lut_init();
     #pragma omp parallel for collapse(2) schedule(dynamic, 1)
     for (uint32_t y = 0; y < groups; y++) {
         for (uint32_t xb = 0; xb < nblk; xb++) {
-            float acc[XB][16];
-            memset(acc, 0, sizeof(acc));
+            float acc[XBMAX][16];
             uint32_t x0 = xb * XB, nx = cols - x0 < XB ? cols - x0 : XB;
+            memset(acc, 0, (size_t)nx * 16 * sizeof(float));
             uint32_t rowOffset = y * dispatchSize / groups;
             for (uint32_t r = 0; r < per; r++) {
                 float d0 = dispatch[2 * (size_t)(rowOffset + r)], d1 = dispatch[2 * (size_t)(rowOffset + r) + 1];

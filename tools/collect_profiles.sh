@@ -42,4 +42,6 @@ python tools/decode_bench.py --tokens 64 > $O/${R}_decode_bench.json 2> $O/decod
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_dec -- python tools/decode_bench.py --tokens 64 --efforts 0.25 > $O/prof_dec.log 2>&1
 cp "$(ls -t $O/prof_dec/*/*kernel_stats.csv | head -1)" $O/${R}_rocprofv3_kernel_stats_decode.csv
 rm -rf $O/prof_dec
+[ -x build/rowbench ] && build/rowbench | grep "^mode" > $O/${R}_rowbench.txt
+[ -x build/rampbench ] && build/rampbench > $O/${R}_rampbench.txt
 ls -la $O | grep ${R}_
