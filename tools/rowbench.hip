@@ -7,6 +7,8 @@
 //   mode 1  an item = (matrix, slice of 256 inputs): whole rows, 1376 bytes                               [full-row items]
 //   mode 2  like 0 with 768 + 608-byte pieces (two tiles)                                                 [E = 6]
 //   mode 3  every row of the slice, whole (dense streaming of the same buffers: the ceiling)
+//   mode 4  like 0, rows stored INPUT-major (r = j * 16 + rank): an input's kept ranks 0 .. k-1 are neighbours in memory
+//   mode 5  like 1, input-major
 // Prints TB/s of bytes actually requested.    hipcc --offload-arch=gfx950 -O3 -o build/rowbench tools/rowbench.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -82,24 +84,29 @@ int main(int argc, char** argv) {
     char* d_base; CK(hipMalloc(&d_base, bytes)); CK(hipMemset(d_base, 1, bytes));
     std::mt19937 rng(1);
     std::normal_distribution<float> nd;
-    for (int mode = 0; mode < 4; mode++) {
+    for (int mode = 0; mode < 6; mode++) {
         std::vector<uint32_t> list; std::vector<Item> items;
         size_t want = 0;
         for (uint32_t m = 0; m < kMats; m++) {
             std::vector<float> av(kIn);
             for (auto& x : av) x = fabsf(nd(rng));
-            const uint32_t sliceIn = mode == 1 || mode == 3 ? 256u : 512u;
+            const uint32_t sliceIn = mode == 1 || mode == 3 || mode == 5 ? 256u : 512u;
             for (uint32_t s0 = 0; s0 < kIn; s0 += sliceIn) {
                 const uint32_t first = (uint32_t)list.size();
-                for (uint32_t rank = 0; rank < kRanks; rank++)
-                    for (uint32_t j = s0; j < s0 + sliceIn; j++) {
-                        // threshold per rank: P(|N| > t) from 0.95 at rank 0 falling to ~0.001 at rank 15; averages ~0.25
-                        const float t = 0.06f + 0.22f * (float)rank * (1.0f + 0.035f * (float)rank);
-                        if (mode == 3 || av[j] > t) list.push_back(m * kRowsPerMat + rank * kIn + j);
-                    }
+                // threshold per rank: P(|N| > t) from 0.95 at rank 0 falling to ~0.001 at rank 15; averages ~0.25
+                auto thr = [](uint32_t rank) { return 0.06f + 0.22f * (float)rank * (1.0f + 0.035f * (float)rank); };
+                if (mode >= 4) {
+                    for (uint32_t j = s0; j < s0 + sliceIn; j++)
+                        for (uint32_t rank = 0; rank < kRanks; rank++)
+                            if (av[j] > thr(rank)) list.push_back(m * kRowsPerMat + j * kRanks + rank);
+                } else {
+                    for (uint32_t rank = 0; rank < kRanks; rank++)
+                        for (uint32_t j = s0; j < s0 + sliceIn; j++)
+                            if (mode == 3 || av[j] > thr(rank)) list.push_back(m * kRowsPerMat + rank * kIn + j);
+                }
                 const uint32_t count = (uint32_t)list.size() - first;
                 if (!count) continue;
-                if (mode == 0) for (uint32_t t = 0; t < 3; t++) { const uint32_t b = t < 2 ? 512u : kRowBytes - 1024u; items.push_back({first, count, t * 512u, b}); want += (size_t)count * b; }
+                if (mode == 0 || mode == 4) for (uint32_t t = 0; t < 3; t++) { const uint32_t b = t < 2 ? 512u : kRowBytes - 1024u; items.push_back({first, count, t * 512u, b}); want += (size_t)count * b; }
                 else if (mode == 2) for (uint32_t t = 0; t < 2; t++) { const uint32_t b = t < 1 ? 768u : kRowBytes - 768u; items.push_back({first, count, t * 768u, b}); want += (size_t)count * b; }
                 else { items.push_back({first, count, 0u, kRowBytes}); want += (size_t)count * kRowBytes; }
             }
@@ -113,14 +120,15 @@ int main(int argc, char** argv) {
         for (int rep = 0; rep < 6; rep++) {
             CK(hipMemset(d_queue, 0, 4));
             CK(hipEventRecord(e0));
-            if (mode == 0) hipLaunchKernelGGL(read_kernel<0>, dim3(512), dim3(512), 0, 0, d_base, d_list, d_items, (uint32_t)items.size(), d_queue, d_sink);
+            if (mode == 0 || mode == 4) hipLaunchKernelGGL(read_kernel<0>, dim3(512), dim3(512), 0, 0, d_base, d_list, d_items, (uint32_t)items.size(), d_queue, d_sink);
             else if (mode == 2) hipLaunchKernelGGL(read_kernel<2>, dim3(512), dim3(512), 0, 0, d_base, d_list, d_items, (uint32_t)items.size(), d_queue, d_sink);
             else hipLaunchKernelGGL(read_kernel<1>, dim3(512), dim3(512), 0, 0, d_base, d_list, d_items, (uint32_t)items.size(), d_queue, d_sink);
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
             if (rep) best = fminf(best, ms);
         }
-        const char* names[4] = {"512-byte pieces (3 tiles), 512-input slices", "whole rows, 256-input slices", "768/608-byte pieces (2 tiles), 512-input slices", "dense: every row, whole"};
+        const char* names[6] = {"512-byte pieces (3 tiles), 512-input slices", "whole rows, 256-input slices", "768/608-byte pieces (2 tiles), 512-input slices", "dense: every row, whole",
+                                "512-byte pieces, rows stored input-major", "whole rows, stored input-major"};
         printf("mode %d  %-52s items %6zu  rows kept %.3f  %7.1f MB  %8.1f us  %.2f TB/s\n", mode, names[mode], items.size(),
                mode == 3 ? 1.0 : (double)list.size() / ((double)kMats * kRowsPerMat) / (mode == 1 ? 1.0 : 1.0), want / 1e6, best * 1e3, want / (best * 1e-3) / 1e12);
         CK(hipFree(d_list)); CK(hipFree(d_items)); CK(hipFree(d_queue)); CK(hipFree(d_sink));
