@@ -351,7 +351,8 @@ static int copy_aligned(effort_w* w) {
 extern "C" int effort_weights_refresh(effort_w* w) {
     if (!w || !w->ctx) return EFFORT_ERR_ARG;
     hipSetDevice(w->ctx->device);
-    int rc = register_bound(w->ctx, w);          // in place: graphs captured earlier keep valid pointers
+    int rc = join_lanes(w->ctx);                 // multiplies still in flight on the lanes read what is recomputed here
+    if (rc == EFFORT_OK) rc = register_bound(w->ctx, w);          // in place: graphs captured earlier keep valid pointers
     if (rc == EFFORT_OK && w->aligned) rc = copy_aligned(w);
     return rc;
 }
@@ -385,6 +386,7 @@ extern "C" int effort_weights_get_bound(effort_w* w, float* host_out) {
 extern "C" int effort_weights_set_bound(effort_w* w, const float* host_in) {
     if (!w || !w->ctx || !host_in || !w->rankBound) return EFFORT_ERR_ARG;
     for (uint32_t e = 0; e < w->numExperts; e++) if (!(host_in[e] >= 0.0f)) return EFFORT_ERR_ARG;
+    if (join_lanes(w->ctx) != EFFORT_OK) return EFFORT_ERR_HIP;
     HIP_TRY(w->ctx, hipStreamSynchronize(w->ctx->stream));
     HIP_TRY(w->ctx, hipMemcpy(w->rankBound, host_in, (size_t)w->numExperts * 4, hipMemcpyHostToDevice));
     return EFFORT_OK;

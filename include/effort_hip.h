@@ -61,8 +61,8 @@ EFFORT_API int effort_sync(effort_ctx* ctx);
  *   - after earlier multiplies of this context whose outputs it reads or overwrites, or whose inputs it overwrites (address
  *     ranges of v / expNo / aux / resid / out are compared);
  * otherwise it runs beside the multiplies still in flight: the head of one launch (staging, cutoffs, selection: HBM idle)
- * hides under the streaming of the others (one 32-call launch after another: 0.57 -> 0.75 of the HBM roofline).  Results
- * are bit-identical.  The multiplies become visible to the context's stream at effort_join (enqueues waits, returns at
+ * hides under the streaming of the others (one 32-call launch after another, each on its own matrices: 0.60 -> 0.70 of the
+ * HBM roofline).  Results are bit-identical.  The multiplies become visible to the context's stream at effort_join (enqueues waits, returns at
  * once), and implicitly at effort_sync, at any other effort_* call on the context and at the test hooks.  A caller who
  * enqueues its OWN work on the stream to consume an output calls effort_join first; inside a hipGraph capture call
  * effort_join before ending the capture (the lanes fork from and must rejoin the capturing stream).
