@@ -340,6 +340,7 @@ def main():
     launches_per_step = (N_MATS + G - 1) // G
 
     # ---------------- the timed job: K steps at the headline effort --------------------------------
+    g_timed = None
     if dist:
         # Every rank: its 32 matrices per step; the steps run a ROUND (4S steps: one hipGraph with S steps in flight, as
         # on one GPU) and ONE all-gather per round exchanges the round's output vectors.  Pipelined: round r's all-gather runs
@@ -435,8 +436,10 @@ def main():
         "vs_baseline": None, "dtype": "f16", "data": "synthetic",
         "config": {"workload": f"bucketMul {inDim}x{outDim} fp16 buckets, effort {args.effort}, {N_MATS} distinct matrices rotated "
                                f"(one call each per step), fixed-point accumulate (f32 out); {G} independent calls per fused "
-                               f"kernel launch; the job's steps are independent: ONE hipGraph through ONE context, {in_flight} step(s) "
-                               f"in flight (effort_set_overlap), each on its own {N_MATS} matrices", "effort": args.effort, "matrices_per_step": N_MATS,
+                               f"kernel launch; the job's steps are independent: " + (f"rounds of {4 * S} steps (one hipGraph each, four contexts on four streams), "
+                               f"one all-gather of the round's outputs per round under the next round's compute, {in_flight} step(s) " if dist else
+                               f"ONE hipGraph through ONE context, {in_flight} step(s) ") +
+                               f"in flight{'' if dist else ' (effort_set_overlap)'}, each on its own {N_MATS} matrices", "effort": args.effort, "matrices_per_step": N_MATS,
                    "distinct_matrices": n_sets * N_MATS,
                    "inDim": inDim, "outDim": outDim, "calls_per_launch": G, "steps_in_flight": in_flight,
                    "bucket_row_pitch_bytes": (outDim // 16 * 2 + 127) // 128 * 128 if ALIGN_ROWS else outDim // 16 * 2,
@@ -799,7 +802,8 @@ def main():
                 # EVERY output set the timed graph wrote (its last replay): step k in flight multiplied ew_sets[k] into set k
                 for o in out_sets:
                     o.fill_(float("nan"))
-                g_timed.replay()                                 # the timed graph itself, once more, into cleared output sets
+                # the timed graph itself, once more, into cleared output sets (BENCH_FORCE_DIST on one GPU timed rounds: S steps of the same job)
+                (g_timed or job.capture(mul_step(args.effort, wsets=ew_sets), min(S, args.steps))).replay()
                 torch.cuda.synchronize()
                 timed_outputs = [o.clone() for o in out_sets[:min(S, args.steps)]]
                 worst, bad, checked, counts_checked, refs_by_set = 0.0, 0, 0, 0, {}
