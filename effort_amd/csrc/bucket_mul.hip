@@ -75,6 +75,16 @@ constexpr int kRounds = 16;  // selection rounds of NT candidate slots a workgro
 #define EFFORT_ROW_AUX 0
 #endif
 constexpr int kRowAux = EFFORT_ROW_AUX;
+// PERSIST (template parameter of the kernel and of mul_item) = false: the instantiation for PLAIN grids -- one item per workgroup, no
+// item queues, no cutoff jobs, no staging of a next item, no stamps or ablation switches.  It is the same kernel with those
+// compiled out: half the code (28 against 53 KB at E = 1, 8 waves) and 116 instead of 128 VGPRs, and a plain grid runs its code
+// once, cold (the instruction cache starts every launch empty), so size IS latency: lone calls 22.8 -> 21.9 us, the decode
+// loop 267 -> 284 tokens/s (measured A/B on one box).  The generic instantiation serves persistent launches and the debug modes.
+#define GA_PERSISTENT(ga) (PERSIST ? (ga).persistent : 0u)
+#define GA_CUTJOBS(ga) (PERSIST ? (ga).cutJobs : 0u)
+#define GA_TSTAMP(ga) (PERSIST ? (ga).tstamp : nullptr)
+#define GA_ABLATE(ga) (PERSIST ? (ga).ablate : 0u)
+#define GA_TRACE(ga) (PERSIST ? (ga).trace : 0u)
 constexpr int kSc1 = 16;     // buffer aux bit: sc1 = write-through store / L1-bypassing load (cross-XCD visible)
 
 template <int FMT> struct Fmt;
@@ -258,7 +268,7 @@ __device__ __forceinline__ void stage_issue(const GroupKArgs& ga, const ItemRef&
 // `staged` (per wave): this wave's share of the item's stage loads was issued while the previous item streamed (into vblk
 // buffer `par`).  `prefetch` is polled by every wave near the end of its streaming loop until it returns true: there the
 // caller pulls the next item from the queue (wave 0) and issues the wave's share of its stage loads (into buffer par ^ 1).
-template <int FMT, int E, int W, bool FUSED, bool COMPACT, typename Prefetch>
+template <int FMT, int E, int W, bool FUSED, bool COMPACT, bool PERSIST, typename Prefetch>
 __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t item, const ItemRef& ref, char* smem, const LdsPlan& lp, uint32_t& cachedCall,
                                          float& cachedCutoff, const uint32_t par, const bool staged, const bool firstItem, Prefetch prefetch) {
     constexpr int NACC = Fmt<FMT>::kAcc;
@@ -284,12 +294,12 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
 #ifdef EFFORT_NO_STAMPS
     const bool wstamp = false;
 #else
-    const bool wstamp = ga.tstamp && tid == 0;
+    const bool wstamp = GA_TSTAMP(ga) && tid == 0;
 #endif                        // every workgroup: phase durations summed into tstamp[32..]
     unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};
     if (wstamp) ph[0] = wall_clock64();
-    const bool stamp = ga.tstamp && item == 0 && tid == 0;            // phase stamps of item 0 (profiling aid)
-    if (stamp) ga.tstamp[16] = wall_clock64();
+    const bool stamp = GA_TSTAMP(ga) && item == 0 && tid == 0;            // phase stamps of item 0 (profiling aid)
+    if (stamp) GA_TSTAMP(ga)[16] = wall_clock64();
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t B = g.sliceRows;
     const uint32_t offC = __builtin_amdgcn_readfirstlane(lp.offC), offL = __builtin_amdgcn_readfirstlane(lp.offL), offM = __builtin_amdgcn_readfirstlane(lp.offM);
@@ -317,7 +327,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     const bool needCut = fused && cachedCall != ci;              // uniform: a persistent workgroup evaluates a call's cutoff once
     // ... or takes it from the call's cutoff job -- except for its FIRST item: the launch has just started, no job can have
     // finished, and evaluating the cutoff here (5 us, its inputs loaded beside the stage loads) beats waiting for one
-    const bool viaJob = needCut && ga.cutJobs != 0u && !firstItem;
+    const bool viaJob = needCut && GA_CUTJOBS(ga) != 0u && !firstItem;
     // Input prologue (uniform per call): the multiply's input is v itself, or silu(v) * vAux (the FFN gate,
     // runNetwork.swift:181), or rmsNorm(v) * vAux (runNetwork.swift:121-122,173-175) -- evaluated here, per workgroup,
     // instead of in a launch of its own.
@@ -378,7 +388,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     // asks for it here, before the staged loads are awaited
     uint32_t* const cutWords = ga.queue + 9 * 16;
     uint32_t cutWord = 0;
-    if (viaJob && tid == 0 && !(ga.ablate & 32u)) cutWord = __hip_atomic_load(&cutWords[ci], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (viaJob && tid == 0 && !(GA_ABLATE(ga) & 32u)) cutWord = __hip_atomic_load(&cutWords[ci], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // the staged loads have landed (each thread waits for its own; it reads back only what its own lane loaded until the
     // next barrier).  The slice's absolute sum bounds every partial sum of this workgroup (see the scale below).
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -395,7 +405,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     bound = wave_sum_f32(bound);                                  // (only the exponent of the slice's bound matters: any order)
     if (lane == 0) wbound[wave] = bound;
     if (tid == 0) { flags[4] = 0u; flags[5] = 0u; }               // the list is empty, none of it handed out
-    if (stamp) ga.tstamp[17] = wall_clock64();
+    if (stamp) GA_TSTAMP(ga)[17] = wall_clock64();
     if (wstamp) ph[1] = wall_clock64();
 
     // ---- B. cutoff (findCutoff32), redundantly per workgroup; its first barrier also publishes vblk / wbound.
@@ -407,7 +417,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
         // the call's cutoff job (head of the item queues, see bucket_mul_kernel) publishes the value and raises the flag;
         // it never waits on anything, so this wait ends -- and should it not within ~4 ms, the cutoff is evaluated here
         if (tid == 0) {
-            for (int spin = 0; spin < ((ga.ablate & 32u) ? 0 : 20000) && !(cutWord >> 31); spin++) {      // (ablate 32: exercise the fallback)
+            for (int spin = 0; spin < ((GA_ABLATE(ga) & 32u) ? 0 : 20000) && !(cutWord >> 31); spin++) {      // (ablate 32: exercise the fallback)
                 __builtin_amdgcn_s_sleep(8);
                 cutWord = __hip_atomic_load(&cutWords[ci], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -421,12 +431,12 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     }
     if (fromJob) {
     } else if (needCut) {
-        cutoff = block_find_cutoff<NT>(vj, prj, a.q, smem + offC, tbl, []() {}, stamp ? ga.tstamp + 8 : nullptr);
+        cutoff = block_find_cutoff<NT>(vj, prj, a.q, smem + offC, tbl, []() {}, stamp ? GA_TSTAMP(ga) + 8 : nullptr);
         cachedCall = ci; cachedCutoff = cutoff;
-        if (b == 0 && tid == 0 && !ga.cutJobs) a_cutoff[0] = cutoff;             // BucketMul.cutoff (bucketMul.swift:22)
+        if (b == 0 && tid == 0 && !GA_CUTJOBS(ga)) a_cutoff[0] = cutoff;             // BucketMul.cutoff (bucketMul.swift:22)
     } else if (fused) {
         cutoff = cachedCutoff;
-        if (b == 0 && tid == 0 && !ga.cutJobs) a_cutoff[0] = cutoff;
+        if (b == 0 && tid == 0 && !GA_CUTJOBS(ga)) a_cutoff[0] = cutoff;
         __syncthreads();                                             // publishes vblk / wbound / the list length
     } else {
         // split mode: the standalone cutoff kernel ran first on this stream (cheaper in aggregate when several
@@ -447,7 +457,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     int kexp = 30 - (int)((__float_as_uint(L) >> 23) & 0xFFu) + 126;     // L < 2^(e-126)  =>  2^kexp * L < 2^30
     kexp = L > 0.0f ? max(-100, min(100, kexp)) : 0;
     const float scale = __uint_as_float((uint32_t)(127 + kexp) << 23), unscale = __uint_as_float((uint32_t)(127 - kexp) << 23);
-    if (stamp) ga.tstamp[18] = wall_clock64();
+    if (stamp) GA_TSTAMP(ga)[18] = wall_clock64();
     if (wstamp) ph[2] = wall_clock64();
 
     // ---- C. keep test (bucketMul.metal:69 / bucketMulQ4.metal:47) + compaction -------------------
@@ -463,7 +473,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     // (the rounds go in blocks of four, a block's reads issued together; blocks wholly past the slice's slots are skipped with a
     //  uniform branch: a lone call's slices have 2048 slots -- one block of four rounds with 512 threads -- a 32-call launch's
     //  8192)
-    const bool sel = !(ga.ablate & 8u);
+    const bool sel = !(GA_ABLATE(ga) & 8u);
     uint32_t keepMask = 0;                                  // bit r: this thread's slot of round r is kept
     uint32_t before[kRounds];                               // (wave-uniform) survivors of the wave's earlier rounds
     uint32_t wtot = 0;
@@ -509,7 +519,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     __syncthreads();
     const uint32_t n = flags[4];
     if (t == 0 && tid == 0) a_sliceCounts[s] = n;                  // dispatch.size = sum over slices (test hook)
-    if (stamp) ga.tstamp[19] = wall_clock64();
+    if (stamp) GA_TSTAMP(ga)[19] = wall_clock64();
     if (wstamp) ph[3] = wall_clock64();
 
     // ---- D. stream the kept rows, scatter-accumulate into the LDS tile ----------------
@@ -520,7 +530,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     // lanes past the last column re-read the row's LAST piece -- the line their neighbours are fetching anyway.  (They used to
     // re-read column 0: one more 128-byte line per kept row for the ragged last tile, 68 MB of a 32-call launch's 824.)
     const uint32_t voff = (colOK ? col : (g.cols - 1u) / (uint32_t)E * (uint32_t)E) * 2u;
-    const uint32_t nU = (ga.ablate & 4u) ? 0u : __builtin_amdgcn_readfirstlane(n);   // n is workgroup-uniform; keep it in an SGPR
+    const uint32_t nU = (GA_ABLATE(ga) & 4u) ? 0u : __builtin_amdgcn_readfirstlane(n);   // n is workgroup-uniform; keep it in an SGPR
     // The waves of a workgroup do NOT run at one speed (the older wave wins the arbitration for issue slots and the memory
     // pipeline: measured, wave 0 gets through a static share of the rows 2-3x sooner than the last wave and then idles at
     // the barrier), so the list is handed out dynamically: a wave takes the next KB entries with one LDS atomic.
@@ -627,9 +637,9 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
         if (baseA < nU) { decode(baseA, boffA, dvA); issue(pa, boffA); }
         while (baseA < nU) {
             if (!asked && nU - baseA <= 4u * KB * W) asked = prefetch();
-            if (wstamp && ga.trace && item + ga.cutJobs < (uint32_t)kTraceItems) {       // progress stamps (trace mode only)
+            if (wstamp && GA_TRACE(ga) && item + GA_CUTJOBS(ga) < (uint32_t)kTraceItems) {       // progress stamps (trace mode only)
                 const uint32_t q0 = (4u * baseA) / nU, q1 = min(4u, (4u * (baseA + 2u * KB * W)) / nU);
-                for (uint32_t q = q0 + 1u; q <= q1 && q < 4u; q++) ga.tstamp[kTraceOff + (size_t)kTraceItems * 8u + (size_t)(item + ga.cutJobs) * 4u + q - 1u] = wall_clock64();
+                for (uint32_t q = q0 + 1u; q <= q1 && q < 4u; q++) GA_TSTAMP(ga)[kTraceOff + (size_t)kTraceItems * 8u + (size_t)(item + GA_CUTJOBS(ga)) * 4u + q - 1u] = wall_clock64();
             }
             baseB = grab();
             decode(baseB, boffB, dvB);
@@ -644,7 +654,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     // (measured too: everything BUT this loop at raised priority -- no effect, 173.9 vs 173.5 us per 32-call launch)
     if (!asked) asked = prefetch();            // (a wave without rows; wave 0 always gets an answer: it is the one that pulls)
     __syncthreads();                           // every wave's atomics have landed in the tile
-    if (stamp) ga.tstamp[20] = wall_clock64();
+    if (stamp) GA_TSTAMP(ga)[20] = wall_clock64();
     if (wstamp) ph[4] = wall_clock64();
 
     // ---- O. Q4 outliers (calcOutliers, bucketMulQ4.metal:13-21: out[o] += v[in]*value per outlier; the reference fires
@@ -808,28 +818,28 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
         __builtin_amdgcn_raw_buffer_store_b64(pk, srs, (uint32_t)o * 4u, slabOff, kSc1);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's slab stores have left the CU
-    if (stamp) { ga.tstamp[21] = wall_clock64(); ga.tstamp[22] = n; }
+    if (stamp) { GA_TSTAMP(ga)[21] = wall_clock64(); GA_TSTAMP(ga)[22] = n; }
     if (wstamp) ph[5] = wall_clock64();
     // the stamps are flushed off the critical path (after the ticket), spread over 32 cache lines
     auto flush_stamps = [&]() {
         if (!wstamp) return;
-        if (ga.trace && item + ga.cutJobs < (uint32_t)kTraceItems) {           // one record per item: who / where / when
-            unsigned long long* rec = ga.tstamp + kTraceOff + (size_t)(item + ga.cutJobs) * 8u;
-            rec[0] = (unsigned long long)(item + ga.cutJobs) | ((unsigned long long)blockIdx.x << 32);
+        if (GA_TRACE(ga) && item + GA_CUTJOBS(ga) < (uint32_t)kTraceItems) {           // one record per item: who / where / when
+            unsigned long long* rec = GA_TSTAMP(ga) + kTraceOff + (size_t)(item + GA_CUTJOBS(ga)) * 8u;
+            rec[0] = (unsigned long long)(item + GA_CUTJOBS(ga)) | ((unsigned long long)blockIdx.x << 32);
             rec[1] = (unsigned long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xFu) | ((unsigned long long)(n & 0xFFFFu) << 8) | ((unsigned long long)(t & 0xFFu) << 24) |
                      ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 32);   // XCC_ID | kept rows | tile | HW_ID
 #pragma unroll
             for (int i = 0; i < 6; i++) rec[2 + i] = ph[i];
         }
-        unsigned long long* line = ga.tstamp + 64 + (item & 31u) * 8u;
+        unsigned long long* line = GA_TSTAMP(ga) + 64 + (item & 31u) * 8u;
 #pragma unroll
         for (int i = 0; i < 5; i++) atomicAdd(&line[i], ph[i + 1] - ph[i]);
         atomicAdd(&line[5], 1ull);
-        atomicMin(&ga.tstamp[0], ph[0]);
-        atomicMax(&ga.tstamp[26], ph[0]);                                       // latest workgroup start
-        atomicMax(&ga.tstamp[28], ph[5] - ph[0]);                               // longest workgroup (start .. slab drained)
-        atomicMax(&ga.tstamp[29], ph[4] - ph[3]);                               // longest streaming phase
-        atomicMax(&ga.tstamp[1], (unsigned long long)wall_clock64());
+        atomicMin(&GA_TSTAMP(ga)[0], ph[0]);
+        atomicMax(&GA_TSTAMP(ga)[26], ph[0]);                                       // latest workgroup start
+        atomicMax(&GA_TSTAMP(ga)[28], ph[5] - ph[0]);                               // longest workgroup (start .. slab drained)
+        atomicMax(&GA_TSTAMP(ga)[29], ph[4] - ph[3]);                               // longest streaming phase
+        atomicMax(&GA_TSTAMP(ga)[1], (unsigned long long)wall_clock64());
     };
     __syncthreads();
     if (tid == 0) {
@@ -838,14 +848,14 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     }
     __syncthreads();
     if (flags[0] == 0u) { flush_stamps(); return; }
-    if (ga.ablate & 2u) { if (tid == 0) __hip_atomic_store(&a_counters[t], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+    if (GA_ABLATE(ga) & 2u) { if (tid == 0) __hip_atomic_store(&a_counters[t], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
 
     // last arriver of tile t: every slab of the tile was stored write-through (sc1) and drained before its ticket;
     // read them past L1 (sc1), sum in slice order, un-permute, add the Q4 outliers, write out[].  Each thread owns
     // four adjacent tile slots and keeps up to kRed 16-byte loads in flight (each is a fabric round trip); the four
     // running sums per slot are combined in a fixed order.
-    const bool rstamp = ga.tstamp && ci == 0 && t == 0 && tid == 0;
-    if (rstamp) ga.tstamp[23] = wall_clock64();
+    const bool rstamp = GA_TSTAMP(ga) && ci == 0 && t == 0 && tid == 0;
+    if (rstamp) GA_TSTAMP(ga)[23] = wall_clock64();
     typedef uint32_t u4v __attribute__((ext_vector_type(4)));
     const uint32_t sliceStride = g.tiles * (uint32_t)(TILE_F * 4);
     // G thread groups share the slices when the workgroup has more threads than the tile has float4 columns (E = 1): each
@@ -903,20 +913,20 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     //  Up to 16 slices per thread group the whole reduction is ONE memory round trip per thread.)
     if (g.slices <= 8u * G) reduce_tile(std::integral_constant<int, 8>{});
     else reduce_tile(std::integral_constant<int, 16>{});
-    if (rstamp) ga.tstamp[24] = wall_clock64();
+    if (rstamp) GA_TSTAMP(ga)[24] = wall_clock64();
     if (tid == 0) {
         __hip_atomic_store(&a_counters[t], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next call
-        if (ga.tstamp) {
+        if (GA_TSTAMP(ga)) {
             flush_stamps();
             const uint32_t done = __hip_atomic_fetch_add(ga.groupDone, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (done == ga.totalTiles - 1u) {                                  // whole kernel finished: fold the stamps
-                const unsigned long long t0 = __hip_atomic_load(&ga.tstamp[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned long long t1 = __hip_atomic_load(&ga.tstamp[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ga.tstamp[2] += t1 - t0; ga.tstamp[3] += 1;
-                ga.tstamp[27] += __hip_atomic_load(&ga.tstamp[26], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - t0;   // dispatch ramp
-                __hip_atomic_store(&ga.tstamp[26], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&ga.tstamp[0], ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&ga.tstamp[1], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long t0 = __hip_atomic_load(&GA_TSTAMP(ga)[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long t1 = __hip_atomic_load(&GA_TSTAMP(ga)[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                GA_TSTAMP(ga)[2] += t1 - t0; GA_TSTAMP(ga)[3] += 1;
+                GA_TSTAMP(ga)[27] += __hip_atomic_load(&GA_TSTAMP(ga)[26], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - t0;   // dispatch ramp
+                __hip_atomic_store(&GA_TSTAMP(ga)[26], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&GA_TSTAMP(ga)[0], ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&GA_TSTAMP(ga)[1], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(ga.groupDone, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
@@ -958,13 +968,13 @@ __device__ __forceinline__ void cutoff_job(const GroupKArgs& ga, uint32_t ci, ch
 // dispatcher only places ~40 workgroups/us chip-wide and spreads a large grid unevenly over the CUs (measured with
 // tools/microbench.hip: residency probe), so a group launch sizes its grid to the chip -- R workgroups per CU,
 // R fixed by the LDS each one asks for -- and balances the work itself.
-template <int FMT, int E, int W, bool FUSED, bool COMPACT = false>
+template <int FMT, int E, int W, bool FUSED, bool COMPACT = false, bool PERSIST = true>
 __global__ __launch_bounds__(64 * W, (W <= 8 ? EFFORT_MIN_WAVES_PER_EU : 4)) void bucket_mul_kernel(const GroupKArgs ga) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ uint32_t s_item;
     __shared__ unsigned long long s_next;                  // the item after the current one | the generation (item count) it was pulled in << 32: ONE word,
                                                            // so that a wave polling mid-loop can never pair a new generation with a stale item
-    const uint32_t total = ga.wgEnd[ga.count - 1] + ga.cutJobs;
+    const uint32_t total = ga.wgEnd[ga.count - 1] + GA_CUTJOBS(ga);
     uint32_t cachedCall = 0xFFFFFFFFu; float cachedCutoff = 0.0f;
     const uint32_t x = blockIdx.x & 7u;                    // block b sits on XCD b%8; item i wants XCD i%8
     uint32_t dry = 0;                                      // (thread 0) queues found empty: when its own XCD's queue is dry a workgroup takes items of the others
@@ -980,7 +990,7 @@ __global__ __launch_bounds__(64 * W, (W <= 8 ? EFFORT_MIN_WAVES_PER_EU : 4)) voi
             if ((dry >> q) & 1u) continue;
             const uint32_t cand = __hip_atomic_fetch_add(&ga.queue[q * 16u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * 8u + q;
             if (cand < total) got = cand; else dry |= 1u << q;
-            if (ga.ablate & 64u) break;                    // (ablate 64: no stealing)
+            if (GA_ABLATE(ga) & 64u) break;                    // (ablate 64: no stealing)
         }
         return got;
     };
@@ -1001,29 +1011,29 @@ __global__ __launch_bounds__(64 * W, (W <= 8 ? EFFORT_MIN_WAVES_PER_EU : 4)) voi
     bool staged = false;                                   // (per wave) its share of the item's stage loads is already in flight / landed
     uint32_t gen = 0;                                      // items this workgroup has worked
     if (threadIdx.x == 0) __hip_atomic_store(&s_next, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    uint32_t item = ga.persistent ? pull_sync() : blockIdx.x;
+    uint32_t item = GA_PERSISTENT(ga) ? pull_sync() : blockIdx.x;
     while (item < total) {
-        if (item < ga.cutJobs) {                           // uniform: a cutoff job (the queues hand these out first)
+        if (item < GA_CUTJOBS(ga)) {                           // uniform: a cutoff job (the queues hand these out first)
             if (item < ga.count) cutoff_job<64 * W>(ga, item, smem);
-            item = ga.persistent ? pull_sync() : total;
+            item = GA_PERSISTENT(ga) ? pull_sync() : total;
             continue;
         }
         ItemRef ref;
-        if (!locate_item(ga, item - ga.cutJobs, ref)) {    // padding of the item grid (slices are dealt in rounds of 8)
-            item = ga.persistent ? pull_sync() : total;
+        if (!locate_item(ga, item - GA_CUTJOBS(ga), ref)) {    // padding of the item grid (slices are dealt in rounds of 8)
+            item = GA_PERSISTENT(ga) ? pull_sync() : total;
             continue;
         }
         gen++;
         bool stagedNext = false;
-        mul_item<FMT, E, W, FUSED, COMPACT>(ga, item - ga.cutJobs, ref, smem, lp, cachedCall, cachedCutoff, par, staged, gen == 1u && (ga.ablate & 512u) != 0u /* (measured: evaluating the first item's cutoff locally instead of waiting for the job is 1 us slower per 32-call launch; kept as an ablation) */, [&]() -> bool {
-            if (!ga.persistent) return true;
+        mul_item<FMT, E, W, FUSED, COMPACT, PERSIST>(ga, item - GA_CUTJOBS(ga), ref, smem, lp, cachedCall, cachedCutoff, par, staged, gen == 1u && (GA_ABLATE(ga) & 512u) != 0u /* (measured: evaluating the first item's cutoff locally instead of waiting for the job is 1 us slower per 32-call launch; kept as an ablation) */, [&]() -> bool {
+            if (!GA_PERSISTENT(ga)) return true;
             if (threadIdx.x == 0)                                  // wave 0's first call: pull, publish (item and generation in one store)
                 __hip_atomic_store(&s_next, ((unsigned long long)gen << 32) | (unsigned long long)pull(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             const unsigned long long nx = __hip_atomic_load(&s_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (__builtin_amdgcn_readfirstlane((uint32_t)(nx >> 32)) != gen) return false;   // no answer yet
             const uint32_t next = __builtin_amdgcn_readfirstlane((uint32_t)nx);
             ItemRef nref;
-            if (kPipe && !(ga.ablate & 128u) && next >= ga.cutJobs && next < total && locate_item(ga, next - ga.cutJobs, nref)) {
+            if (kPipe && !(GA_ABLATE(ga) & 128u) && next >= GA_CUTJOBS(ga) && next < total && locate_item(ga, next - GA_CUTJOBS(ga), nref)) {
                 int tid0 = threadIdx.x;
                 asm volatile("" : "+v"(tid0));
                 stage_issue<FMT, W, COMPACT>(ga, nref, tid0, smem, lp, par ^ 1u);
@@ -1032,11 +1042,11 @@ __global__ __launch_bounds__(64 * W, (W <= 8 ? EFFORT_MIN_WAVES_PER_EU : 4)) voi
             return true;
         });
         // (mul_item's barriers lie between wave 0's publication and this read)
-        item = ga.persistent ? __builtin_amdgcn_readfirstlane((uint32_t)__hip_atomic_load(&s_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) : total;
+        item = GA_PERSISTENT(ga) ? __builtin_amdgcn_readfirstlane((uint32_t)__hip_atomic_load(&s_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) : total;
         staged = stagedNext;
         par ^= 1u;
     }
-    if (ga.persistent && threadIdx.x == 0) {               // the last workgroup out rewinds the queues (and flags) for the next launch
+    if (GA_PERSISTENT(ga) && threadIdx.x == 0) {               // the last workgroup out rewinds the queues (and flags) for the next launch
         const uint32_t gone = __hip_atomic_fetch_add(&ga.queue[8 * 16], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (gone == gridDim.x - 1u) {
             for (int i = 0; i <= 8; i++) __hip_atomic_store(&ga.queue[i * 16], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1069,23 +1079,32 @@ static hipError_t launch_mul_t(const GroupKArgs& ga, hipStream_t st) {
     bool fusedAny = false;
     for (uint32_t i = 0; i < ga.count; i++) fusedAny = fusedAny || ga.call[i].pre || ga.call[i].resid;
     if (fusedAny && FMT != kFp16) return hipErrorInvalidValue;
+    // plain grids of the product path (no stamps, no ablation switches) run the lean instantiation (PERSIST = false, see above);
+    // built for 8-wave workgroups, the only size the heuristics choose
+    constexpr bool kLean = W == 8;
     if (lds > maxSet) {
-        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&bucket_mul_kernel<FMT, E, W, false>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (err == hipSuccess && FMT == kFp16)
-            err = hipFuncSetAttribute(reinterpret_cast<const void*>(&bucket_mul_kernel<kFp16, E, W, true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (err == hipSuccess && FMT == kFp16)
-            err = hipFuncSetAttribute(reinterpret_cast<const void*>(&bucket_mul_kernel<kFp16, E, W, false, true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        auto set = [&](const void* f) { return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); };
+        hipError_t err = set(reinterpret_cast<const void*>(&bucket_mul_kernel<FMT, E, W, false>));
+        if constexpr (kLean) if (err == hipSuccess) err = set(reinterpret_cast<const void*>(&bucket_mul_kernel<FMT, E, W, false, false, false>));
+        if constexpr (FMT == kFp16) {
+            if (err == hipSuccess) err = set(reinterpret_cast<const void*>(&bucket_mul_kernel<kFp16, E, W, true>));
+            if (err == hipSuccess) err = set(reinterpret_cast<const void*>(&bucket_mul_kernel<kFp16, E, W, false, true>));
+            if constexpr (kLean) if (err == hipSuccess) err = set(reinterpret_cast<const void*>(&bucket_mul_kernel<kFp16, E, W, true, false, false>));
+        }
         if (err != hipSuccess) return err;
         maxSet = lds;
     }
     const bool compact = (ga.split & 4u) != 0u;                   // (api.hip: persistent FP16 launches of plain calls)
-    if (compact && (FMT != kFp16 || fusedAny)) return hipErrorInvalidValue;
-    if (fusedAny) hipLaunchKernelGGL((bucket_mul_kernel<kFp16, E, W, true>), dim3(grid), dim3(64 * W), lds, st, ga);
-    else if (compact) hipLaunchKernelGGL((bucket_mul_kernel<kFp16, E, W, false, true>), dim3(grid), dim3(64 * W), lds, st, ga);
-    else hipLaunchKernelGGL((bucket_mul_kernel<FMT, E, W, false>), dim3(grid), dim3(64 * W), lds, st, ga);
+    if (compact && (FMT != kFp16 || fusedAny || !ga.persistent)) return hipErrorInvalidValue;
+    const bool lean = kLean && !ga.persistent && !ga.tstamp && !ga.ablate;
+    const dim3 gd(grid), bd(64 * W);
+    if constexpr (kLean) {
+        if (lean && fusedAny) { hipLaunchKernelGGL((bucket_mul_kernel<kFp16, E, W, true, false, false>), gd, bd, lds, st, ga); return hipGetLastError(); }
+        if (lean) { hipLaunchKernelGGL((bucket_mul_kernel<FMT, E, W, false, false, false>), gd, bd, lds, st, ga); return hipGetLastError(); }
+    }
+    if (fusedAny) hipLaunchKernelGGL((bucket_mul_kernel<kFp16, E, W, true>), gd, bd, lds, st, ga);
+    else if (compact) hipLaunchKernelGGL((bucket_mul_kernel<kFp16, E, W, false, true>), gd, bd, lds, st, ga);
+    else hipLaunchKernelGGL((bucket_mul_kernel<FMT, E, W, false>), gd, bd, lds, st, ga);
     return hipGetLastError();
 }
 

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--tokens", type=int, default=48)
     ap.add_argument("--efforts", default="0.25,1.0")
     ap.add_argument("--fused-glue", default="", help="comma list of norm,gate,resid (or 1 = all) folded into the multiplies")
+    ap.add_argument("--tunes", default="0,0,0", help="semicolon list of set_tuning triples (waves,elems,slices) to time, e.g. 0,0,0;8,1,0")
     ap.add_argument("--split", type=int, default=0, help="also time every knob set with the cutoffs in a kernel of their own")
     a = ap.parse_args()
     torch.cuda.set_device(0)
@@ -32,12 +33,12 @@ def main():
     dec.g.set_dense_backend(False)
     _, dt_d, _ = dec.run(prompt, a.tokens, dense=True)
     out["dense_hip_kernel_tokens_per_s"] = round(1 / dt_d, 1)
-    knobs = [{}, {}]
+    knobs = [{"tune": t} for t in a.tunes.split(";")]
     for e in (float(x) for x in a.efforts.split(",")):
         for kn in knobs:
             for k in ("EFFORT_X_NARROW", "EFFORT_X_FULL", "EFFORT_X_GT"):
                 os.environ.pop(k, None)
-            os.environ.update(kn)
+            dec.g.set_tuning(*(int(x) for x in kn["tune"].split(",")))
             for split in ((0, 1) if a.split else (0,)):
                 dec.g.set_split_cutoff(bool(split))
                 dec._graphs.clear()
