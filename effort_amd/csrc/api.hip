@@ -651,7 +651,8 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
         a.pre = (uint16_t)pre; a.vAux = pre ? vAux[i] : nullptr; a.resid = resids ? resids[i] : nullptr;
         a.slabOff = (uint32_t)(slabOff / 256); a.tileOff = (uint16_t)tileOff; a.sliceOff = (uint16_t)sliceOff; a.geom = (uint16_t)gi;
         wg += g.tiles * ((g.slices + 7) / 8 * 8);
-        ga.wgEnd[(uint32_t)i - first] = wg;
+        if (wg / 8u > 0xFFFFu) return fail(c, EFFORT_ERR_SHAPE, "bucketmul: group exceeds the launch descriptor's item range");
+        ga.wgEnd8[(uint32_t)i - first] = (uint16_t)(wg / 8u); ga.totalItems = wg;
         ga.count = (uint32_t)i - first + 1u;
         ga.totalTiles += g.tiles;
         L.lastSliceOff[i] = sliceOff; L.lastSlices[i] = g.slices;                   // dispatch.size = sum of the per-slice counts

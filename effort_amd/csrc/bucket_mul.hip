@@ -140,7 +140,6 @@ template <int E> __host__ __device__ inline uint32_t ol_scratch_bytes(const MulG
 // means / vblk are filled by LDS-direct buffer loads (stage_issue), whose destination (M0) is kept below 64 KB.  Q4: after
 // the streaming phase means | vblk are dead and hold the outlier phase's scratch (sums | whole v); Q4 items are not
 // pipelined and use vblk[0] only.
-struct LdsPlan { uint32_t offM, offV[2], offA, offL, offC, total; };
 template <int FMT, int E, int W>
 __host__ __device__ inline LdsPlan plan_lds(const MulGeom* geoms, int nGeoms) {
     uint32_t slots = 0, vrows = 0, ol = 0;
@@ -174,11 +173,11 @@ struct ItemRef { uint32_t ci, t, s; };
 __device__ __forceinline__ bool locate_item(const GroupKArgs& ga, const uint32_t item, ItemRef& r) {
     // which call of the group this item belongs to (item ranges are multiples of 8, so item%8 is still the XCD)
     uint32_t ci = 0;
-    for (uint32_t i = 0; i + 1 < ga.count; i++) if (item >= ga.wgEnd[i]) ci = i + 1;
+    for (uint32_t i = 0; i + 1 < ga.count; i++) if ((item >> 3) >= (uint32_t)ga.wgEnd8[i]) ci = i + 1;
     ci = __builtin_amdgcn_readfirstlane(ci);
     const MulGeom& g = ga.geom[ga.call[ci].geom];
     // XCD-aware id -> (tile, slice): all tiles of a slice run on one XCD (speed only).
-    const uint32_t b = item - (ci ? ga.wgEnd[ci - 1] : 0u), xcd = b & 7u, k = b >> 3;
+    const uint32_t b = item - (ci ? (uint32_t)ga.wgEnd8[ci - 1] * 8u : 0u), xcd = b & 7u, k = b >> 3;
     // (the slice <-> XCD assignment rotates with the call: calls sharing an input vector -- Wq|Wk|Wv, or a batch on one v --
     //  have the same heavy and light slices, and an XCD that got the same slice of every call would finish 15 % late)
     r.ci = ci; r.s = (k / g.tiles) * 8u + ((xcd + ci) & 7u); r.t = k % g.tiles;
@@ -286,7 +285,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     uint32_t* const a_counters = ga.counters + a.tileOff;
     uint32_t* const a_sliceCounts = ga.sliceCounts + a.sliceOff;
     float* const a_cutoff = ga.cutoff + ci;
-    const uint32_t b = item - (ci ? ga.wgEnd[ci - 1] : 0u);
+    const uint32_t b = item - (ci ? (uint32_t)ga.wgEnd8[ci - 1] * 8u : 0u);
 
     int tid0 = threadIdx.x;
     asm volatile("" : "+v"(tid0));      // opaque per item: keeps the compiler from hoisting every tid-derived value out of the item loop (+50 VGPRs)
@@ -460,6 +459,11 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     if (stamp) GA_TSTAMP(ga)[18] = wall_clock64();
     if (wstamp) ph[2] = wall_clock64();
 
+#if defined(EFFORT_PAD_TEST) && EFFORT_PAD_TEST == 1            // A/B: 24 KB of code nobody executes, in the middle of the kernel
+    if (ga.numCU == 0xdeadu) asm volatile(".rept 6000\n s_nop 0\n .endr" ::: "memory");
+#elif defined(EFFORT_PAD_TEST) && EFFORT_PAD_TEST == 2          // A/B: 4 KB of code everybody executes (1000 cycles by itself)
+    asm volatile(".rept 1000\n s_nop 0\n .endr" ::: "memory");
+#endif
     // ---- C. keep test (bucketMul.metal:69 / bucketMulQ4.metal:47) + compaction -------------------
     // Every thread tests its slot of each round against the means it holds in registers (FP16: all its slots belong to ONE
     // input row, whose |v| it reads once), ballots, and a wave sums its survivors; ONE LDS atomic per wave reserves that
@@ -974,7 +978,7 @@ __global__ __launch_bounds__(64 * W, (W <= 8 ? EFFORT_MIN_WAVES_PER_EU : 4)) voi
     __shared__ uint32_t s_item;
     __shared__ unsigned long long s_next;                  // the item after the current one | the generation (item count) it was pulled in << 32: ONE word,
                                                            // so that a wave polling mid-loop can never pair a new generation with a stale item
-    const uint32_t total = ga.wgEnd[ga.count - 1] + GA_CUTJOBS(ga);
+    const uint32_t total = ga.totalItems + GA_CUTJOBS(ga);
     uint32_t cachedCall = 0xFFFFFFFFu; float cachedCutoff = 0.0f;
     const uint32_t x = blockIdx.x & 7u;                    // block b sits on XCD b%8; item i wants XCD i%8
     uint32_t dry = 0;                                      // (thread 0) queues found empty: when its own XCD's queue is dry a workgroup takes items of the others
@@ -1006,7 +1010,7 @@ __global__ __launch_bounds__(64 * W, (W <= 8 ? EFFORT_MIN_WAVES_PER_EU : 4)) voi
     // issues its share of item i+1's stage loads (row means + slice of v, stage_issue) under its remaining rows.  A wave that
     // finishes its rows before the answer is there stages its share at the start of item i+1 instead.
     constexpr bool kPipe = !FUSED && FMT == kFp16;         // (a fused input prologue transforms v in place; Q4's outlier phase reuses the staging region)
-    const LdsPlan lp = plan_lds<FMT, E, W>(ga.geom, kMaxGeoms);
+    const LdsPlan lp = ga.lp;                              // (the launcher's plan_lds<FMT, E, W> over ga.geom)
     uint32_t par = 0;                                      // vblk buffer of the current item
     bool staged = false;                                   // (per wave) its share of the item's stage loads is already in flight / landed
     uint32_t gen = 0;                                      // items this workgroup has worked
@@ -1057,18 +1061,20 @@ __global__ __launch_bounds__(64 * W, (W <= 8 ? EFFORT_MIN_WAVES_PER_EU : 4)) voi
 
 // ---- host side ------------------------------------------------------------------------------
 template <int FMT, int E, int W>
-static hipError_t launch_mul_t(const GroupKArgs& ga, hipStream_t st) {
-    const LdsPlan lp = plan_lds<FMT, E, W>(ga.geom, kMaxGeoms);
+static hipError_t launch_mul_t(const GroupKArgs& gaIn, hipStream_t st) {
+    GroupKArgs ga = gaIn;
+    const LdsPlan lp = ga.lp = plan_lds<FMT, E, W>(ga.geom, kMaxGeoms);
     uint32_t lds = lp.total;
     if (lp.offA > 65536u && FMT == kFp16) return hipErrorInvalidValue;     // stage_issue's destinations sit below offA
     for (uint32_t i = 0; i < ga.count; i++) {
         const MulGeom& g = ga.geom[ga.call[i].geom];
         if (g.slots > (uint32_t)kRounds * 64 * W || g.slots != (FMT == kFp16 ? (g.rowsPerIn << g.sliceLog2) : g.sliceRows * 8u)) return hipErrorInvalidValue;
         if (FMT == kFp16 ? (1u << g.sliceLog2) > 64u * W : g.sliceRows > 128u * W) return hipErrorInvalidValue;       // stage_issue: a thread lands one (Q4: two) inputs of the slice
-        if (ga.wgEnd[i] - (i ? ga.wgEnd[i - 1] : 0u) != g.tiles * align_up(g.slices, 8)) return hipErrorInvalidValue;
+        if (((uint32_t)ga.wgEnd8[i] - (i ? (uint32_t)ga.wgEnd8[i - 1] : 0u)) * 8u != g.tiles * align_up(g.slices, 8)) return hipErrorInvalidValue;
     }
     static uint32_t maxSet = 0;   // per instantiation
-    uint32_t grid = ga.wgEnd[ga.count - 1];
+    if (ga.totalItems != (uint32_t)ga.wgEnd8[ga.count - 1] * 8u) return hipErrorInvalidValue;
+    uint32_t grid = ga.totalItems;
     if (ga.persistent) {
         // R workgroups per CU, exactly: ask for enough LDS that R+1 cannot share a CU
         const uint32_t R = ga.persistent;

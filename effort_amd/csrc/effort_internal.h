@@ -72,10 +72,12 @@ struct CallDesc {                    // 112 bytes
                                // kPreRmsNorm: norm weights f16 [inDim], input = v / sqrt(mean(v^2) + 1e-5) * w (rmsNormFast + mul(by:))
     const float* resid;        // nullable epilogue: out = resid + product (h.add(by:), runNetwork.swift:172,183); may alias out
 };
+// Where the regions of a workgroup's dynamic LDS start (plan_lds in bucket_mul.hip; computed by the launcher, not by every workgroup).
+struct LdsPlan { uint32_t offM, offV[2], offA, offL, offC, total; };
+// Layout: what EVERY workgroup reads first comes first and together -- the scalars and the LDS plan share the first 64-byte line
+// of the kernel-argument block, the scratch pointers the second -- so that a workgroup's first scalar loads are two lines, not a
+// chain of dependent ones (a plain grid's workgroup runs its prologue once, on the dependent chain of the call).
 struct GroupKArgs {
-    CallDesc call[kMaxGroup];
-    MulGeom geom[kMaxGeoms];
-    uint32_t wgEnd[kMaxGroup];     // exclusive end of each call's item range (multiples of 8)
     uint32_t count;
     uint32_t totalTiles;           // sum of tiles: the workgroup that finishes the last tile folds the timing stamps
     uint32_t persistent;           // 0: one workgroup per item; R > 0: numCU*R persistent workgroups pull items from the queues
@@ -85,6 +87,8 @@ struct GroupKArgs {
                                    // bit 2: FP16 calls' `stats` point at the compact row means (u16 per bucket row), not at the f16x4 stats
     uint32_t cutJobs;              // persistent launches: the first cutJobs items (a multiple of 8 >= count) are cutoff jobs, one per call
     uint32_t trace;                // profiling only: 1 = every item leaves a 64-byte record (who ran it, where, its phase stamps) at tstamp + kTraceOff
+    LdsPlan lp;                    // of the instantiation launched, over geom[] (launch_mul_t)
+    uint32_t totalItems;           // = 8 * wgEnd8[count - 1]: items of the launch (without the cutoff jobs)
     uint32_t* groupDone;           // counter of finished tiles (zero between launches)
     uint32_t* queue;               // [9][16]: per-XCD item cursors (one cache line each), line 8 = exit counter;
                                    // then [32] cutoff words (value | ready bit) of the calls; all zero between launches
@@ -93,6 +97,9 @@ struct GroupKArgs {
     uint32_t* sliceCounts;
     float* cutoff;                 // [count]: BucketMul.cutoff of every call
     unsigned long long* tstamp;    // nullable profiling stamps: [0]=min start, [1]=max end, [2]=sum, [3]=launches, [16..] phases
+    uint16_t wgEnd8[kMaxGroup];    // exclusive end of each call's item range, in units of 8 items (the ranges are multiples of 8)
+    MulGeom geom[kMaxGeoms];
+    CallDesc call[kMaxGroup];
 };
 static_assert(sizeof(CallDesc) == 112 && sizeof(GroupKArgs) <= 4000, "the launch descriptor must fit the kernel-argument segment");
 
