@@ -82,6 +82,34 @@ def test_cutoff_and_dispatch_bit_exact(ea, oracle_cpu, outDim, inDim, heavy):
         assert got.tobytes() == disp[:n].tobytes()
 
 
+def test_cutoff_across_input_scales(ea, oracle_cpu):
+    """The same input scaled over twelve decades: the cutoff crosses 128, below which the kernel runs the reference's last
+    bisection rounds as a loop and from which it takes their fixed point directly (cutoff_device.h, bisect_to_cell_edge) --
+    bit-exact with the oracle either way, through the fused multiply as well as the standalone kernel."""
+    outDim, inDim = 1024, 4096
+    W, b, s, p = converted(oracle_cpu, outDim, inDim)
+    ew = gpu_weights(ea, W, b, s, p)
+    bm = ea.BucketMul.shared()
+    base = make_v(inDim, seed=17, heavy=True)
+    seen_small = seen_big = 0
+    for k in range(-9, 4):
+        for mult in (1.0, 1.7, 3.1):
+            v = (base * np.float32(mult * 10.0 ** k)).astype(np.float32)
+            vd = devf(v)
+            for effort in (0.1, 0.25, 0.6):
+                cutoff, _ = oracle_cpu.find_cutoff(v, p, 0, effort)
+                bm.calcDispatch(vd, ew, None, effort)
+                ea.gpu().eval()
+                assert np.float32(bm.cutoff).tobytes() == np.float32(cutoff).tobytes(), (k, mult, effort, bm.cutoff, cutoff)
+                out = torch.zeros(outDim, device=DEV)
+                ea.bucketMul(vd, ew, None, out, effort)
+                ea.gpu().eval()
+                assert np.float32(ea.gpu().last_cutoff()).tobytes() == np.float32(cutoff).tobytes(), (k, mult, effort)
+                seen_small += cutoff < 128.0
+                seen_big += cutoff >= 128.0
+    assert seen_small > 10 and seen_big > 10, (seen_small, seen_big)
+
+
 def test_cutoff_with_exact_zero_inputs(ea, oracle_cpu):
     """Exact zeros among the probe products (zero inputs; Q4 probes zeroed as outliers) stretch the value range down to
     0: the cutoff stays bit-exact at every effort, including effort 1 where the reference bisects towards 0 for its
