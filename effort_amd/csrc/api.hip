@@ -590,11 +590,12 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
         for (uint32_t i = 0; i < ga.count; i++) plain = plain && !ga.call[i].pre;
         static const bool noJobs = getenv("EFFORT_NO_CUTJOBS") != nullptr;
         ga.cutJobs = (ga.persistent && !c->splitCutoff && plain && !noJobs) ? (ga.count + 7u) / 8u * 8u : 0u;
-        // FP16: the multiply stages the compact row means where every slice starts on an even row (an LDS-direct load lands two)
+        // FP16: the multiply stages the compact row means where every slice starts on an even row (an LDS-direct load lands two):
+        // a quarter of the lines of the 8-byte stats entries, half the loads.  Persistent launches, and the plain grids the lean
+        // instantiation serves (8 waves, no stamps): with the path a template parameter it costs them no code (as a run-time
+        // switch inside one kernel it cost lone calls 3 %); measured on plain grids: decode 298 -> 300 tokens/s.
         static const bool noCompact = getenv("EFFORT_NO_COMPACT_MEANS") != nullptr;
-        // (persistent launches only: the plain grids of lone calls and small groups are latency chains that a second code path
-        //  in the kernel slows by 3 % -- measured -- and whose staged bytes do not matter)
-        bool compact = fmt == kFp16 && !noCompact && ga.persistent != 0u && plain;
+        bool compact = fmt == kFp16 && !noCompact && (ga.persistent != 0u || (W == 8 && !c->clock && !ablate)) && plain;
         for (uint32_t i = 0; compact && i < ga.count; i++) compact = !ga.call[i].resid;
         for (uint32_t i = 0; compact && i < ga.count; i++) {
             const MulGeom& g = ga.geom[ga.call[i].geom];

@@ -1096,15 +1096,17 @@ static hipError_t launch_mul_t(const GroupKArgs& gaIn, hipStream_t st) {
             if (err == hipSuccess) err = set(reinterpret_cast<const void*>(&bucket_mul_kernel<kFp16, E, W, true>));
             if (err == hipSuccess) err = set(reinterpret_cast<const void*>(&bucket_mul_kernel<kFp16, E, W, false, true>));
             if constexpr (kLean) if (err == hipSuccess) err = set(reinterpret_cast<const void*>(&bucket_mul_kernel<kFp16, E, W, true, false, false>));
+            if constexpr (kLean) if (err == hipSuccess) err = set(reinterpret_cast<const void*>(&bucket_mul_kernel<kFp16, E, W, false, true, false>));
         }
         if (err != hipSuccess) return err;
         maxSet = lds;
     }
     const bool compact = (ga.split & 4u) != 0u;                   // (api.hip: persistent FP16 launches of plain calls)
-    if (compact && (FMT != kFp16 || fusedAny || !ga.persistent)) return hipErrorInvalidValue;
+    if (compact && (FMT != kFp16 || fusedAny)) return hipErrorInvalidValue;
     const bool lean = kLean && !ga.persistent && !ga.tstamp && !ga.ablate;
     const dim3 gd(grid), bd(64 * W);
     if constexpr (kLean) {
+        if (lean && compact) { hipLaunchKernelGGL((bucket_mul_kernel<kFp16, E, W, false, true, false>), gd, bd, lds, st, ga); return hipGetLastError(); }
         if (lean && fusedAny) { hipLaunchKernelGGL((bucket_mul_kernel<kFp16, E, W, true, false, false>), gd, bd, lds, st, ga); return hipGetLastError(); }
         if (lean) { hipLaunchKernelGGL((bucket_mul_kernel<FMT, E, W, false, false, false>), gd, bd, lds, st, ga); return hipGetLastError(); }
     }
