@@ -564,18 +564,18 @@ def main():
         for ns in (1, 2, 3, 4):                              # ONE context, `ns` launches in flight (effort_set_overlap), each step on its own matrices
             log(f"by_streams: {ns} lane(s)")
             jb = job if ns == S else LaneJob(ea, local, ns, tune)
-            gn = jb.capture(mul_step(args.effort, wsets=ew_sets[:max(1, min(ns, len(ew_sets)))]), 48)
-            bs[str(ns)] = rate(time_graph(gn, None, reps=4) / 48 / N_MATS)
+            gn = jb.capture(mul_step(args.effort, wsets=ew_sets[:max(1, min(ns, len(ew_sets)))]), 192)      # (one long graph, like the headline: no drains)
+            bs[str(ns)] = rate(time_graph(gn, None) / 192 / N_MATS)
             del gn
         result["by_streams"] = bs
         result["by_streams_note"] = "one effort_ctx, effort_set_overlap(n): the library keeps n launches in flight; every step in flight on its own 32 matrices"
         # round 2's job beside it: every step in flight on the SAME 32 matrices, and the overlap built by the caller from four contexts
-        gn = job.capture(mul_step(args.effort), 48)
-        result["shared_matrices"] = rate(time_graph(gn, None, reps=4) / 48 / N_MATS)
+        gn = job.capture(mul_step(args.effort), 192)
+        result["shared_matrices"] = rate(time_graph(gn, None) / 192 / N_MATS)
         del gn
         four_ctx = Job(ea, local, S, tune)
-        gn = four_ctx.capture(mul_step(args.effort, wsets=ew_sets), 48)
-        result["four_contexts"] = rate(time_graph(gn, None, reps=4) / 48 / N_MATS)
+        gn = four_ctx.capture(mul_step(args.effort, wsets=ew_sets), 192)
+        result["four_contexts"] = rate(time_graph(gn, None) / 192 / N_MATS)
         del gn, four_ctx
         ts = by["1"]["us_per_call"] * 1e-6
         # ---------------- dense baseline (basicMul over the rotating cores) ---------------------------

@@ -82,9 +82,15 @@ constexpr int kRowAux = EFFORT_ROW_AUX;
 // loop 267 -> 284 tokens/s (measured A/B on one box).  The generic instantiation serves persistent launches and the debug modes.
 #define GA_PERSISTENT(ga) (PERSIST ? (ga).persistent : 0u)
 #define GA_CUTJOBS(ga) (PERSIST ? (ga).cutJobs : 0u)
+#ifdef EFFORT_PRODUCT_ONLY               // A/B build: no stamps / ablation switches in ANY instantiation
+#define GA_TSTAMP(ga) ((unsigned long long*)nullptr)
+#define GA_ABLATE(ga) 0u
+#define GA_TRACE(ga) 0u
+#else
 #define GA_TSTAMP(ga) (PERSIST ? (ga).tstamp : nullptr)
 #define GA_ABLATE(ga) (PERSIST ? (ga).ablate : 0u)
 #define GA_TRACE(ga) (PERSIST ? (ga).trace : 0u)
+#endif
 constexpr int kSc1 = 16;     // buffer aux bit: sc1 = write-through store / L1-bypassing load (cross-XCD visible)
 
 template <int FMT> struct Fmt;
