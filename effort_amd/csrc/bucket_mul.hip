@@ -75,11 +75,13 @@ constexpr int kRounds = 16;  // selection rounds of NT candidate slots a workgro
 #define EFFORT_ROW_AUX 0
 #endif
 constexpr int kRowAux = EFFORT_ROW_AUX;
-// PERSIST (template parameter of the kernel and of mul_item) = false: the instantiation for PLAIN grids -- one item per workgroup, no
-// item queues, no cutoff jobs, no staging of a next item, no stamps or ablation switches.  It is the same kernel with those
-// compiled out: half the code (28 against 53 KB at E = 1, 8 waves) and 116 instead of 128 VGPRs, and a plain grid runs its code
-// once, cold (the instruction cache starts every launch empty), so size IS latency: lone calls 22.8 -> 21.9 us, the decode
-// loop 267 -> 284 tokens/s (measured A/B on one box).  The generic instantiation serves persistent launches and the debug modes.
+// PERSIST (template parameter of the kernel and of mul_item) = false: the LEAN instantiation for PLAIN grids -- one item per
+// workgroup, no item queues, no cutoff jobs, no staging of a next item, no stamps or ablation switches.  It is the same kernel
+// with those compiled out: 4300 instead of 8000 instructions and 116 instead of 128 VGPRs.  A plain grid's workgroup runs its
+// path once and every instruction on it is four cycles of the call's dependent chain (a wave issues one instruction per four
+// cycles; A/B with EFFORT_PAD_TEST: 1000 executed s_nop = +1.65 us per launch, 24 KB of code nobody executes = nothing), so the
+// polls, flag tests and queue handling a plain grid does not need were a microsecond of every lone call: 22.8 -> 21.5 us, the
+// decode loop 267 -> 290 tokens/s (A/B on one box).  The generic instantiation serves persistent launches and the debug modes.
 #define GA_PERSISTENT(ga) (PERSIST ? (ga).persistent : 0u)
 #define GA_CUTJOBS(ga) (PERSIST ? (ga).cutJobs : 0u)
 #ifdef EFFORT_PRODUCT_ONLY               // A/B build: no stamps / ablation switches in ANY instantiation
