@@ -595,8 +595,9 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
         // instantiation serves (8 waves, no stamps): with the path a template parameter it costs them no code (as a run-time
         // switch inside one kernel it cost lone calls 3 %); measured on plain grids: decode 298 -> 300 tokens/s.
         static const bool noCompact = getenv("EFFORT_NO_COMPACT_MEANS") != nullptr;
-        bool compact = fmt == kFp16 && !noCompact && (ga.persistent != 0u || (W == 8 && !c->clock && !ablate)) && plain;
-        for (uint32_t i = 0; compact && i < ga.count; i++) compact = !ga.call[i].resid;
+        const bool leanGrid = ga.persistent == 0u && W == 8 && !c->clock && !ablate;      // (launch_mul_t's condition for the lean instantiations)
+        bool compact = fmt == kFp16 && !noCompact && (leanGrid || (ga.persistent != 0u && plain));    // lean: with prologues / residuals too
+        for (uint32_t i = 0; compact && !leanGrid && i < ga.count; i++) compact = !ga.call[i].resid;
         for (uint32_t i = 0; compact && i < ga.count; i++) {
             const MulGeom& g = ga.geom[ga.call[i].geom];
             compact = ws[first + i]->means16 != nullptr && g.inDim % 2u == 0u && g.sliceRows % 2u == 0u;

@@ -339,9 +339,31 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     // runNetwork.swift:181), or rmsNorm(v) * vAux (runNetwork.swift:121-122,173-175) -- evaluated here, per workgroup,
     // instead of in a launch of its own.
     const uint32_t pre = FUSED ? a.pre : (uint32_t)kPreNone;      // FUSED is a separate instantiation: the plain multiply pays nothing
-    float rawn[VPT];                                              // rmsNorm: the first 4096 raw inputs, loaded with everything else
+    // A prologue's operands are ALL asked for here, in one memory round trip beside the stage loads: the first 4096 raw inputs,
+    // their partners from vAux (the gate's x3 as f32, the norm weights as f16: kept as raw bits), the probes, and vAux for this
+    // thread's element of the slice.  (Asked for where they were used -- vAux after the norm's reduction, the slice's vAux after
+    // the staged loads had landed -- they were two more dependent round trips: a fused launch cost 3-4 us more than a plain one.)
+    float rawn[VPT]; uint32_t auxc[VPT]; uint32_t auxS = 0u;
+    const bool preAny = FUSED && pre != (uint32_t)kPreNone;       // uniform
+    const bool needCutEarly = fused && cachedCall != ci;          // (= needCut below)
 #pragma unroll
-    for (int i = 0; i < VPT; i++) rawn[i] = (FUSED && pre == kPreRmsNorm) ? a.v[tid + NT * i] : 0.0f;
+    for (int i = 0; i < VPT; i++) { rawn[i] = 0.0f; auxc[i] = 0u; }
+    if (preAny) {
+        const bool gate = pre == (uint32_t)kPreSiluGate;
+        if (needCutEarly || !gate) {
+#pragma unroll
+            for (int i = 0; i < VPT; i++) rawn[i] = a.v[tid + NT * i];
+        }
+        if (needCutEarly) {
+#pragma unroll
+            for (int i = 0; i < VPT; i++) {
+                auxc[i] = gate ? __float_as_uint(reinterpret_cast<const float*>(a.vAux)[tid + NT * i]) : (uint32_t)reinterpret_cast<const uint16_t*>(a.vAux)[tid + NT * i];
+                prj[i] = pr[tid + NT * i];
+            }
+        }
+        const uint32_t js = j0 + min((uint32_t)tid, nb - 1u);
+        auxS = gate ? __float_as_uint(reinterpret_cast<const float*>(a.vAux)[js]) : (uint32_t)reinterpret_cast<const uint16_t*>(a.vAux)[js];
+    }
     const uint32_t lg = g.sliceLog2;
     const uint32_t nSlots = FMT == kFp16 ? (g.rowsPerIn << lg) : (nb << 3);
     float normInv = 1.0f;
@@ -376,18 +398,19 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
         normInv = 1.0f / sqrtf(tot / (float)g.inDim + 1e-5f);                  // aux.metal:150
         __syncthreads();                                                         // wbound is reused below
     }
-    auto xform = [&](float x, uint32_t j) -> float {               // the input prologue applied to v[j]
+    auto xform = [&](float x, uint32_t aux) -> float {             // the input prologue applied to an input and its partner from vAux (raw bits)
         if (!FUSED) return x;
-        if (pre == kPreSiluGate) return reinterpret_cast<const float*>(a.vAux)[j] * x / (1.0f + expf(-x));
-        if (pre == kPreRmsNorm) return (x * normInv) * half_bits_to_float(reinterpret_cast<const uint16_t*>(a.vAux)[j]);
+        if (pre == kPreSiluGate) return __uint_as_float(aux) * x / (1.0f + expf(-x));
+        if (pre == kPreRmsNorm) return (x * normInv) * half_bits_to_float((uint16_t)aux);
         return x;
     };
     auto load_cut_inputs = [&]() {
+        if (preAny) {                                              // (operands in registers since the top of the item)
 #pragma unroll
-        for (int i = 0; i < VPT; i++) {
-            vj[i] = (FUSED && pre == kPreRmsNorm) ? (rawn[i] * normInv) * half_bits_to_float(reinterpret_cast<const uint16_t*>(a.vAux)[tid + NT * i])
-                                                  : xform(a.v[tid + NT * i], tid + NT * i);
-            prj[i] = pr[tid + NT * i];
+            for (int i = 0; i < VPT; i++) vj[i] = xform(rawn[i], auxc[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < VPT; i++) { vj[i] = a.v[tid + NT * i]; prj[i] = pr[tid + NT * i]; }
         }
     };
     if (needCut && !viaJob) load_cut_inputs();
@@ -405,7 +428,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
         const uint32_t jl = tid + u * NT;
         if (jl < nb) {
             float x = vblk[jl];
-            if (FUSED) { x = xform(x, j0 + jl); vblk[jl] = x; }
+            if (preAny) { x = xform(x, auxS); vblk[jl] = x; }       // (FP16: u == 0, jl == tid: the element auxS was loaded for)
             bound += fabsf(x);
         }
     }
@@ -882,6 +905,17 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
         const uint32_t sl0 = (uint32_t)grp * per, sl1 = min(g.slices, sl0 + per);
         for (int o = (G > 1 ? tid % kCols4 : tid) * 4; o < TILE_F; o += (G > 1 ? kCols4 : NT) * 4) {
             const uint32_t vo = t * (uint32_t)(TILE_F * 4) + (uint32_t)o * 4u;
+            // the residual of this thread's four outputs is asked for BEFORE the slabs (it was a dependent round trip after them:
+            // +1.7 us per launch with the epilogue)
+            float res[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (FUSED && a.resid && (G == 1 || grp == 0)) {
+#pragma unroll
+                for (int h = 0; h < 4; h++) {
+                    const uint32_t oo = (uint32_t)o + h, lane2 = oo & 63u, sj = oo >> 6, j = sj % E, slot = sj / E;
+                    const uint32_t c2 = t * (64u * E) + lane2 * E + j;
+                    if (c2 < g.cols) res[h] = a.resid[c2 * NACC + slot];
+                }
+            }
             float sm[4][4];                                // [tile slot of this thread][slice % 4]: fixed summation order
 #pragma unroll
             for (int h = 0; h < 4; h++) { sm[h][0] = 0.0f; sm[h][1] = 0.0f; sm[h][2] = 0.0f; sm[h][3] = 0.0f; }
@@ -917,7 +951,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
                 const uint32_t oo = (uint32_t)o + h;
                 const uint32_t lane2 = oo & 63u, sj = oo >> 6, j = sj % E, slot = sj / E;
                 const uint32_t c2 = t * (64u * E) + lane2 * E + j;
-                if (c2 < g.cols) { const uint32_t oi = c2 * NACC + slot; a.out[oi] = (FUSED && a.resid) ? a.resid[oi] + tot[h] : tot[h]; }
+                if (c2 < g.cols) { const uint32_t oi = c2 * NACC + slot; a.out[oi] = (FUSED && a.resid) ? res[h] + tot[h] : tot[h]; }
             }
         }
     };
@@ -1105,15 +1139,17 @@ static hipError_t launch_mul_t(const GroupKArgs& gaIn, hipStream_t st) {
             if (err == hipSuccess) err = set(reinterpret_cast<const void*>(&bucket_mul_kernel<kFp16, E, W, false, true>));
             if constexpr (kLean) if (err == hipSuccess) err = set(reinterpret_cast<const void*>(&bucket_mul_kernel<kFp16, E, W, true, false, false>));
             if constexpr (kLean) if (err == hipSuccess) err = set(reinterpret_cast<const void*>(&bucket_mul_kernel<kFp16, E, W, false, true, false>));
+            if constexpr (kLean) if (err == hipSuccess) err = set(reinterpret_cast<const void*>(&bucket_mul_kernel<kFp16, E, W, true, true, false>));
         }
         if (err != hipSuccess) return err;
         maxSet = lds;
     }
     const bool compact = (ga.split & 4u) != 0u;                   // (api.hip: persistent FP16 launches of plain calls)
-    if (compact && (FMT != kFp16 || fusedAny)) return hipErrorInvalidValue;
     const bool lean = kLean && !ga.persistent && !ga.tstamp && !ga.ablate;
+    if (compact && (FMT != kFp16 || (fusedAny && !lean))) return hipErrorInvalidValue;
     const dim3 gd(grid), bd(64 * W);
     if constexpr (kLean) {
+        if (lean && compact && fusedAny) { hipLaunchKernelGGL((bucket_mul_kernel<kFp16, E, W, true, true, false>), gd, bd, lds, st, ga); return hipGetLastError(); }
         if (lean && compact) { hipLaunchKernelGGL((bucket_mul_kernel<kFp16, E, W, false, true, false>), gd, bd, lds, st, ga); return hipGetLastError(); }
         if (lean && fusedAny) { hipLaunchKernelGGL((bucket_mul_kernel<kFp16, E, W, true, false, false>), gd, bd, lds, st, ga); return hipGetLastError(); }
         if (lean) { hipLaunchKernelGGL((bucket_mul_kernel<FMT, E, W, false, false, false>), gd, bd, lds, st, ga); return hipGetLastError(); }

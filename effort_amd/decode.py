@@ -155,12 +155,14 @@ def _p(t):
 class Decoder:
     """State of one sequence (the globals of main.swift:78-140: h, xq, KV caches, scores ...) + the token step."""
 
-    def __init__(self, model: Model, maxTokens: int = 256, fused_attention: bool = True, fused_glue: bool = False):
+    def __init__(self, model: Model, maxTokens: int = 256, fused_attention: bool = True, fused_glue=True):
         cfg = self.cfg = model.cfg
         self.fused_attention = bool(fused_attention)      # rope + cache + attention in one launch per layer (else two)
         # rmsNorm, silu and the residual adds folded into the multiplies (effort_bucketmul_group_fused): 5 launches per layer
-        # instead of 8.  Dense-FFN models only; the dense baseline keeps the separate glue kernels.  Off by default: measured
-        # 4.45 vs 4.39 ms/token -- the folded work sits on every workgroup's critical path and costs what the launches saved.
+        # instead of 8.  Dense-FFN models only; the dense baseline keeps the separate glue kernels.  On by default since round 3:
+        # with every operand of a prologue asked for at the top of the item (they were two more dependent round trips) and the
+        # residual asked for before the slabs, all three folded are 306 against 300 tokens/s at 25 % effort (253 against 247 at
+        # 50 %); the gate alone or the residuals alone still lose 1 % (tools/decode_ab.py --fused-glue ...).  Bit-identical logits.
         # fused_glue may also name WHICH steps fold into the multiplies: any of "norm" (rmsNorm into wq|wk|wv and w1|w3), "gate"
         # (silu into w2), "resid" (the residual adds after wo and w2); True = all three
         parts = ("norm", "gate", "resid") if fused_glue is True else tuple(fused_glue or ())

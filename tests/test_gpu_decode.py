@@ -101,7 +101,7 @@ def test_dense_path_matches_torch_reference(small_model):
 def test_effort_one_tracks_dense_and_low_effort_degrades(small_model):
     from effort_amd.decode import Decoder, kl_divergence
     prompt, steps = [3, 77, 130], 10
-    dec = Decoder(small_model, maxTokens=16)
+    dec = Decoder(small_model, maxTokens=16, fused_glue=False)
     ids_d, _, lg_d = dec.run(prompt, steps, dense=True, collect_logits=True)
     forced = prompt + ids_d[len(prompt) - 1:-1]                                   # the inputs the dense run saw
     ids_1, dt, lg_1 = dec.run(forced, steps, effort=1.0, forced=True, collect_logits=True)
@@ -115,8 +115,8 @@ def test_effort_one_tracks_dense_and_low_effort_degrades(small_model):
     ids_g, dt_g, _ = dec.run(prompt, steps, effort=1.0)                             # free-running greedy at effort 1
     assert ids_g == ids_d and dt_g > 0
     # the same loop with rmsNorm, silu and the residual adds folded into the multiplies: same tokens, logits to rounding
-    sep = Decoder(small_model, maxTokens=16, fused_glue=True)                       # (kept: the loop with the glue folded into the multiplies)
-    assert sep.fused_glue and not dec.fused_glue
+    sep = Decoder(small_model, maxTokens=16, fused_glue=True)                       # the loop with the glue folded into the multiplies (the default since round 3)
+    assert sep.fused_glue and not dec.fused_glue and Decoder(small_model, maxTokens=16).fused_glue
     ids_s, _, lg_s = sep.run(forced, steps, effort=1.0, forced=True, collect_logits=True)
     assert ids_s == ids_1 and float((lg_s - lg_1).abs().max() / lg_1.abs().max()) < 2e-3
 
@@ -218,7 +218,7 @@ def test_in_graph_multiplies_match_the_oracle(small_model, oracle_cpu):
         assert close(out.cpu().numpy(), want), what
         return n
     for effort in (0.25, 0.6):
-        dec = Decoder(small_model, maxTokens=16)
+        dec = Decoder(small_model, maxTokens=16, fused_glue=False)
         dec.run([3, 77, 130, 9], 4, effort=effort, forced=True)                  # four replayed steps; the buffers hold the last one
         check(L.wq, dec.h_norm, dec.xq_temp, effort, "wq")
         check(L.wk, dec.h_norm, dec.xk_temp, effort, "wk")

@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--steps-per-graph", type=int, default=1, help="steps captured into one graph")
     ap.add_argument("--overlap", type=int, default=1, help="K > 1: ONE context with effort_set_overlap(K); the steps of a graph write K rotating output sets")
     ap.add_argument("--no-outliers", type=int, default=0, help="Q4: register the bundles without their outlier tables")
+    ap.add_argument("--fused", default="", help="comma list of gate,norm,resid: every call derives its input / adds its residual in the launch (effort_bucketmul_group_fused)")
     ap.add_argument("--split", type=int, default=0, help="1: the cutoffs in a kernel of their own before the multiply (the device-clock span then covers the multiply alone)")
     args = ap.parse_args()
     inDim, outDim = (int(x) for x in args.shape.split("x"))
@@ -49,6 +50,12 @@ def main():
     osets = [[torch.zeros(outDim, device=dev) for _ in ews] for _ in range(max(1, args.overlap))]
     if args.overlap > 1:
         g.set_overlap(args.overlap)
+    fz = {}
+    if "gate" in args.fused:
+        fz["gate"] = torch.randn(inDim, generator=gen, device=dev)
+    if "norm" in args.fused:
+        fz["norm"] = (1 + 0.1 * torch.randn(inDim, generator=gen, device=dev)).to(torch.float16)
+    resid = torch.randn(outDim, generator=gen, device=dev) if "resid" in args.fused else None
     items = list(zip(ews, outs))
     chunks = [items[i:i + args.group] for i in range(0, len(items), args.group)]
     for rep in range(args.reps):
@@ -74,7 +81,10 @@ def main():
                             ea.bucketMulGroup([(v, ews[k], None, oo[k], args.effort) for k in range(c0, min(len(ews), c0 + args.group))])
                     elif K == 1:
                         for ch in chunks:
-                            ea.bucketMulGroup([(v, ew, None, o, args.effort) for ew, o in ch])
+                            if fz or resid is not None:
+                                ea.bucketMulGroup([(v, ew, None, o, args.effort, dict(fz, **({"resid": resid} if resid is not None else {}))) for ew, o in ch])
+                            else:
+                                ea.bucketMulGroup([(v, ew, None, o, args.effort) for ew, o in ch])
                     else:                                # step `rep_` of the graph goes to stream rep_ % K (own context: own scratch)
                         s0 = torch.cuda.current_stream()
                         st, cx = main.sts[rep_ % K], main.ctxs[rep_ % K]
