@@ -364,7 +364,7 @@ def main():
         class Exchange:
             def __init__(self, weights, localOut):
                 self.lo = localOut
-                self.R = 4 * S                           # steps per round: four per stream, so that heads and tails overlap inside a round too
+                self.R = 16 * S                          # steps per round: sixteen per stream -- a round is one hipGraph whose launches drain at its end, so long rounds
                 self.send = [torch.zeros((self.R, N_MATS, localOut), device=dev) for _ in range(2)]
                 self.recv = [torch.zeros(world * self.R * N_MATS * localOut, device=dev) for _ in range(2)]
                 self.ev = [(torch.cuda.Event(), torch.cuda.Event()) for _ in range(2)]
@@ -392,27 +392,31 @@ def main():
                             self.ev[b][1].record(comm)
                 main.wait_stream(comm)
 
-            def timed(self, exchange):
+            def timed(self, exchange, nsteps=None):
+                nsteps = nsteps or args.steps
                 for b in (0, 1):                         # captures happen outside the timed region
-                    for n in {self.R, args.steps % self.R, args.warmup % self.R} - {0}:
+                    for n in {self.R, nsteps % self.R, args.warmup % self.R} - {0}:
                         self.graph(b, n)
                 self.run(args.warmup, exchange)
                 barrier()
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                self.run(args.steps, exchange)
+                self.run(nsteps, exchange)
                 torch.cuda.synchronize()
                 barrier()
-                x = torch.tensor([(time.perf_counter() - t0) / args.steps], device=dev, dtype=torch.float64)
+                x = torch.tensor([(time.perf_counter() - t0) / nsteps], device=dev, dtype=torch.float64)
                 dist.all_reduce(x, op=dist.ReduceOp.MAX)
                 return float(x.item())
         ex = Exchange(ew_sets, outDim)
         ex.timed(False)                                      # (first pass: every graph's first replay uploads it)
-        dt_kernel = ex.timed(False)                          # the steps without the exchange (kernel only)
-        dt = ex.timed(True)
+        # as on one GPU the K-step job is repeated back to back until the timed region is >= 50 ms (the same count on every rank:
+        # from the max-over-ranks estimate); the rounds and their all-gathers simply continue across the repetitions
+        reps = max(1, int(0.06 / max(ex.timed(True) * args.steps, 1e-6)) + 1)
+        ex.timed(False, args.steps * reps)                   # (uploads the remainder round's graph)
+        dt_kernel = ex.timed(False, args.steps * reps)       # the steps without the exchange (kernel only)
+        dt = ex.timed(True, args.steps * reps)
         D = job.ctxs[0].last_dispatch_count((N_MATS - 1) % G)
         in_flight = min(S, args.steps)
-        reps = 1
         dt_replayed = dt
     else:
         head_step = mul_step(args.effort, wsets=ew_sets)
@@ -447,7 +451,7 @@ def main():
         "vs_baseline": None, "dtype": "f16", "data": "synthetic",
         "config": {"workload": f"bucketMul {inDim}x{outDim} fp16 buckets, effort {args.effort}, {N_MATS} distinct matrices rotated "
                                f"(one call each per step), fixed-point accumulate (f32 out); {G} independent calls per fused "
-                               f"kernel launch; the job's steps are independent: " + (f"rounds of {4 * S} steps (one hipGraph each, four contexts on four streams), "
+                               f"kernel launch; the job's steps are independent: " + (f"rounds of {16 * S} steps (one hipGraph each, four contexts on four streams), "
                                f"one all-gather of the round's outputs per round under the next round's compute, {in_flight} step(s) " if dist else
                                f"ONE hipGraph through ONE context, {in_flight} step(s) ") +
                                f"in flight{'' if dist else ' (effort_set_overlap)'}, each on its own {N_MATS} matrices", "effort": args.effort, "matrices_per_step": N_MATS,
@@ -458,13 +462,13 @@ def main():
                    "partition": "matrices" if world > 1 else "none", "dispatch_rows": D},
         "bytes_per_launch": G * kb, "us_per_call": round(t_call * 1e6, 3),
         "tokens_per_s": round(1.0 / (t_call * 4 * 32), 2),
-        "timed_region_ms": round(dt * args.steps * reps * 1e3, 3), "timed_replays": 1 if not dist else reps, "timed_steps": args.steps * reps,
-        "timed_region_note": None if dist else f"the {args.steps}-step job {reps} times back to back in ONE hipGraph, one launch; the {args.steps}-step graph replayed {reps} times instead (its lanes drain at every replay's end): {dt_replayed * 1e3:.5f} ms per step",
+        "timed_region_ms": round(dt * args.steps * reps * 1e3, 3), "timed_replays": 1, "timed_steps": args.steps * reps,
+        "timed_region_note": f"the {args.steps}-step job {reps} times back to back: rounds of {16 * S} steps (one hipGraph each), a round's all-gather under the next round's compute" if dist else f"the {args.steps}-step job {reps} times back to back in ONE hipGraph, one launch; the {args.steps}-step graph replayed {reps} times instead (its lanes drain at every replay's end): {dt_replayed * 1e3:.5f} ms per step",
     }
     if dist:
         result["rccl_ranks"] = dist.get_world_size()
         result["multi_gpu"] = {"partition": "matrices (weak scaling: every rank its own 32 matrices)", "ms_per_step_kernel_only": round(dt_kernel * 1e3, 5),
-                               "ms_per_step_with_all_gather": round(dt * 1e3, 5), "steps_per_round": 4 * S, "all_gather_bytes_per_rank_per_round": 4 * S * N_MATS * outDim * 4}
+                               "ms_per_step_with_all_gather": round(dt * 1e3, 5), "steps_per_round": 16 * S, "all_gather_bytes_per_rank_per_round": 16 * S * N_MATS * outDim * 4}
         # bucket-column sharding: every rank multiplies ITS columns of the same 32 matrices (seed 1234 on every
         # rank), one all-gather per round of [world, S * 32 * outDim/world] floats; strong scaling
         try:
@@ -479,11 +483,12 @@ def main():
                 shards.append(sh)
             exc = Exchange(shards, outDim // world)
             exc.timed(False)                                 # (uploads the graphs)
-            ck, ca = exc.timed(False), exc.timed(True)
+            exc.timed(False, args.steps * reps)
+            ck, ca = exc.timed(False, args.steps * reps), exc.timed(True, args.steps * reps)
             result["multi_gpu"]["columns"] = {
                 "partition": f"bucket columns: {outDim // 16 // world} of {outDim // 16} columns per rank, stats / probes replicated (strong scaling: the same 32 matrices on every N)",
                 "ms_per_step_kernel_only": round(ck * 1e3, 5), "ms_per_step_with_all_gather": round(ca * 1e3, 5),
-                "effective_GBps_whole_job": round(N_MATS * eff_bytes / ca / 1e9, 1), "all_gather_bytes_per_rank_per_round": 4 * S * N_MATS * (outDim // world) * 4}
+                "effective_GBps_whole_job": round(N_MATS * eff_bytes / ca / 1e9, 1), "all_gather_bytes_per_rank_per_round": 16 * S * N_MATS * (outDim // world) * 4}
             del shards, exc
         except Exception as ex2:
             result["multi_gpu"]["columns"] = {"error": repr(ex2)}
