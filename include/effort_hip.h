@@ -175,7 +175,8 @@ EFFORT_API int effort_bucketmul_group(effort_ctx* ctx, int n, const effort_w* co
  *                          feeding wq|wk|wv and w1|w3 (runNetwork.swift:121-122,173-175; aux.metal:113-152)
  *   resids[i] (NULL array or entry = none): out = resid + product -- h.add(by:) after wo and w2 (runNetwork.swift:172,183);
  *     resid may alias outs[i] (h += product in place).
- * Cutoff, dispatch and accumulation see the derived input exactly as if it had been materialised first. */
+ * Cutoff, dispatch and accumulation see the derived input exactly as if it had been materialised first.  A decoder layer
+ * is then five launches instead of eight (Mistral-7B shapes at 25 % effort: 307 against 300 tokens/s, bit-identical logits). */
 #define EFFORT_PRE_NONE 0
 #define EFFORT_PRE_SILU_GATE 1
 #define EFFORT_PRE_RMSNORM 2
