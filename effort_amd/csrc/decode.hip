@@ -153,21 +153,36 @@ __global__ __launch_bounds__(256) void rope_attention_kernel(const float* __rest
     __shared__ float red[17];
     __shared__ float qs[256], ks[256], vs[256];        // this head's roped q, roped k and v of the newest token
     const uint32_t head = blockIdx.x, tid = threadIdx.x, half = headDim / 2;
+    // this head's q / k / v do not depend on the position: asked for beside it, not after it (one dependent round trip less)
+    float qa = 0.0f, qb = 0.0f, ka = 0.0f, kb = 0.0f, vv = 0.0f, freq = 0.0f;
+    if (tid < headDim) {
+        const uint32_t d = tid, j = d % half, dp = d < half ? d + half : d - half;
+        const float* q = xq + head * headDim;
+        const float* k = xk + (head / kvRepeats) * headDim;
+        qa = q[d]; qb = q[dp]; ka = k[d]; kb = k[dp];
+        vv = xv[(head / kvRepeats) * headDim + d];
+        freq = (float)exp((double)logBase * (-(double)j / (double)half));
+    }
     if (posPtr[0] >= maxTokens) {                      // past the cache (uniform): nothing is written, the status word says so
         if (head == 0 && tid == 0) atomicOr(status, 1);
         return;
     }
     const uint32_t pos = posPtr[0], nTok = pos + 1u;
+    // the first pass of key rows needs only the position: asked for here, under the rotation's arithmetic and its barrier
+    const uint32_t lpt = headDim / 8u, tokPerPass = 256u / lpt, sub = tid % lpt, tk = tid / lpt;
+    float4 ka0[4], kb0[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const uint32_t t = min((uint32_t)u * tokPerPass + tk, pos);
+        const float4* kh = reinterpret_cast<const float4*>(kCache + ((size_t)t * numHeads + head) * headDim + sub * 8u);
+        ka0[u] = kh[0]; kb0[u] = kh[1];
+    }
     if (tid < headDim) {
-        const uint32_t d = tid, j = d % half;
-        const float freq = (float)exp((double)logBase * (-(double)j / (double)half));
+        const uint32_t d = tid;
         const float angle = (float)pos * freq;
         const float c = cosf(angle), s = sinf(angle);
-        const float* q = xq + head * headDim;
-        const float* k = xk + (head / kvRepeats) * headDim;
-        const float qr = d < half ? q[d] * c - q[d + half] * s : q[d] * c + q[d - half] * s;
-        const float kr = d < half ? k[d] * c - k[d + half] * s : k[d] * c + k[d - half] * s;
-        const float vv = xv[(head / kvRepeats) * headDim + d];
+        const float qr = d < half ? qa * c - qb * s : qa * c + qb * s;
+        const float kr = d < half ? ka * c - kb * s : ka * c + kb * s;
         const size_t slot = ((size_t)pos * numHeads + head) * headDim + d;
         qs[d] = qr; ks[d] = kr; vs[d] = vv;
         kCache[slot] = kr; vCache[slot] = vv;
@@ -176,7 +191,6 @@ __global__ __launch_bounds__(256) void rope_attention_kernel(const float* __rest
     // scores: headDim/8 threads per token, 8 dims each as two float4 loads; four token passes are issued before any is
     // consumed, so the cache reads overlap instead of costing one memory round trip per token
     const float scale = 1.0f / sqrtf((float)headDim);
-    const uint32_t lpt = headDim / 8u, tokPerPass = 256u / lpt, sub = tid % lpt, tk = tid / lpt;
     float q8[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) q8[i] = qs[sub * 8u + i];
@@ -186,7 +200,8 @@ __global__ __launch_bounds__(256) void rope_attention_kernel(const float* __rest
         for (int u = 0; u < 4; u++) {
             const uint32_t t = min(t0 + u * tokPerPass + tk, pos);           // clamped: surplus lanes re-read the newest row
             const float4* kh = reinterpret_cast<const float4*>(kCache + ((size_t)t * numHeads + head) * headDim + sub * 8u);
-            ka[u] = kh[0]; kb[u] = kh[1];
+            if (t0 == 0u) { ka[u] = ka0[u]; kb[u] = kb0[u]; }                  // (uniform: the first pass was asked for before the rotation)
+            else { ka[u] = kh[0]; kb[u] = kh[1]; }
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -209,6 +224,16 @@ __global__ __launch_bounds__(256) void rope_attention_kernel(const float* __rest
             }
         }
     }
+    // the first eight tokens' value rows of this thread's phase do not depend on the scores: asked for HERE, their round trip runs
+    // under the softmax instead of after it (a decode step's attention is a chain of dependent round trips: position, q/k/v,
+    // keys, values)
+    const uint32_t tpr = headDim / 4u, nph = 256u / tpr, d4 = (tid % tpr) * 4u, ph = tid / tpr;
+    float4 vv0[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        const uint32_t tc = min(ph + (uint32_t)u * nph, pos);
+        vv0[u] = *reinterpret_cast<const float4*>(vCache + ((size_t)tc * numHeads + head) * headDim + d4);
+    }
     __syncthreads();
     float m = -INFINITY;
     for (uint32_t t = tid; t < nTok; t += 256) m = fmaxf(m, sc[t]);
@@ -219,7 +244,6 @@ __global__ __launch_bounds__(256) void rope_attention_kernel(const float* __rest
     const float inv = 1.0f / sum;
     // weighted sum: headDim/4 threads per token phase (one float4 of the head each), 256/(headDim/4) phases; eight
     // tokens' loads in flight per thread
-    const uint32_t tpr = headDim / 4u, nph = 256u / tpr, d4 = (tid % tpr) * 4u, ph = tid / tpr;
     float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     for (uint32_t t0 = ph; t0 < nTok; t0 += nph * 8u) {
         float4 vv[8]; float p8[8];
@@ -227,7 +251,8 @@ __global__ __launch_bounds__(256) void rope_attention_kernel(const float* __rest
         for (int u = 0; u < 8; u++) {
             const uint32_t t = t0 + u * nph;
             const uint32_t tc = min(t, pos);
-            vv[u] = *reinterpret_cast<const float4*>(vCache + ((size_t)tc * numHeads + head) * headDim + d4);
+            if (t0 == ph) vv[u] = vv0[u];                                   // (the first pass was asked for before the softmax)
+            else vv[u] = *reinterpret_cast<const float4*>(vCache + ((size_t)tc * numHeads + head) * headDim + d4);
             p8[u] = t < nTok ? sc[t] : 0.0f;
             if (t == pos) vv[u] = make_float4(vs[d4], vs[d4 + 1], vs[d4 + 2], vs[d4 + 3]);
         }
