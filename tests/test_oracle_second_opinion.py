@@ -81,3 +81,42 @@ def test_dispatch_and_product_match(oracle_cpu, layout):
             sref[:d] = sref[:d] + sref[d:2 * d]
             d //= 2
         assert np.array_equal(sref[0], out_c), k
+
+
+def test_bisection_tail_reaches_the_cell_edge():
+    """The claim the HIP kernel's closed-form tail rests on (cutoff_device.h, bisect_to_cell_edge): once findCutoff32's bounds sit in
+    adjacent bfloat cells, its remaining rounds -- the count test decided by `newBound >= X`, X the first float of the upper cell --
+    end on X itself whenever X >= 128 and fewer than 60 rounds are spent, in at most 19 more rounds.  The loop below is the
+    reference's (bucketMul.metal:199-246 with the count replaced by its known outcome), in float32."""
+    f = np.float32
+    rng = np.random.default_rng(7)
+
+    def tail(nb, mn, mx, X, loops):
+        while True:
+            loops += 1
+            if nb >= X:
+                mx = nb
+            else:
+                mn = nb
+            prev = nb
+            nb = f(f(mx + mn) / f(2))
+            if f(mx - mn) < f(0.00001) or loops > 100 or nb == prev:
+                return nb, loops
+
+    checked = longest = 0
+    for _ in range(20000):
+        X = f(int(rng.integers(128, 256)) * 2.0 ** (int(rng.integers(0, 40)) - 7))          # a bfloat pattern >= 1
+        pat = int(X.view(np.uint32)) >> 16
+        lo_cell = np.uint32((pat - 1) << 16).view(np.float32)
+        hi_end = np.uint32((pat + 1) << 16).view(np.float32)
+        mn = f(lo_cell + (X - lo_cell) * f(rng.random()))
+        mn = mn if mn < X else lo_cell
+        mx = f(X + (hi_end - X) * f(rng.random()))
+        mx = mx if mx < hi_end else X
+        l0 = int(rng.integers(1, 60))
+        got, l1 = tail(f(f(mx + mn) / f(2)), mn, mx, X, l0)
+        if X >= 128:
+            checked += 1
+            longest = max(longest, l1 - l0)
+            assert got == X, (X, mn, mx, got)
+    assert checked > 10000 and longest <= 19, (checked, longest)
