@@ -25,7 +25,7 @@ class EffortError(RuntimeError):
 
 def build(verbose: bool = False) -> str:
     """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j8"]
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j8", "all", "c_client"]      # (+ the header compiled as C, + tests/c_client)
     res = subprocess.run(cmd, capture_output=not verbose, text=True)
     if res.returncode != 0:
         raise RuntimeError("building libeffort_hip.so failed:\n" + (res.stdout or "") + (res.stderr or ""))

@@ -5,6 +5,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -55,6 +56,7 @@ struct effort_ctx {
     int* d_status = nullptr;
     int persistent = -1;              // workgroups per CU of group launches: -1 heuristic, 0 plain grid, R > 0 persistent
     static constexpr uint32_t kMaxTiles = 1024, kMaxSlices = 4096;
+    static constexpr size_t kMaxRanges = 1024;   // address ranges a lane records between joins (do_group)
     unsigned long long* d_tstamp = nullptr;   // device-clock stamps of the multiply kernel (timing mode)
     double wallClockKHz = 100000.0;
     rocblas_handle blas = nullptr;
@@ -124,27 +126,31 @@ static bool lane_alloc(effort_ctx* c, Lane& L) {
 // capture and is destroyed while other captured graphs are alive crashes a later hipGraphLaunch inside the runtime (ROCm 7.2:
 // segfault in hipGraphLaunch after a multi-lane context was destroyed; tools/lane_crash.py reproduces it).  A context returns
 // them to the pool; the next one takes them from there.
+// The pools are keyed by DEVICE: a stream or event belongs to the device that was current when it was created, and a context
+// of another device must never be handed one (its launches would go to the wrong GPU).  The caller has made `device` current.
 static std::mutex g_poolMutex;
-static std::vector<hipStream_t> g_streamPool;
-static std::vector<hipEvent_t> g_eventPool;
-static hipStream_t pool_stream() {
+static std::map<int, std::vector<hipStream_t>> g_streamPool;
+static std::map<int, std::vector<hipEvent_t>> g_eventPool;
+static hipStream_t pool_stream(int device) {
     std::lock_guard<std::mutex> lk(g_poolMutex);
-    if (!g_streamPool.empty()) { hipStream_t s = g_streamPool.back(); g_streamPool.pop_back(); return s; }
+    auto& pool = g_streamPool[device];
+    if (!pool.empty()) { hipStream_t s = pool.back(); pool.pop_back(); return s; }
     hipStream_t s = nullptr;
     return hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess ? s : nullptr;
 }
-static hipEvent_t pool_event() {
+static hipEvent_t pool_event(int device) {
     std::lock_guard<std::mutex> lk(g_poolMutex);
-    if (!g_eventPool.empty()) { hipEvent_t e = g_eventPool.back(); g_eventPool.pop_back(); return e; }
+    auto& pool = g_eventPool[device];
+    if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
     hipEvent_t e = nullptr;
     return hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess ? e : nullptr;
 }
-static void pool_put(hipStream_t s) { if (s) { std::lock_guard<std::mutex> lk(g_poolMutex); g_streamPool.push_back(s); } }
-static void pool_put(hipEvent_t e) { if (e) { std::lock_guard<std::mutex> lk(g_poolMutex); g_eventPool.push_back(e); } }
+static void pool_put(int device, hipStream_t s) { if (s) { std::lock_guard<std::mutex> lk(g_poolMutex); g_streamPool[device].push_back(s); } }
+static void pool_put(int device, hipEvent_t e) { if (e) { std::lock_guard<std::mutex> lk(g_poolMutex); g_eventPool[device].push_back(e); } }
 
-static void lane_free(Lane& L) {
-    pool_put(L.own);
-    pool_put(L.done);
+static void lane_free(int device, Lane& L) {
+    pool_put(device, L.own);
+    pool_put(device, L.done);
     hipFree(L.d_cutoff); hipFree(L.d_count); hipFree(L.d_slabs); hipFree(L.d_counters); hipFree(L.d_sliceCounts); hipFree(L.d_queue);
     L = Lane();
 }
@@ -158,6 +164,14 @@ extern "C" effort_ctx* effort_create(int device, void* stream) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->numCU = prop.multiProcessorCount;
     c->slabBytes = (size_t)64 << 20;
+    {   // function attributes belong to a device: set them when the device's first context is created
+        static std::mutex m; static std::map<int, bool> prepared;
+        std::lock_guard<std::mutex> lk(m);
+        if (!prepared[device]) {
+            if (bucket_mul_prepare_device() != hipSuccess) { delete c; return nullptr; }
+            prepared[device] = true;
+        }
+    }
     bool ok = lane_alloc(c, c->lane[0]) && hipMalloc(&c->d_blockScratch, 4096 * 4) == hipSuccess &&
               hipMalloc(&c->d_cos, 16) == hipSuccess && hipMalloc(&c->d_status, 16) == hipSuccess &&
               hipMalloc(&c->d_tstamp, kStampBytes) == hipSuccess;
@@ -196,12 +210,12 @@ extern "C" int effort_set_overlap(effort_ctx* c, int lanes) {
     int rc = join_lanes(c);
     if (rc != EFFORT_OK) return rc;
     if (lanes > 1) {
-        if (!c->forkEv && !(c->forkEv = pool_event())) return fail(c, EFFORT_ERR_HIP, "set_overlap: event");
+        if (!c->forkEv && !(c->forkEv = pool_event(c->device))) return fail(c, EFFORT_ERR_HIP, "set_overlap: event");
         for (int i = 0; i < lanes; i++) {
             Lane& L = c->lane[i];
             if (!L.d_slabs && !lane_alloc(c, L)) return fail(c, EFFORT_ERR_HIP, "set_overlap: out of device memory for a lane's scratch");
-            if (!L.own && !(L.own = pool_stream())) return fail(c, EFFORT_ERR_HIP, "set_overlap: stream");
-            if (!L.done && !(L.done = pool_event())) return fail(c, EFFORT_ERR_HIP, "set_overlap: event");
+            if (!L.own && !(L.own = pool_stream(c->device))) return fail(c, EFFORT_ERR_HIP, "set_overlap: stream");
+            if (!L.done && !(L.done = pool_event(c->device))) return fail(c, EFFORT_ERR_HIP, "set_overlap: event");
         }
     }
     c->nLanes = lanes; c->lastLane = 0; c->nextLane = 0;
@@ -219,8 +233,8 @@ extern "C" void effort_destroy(effort_ctx* c) {
     hipStreamSynchronize(c->stream);
     if (c->blas) rocblas_destroy_handle(c->blas);
     if (c->ev) { for (int i = 0; i < effort_ctx::kMaxSamples * 4; i++) hipEventDestroy(c->ev[i]); delete[] c->ev; }
-    for (int i = 0; i < effort_ctx::kMaxLanes; i++) lane_free(c->lane[i]);
-    pool_put(c->forkEv);
+    for (int i = 0; i < effort_ctx::kMaxLanes; i++) lane_free(c->device, c->lane[i]);
+    pool_put(c->device, c->forkEv);
     hipFree(c->d_blockScratch); hipFree(c->d_vhalf); hipFree(c->d_cos); hipFree(c->d_convVals); hipFree(c->d_status); hipFree(c->d_tstamp);
     delete c;
 }
@@ -270,7 +284,7 @@ static int register_bound(effort_ctx* c, effort_w* w) {
 }
 
 extern "C" int effort_aligned_row_pitch(int outDim) {
-    if (outDim <= 0 || outDim % 16) return EFFORT_ERR_SHAPE;
+    if (outDim <= 0 || outDim % 32 || outDim > 16384) return EFFORT_ERR_SHAPE;      // (what registration accepts: check_shape)
     return (outDim / 16 * 2 + 127) / 128 * 128;
 }
 
@@ -520,7 +534,13 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
                     const int* prologues = nullptr, const void* const* vAux = nullptr, const float* const* resids = nullptr) {
     if (!c || !ws || !vs || !outs || !efforts) return fail(c, EFFORT_ERR_ARG, "bucketmul: null argument");
     if (n < 1 || n > kMaxGroup) return fail(c, EFFORT_ERR_ARG, "bucketmul: group size outside 1..32");
+    // The A/B switches below read the environment in LAB builds only (-DEFFORT_LAB: tools/build_variant*.sh); the shipped
+    // library has no getenv on this path.
+#ifdef EFFORT_LAB
     static const uint32_t ablate = getenv("EFFORT_ABLATE") ? (uint32_t)atoi(getenv("EFFORT_ABLATE")) : 0u;   // profiling only
+#else
+    constexpr uint32_t ablate = 0u;
+#endif
     for (int i = 0; i < n; i++) {                      // every argument first: nothing is launched for a group with a bad call
         if (!ws[i] || !vs[i] || !outs[i]) return fail(c, EFFORT_ERR_ARG, "bucketmul: null argument");
         if (ws[i]->fmt != fmt) return fail(c, EFFORT_ERR_KIND, "bucketmul: weight handle of the wrong kind");
@@ -535,9 +555,21 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
     // ---- which lane (overlap mode): the launch may run beside the launches in flight on the OTHER lanes unless it reads or
     // writes what one of them writes, or writes what one of them reads; then it waits for that lane (or simply joins it: a
     // lane's stream is in order).  Always ordered after everything enqueued on the context's stream before this call.
+    // The lane is CHOSEN here and forked (made to wait) only when the first kernel of the group is about to be launched:
+    // a group that fails validation or finds no launch geometry has then touched no stream.  From the fork on, every way out
+    // records the lane's `done` event and marks the lane pending (LaneGuard), so a later join -- in particular the join a
+    // caller owes the capturing stream before it ends a hipGraph capture -- always rejoins a lane that was forked.
     int li = 0;
-    if (c->nLanes > 1 && !c->timing && !c->clock) {
-        std::vector<Lane::Range> rd, wr;
+    const bool laned = c->nLanes > 1 && !c->timing && !c->clock;
+    std::vector<Lane::Range> rd, wr;
+    int hazard[effort_ctx::kMaxLanes], nh = 0;
+    if (laned) {
+        // bounded bookkeeping: a caller may enqueue arbitrarily many multiplies between joins (helpers/gpu.swift:109-119: one
+        // eval() per token); once a lane has recorded kMaxRanges ranges the lanes are JOINED -- the context's stream waits for
+        // all of them, and every later launch forks from that stream -- never forgotten
+        bool full = false;
+        for (int i = 0; i < c->nLanes; i++) full = full || c->lane[i].reads.size() + c->lane[i].writes.size() > effort_ctx::kMaxRanges;
+        if (full && join_lanes(c) != EFFORT_OK) return EFFORT_ERR_HIP;
         auto add = [](std::vector<Lane::Range>& v, const void* p, size_t bytes) { if (p && bytes) v.push_back({(uintptr_t)p, (uintptr_t)p + bytes}); };
         for (int i = 0; i < n; i++) {
             add(rd, vs[i], (size_t)ws[i]->inDim * 4);
@@ -546,25 +578,31 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
             if (resids && resids[i]) add(rd, resids[i], (size_t)ws[i]->outDim * 4);
             add(wr, outs[i], (size_t)ws[i]->outDim * 4);
         }
-        int hazard[effort_ctx::kMaxLanes], nh = 0;
         for (int i = 0; i < c->nLanes; i++) {
             const Lane& L = c->lane[i];
             if (L.pending && (overlaps(rd, L.writes) || overlaps(wr, L.writes) || overlaps(wr, L.reads))) hazard[nh++] = i;
         }
         li = nh ? hazard[0] : c->nextLane;
-        if (!nh) c->nextLane = (c->nextLane + 1) % c->nLanes;
-        Lane& L = c->lane[li];
-        HIP_TRY(c, hipEventRecord(c->forkEv, c->stream));
-        HIP_TRY(c, hipStreamWaitEvent(L.own, c->forkEv, 0));
-        for (int k = 0; k < nh; k++) if (hazard[k] != li) HIP_TRY(c, hipStreamWaitEvent(L.own, c->lane[hazard[k]].done, 0));
-        if (L.reads.size() + L.writes.size() > 4096) { L.reads.clear(); L.writes.clear(); }     // (cannot happen between joins of a sane caller; stay bounded)
-        L.reads.insert(L.reads.end(), rd.begin(), rd.end());
-        L.writes.insert(L.writes.end(), wr.begin(), wr.end());
     } else if (c->nLanes > 1) {
         if (join_lanes(c) != EFFORT_OK) return EFFORT_ERR_HIP;        // timing modes: one launch at a time, on lane 0
     }
     Lane& L = c->lane[li];
-    const hipStream_t st = (c->nLanes > 1 && !c->timing && !c->clock) ? L.own : c->stream;
+    const hipStream_t st = laned ? L.own : c->stream;
+    struct LaneGuard {                                 // (see above)
+        Lane& L; hipStream_t st; bool forked = false;
+        ~LaneGuard() { if (forked) { hipEventRecord(L.done, st); L.pending = true; } }
+    } guard{L, st};
+    auto fork_lane = [&]() -> int {                    // before the group's first launch
+        if (!laned || guard.forked) return EFFORT_OK;
+        HIP_TRY(c, hipEventRecord(c->forkEv, c->stream));
+        HIP_TRY(c, hipStreamWaitEvent(L.own, c->forkEv, 0));
+        guard.forked = true;
+        for (int k = 0; k < nh; k++) if (hazard[k] != li) HIP_TRY(c, hipStreamWaitEvent(L.own, c->lane[hazard[k]].done, 0));
+        if (!nh) c->nextLane = (c->nextLane + 1) % c->nLanes;
+        L.reads.insert(L.reads.end(), rd.begin(), rd.end());
+        L.writes.insert(L.writes.end(), wr.begin(), wr.end());
+        return EFFORT_OK;
+    };
     c->lastLane = li;
     if (tm) HIP_TRY(c, hipEventRecord(ev[0], st));
     GroupKArgs ga;
@@ -588,13 +626,21 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
         // of once per workgroup and call (measured: 6.8 of the ~90 us of an item at 32 calls per launch)
         bool plain = true;
         for (uint32_t i = 0; i < ga.count; i++) plain = plain && !ga.call[i].pre;
+#ifdef EFFORT_LAB
         static const bool noJobs = getenv("EFFORT_NO_CUTJOBS") != nullptr;
+#else
+        constexpr bool noJobs = false;
+#endif
         ga.cutJobs = (ga.persistent && !c->splitCutoff && plain && !noJobs) ? (ga.count + 7u) / 8u * 8u : 0u;
         // FP16: the multiply stages the compact row means where every slice starts on an even row (an LDS-direct load lands two):
         // a quarter of the lines of the 8-byte stats entries, half the loads.  Persistent launches, and the plain grids the lean
         // instantiation serves (8 waves, no stamps): with the path a template parameter it costs them no code (as a run-time
         // switch inside one kernel it cost lone calls 3 %); measured on plain grids: decode 298 -> 300 tokens/s.
+#ifdef EFFORT_LAB
         static const bool noCompact = getenv("EFFORT_NO_COMPACT_MEANS") != nullptr;
+#else
+        constexpr bool noCompact = false;
+#endif
         const bool leanGrid = ga.persistent == 0u && W == 8 && !c->clock && !ablate;      // (launch_mul_t's condition for the lean instantiations)
         bool compact = fmt == kFp16 && !noCompact && (leanGrid || (ga.persistent != 0u && plain));    // lean: with prologues / residuals too
         for (uint32_t i = 0; compact && !leanGrid && i < ga.count; i++) compact = !ga.call[i].resid;
@@ -606,6 +652,8 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
             for (uint32_t i = 0; i < ga.count; i++) ga.call[i].stats = ws[first + i]->means16;
             ga.split |= 4u;
         }
+        const int frc = fork_lane();
+        if (frc != EFFORT_OK) return frc;
         if (c->splitCutoff && !(ablate & 1u)) HIP_TRY(c, launch_find_cutoff_group(ga, st));
         HIP_TRY(c, launch_bucket_mul(fmt, W, E, ga, st));
         return EFFORT_OK;
@@ -621,6 +669,7 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
         // (knob, off by default) The calls at the END of a big group can be cut into thinner slices: their items are the last
         // ones the persistent workgroups pull, and the launch ends when the last item does.
         uint32_t mult = 1;
+#ifdef EFFORT_LAB
         if (n >= 8 && !c->tuneS) {
             static const int tailCalls = getenv("EFFORT_TAIL_CALLS") ? atoi(getenv("EFFORT_TAIL_CALLS")) : -1;     // profiling knobs
             static const int tailMult = getenv("EFFORT_TAIL_MULT") ? atoi(getenv("EFFORT_TAIL_MULT")) : 2;
@@ -628,6 +677,7 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
             if (i >= n - tc) mult = (uint32_t)tailMult;
             if (tailMult >= 4 && i >= n - tc && i < n - tc / 2) mult = (uint32_t)tailMult / 2;      // two steps: ... x2 x2 x4 x4
         }
+#endif
         int rc = choose_geom(c, w, n, groupE, &g, &Wi, &Ei, mult, groupTiles);
         if (rc != EFFORT_OK) return fail(c, rc, "bucketmul: no launch geometry for this shape/tuning");
         if (i == 0) { W = Wi; E = Ei; }
@@ -664,8 +714,7 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
     int rc = flush();
     if (rc != EFFORT_OK) return rc;
     if (tm) { HIP_TRY(c, hipEventRecord(ev[1], st)); c->nSamples++; }
-    if (st != c->stream) { HIP_TRY(c, hipEventRecord(L.done, st)); L.pending = true; }
-    return EFFORT_OK;
+    return EFFORT_OK;                                  // (LaneGuard records the lane's `done` event)
 }
 
 extern "C" int effort_bucketmul(effort_ctx* c, const effort_w* w, const float* v, const uint32_t* expNo, float* out, double effort) {

@@ -93,6 +93,7 @@ constexpr int kRowAux = EFFORT_ROW_AUX;
 #define GA_ABLATE(ga) (PERSIST ? (ga).ablate : 0u)
 #define GA_TRACE(ga) (PERSIST ? (ga).trace : 0u)
 #endif
+constexpr uint32_t kMaxLdsBytes = 160u * 1024u;     // LDS of a gfx950 CU
 constexpr int kSc1 = 16;     // buffer aux bit: sc1 = write-through store / L1-bypassing load (cross-XCD visible)
 
 template <int FMT> struct Fmt;
@@ -170,7 +171,8 @@ __host__ __device__ inline LdsPlan plan_lds(const MulGeom* geoms, int nGeoms) {
     p.offL = o; o += align_up(slots * 2, 16);
     const uint32_t tbl = cutoff_table_bytes(64 * W);        // (>= the tile reduction's [G][tileFloats] partial sums)
     if (o < p.offA + tbl) o = p.offA + tbl;
-    p.offC = o; o += 2048;           // [0..255] cutoff scratch, [1280] flags, [1344..1407] wave bounds, [1408..1471] Q4 outlier bounds
+    p.offC = o; o += 2048;           // [0..kCutoffLdsBytes) cutoff scratch, [1280] flags, [1344..1407] wave bounds, [1408..1471] Q4 outlier bounds
+    static_assert(kCutoffLdsBytes <= 1280, "the cutoff scratch must end below the flags of the misc region");
     p.total = o;
     return p;
 }
@@ -959,6 +961,9 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     //  Up to 16 slices per thread group the whole reduction is ONE memory round trip per thread.)
     if (g.slices <= 8u * G) reduce_tile(std::integral_constant<int, 8>{});
     else reduce_tile(std::integral_constant<int, 16>{});
+    // (G > 1: thread group 0 reads the partial sums in the accumulator region after reduce_tile's only barrier; a persistent
+    //  workgroup's next item -- or cutoff job -- zeroes its count table there, so the region must be quiescent first)
+    if (PERSIST && G > 1) __syncthreads();
     if (rstamp) GA_TSTAMP(ga)[24] = wall_clock64();
     if (tid == 0) {
         __hip_atomic_store(&a_counters[t], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next call
@@ -1114,7 +1119,6 @@ static hipError_t launch_mul_t(const GroupKArgs& gaIn, hipStream_t st) {
         if (FMT == kFp16 ? (1u << g.sliceLog2) > 64u * W : g.sliceRows > 128u * W) return hipErrorInvalidValue;       // stage_issue: a thread lands one (Q4: two) inputs of the slice
         if (((uint32_t)ga.wgEnd8[i] - (i ? (uint32_t)ga.wgEnd8[i - 1] : 0u)) * 8u != g.tiles * align_up(g.slices, 8)) return hipErrorInvalidValue;
     }
-    static uint32_t maxSet = 0;   // per instantiation
     if (ga.totalItems != (uint32_t)ga.wgEnd8[ga.count - 1] * 8u) return hipErrorInvalidValue;
     uint32_t grid = ga.totalItems;
     if (ga.persistent) {
@@ -1130,20 +1134,8 @@ static hipError_t launch_mul_t(const GroupKArgs& gaIn, hipStream_t st) {
     // plain grids of the product path (no stamps, no ablation switches) run the lean instantiation (PERSIST = false, see above);
     // built for 8-wave workgroups, the only size the heuristics choose
     constexpr bool kLean = W == 8;
-    if (lds > maxSet) {
-        auto set = [&](const void* f) { return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); };
-        hipError_t err = set(reinterpret_cast<const void*>(&bucket_mul_kernel<FMT, E, W, false>));
-        if constexpr (kLean) if (err == hipSuccess) err = set(reinterpret_cast<const void*>(&bucket_mul_kernel<FMT, E, W, false, false, false>));
-        if constexpr (FMT == kFp16) {
-            if (err == hipSuccess) err = set(reinterpret_cast<const void*>(&bucket_mul_kernel<kFp16, E, W, true>));
-            if (err == hipSuccess) err = set(reinterpret_cast<const void*>(&bucket_mul_kernel<kFp16, E, W, false, true>));
-            if constexpr (kLean) if (err == hipSuccess) err = set(reinterpret_cast<const void*>(&bucket_mul_kernel<kFp16, E, W, true, false, false>));
-            if constexpr (kLean) if (err == hipSuccess) err = set(reinterpret_cast<const void*>(&bucket_mul_kernel<kFp16, E, W, false, true, false>));
-            if constexpr (kLean) if (err == hipSuccess) err = set(reinterpret_cast<const void*>(&bucket_mul_kernel<kFp16, E, W, true, true, false>));
-        }
-        if (err != hipSuccess) return err;
-        maxSet = lds;
-    }
+    // (every instantiation may use the whole LDS: bucket_mul_prepare_device, once per device at effort_create)
+    if (lds > kMaxLdsBytes) return hipErrorInvalidValue;
     const bool compact = (ga.split & 4u) != 0u;                   // (api.hip: persistent FP16 launches of plain calls)
     const bool lean = kLean && !ga.persistent && !ga.tstamp && !ga.ablate;
     if (compact && (FMT != kFp16 || (fusedAny && !lean))) return hipErrorInvalidValue;
@@ -1161,6 +1153,32 @@ static hipError_t launch_mul_t(const GroupKArgs& gaIn, hipStream_t st) {
 }
 
 #define EFFORT_GEOMS(X) X(16, 1) X(16, 2) X(16, 4) X(8, 1) X(8, 2) X(8, 4) X(4, 1) X(4, 2) X(4, 4) X(2, 4)
+
+// Lets every instantiation of the kernel ask for up to the whole LDS of a CU as dynamic shared memory, on the CURRENT device.
+// Done once per device when its first context is created (api.hip), not lazily at launch: a function attribute belongs to a
+// device, launches may come from several threads and devices, and a launch may sit inside a hipGraph capture.
+template <int FMT, int E, int W>
+static hipError_t prepare_t() {
+    auto set = [&](const void* f) { return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes); };
+    constexpr bool kLean = W == 8;
+    hipError_t err = set(reinterpret_cast<const void*>(&bucket_mul_kernel<FMT, E, W, false>));
+    if constexpr (kLean) if (err == hipSuccess) err = set(reinterpret_cast<const void*>(&bucket_mul_kernel<FMT, E, W, false, false, false>));
+    if constexpr (FMT == kFp16) {
+        if (err == hipSuccess) err = set(reinterpret_cast<const void*>(&bucket_mul_kernel<kFp16, E, W, true>));
+        if (err == hipSuccess) err = set(reinterpret_cast<const void*>(&bucket_mul_kernel<kFp16, E, W, false, true>));
+        if constexpr (kLean) if (err == hipSuccess) err = set(reinterpret_cast<const void*>(&bucket_mul_kernel<kFp16, E, W, true, false, false>));
+        if constexpr (kLean) if (err == hipSuccess) err = set(reinterpret_cast<const void*>(&bucket_mul_kernel<kFp16, E, W, false, true, false>));
+        if constexpr (kLean) if (err == hipSuccess) err = set(reinterpret_cast<const void*>(&bucket_mul_kernel<kFp16, E, W, true, true, false>));
+    }
+    return err;
+}
+hipError_t bucket_mul_prepare_device() {
+    hipError_t err = hipSuccess;
+#define EFFORT_CASE(w, e) if (err == hipSuccess) err = prepare_t<kFp16, e, w>(); if (err == hipSuccess) err = prepare_t<kQ4, e, w>();
+    EFFORT_GEOMS(EFFORT_CASE)
+#undef EFFORT_CASE
+    return err;
+}
 
 template <int FMT>
 static hipError_t launch_mul_fmt(int W, int E, const GroupKArgs& a, hipStream_t st) {

@@ -87,13 +87,16 @@ EFFORT_API effort_w* effort_weights_fp16(effort_ctx* ctx, const void* buckets_de
                               const void* probes_dev, int inDim, int outDim, int percentLoad,
                               int numExperts);
 
-/* The same with bucket rows `rowPitchBytes` apart (0 = 2*outDim/16, the reference's dense layout; a multiple of 4 >= that).
+/* The same with bucket rows `rowPitchBytes` apart (0 = 2*outDim/16, the reference's dense layout; otherwise a multiple of 4
+ * bytes >= that: rows are read as dwords.  The CONVERTER is stricter -- effort_convert_fp16_pitched writes pitches that are
+ * multiples of 8 -- and effort_aligned_row_pitch returns multiples of 128; one shape rule everywhere: outDim % 32 == 0).
  * The reference's rows are 2*cols bytes apart (1376 for 11008 outputs): the 512-byte row pieces the multiply streams then
  * straddle 128-byte lines and HBM delivers 5.4-5.6 TB/s where line-aligned rows reach 6.1-6.9.  A loader that places the rows
  * effort_aligned_row_pitch(outDim) bytes apart (effort_convert_fp16_pitched writes them so) gets the fast stream with no
  * second copy of the buckets (+2.3 % bytes for 11008 outputs).  Results are bit-identical for any pitch. */
 EFFORT_API effort_w* effort_weights_fp16_pitched(effort_ctx* ctx, const void* buckets_dev, int rowPitchBytes, const void* stats_dev,
                                       const void* probes_dev, int inDim, int outDim, int percentLoad, int numExperts);
+/* 2*outDim/16 rounded up to whole 128-byte lines; EFFORT_ERR_SHAPE for an outDim registration would refuse (outDim % 32, <= 16384). */
 EFFORT_API int effort_aligned_row_pitch(int outDim);
 
 /* Q4 bundle (layout written by q4_draft.py:70-322; loaded by loader.swift:70,98,124):
@@ -158,7 +161,7 @@ EFFORT_API int effort_set_dense_backend(effort_ctx* ctx, int rocblas);
 /* A GROUP of n (1..32) independent bucketMul calls in ONE kernel launch: call i multiplies vs[i] by ws[i] at
  * efforts[i] into outs[i] (expNos may be NULL, or hold NULL entries = expert 0).  Same row selection as n
  * effort_bucketmul calls, exactly; outputs equal up to the f32 rounding of the per-slice partial sums (the slicing
- * depends on how many calls share the launch; bit for bit when it is pinned with effort_set_tuning).  The point is
+ * depends on how many calls share the launch; bit for bit when it is pinned with effort_hip_debug.h's effort_set_tuning).  The point is
  * throughput: the decode loop issues such groups back to back on unchanged
  * input -- Wq|Wk|Wv (runNetwork.swift:132-134) and W1|W3 (runNetwork.swift:178-182) -- and the reference's command
  * buffer lets them overlap; here their workgroups share the CUs inside one launch.  All handles of a group are of
@@ -248,7 +251,8 @@ EFFORT_API int effort_decode_status(effort_ctx* ctx, int* host_out);
  * percentLoad 16, one expert.  Runs on the GPU (all device pointers), enqueued on the stream. */
 EFFORT_API int effort_convert_fp16(effort_ctx* ctx, const void* W_f16_dev, int outDim, int inDim,
                         void* buckets_dev, void* stats_dev, void* probes_dev);
-/* The same, writing bucket rows `rowPitchBytes` apart (see effort_weights_fp16_pitched; the padding is left untouched). */
+/* The same, writing bucket rows `rowPitchBytes` apart (0 = dense; otherwise a multiple of 8 bytes >= 2*outDim/16 -- the stats pass
+ * reads 8 bytes at a time; see effort_weights_fp16_pitched; the padding is left untouched). */
 EFFORT_API int effort_convert_fp16_pitched(effort_ctx* ctx, const void* W_f16_dev, int outDim, int inDim,
                                 void* buckets_dev, int rowPitchBytes, void* stats_dev, void* probes_dev);
 /* Elements the last effort_convert_fp16 calls could not place: the reference's preBucketize (convert.metal:40-61) drops an
@@ -270,17 +274,7 @@ EFFORT_API int effort_convert_q4(effort_ctx* ctx, const void* core2_f16_dev, int
 /* VectorFloat.cosineSimilarityTo (model.swift:511-519; aux.metal:293-312).  Synchronises. */
 EFFORT_API int effort_cosine(effort_ctx* ctx, const float* a_dev, const float* b_dev, int n, float* host_out);
 
-/* ---- tuning knobs (not part of the reference surface) ------------------------------------------ */
-
-/* Override the launch geometry heuristics of the multiply kernel: waves per workgroup (4, 8 or 16),
- * elements per lane (1, 2 or 4) and number of row slices (0 = heuristic).  Returns EFFORT_ERR_ARG
- * for unsupported combinations. */
-EFFORT_API int effort_set_tuning(effort_ctx* ctx, int wavesPerGroup, int elemsPerLane, int rowSlices);
-/* split = 1: evaluate findCutoff32 in its own one-workgroup launch ahead of the multiply kernel instead of
- * inside it.  Costs a kernel boundary per call.  Results are bit-identical.  Default 0 (fused). */
-EFFORT_API int effort_set_split_cutoff(effort_ctx* ctx, int split);
-
-/* Profiling, tracing and ablation hooks live in effort_hip_debug.h: they are not part of the drop-in surface. */
+/* Tuning knobs, profiling, tracing and ablation hooks live in effort_hip_debug.h: they are not part of the drop-in surface. */
 
 #ifdef __cplusplus
 }

@@ -12,6 +12,15 @@
 extern "C" {
 #endif
 
+/* Tuning knobs (nothing in the reference corresponds to them; the tests pin launch geometries with them). */
+/* Override the launch geometry heuristics of the multiply kernel: waves per workgroup (4, 8 or 16),
+ * elements per lane (1, 2 or 4) and number of row slices (0 = heuristic).  Returns EFFORT_ERR_ARG
+ * for unsupported combinations. */
+EFFORT_API int effort_set_tuning(effort_ctx* ctx, int wavesPerGroup, int elemsPerLane, int rowSlices);
+/* split = 1: evaluate findCutoff32 in its own one-workgroup launch ahead of the multiply kernel instead of
+ * inside it.  Costs a kernel boundary per call.  Results are bit-identical.  Default 0 (fused). */
+EFFORT_API int effort_set_split_cutoff(effort_ctx* ctx, int split);
+
 /* Group launches with more work items than wgPerCU workgroups per CU run as that many PERSISTENT workgroups pulling
  * items from per-XCD queues.  -1 = heuristic (default), 0 = always one workgroup per item. */
 EFFORT_API int effort_set_persistent(effort_ctx* ctx, int wgPerCU);

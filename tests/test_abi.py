@@ -20,11 +20,60 @@ def _header_functions(names=("effort_hip.h", "effort_hip_debug.h")):
 def test_header_declares_the_expected_surface():
     fns = _header_functions(("effort_hip.h",))
     # the lab bench (profiling / tracing / ablation hooks) is not part of the drop-in boundary
-    assert not [f for f in fns if f.startswith(("effort_debug_", "effort_kernel_", "effort_enable_kernel_timing", "effort_set_persistent"))]
+    assert not [f for f in fns if f.startswith(("effort_debug_", "effort_kernel_", "effort_enable_kernel_timing", "effort_set_persistent",
+                                                 "effort_set_tuning", "effort_set_split_cutoff"))]
     for must in ("effort_create", "effort_destroy", "effort_sync", "effort_weights_fp16", "effort_weights_q4",
                  "effort_bucketmul", "effort_bucketmul_q4", "effort_dense_gemv", "effort_convert_fp16",
                  "effort_last_dispatch_count", "effort_calc_dispatch"):
         assert must in fns
+
+
+def test_headers_compile_as_c11():
+    """A Swift / cgo / JNI binding imports the header as C: it must be C on its own, not only when included from .hip."""
+    import subprocess
+    for n in ("effort_hip.h", "effort_hip_debug.h"):
+        subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-x", "c", os.path.join(ROOT, "include", n)])
+
+
+def _prototypes():
+    """{name: (return type, [parameter types])} parsed from the headers, types reduced to what an ABI sees: every pointer is
+    'ptr', scalars keep their C type."""
+    protos = {}
+    for n in ("effort_hip.h", "effort_hip_debug.h"):
+        src = open(os.path.join(ROOT, "include", n)).read()
+        src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)                       # comments may hold parentheses and commas
+        for ret, name, params in re.findall(r"EFFORT_API\s+([\w\s\*]+?)\b(effort_\w+)\s*\(([^)]*)\)\s*;", src):
+            def kind(t):
+                t = t.strip()
+                if "*" in t:
+                    return "ptr"
+                words = [w for w in t.split() if w not in ("const", "unsigned")]
+                return ("u" if "unsigned" in t.split() else "") + words[0]
+            plist = [] if params.strip() in ("", "void") else [kind(re.sub(r"\b\w+\s*$", "", p) if not p.strip().endswith("*") else p) for p in params.split(",")]
+            protos[name] = (kind(ret), plist)
+    return protos
+
+
+def test_python_binding_matches_the_prototypes():
+    """Argument COUNT and C TYPES of every entry of effort_amd._lib._SIGS against the header's prototypes: a drifted
+    `int` vs `int64_t` or a missing parameter would pass the name check and corrupt the stack at run time."""
+    import ctypes as C
+
+    from effort_amd import _lib
+    protos = _prototypes()
+    assert sorted(protos) == sorted(_lib._SIGS)
+
+    def ckind(t):
+        if t is None:
+            return "void"
+        if t in (C.c_void_p, C.c_char_p) or isinstance(t, type(C.POINTER(C.c_int))):
+            return "ptr"
+        return {C.c_int: "int", C.c_int64: "int64_t", C.c_double: "double", C.c_float: "float", C.c_uint32: "uint32_t"}[t]
+
+    for name, (res, args) in _lib._SIGS.items():
+        ret, params = protos[name]
+        assert ckind(res) == ret, (name, "return", ckind(res), ret)
+        assert [ckind(a) for a in args] == params, (name, [ckind(a) for a in args], params)
 
 
 def test_library_loads_and_exports_every_declared_symbol(hip_lib_built):
@@ -48,6 +97,22 @@ def test_null_arguments_are_reported_not_crashed(hip_lib_built):
     assert lib.effort_bucketmul(None, None, None, None, None, 0.25) == -1
     assert lib.effort_set_tuning(None, 0, 0, 0) == -1
     assert lib.effort_last_error(None) == b"null context"
+
+
+def test_shipped_library_reads_no_environment(hip_lib_built):
+    """The A/B switches of the lab builds (-DEFFORT_LAB: EFFORT_ABLATE, EFFORT_NO_CUTJOBS ...) are compiled out of the shipped
+    library: no EFFORT_* variable name is left in it, and no object of the call path imports getenv (the one import left
+    is rocPRIM's own ROCPRIM_USE_ATOMIC_BLOCK_ID inside the offline Q4 converter's radix sort, convert_q4.o)."""
+    import subprocess
+    blob = open(hip_lib_built, "rb").read()
+    for knob in (b"EFFORT_ABLATE", b"EFFORT_NO_CUTJOBS", b"EFFORT_NO_COMPACT_MEANS", b"EFFORT_TAIL_CALLS", b"EFFORT_TAIL_MULT"):
+        assert knob not in blob, knob
+    csrc = os.path.join(ROOT, "effort_amd", "csrc")
+    for obj in ("api.o", "bucket_mul.o", "cutoff.o", "dispatch.o", "decode.o", "gemv.o", "convert.o", "comm.o"):
+        path = os.path.join(csrc, obj)
+        if os.path.exists(path):
+            syms = subprocess.run(["nm", "--undefined-only", path], capture_output=True, text=True, check=True).stdout
+            assert "getenv" not in syms, obj
 
 
 def test_product_has_no_oracle_dependency():

@@ -162,6 +162,55 @@ def test_overlap_orders_dependent_launches(ea, oracle_cpu):
     ctx.close()
 
 
+def test_long_dependent_chains_without_a_join(ea, oracle_cpu):
+    """The reference's style is one gpu.eval() after arbitrarily many enqueues (helpers/gpu.swift:109-119).  Two interleaved
+    chains x <- A x of 800 dependent lone calls each (1 600 launches, no effort_join in between) under effort_set_overlap(4):
+    the lanes' hazard bookkeeping is bounded (1 024 recorded ranges per lane), and when it fills up the lanes are JOINED --
+    the dependencies are kept, never dropped.  Bit-identical with the same chains on one lane, eager and with the whole
+    chain captured into one hipGraph."""
+    inDim = outDim = 4096
+    W, b, s, p = converted(oracle_cpu, outDim, inDim, scale=1.0 / 64.0)          # gain ~ 1 per step: the values stay alive
+    W2, b2, s2, p2 = converted(oracle_cpu, outDim, inDim, seed=99, scale=1.0 / 64.0)
+    ewA, ewB = gpu_weights(ea, W, b, s, p), gpu_weights(ea, W2, b2, s2, p2)
+    ctx = ea.Gpu(0)
+    x0, u0 = devf(make_v(inDim, seed=3)), devf(make_v(inDim, seed=4, heavy=True))
+    x, y, u, w = (torch.zeros(inDim, device=DEV) for _ in range(4))
+    steps = 400                                                                 # two calls per chain and step
+
+    def chains():
+        x.copy_(x0); u.copy_(u0)
+        for _ in range(steps):
+            ea.bucketMul(x, ewA, None, y, 0.5, gpu=ctx)                         # y = A x   (RAW on x, WAR on y)
+            ea.bucketMul(u, ewB, None, w, 0.5, gpu=ctx)                         # w = B u   (the other chain: another lane)
+            ea.bucketMul(y, ewA, None, x, 0.5, gpu=ctx)                         # x = A y
+            ea.bucketMul(w, ewB, None, u, 0.5, gpu=ctx)                         # u = B w
+    res = {}
+    for lanes in (1, 4):
+        ctx.set_overlap(lanes)
+        chains()
+        ctx.eval()
+        res[lanes] = (x.clone(), u.clone())
+        assert torch.isfinite(res[lanes][0]).all() and float(res[lanes][0].abs().max()) > 0 and float(res[lanes][1].abs().max()) > 0
+    assert torch.equal(res[1][0], res[4][0]) and torch.equal(res[1][1], res[4][1])
+    ctx.set_overlap(4)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+        chains()
+        ctx.join()
+    ctx._bind_stream()
+    x.zero_(); u.zero_()
+    graph.replay()
+    ctx.eval()
+    assert torch.equal(res[1][0], x) and torch.equal(res[1][1], u)
+    # the first link against the oracle
+    want, n, cutoff = oracle_cpu.bucket_mul(x0.cpu().numpy(), b, s, p, inDim, outDim, 0.5)
+    ctx.set_overlap(1)
+    ea.bucketMul(x0, ewA, None, y, 0.5, gpu=ctx)
+    ctx.eval()
+    assert close(y.cpu().numpy(), want) and ctx.last_dispatch_count() == n
+    ctx.close()
+
+
 def test_timed_configuration_as_a_whole(ea, oracle_cpu):
     """bench.py's timed job, as a whole: 4096 x 11008 matrices converted on line-aligned rows (pitch 1408), 32 calls per
     launch at 25 % effort on the heuristic geometry (persistent workgroups, cutoff jobs, COMPACT means, E = 4), ONE context

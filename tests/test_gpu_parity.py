@@ -31,10 +31,10 @@ def devf(a: np.ndarray) -> torch.Tensor:
 _CACHE = {}
 
 
-def converted(oracle_cpu, outDim, inDim, seed=1234, zeros=0):
-    key = (outDim, inDim, seed, zeros)
+def converted(oracle_cpu, outDim, inDim, seed=1234, zeros=0, scale=0.02):
+    key = (outDim, inDim, seed, zeros, scale)
     if key not in _CACHE:
-        W = make_w(outDim, inDim, seed=seed, zeros=zeros)
+        W = make_w(outDim, inDim, seed=seed, zeros=zeros, scale=scale)
         b, s, p, oob = oracle_cpu.convert_fp16(W)
         assert oob == 0
         _CACHE[key] = (W, b, s, p)
