@@ -108,7 +108,8 @@ static int fail(effort_ctx* c, int code, const char* what, hipError_t e = hipSuc
     } while (0)
 
 extern "C" const char* effort_version(void) { return "effort-hip 0.1 (gfx950)"; }
-extern "C" const char* effort_last_error(effort_ctx* c) { return c ? c->err : "null context"; }
+static char g_createErr[256] = "null context";       // effort_last_error(NULL): why the last effort_create failed, if one did
+extern "C" const char* effort_last_error(effort_ctx* c) { return c ? c->err : g_createErr; }
 
 static bool lane_alloc(effort_ctx* c, Lane& L) {
     bool ok = hipMalloc(&L.d_cutoff, 512) == hipSuccess && hipMalloc(&L.d_count, 16) == hipSuccess &&
@@ -168,14 +169,15 @@ extern "C" effort_ctx* effort_create(int device, void* stream) {
         static std::mutex m; static std::map<int, bool> prepared;
         std::lock_guard<std::mutex> lk(m);
         if (!prepared[device]) {
-            if (bucket_mul_prepare_device() != hipSuccess) { delete c; return nullptr; }
+            const hipError_t pe = bucket_mul_prepare_device();
+            if (pe != hipSuccess) { snprintf(g_createErr, sizeof(g_createErr), "effort_create: kernel attributes: %s", hipGetErrorString(pe)); delete c; return nullptr; }
             prepared[device] = true;
         }
     }
     bool ok = lane_alloc(c, c->lane[0]) && hipMalloc(&c->d_blockScratch, 4096 * 4) == hipSuccess &&
               hipMalloc(&c->d_cos, 16) == hipSuccess && hipMalloc(&c->d_status, 16) == hipSuccess &&
               hipMalloc(&c->d_tstamp, kStampBytes) == hipSuccess;
-    if (!ok) { effort_destroy(c); return nullptr; }
+    if (!ok) { snprintf(g_createErr, sizeof(g_createErr), "effort_create: out of device memory for the context scratch"); effort_destroy(c); return nullptr; }
     int khz = 0;
     if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0) c->wallClockKHz = khz;
     hipMemset(c->d_tstamp, 0, kStampBytes);

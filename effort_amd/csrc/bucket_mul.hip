@@ -93,7 +93,7 @@ constexpr int kRowAux = EFFORT_ROW_AUX;
 #define GA_ABLATE(ga) (PERSIST ? (ga).ablate : 0u)
 #define GA_TRACE(ga) (PERSIST ? (ga).trace : 0u)
 #endif
-constexpr uint32_t kMaxLdsBytes = 160u * 1024u;     // LDS of a gfx950 CU
+constexpr uint32_t kMaxLdsBytes = 160u * 1024u - 1024u;     // dynamic LDS a launch may ask for: a gfx950 CU's 160 KB less the kernel's static words (rounded up generously)
 constexpr int kSc1 = 16;     // buffer aux bit: sc1 = write-through store / L1-bypassing load (cross-XCD visible)
 
 template <int FMT> struct Fmt;
@@ -1159,7 +1159,13 @@ static hipError_t launch_mul_t(const GroupKArgs& gaIn, hipStream_t st) {
 // device, launches may come from several threads and devices, and a launch may sit inside a hipGraph capture.
 template <int FMT, int E, int W>
 static hipError_t prepare_t() {
-    auto set = [&](const void* f) { return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes); };
+    auto set = [&](const void* f) {            // (the kernel's static words come out of the same 160 KB)
+        hipFuncAttributes fa;
+        hipError_t e = hipFuncGetAttributes(&fa, f);
+        if (e != hipSuccess) return e;
+        if (fa.sharedSizeBytes > 1024u) return hipErrorInvalidValue;
+        return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160u * 1024u - (uint32_t)fa.sharedSizeBytes));
+    };
     constexpr bool kLean = W == 8;
     hipError_t err = set(reinterpret_cast<const void*>(&bucket_mul_kernel<FMT, E, W, false>));
     if constexpr (kLean) if (err == hipSuccess) err = set(reinterpret_cast<const void*>(&bucket_mul_kernel<FMT, E, W, false, false, false>));

@@ -188,30 +188,62 @@ __device__ __forceinline__ float block_find_cutoff(const float (&vj)[4096 / NT],
                 // below the first cell: everything at or above it (zeros never count); beyond the last: `above`
                 return p < base ? allGE : (p > top ? above : c);
             };
-            // The loop state is kept in VECTOR registers on purpose (the empty asm makes it opaque to hipcc's uniformity
-            // analysis): left to itself the compiler splits every round between SALU and VALU -- v_readfirstlane of the count,
-            // s_cmp / s_cselect for the integers, v_cmp -> vcc -> s_cbranch for the floats -- and each crossing waits out a
-            // pipeline: 390 cycles per round measured (9 rounds 1.5 us, 29 rounds 3.0 us).  All lanes run the same values.
+            // THE BISECTION WITHOUT ITS LOOKUPS.  A count enters a round of the reference's loop twice: through the comparison
+            // `countAbove < effort`, which steers the bounds, and through the exit tests (count == effort, |maxCount - minCount|
+            // < 3).  Counts are monotone in the threshold's cell, so the comparison is `cell >= P*`, P* = the first cell whose
+            // count is below the target -- found once, with two 64-lane probes of the table.  The rounds then run as a chain of a
+            // dozen VALU instructions each, no LDS round trip inside (it was ~330 cycles a round with the lookup on the chain:
+            // 1.4 us for 9 rounds, 2.7 for 29).  The count-driven exits are checked AFTERWARDS for all rounds at once: the loop
+            // is run divergently -- lane r leaves it after round r -- so lane r's registers hold the state after round r, three
+            // table lookups per lane give the counts the reference would have seen there, and the first lane that satisfies
+            // an exit test names the round the reference's loop ends in.  Same float operations in the same order: bit-identical.
+            // (All lanes of a round hold the same values; the state lives in VGPRs, as before.)
+            uint32_t pStar;
             {
-                float nb = newBound, lo = minBound, hi = maxBound;
-                uint32_t minC = (uint32_t)minCount, maxC = (uint32_t)maxCount, pLo = patLo, pHi = patHi, nLoops = (uint32_t)loops;
-                asm volatile("" : "+v"(nb), "+v"(lo), "+v"(hi), "+v"(minC), "+v"(maxC), "+v"(pLo), "+v"(pHi), "+v"(nLoops));
-                bool fin = done;
-                while (!fin && pHi != pLo + 1u) {
-                    const uint32_t p = __float_as_uint(nb) >> 16;
-                    const uint32_t cnt = count_above(p);
-                    nLoops += 1u;                                                      // :199-246, as `round` above
-                    const bool below = cnt < effort;
-                    hi = below ? nb : hi; maxC = below ? cnt : maxC; pHi = below ? p : pHi;        // :214-220
-                    lo = below ? lo : nb; minC = below ? minC : cnt; pLo = below ? pLo : p;
-                    const float prev = nb;
-                    nb = (hi + lo) / 2;                                                // :222
-                    int d = (int)maxC - (int)minC; d = d < 0 ? -d : d;
-                    fin = (cnt == effort) | (hi - lo < 0.00001f) | (d < 3) | (nLoops > 100u) | (nb == prev);   // :227-229,236; fixed point
-                }
-                newBound = nb; minBound = lo; maxBound = hi; minCount = (int)minC; maxCount = (int)maxC; patLo = pLo; patHi = pHi;
-                loops = (int)nLoops; done = fin;
+                uint32_t c1 = tbl[(uint32_t)lane * 64u + 63u];                  // the last cell of each 64-cell segment (cells past `top` hold `above` < target)
+                const uint32_t seg = (uint32_t)__popcll(__ballot(c1 >= effort));
+                uint32_t c2 = tbl[min(seg, 63u) * 64u + (uint32_t)lane];
+                const uint32_t nge = seg >= 64u ? CAP : seg * 64u + (uint32_t)__popcll(__ballot(c2 >= effort));
+                pStar = allGE < effort ? 0u : base + nge;                          // cells below `base` count allGE
             }
+            float nb = newBound, lo = minBound, hi = maxBound;
+            uint32_t pLo = patLo, pHi = patHi, nLoops = (uint32_t)loops;
+            for (;;) {
+                asm volatile("" : "+v"(nb), "+v"(lo), "+v"(hi), "+v"(pLo), "+v"(pHi), "+v"(nLoops));
+                uint32_t pT = 0;
+                bool finTraj = false, adj = false;
+                for (uint32_t r = 0; r <= (uint32_t)lane; r++) {                   // divergent on purpose: lane r keeps the state after round r
+                    const uint32_t p = __float_as_uint(nb) >> 16;
+                    const bool below = p >= pStar;                                 // == (count_above(p) < effort)
+                    nLoops += 1u;                                                  // :199-246, as `round` above
+                    hi = below ? nb : hi; pHi = below ? p : pHi;                   // :214-220
+                    lo = below ? lo : nb; pLo = below ? pLo : p;
+                    const float prev = nb;
+                    nb = (hi + lo) / 2;                                            // :222
+                    pT = p;
+                    finTraj = (hi - lo < 0.00001f) | (nLoops > 100u) | (nb == prev);   // :227-229 (the bounds), :236, fixed point
+                    adj = pHi == pLo + 1u;                                         // the while-condition: adjacent cells -> the tail
+                    if (finTraj | adj) break;                                      // (uniform among the lanes still in the loop)
+                }
+                // the counts the reference had in hand after this lane's round
+                const uint32_t cnt = count_above(pT);
+                const uint32_t maxC = pHi != kNoHi ? count_above(pHi) : (uint32_t)maxCount;     // count at the upper bound's cell (initial: maxCount)
+                const uint32_t minC = pLo != kNoLo ? count_above(pLo) : (uint32_t)minCount;
+                int d = (int)maxC - (int)minC; d = d < 0 ? -d : d;
+                const bool fin = (cnt == effort) | (d < 3) | finTraj;
+                const unsigned long long flagged = __ballot(fin | adj);
+                const int f = flagged ? (int)__builtin_ctzll(flagged) : 63;        // the round the loop ends in (none yet: go on from round 63's state)
+                nb = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(nb), f));
+                lo = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(lo), f));
+                hi = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(hi), f));
+                pLo = __builtin_amdgcn_readlane(pLo, f); pHi = __builtin_amdgcn_readlane(pHi, f); nLoops = __builtin_amdgcn_readlane(nLoops, f);
+                if (flagged) {
+                    done = (__builtin_amdgcn_readlane((uint32_t)fin, f) & 1u) != 0u;
+                    minCount = (int)__builtin_amdgcn_readlane(minC, f); maxCount = (int)__builtin_amdgcn_readlane(maxC, f);
+                    break;
+                }
+            }
+            newBound = nb; minBound = lo; maxBound = hi; patLo = pLo; patHi = pHi; loops = (int)nLoops;
             if (!done) {
                 // tail: bounds in adjacent cells with known counts (below the target at and above X, not below it
                 // under X); those counts differ by >= 3 and neither equals the target, or the loop had exited.

@@ -24,7 +24,7 @@ class Gpu:
             stream = torch.cuda.current_stream(self.device).cuda_stream
             self.ctx = self._lib.effort_create(self.device, C.c_void_p(stream))
         if not self.ctx:
-            raise RuntimeError("effort_create failed")
+            raise RuntimeError("effort_create failed: " + (self._lib.effort_last_error(None) or b"").decode())
         self._stream = stream
 
     # -- helpers ---------------------------------------------------------------------------------

@@ -69,6 +69,7 @@ EFFORT_API int effort_sync(effort_ctx* ctx);
  * Costs 64 MiB of scratch per extra lane. */
 EFFORT_API int effort_set_overlap(effort_ctx* ctx, int lanes);
 EFFORT_API int effort_join(effort_ctx* ctx);
+/* Text of the context's last error; with ctx == NULL: why the last effort_create returned NULL ("null context" if none did). */
 EFFORT_API const char* effort_last_error(effort_ctx* ctx);
 EFFORT_API const char* effort_version(void);
 

@@ -49,7 +49,7 @@ int main(int argc, char** argv) {
 
     HIP_OK(hipSetDevice(0));
     effort_ctx* ctx = effort_create(0, NULL);                  /* Gpu() + BucketMul.shared */
-    if (!ctx) { fprintf(stderr, "c_client: effort_create failed\n"); return 3; }
+    if (!ctx) { fprintf(stderr, "c_client: effort_create failed: %s\n", effort_last_error(NULL)); return 3; }
 
     void *dW, *dBuckets, *dStats, *dProbes, *dV, *dOut;
     HIP_OK(hipMalloc(&dW, (size_t)inDim * outDim * 2));

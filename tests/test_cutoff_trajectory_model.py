@@ -1,0 +1,148 @@
+"""CPU model of the HIP cutoff's lookup-free bisection (effort_amd/csrc/cutoff_device.h, "THE BISECTION WITHOUT ITS
+LOOKUPS") against the oracle's findCutoff32.  The device code steers the reference's loop with `cell >= P*` instead of a
+count per round and checks the count-driven exits afterwards, one lane per round; this restates that control flow in
+numpy f32 arithmetic -- including the 64-round chunks, the hand-over to the closed-form tail and the ballot rounds for
+value ranges wider than the table -- and compares the float BITS with the C oracle over seeded inputs that leave the loop
+through every exit.  (The device code itself is compared with the oracle by the -m gpu tests: test_cutoff_*.)"""
+import numpy as np
+import pytest
+
+F = np.float32
+CAP = 4096                      # cells the device table holds (kCutoffBinsPerThread * 512 threads)
+NO_LO, NO_HI = 0xFFFF0000, 0xFFF00000
+
+
+def _bf16(x):
+    u = np.asarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    r = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return r.astype(np.uint32).view(np.float32)
+
+
+def _pat(f):
+    return int(np.asarray(F(f)).view(np.uint32)) >> 16
+
+
+def _cell_edge_tail(nb, lo, hi, X, loops):
+    """bisect_to_cell_edge: the loop form (the closed form is checked against it on the GPU)."""
+    while True:
+        loops += 1
+        if nb >= X:
+            hi = nb
+        else:
+            lo = nb
+        prev = nb
+        nb = F((hi + lo) / F(2))
+        if F(hi - lo) < F(0.00001) or loops > 100 or nb == prev:
+            return nb
+
+
+def model_cutoff(v, probes_u16, q):
+    pr = _bf16(probes_u16.view(np.float16).astype(np.float32))
+    t = (F(100000.0) * v.astype(np.float32)).astype(np.float32)
+    vals = _bf16(np.abs((t * pr).astype(np.float32)))
+    vp = (vals.view(np.uint32) >> 16).astype(np.int64)
+    effort = 4096 - q
+    pmin, pmax = int(vp.min()), int(vp.max())
+    nz = vp[vp > 0]
+    pminNZ = min(int(nz.min()) if nz.size else 0xFFFF, pmax)
+    frompat = lambda p: np.asarray(np.uint32(p << 16)).view(np.float32)[()]          # noqa: E731
+    lo, hi = F(min(frompat(pmin), F(1000.0))), F(frompat(pmax))
+    nb = F((lo + hi) / F(2))
+    loops, minC, maxC, pLo, pHi, done = 0, 4096, 0, NO_LO, NO_HI, False
+    CA = lambda p: int((vp > p).sum())                                               # noqa: E731
+
+    def rnd(cnt):                                                                    # `round` of the device code
+        nonlocal loops, lo, hi, nb, minC, maxC, pLo, pHi
+        loops += 1
+        p = _pat(nb)
+        if cnt < effort:
+            hi, maxC, pHi = nb, cnt, p
+        else:
+            lo, minC, pLo = nb, cnt, p
+        prev = nb
+        nb = F((hi + lo) / F(2))
+        if cnt == effort or F(hi - lo) < F(0.00001) or abs(maxC - minC) < 3 or loops > 100:
+            return True
+        return nb == prev
+    low = lambda: max(pLo, pminNZ) if pLo != NO_LO else pminNZ                       # noqa: E731
+    top = lambda: pHi if pHi != NO_HI else pmax                                      # noqa: E731
+    while not done and pHi != pLo + 1 and top() - low() + 1 > CAP:
+        done = rnd(CA(_pat(nb)))
+    if done:
+        return nb
+    if pHi == pLo + 1:
+        return _cell_edge_tail(nb, lo, hi, frompat(pHi), loops)
+    base, tp = low(), top()
+    above = maxC if pHi != NO_HI else 0
+    allGE = int((vp >= base).sum())
+
+    def count_above(p):                                                              # the table lookup
+        if p < base:
+            return allGE
+        if p > tp:
+            return above
+        return int((vp > p).sum())
+    tbl = [count_above(base + c) if base + c <= tp else above for c in range(CAP)]
+    nge = sum(1 for c in tbl if c >= effort)                                         # (monotone: a prefix)
+    assert all(tbl[c] >= effort for c in range(nge)) and all(tbl[c] < effort for c in range(nge, CAP))
+    pStar = 0 if allGE < effort else base + nge
+    while True:
+        recs = []
+        for r in range(64):                                                          # lane r keeps the state after round r
+            p = _pat(nb)
+            below = p >= pStar
+            assert below == (count_above(p) < effort)
+            loops += 1
+            if below:
+                hi, pHi = nb, p
+            else:
+                lo, pLo = nb, p
+            prev = nb
+            nb = F((hi + lo) / F(2))
+            finTraj = bool(F(hi - lo) < F(0.00001)) or loops > 100 or bool(nb == prev)
+            adj = pHi == pLo + 1
+            recs.append((p, nb, lo, hi, pLo, pHi, loops, finTraj, adj))
+            if finTraj or adj:
+                break
+        for (p, nb_r, lo_r, hi_r, pLo_r, pHi_r, loops_r, finTraj, adj) in recs:
+            cnt = count_above(p)
+            mx = count_above(pHi_r) if pHi_r != NO_HI else maxC
+            mn = count_above(pLo_r) if pLo_r != NO_LO else minC
+            fin = cnt == effort or abs(mx - mn) < 3 or finTraj
+            if fin or adj:
+                if fin:
+                    return nb_r
+                return _cell_edge_tail(nb_r, lo_r, hi_r, frompat(pHi_r), loops_r)
+        # 64 rounds without an exit: go on from round 63's state (the loop variables already hold it)
+
+
+def _inputs(seed, kind):
+    rng = np.random.default_rng(seed)
+    v = rng.standard_normal(4096).astype(np.float32)
+    pr = (rng.standard_normal(4096) * 0.02).astype(np.float16)
+    if kind == "heavy":
+        v = (v * np.exp(2.0 * rng.standard_normal(4096))).astype(np.float32)
+    elif kind == "zeros":
+        v[rng.integers(0, 4096, 1500)] = 0
+        pr[rng.integers(0, 4096, 300)] = 0
+    elif kind == "wide":                                   # > 64 octaves of range: ballot rounds before the table
+        v = (v * np.exp2(rng.integers(-60, 40, 4096).astype(np.float32))).astype(np.float32)
+    elif kind == "few":                                    # few distinct values: the count == effort / counts exits
+        v = rng.choice(np.array([0.5, 1.0, 2.0, 3.0], np.float32), 4096)
+        pr = rng.choice(np.array([0.01, 0.02], np.float16), 4096)
+    elif kind == "tiny":
+        v = (v * 1e-9).astype(np.float32)
+    return v, pr.view(np.uint16)
+
+
+@pytest.mark.parametrize("kind", ["gauss", "heavy", "zeros", "wide", "few", "tiny"])
+def test_lookup_free_bisection_model_matches_oracle(oracle_cpu, kind):
+    mism = 0
+    for seed in range(40):
+        v, pr = _inputs(seed, kind)
+        for effort in (0.0, 0.02, 0.1, 0.25, 0.5, 0.9, 1.0):
+            want, _ = oracle_cpu.find_cutoff(v, pr, 0, effort)
+            got = model_cutoff(v, pr, oracle_cpu.effort_to_q(effort))
+            if np.float32(want).view(np.uint32) != np.float32(got).view(np.uint32):
+                mism += 1
+    assert mism == 0
