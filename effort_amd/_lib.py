@@ -57,6 +57,7 @@ _SIGS = {
     "effort_bucketmul_group": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P]),
     "effort_bucketmul_q4_group": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P]),
     "effort_bucketmul_group_fused": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "effort_bucketmul_chain": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "effort_group_dispatch_count": (C.c_int, [_P, C.c_int, C.POINTER(C.c_uint32)]),
     "effort_group_cutoff": (C.c_int, [_P, C.c_int, C.POINTER(C.c_float)]),
     "effort_debug_occupancy": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int]),

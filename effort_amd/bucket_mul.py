@@ -49,6 +49,40 @@ def bucketMulQ4(v: torch.Tensor, by: ExpertWeights, expNo: torch.Tensor | None, 
     (BucketMulQ4.shared() if gpu is None else BucketMulQ4(gpu.device, gpu)).fullMul(v, by, expNo, out, effort)
 
 
+def _marshal(calls, q4: bool):
+    """ctypes arrays of a list of calls [(v, by, expNo, out, effort[, extras])]: (n, ws, vs, es, outs, eff, pre, aux, res);
+    the last three are None when no call folds glue into the launch."""
+    n = len(calls)
+    P = C.c_void_p * n
+    addr = lambda x: None if x is None else (x.data_ptr() if isinstance(x, torch.Tensor) else (x.value if hasattr(x, "value") else int(x)))   # noqa: E731
+    ws = P(*[addr(c[1].handle) for c in calls])
+    vs = P(*[addr(c[0]) for c in calls])
+    es = P(*[addr(c[2]) for c in calls])
+    outs = P(*[addr(c[3]) for c in calls])
+    eff = (C.c_double * n)(*[float(c[4]) for c in calls])
+    extras = [c[5] if len(c) > 5 and c[5] else {} for c in calls]
+    if not any(extras):
+        return n, ws, vs, es, outs, eff, None, None, None
+    if q4:
+        raise ValueError("fused prologues / epilogues are implemented for FP16 bundles")
+    pre, aux, res = [], [], []
+    for c, x in zip(calls, extras):
+        if set(x) - {"gate", "norm", "resid"} or ("gate" in x and "norm" in x):
+            raise ValueError("a call takes one of gate= / norm=, and optionally resid=")
+        if "gate" in x:
+            _check_vec("gate", x["gate"], c[1].inSize)
+        if "norm" in x:
+            w = x["norm"]
+            if not (w.is_cuda and w.element_size() == 2 and w.is_contiguous() and w.numel() >= c[1].inSize):
+                raise ValueError("norm weights must be a contiguous f16 CUDA vector of inSize elements")
+        if "resid" in x:
+            _check_vec("resid", x["resid"], c[1].outSize)
+        pre.append(1 if "gate" in x else 2 if "norm" in x else 0)
+        aux.append(addr(x.get("gate", x.get("norm"))))
+        res.append(addr(x.get("resid")))
+    return n, ws, vs, es, outs, eff, (C.c_int * n)(*pre), P(*aux), P(*res)
+
+
 def bucketMulGroup(calls, gpu=None):
     """One launch for up to 32 independent multiplies: ``calls`` = [(v, by, expNo, out, effort), ...], all FP16 or all
     Q4 bundles.  Same results as calling bucketMul / bucketMulQ4 on each; the group is how independent projections of
@@ -65,39 +99,33 @@ def bucketMulGroup(calls, gpu=None):
     bm = cls.shared() if gpu is None else cls(gpu.device, gpu)
     for c in calls:
         bm._validate(c[0], c[1], c[2], c[3])
-    n = len(calls)
-    P = C.c_void_p * n
-    addr = lambda x: None if x is None else (x.data_ptr() if isinstance(x, torch.Tensor) else (x.value if hasattr(x, "value") else int(x)))
-    ws = P(*[addr(c[1].handle) for c in calls])
-    vs = P(*[addr(c[0]) for c in calls])
-    es = P(*[addr(c[2]) for c in calls])
-    outs = P(*[addr(c[3]) for c in calls])
-    eff = (C.c_double * n)(*[float(c[4]) for c in calls])
+    n, ws, vs, es, outs, eff, pre, aux, res = _marshal(calls, q4)
     g = bm.gpu
     g._bind_stream()
-    extras = [c[5] if len(c) > 5 and c[5] else {} for c in calls]
-    if any(extras):
-        if q4:
-            raise ValueError("fused prologues / epilogues are implemented for FP16 bundles")
-        pre, aux, res = [], [], []
-        for c, x in zip(calls, extras):
-            if set(x) - {"gate", "norm", "resid"} or ("gate" in x and "norm" in x):
-                raise ValueError("a call takes one of gate= / norm=, and optionally resid=")
-            if "gate" in x:
-                _check_vec("gate", x["gate"], c[1].inSize)
-            if "norm" in x:
-                w = x["norm"]
-                if not (w.is_cuda and w.element_size() == 2 and w.is_contiguous() and w.numel() >= c[1].inSize):
-                    raise ValueError("norm weights must be a contiguous f16 CUDA vector of inSize elements")
-            if "resid" in x:
-                _check_vec("resid", x["resid"], c[1].outSize)
-            pre.append(1 if "gate" in x else 2 if "norm" in x else 0)
-            aux.append(addr(x.get("gate", x.get("norm"))))
-            res.append(addr(x.get("resid")))
-        g.check(_lib.lib().effort_bucketmul_group_fused(g.ctx, n, ws, vs, es, outs, eff, (C.c_int * n)(*pre), P(*aux), P(*res)), "bucketMulGroup")
+    if pre is not None:
+        g.check(_lib.lib().effort_bucketmul_group_fused(g.ctx, n, ws, vs, es, outs, eff, pre, aux, res), "bucketMulGroup")
         return
     fn = _lib.lib().effort_bucketmul_q4_group if q4 else _lib.lib().effort_bucketmul_group
     g.check(fn(g.ctx, n, ws, vs, es, outs, eff), "bucketMulGroup")
+
+
+def bucketMulChain(stages, gpu=None):
+    """A chain of dependent groups in ONE launch (effort_bucketmul_chain): ``stages`` = [[call, ...], [call, ...], ...], calls as
+    in ``bucketMulGroup`` (FP16 bundles); a call may read -- as its input, its gate partner or its residual -- what calls of
+    EARLIER stages write; the calls of one stage are independent.  The decode loop's wo -> w1|w3 -> w2 -> wq|wk|wv of the next
+    layer (runNetwork.swift:121-183) is such a chain: one launch instead of four."""
+    stages = [[tuple(c) for c in st] for st in stages]
+    calls = [c for st in stages for c in st]
+    if not stages or any(not st for st in stages) or len(stages) > 8 or len(calls) > 32:
+        raise ValueError("a chain holds 1..8 non-empty stages and at most 32 calls")
+    bm = BucketMul.shared() if gpu is None else BucketMul(gpu.device, gpu)
+    for c in calls:
+        bm._validate(c[0], c[1], c[2], c[3])
+    n, ws, vs, es, outs, eff, pre, aux, res = _marshal(calls, False)
+    g = bm.gpu
+    g._bind_stream()
+    counts = (C.c_int * len(stages))(*[len(st) for st in stages])
+    g.check(_lib.lib().effort_bucketmul_chain(g.ctx, len(stages), counts, ws, vs, es, outs, eff, pre, aux, res), "bucketMulChain")
 
 
 def basicMul(v: torch.Tensor, by: torch.Tensor, out: torch.Tensor, gpu=None):

@@ -114,11 +114,11 @@ extern "C" const char* effort_last_error(effort_ctx* c) { return c ? c->err : g_
 static bool lane_alloc(effort_ctx* c, Lane& L) {
     bool ok = hipMalloc(&L.d_cutoff, 512) == hipSuccess && hipMalloc(&L.d_count, 16) == hipSuccess &&
               hipMalloc(&L.d_slabs, c->slabBytes) == hipSuccess && hipMalloc(&L.d_counters, effort_ctx::kMaxTiles * 4) == hipSuccess &&
-              hipMalloc(&L.d_sliceCounts, effort_ctx::kMaxSlices * 4) == hipSuccess && hipMalloc(&L.d_queue, 11 * 16 * 4) == hipSuccess;
+              hipMalloc(&L.d_sliceCounts, effort_ctx::kMaxSlices * 4) == hipSuccess && hipMalloc(&L.d_queue, kQueueWords * 4) == hipSuccess;
     if (!ok) return false;
     hipMemset(L.d_counters, 0, effort_ctx::kMaxTiles * 4);
     hipMemset(L.d_sliceCounts, 0, effort_ctx::kMaxSlices * 4);
-    hipMemset(L.d_queue, 0, 11 * 16 * 4);
+    hipMemset(L.d_queue, 0, kQueueWords * 4);
     hipMemset(L.d_cutoff, 0, 512);
     hipMemset(L.d_count, 0, 16);
     return true;
@@ -492,6 +492,7 @@ static int choose_geom(const effort_ctx* c, const effort_w* w, int groupSize, in
     g->inDim = w->inDim; g->outDim = w->outDim; g->cols = w->cols; g->rowsPerIn = w->rowsPerIn;
     g->expertRows = w->rowsPerIn * w->inDim; g->numExperts = w->numExperts;
     g->tiles = (w->cols + 64 * E - 1) / (64 * E);
+    g->elems = (uint32_t)E;
     g->rowPitch = w->rowPitch;
     const uint32_t tileFloats = nacc * E * 64;
     const size_t ldsMax = 160 * 1024;
@@ -533,7 +534,10 @@ static int ensure_timing(effort_ctx* c) {
 // One launch for a group of independent calls (a lone call is a group of one).
 static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws, const float* const* vs,
                     const uint32_t* const* expNos, float* const* outs, const double* efforts,
-                    const int* prologues = nullptr, const void* const* vAux = nullptr, const float* const* resids = nullptr) {
+                    const int* prologues = nullptr, const void* const* vAux = nullptr, const float* const* resids = nullptr,
+                    const int* stages = nullptr) {
+    // `stages` (chain launches, effort_bucketmul_chain): the stage of every call, non-decreasing from 0; a stage's calls may read
+    // what the calls of earlier stages write.  ONE persistent launch (bucket_mul.hip: CHAIN).
     if (!c || !ws || !vs || !outs || !efforts) return fail(c, EFFORT_ERR_ARG, "bucketmul: null argument");
     if (n < 1 || n > kMaxGroup) return fail(c, EFFORT_ERR_ARG, "bucketmul: group size outside 1..32");
     // The A/B switches below read the environment in LAB builds only (-DEFFORT_LAB: tools/build_variant*.sh); the shipped
@@ -551,7 +555,37 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
         if (pre < 0 || pre > 2 || (pre && (!vAux || !vAux[i]))) return fail(c, EFFORT_ERR_ARG, "bucketmul: bad input prologue");
         if (pre && (fmt != kFp16 || c->splitCutoff)) return fail(c, EFFORT_ERR_KIND, "bucketmul: input prologues need FP16 weights and the fused cutoff");
     }
-    const int groupE = pick_elems(c, fmt, n, ws);
+    const bool chain = stages != nullptr;
+    int stageFirst[kMaxStages + 1] = {0}, nStages = 0;         // calls [stageFirst[k], stageFirst[k+1]) make up stage k
+    if (chain) {
+        if (fmt != kFp16 || c->splitCutoff) return fail(c, EFFORT_ERR_KIND, "bucketmul_chain: FP16 weights and the fused cutoff");
+        for (int i = 0; i < n; i++) {
+            if (stages[i] != nStages - 1) {
+                if (stages[i] != nStages || nStages == kMaxStages) return fail(c, EFFORT_ERR_ARG, "bucketmul_chain: stages must count up from 0 without gaps (at most 8)");
+                stageFirst[nStages++] = i;
+            }
+            if (!ws[i]->means16 || ws[i]->inDim % 2u) return fail(c, EFFORT_ERR_SHAPE, "bucketmul_chain: an even inDim is needed");
+        }
+        stageFirst[nStages] = n;
+        // calls of ONE stage run concurrently: none may write what another one of them reads or writes
+        auto hit = [](const void* p, size_t pb, const void* q, size_t qb) { return p && q && (uintptr_t)p < (uintptr_t)q + qb && (uintptr_t)q < (uintptr_t)p + pb; };
+        for (int k = 0; k < nStages; k++)
+            for (int i = stageFirst[k]; i < stageFirst[k + 1]; i++)
+                for (int j = stageFirst[k]; j < stageFirst[k + 1]; j++) {
+                    const size_t ob = (size_t)ws[i]->outDim * 4, ib = (size_t)ws[j]->inDim * 4;
+                    const bool aliasOwnResid = i == j && resids && resids[j] == outs[i];       // h += product in place
+                    if (hit(outs[i], ob, vs[j], ib) || (vAux && prologues && prologues[j] == EFFORT_PRE_SILU_GATE && hit(outs[i], ob, vAux[j], ib)) ||
+                        (resids && !aliasOwnResid && hit(outs[i], ob, resids[j], (size_t)ws[j]->outDim * 4)) || (i != j && hit(outs[i], ob, outs[j], (size_t)ws[j]->outDim * 4)))
+                        return fail(c, EFFORT_ERR_ARG, "bucketmul_chain: a call writes what a call of the same stage reads or writes");
+                }
+    }
+    // columns per lane: one choice for a group launch; per STAGE in a chain (what the stage would get as a launch of its own)
+    int stageE[kMaxStages] = {0};
+    for (int k = 0; k < nStages; k++) {
+        stageE[k] = pick_elems(c, fmt, stageFirst[k + 1] - stageFirst[k], ws + stageFirst[k]);
+        if (stageE[k] > 2) stageE[k] = 2;
+    }
+    const int groupE = chain ? stageE[0] : pick_elems(c, fmt, n, ws);
     const bool tm = c->timing && c->nSamples < effort_ctx::kMaxSamples;
     hipEvent_t* ev = tm ? c->ev + 4 * c->nSamples : nullptr;
     // ---- which lane (overlap mode): the launch may run beside the launches in flight on the OTHER lanes unless it reads or
@@ -656,15 +690,28 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
         }
         const int frc = fork_lane();
         if (frc != EFFORT_OK) return frc;
+        if (chain) {
+            // persistent, no cutoff jobs (a job of a later stage would wait on the stage before it with everybody else: every
+            // workgroup evaluates the cutoff of a call it works on, as a plain grid's do), compact means
+            ga.persistent = R ? R : 2u; ga.cutJobs = 0u; ga.split = 4u | 16u;
+            for (uint32_t i = 0; i < ga.count; i++) ga.call[i].stats = ws[first + i]->means16;
+            HIP_TRY(c, launch_bucket_mul_chain(ga, st));
+            return EFFORT_OK;
+        }
         if (c->splitCutoff && !(ablate & 1u)) HIP_TRY(c, launch_find_cutoff_group(ga, st));
         HIP_TRY(c, launch_bucket_mul(fmt, W, E, ga, st));
         return EFFORT_OK;
     };
     uint32_t groupTiles = 0;
     for (int i = 0; i < n; i++) groupTiles += (ws[i]->cols + 64 * groupE - 1) / (64 * groupE);
+    uint32_t stageTilesAll[kMaxStages] = {0};
+    for (int k = 0; k < nStages; k++)
+        for (int i = stageFirst[k]; i < stageFirst[k + 1]; i++) stageTilesAll[k] += (ws[i]->cols + 64 * stageE[k] - 1) / (64 * stageE[k]);
     begin(0);
+    int curStage = 0;
     for (int i = 0; i < n; i++) {
         const effort_w* w = ws[i];
+        if (chain) curStage = stages[i];
         MulGeom g;
         memset(&g, 0, sizeof(g));
         int Wi, Ei;
@@ -680,13 +727,17 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
             if (tailMult >= 4 && i >= n - tc && i < n - tc / 2) mult = (uint32_t)tailMult / 2;      // two steps: ... x2 x2 x4 x4
         }
 #endif
-        int rc = choose_geom(c, w, n, groupE, &g, &Wi, &Ei, mult, groupTiles);
+        // (a chain's stage is sliced as the launch of its own it replaces: its calls, its column tiles)
+        int rc = chain ? choose_geom(c, w, stageFirst[curStage + 1] - stageFirst[curStage], stageE[curStage], &g, &Wi, &Ei, mult, stageTilesAll[curStage])
+                       : choose_geom(c, w, n, groupE, &g, &Wi, &Ei, mult, groupTiles);
         if (rc != EFFORT_OK) return fail(c, rc, "bucketmul: no launch geometry for this shape/tuning");
+        if (chain && (Wi != 8 || g.sliceRows % 2u)) return fail(c, EFFORT_ERR_SHAPE, "bucketmul_chain: 8-wave workgroups and slices of an even number of rows");
         if (i == 0) { W = Wi; E = Ei; }
-        else if (Wi != W || Ei != E) return fail(c, EFFORT_ERR_SHAPE, "bucketmul: the calls of a group must agree on the kernel variant");
+        else if (Wi != W || (!chain && Ei != E)) return fail(c, EFFORT_ERR_SHAPE, "bucketmul: the calls of a group must agree on the kernel variant");
         uint32_t gi = 0;
         while (gi < nGeoms && memcmp(&ga.geom[gi], &g, sizeof(g)) != 0) gi++;
         if (gi == nGeoms && nGeoms == kMaxGeoms) {     // a launch carries kMaxGeoms distinct shapes: this call opens the next one
+            if (chain) return fail(c, EFFORT_ERR_SHAPE, "bucketmul_chain: more than four distinct launch geometries in one chain");
             rc = flush();
             if (rc != EFFORT_OK) return rc;
             begin((uint32_t)i);
@@ -702,7 +753,8 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
         a.ol = OutlierIndex{fmt == kQ4 ? w->olBlockPtr : nullptr, w->olEntry, w->olRowPtr ? w->olRowPtr + w->outDim + 1 : nullptr};
         a.q = (uint32_t)(int)((double)(kProbes - 1) * (1.0 - efforts[i]));            // bucketMul.swift:39
         const int pre = prologues ? prologues[i] : 0;
-        a.pre = (uint16_t)pre; a.vAux = pre ? vAux[i] : nullptr; a.resid = resids ? resids[i] : nullptr;
+        a.pre = (uint16_t)(pre | (curStage << 8)); a.vAux = pre ? vAux[i] : nullptr; a.resid = resids ? resids[i] : nullptr;
+        if (chain) ga.stageTiles[curStage] = (uint16_t)(ga.stageTiles[curStage] + g.tiles);
         a.slabOff = (uint32_t)(slabOff / 256); a.tileOff = (uint16_t)tileOff; a.sliceOff = (uint16_t)sliceOff; a.geom = (uint16_t)gi;
         wg += g.tiles * ((g.slices + 7) / 8 * 8);
         if (wg / 8u > 0xFFFFu) return fail(c, EFFORT_ERR_SHAPE, "bucketmul: group exceeds the launch descriptor's item range");
@@ -733,6 +785,17 @@ extern "C" int effort_bucketmul_group_fused(effort_ctx* c, int n, const effort_w
                                             const uint32_t* const* expNos, float* const* outs, const double* efforts,
                                             const int* prologues, const void* const* vAux, const float* const* resids) {
     return do_group(c, kFp16, n, ws, vs, expNos, outs, efforts, prologues, vAux, resids);
+}
+extern "C" int effort_bucketmul_chain(effort_ctx* c, int nStages, const int* stageCalls, const effort_w* const* ws, const float* const* vs,
+                                      const uint32_t* const* expNos, float* const* outs, const double* efforts,
+                                      const int* prologues, const void* const* vAux, const float* const* resids) {
+    if (!c || !stageCalls || nStages < 1 || nStages > kMaxStages) return fail(c, EFFORT_ERR_ARG, "bucketmul_chain: 1..8 stages");
+    int stages[kMaxGroup], n = 0;
+    for (int k = 0; k < nStages; k++) {
+        if (stageCalls[k] < 1 || n + stageCalls[k] > kMaxGroup) return fail(c, EFFORT_ERR_ARG, "bucketmul_chain: a stage holds at least one call, a chain at most 32");
+        for (int i = 0; i < stageCalls[k]; i++) stages[n++] = k;
+    }
+    return do_group(c, kFp16, n, ws, vs, expNos, outs, efforts, prologues, vAux, resids, stages);
 }
 extern "C" int effort_bucketmul_q4_group(effort_ctx* c, int n, const effort_w* const* ws, const float* const* vs,
                                          const uint32_t* const* expNos, float* const* outs, const double* efforts) {

@@ -211,10 +211,26 @@ __device__ __forceinline__ bool locate_item(const GroupKArgs& ga, const uint32_t
 // as its own youngest ones, so the first wait after an issue drains the wave's batches in flight once.  Completion is
 // awaited explicitly (s_waitcnt vmcnt(0)) where the data is read.
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// SC1: the load bypasses this CU's L1 and is coherent at device scope -- for data another workgroup of the SAME launch wrote
+// (chain launches: the input vector of a later stage).
+template <bool SC1 = false>
 __device__ __forceinline__ void lds_dma_dword(const u32x4 rsrc, const uint32_t voff, const uint32_t ldsAddr) {
     uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dword %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(ldsAddr), "s"(rsrc) : "memory");
+    if constexpr (SC1)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dword %1, %3, 0 offen sc1 lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(ldsAddr), "s"(rsrc) : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dword %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(ldsAddr), "s"(rsrc) : "memory");
+}
+// A load of data written earlier in the same launch by another workgroup (CHAIN), or an ordinary load.
+template <bool CHAIN, typename T>
+__device__ __forceinline__ T ld_dep(const T* p) {
+    if constexpr (CHAIN) {
+        static_assert(sizeof(T) == 4, "ld_dep: dwords");
+        const uint32_t u = __hip_atomic_load(reinterpret_cast<const uint32_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        T r; __builtin_memcpy(&r, &u, 4); return r;
+    } else return *p;
 }
 __device__ __forceinline__ u32x4 make_rsrc(const void* base, uint32_t bytes) {
     const uint64_t p = (uint64_t)(size_t)base;
@@ -224,8 +240,10 @@ __device__ __forceinline__ u32x4 make_rsrc(const void* base, uint32_t bytes) {
     return r;
 }
 
-template <int FMT, int W, bool COMPACT>
-__device__ __forceinline__ void stage_issue(const GroupKArgs& ga, const ItemRef& r, const int tid, char* smem, const LdsPlan& lp, const uint32_t par) {
+// `parts`: bit 0 = the row means (weights only), bit 1 = the slice of v.  A CHAIN item asks for the means first and for v only once
+// the stage that writes v is complete.
+template <int FMT, int W, bool COMPACT, bool CHAIN = false>
+__device__ __forceinline__ void stage_issue(const GroupKArgs& ga, const ItemRef& r, const int tid, char* smem, const LdsPlan& lp, const uint32_t par, const uint32_t parts = 3u) {
     constexpr int NT = 64 * W;
     using lds_v = __attribute__((address_space(3))) void;
     const CallDesc& a = ga.call[__builtin_amdgcn_readfirstlane(r.ci)];
@@ -241,6 +259,7 @@ __device__ __forceinline__ void stage_issue(const GroupKArgs& ga, const ItemRef&
     const u32x4 rv = make_rsrc(a.v, inDim * 4u);
     const uint32_t ldsM = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(lds_v*)(smem + lp.offM));
     const uint32_t ldsV = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(lds_v*)(smem + ((par & 1u) ? lp.offV[1] : lp.offV[0])));
+    if (parts & 1u) {
     if constexpr (compact) {
         // one dword = the means of candidate slots 2d and 2d+1 (rows j and j+1 of one rank: neighbours in memory; every slice
         // starts on an even row -- the host checks -- so the dword is aligned): half the loads, means[] holds u16 per slot
@@ -266,10 +285,13 @@ __device__ __forceinline__ void stage_issue(const GroupKArgs& ga, const ItemRef&
         }
         lds_dma_dword(rs, voff, ldsM + ((uint32_t)(rr * NT) + wave * 64u) * 4u);
     }
+    }
+    if (parts & 2u) {
 #pragma unroll
     for (int u = 0; u < (FMT == kFp16 ? 1 : 2); u++) {
         if ((uint32_t)(u * NT) + wave * 64u >= nb) continue;    // uniform per wave (reads past inDim return 0; past the slice, a neighbour's input nobody looks at)
-        lds_dma_dword(rv, (j0 + (uint32_t)(u * NT + tid)) * 4u, ldsV + ((uint32_t)(u * NT) + wave * 64u) * 4u);
+        lds_dma_dword<CHAIN>(rv, (j0 + (uint32_t)(u * NT + tid)) * 4u, ldsV + ((uint32_t)(u * NT) + wave * 64u) * 4u);
+    }
     }
 }
 
@@ -277,7 +299,7 @@ __device__ __forceinline__ void stage_issue(const GroupKArgs& ga, const ItemRef&
 // `staged` (per wave): this wave's share of the item's stage loads was issued while the previous item streamed (into vblk
 // buffer `par`).  `prefetch` is polled by every wave near the end of its streaming loop until it returns true: there the
 // caller pulls the next item from the queue (wave 0) and issues the wave's share of its stage loads (into buffer par ^ 1).
-template <int FMT, int E, int W, bool FUSED, bool COMPACT, bool PERSIST, typename Prefetch>
+template <int FMT, int E, int W, bool FUSED, bool COMPACT, bool PERSIST, bool CHAIN, typename Prefetch>
 __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t item, const ItemRef& ref, char* smem, const LdsPlan& lp, uint32_t& cachedCall,
                                          float& cachedCutoff, const uint32_t par, const bool staged, const bool firstItem, Prefetch prefetch) {
     constexpr int NACC = Fmt<FMT>::kAcc;
@@ -326,8 +348,27 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     const uint32_t e = a.expNo ? a.expNo[0] : 0u;
 
     // ---- A. everything the selection needs lands in LDS (stage_issue): the row means of the candidate slots, the slice of v
-    if (!staged) stage_issue<FMT, W, COMPACT>(ga, ref, tid, smem, lp, par);
+    if (!staged) stage_issue<FMT, W, COMPACT, CHAIN>(ga, ref, tid, smem, lp, par, CHAIN ? 1u : 3u);
     const float rankBound = a.rankBound[e];                       // (asked for here: its round trip runs under the staged loads')
+    if constexpr (CHAIN) {
+        // CHAIN launch: this call's inputs (v, the gate's partner, the residual) are outputs of the calls of the previous
+        // stage.  The row means -- weights only -- are on their way into LDS already; thread 0 polls the previous stage's
+        // count of written column tiles (the last arriver of a tile raises it after its stores to out[] have left the CU, see
+        // E), the barrier hands the verdict to the workgroup, and only then the slice of v is asked for.  Every load of such
+        // data bypasses L1 (sc1: ld_dep, lds_dma_dword<true>): this CU may hold the buffer's lines of an earlier token.  Forward
+        // progress: the queues hand out a stage's items after all items of the stages before it, and the workgroups that took
+        // those wait only on still earlier stages.  (A workgroup's second item of a call skips the poll.)
+        const uint32_t stage = (uint32_t)a.pre >> 8;
+        if (stage > 0u && cachedCall != ci) {
+            if (tid == 0) {
+                const uint32_t* const done = ga.queue + kStageDoneOff + (stage - 1u) * 16u;
+                const uint32_t need = ga.stageTiles[stage - 1u];
+                for (int spin = 0; spin < 400000 && __hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need; spin++) __builtin_amdgcn_s_sleep(4);
+            }
+            __syncthreads();
+        }
+        stage_issue<FMT, W, COMPACT, CHAIN>(ga, ref, tid, smem, lp, par, 2u);
+    }
     float vj[VPT]; uint16_t prj[VPT];
     const uint16_t* pr = a.probes + (size_t)e * kProbes;
     const bool fused = (ga.split & 1u) == 0u;                    // uniform
@@ -340,7 +381,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     // Input prologue (uniform per call): the multiply's input is v itself, or silu(v) * vAux (the FFN gate,
     // runNetwork.swift:181), or rmsNorm(v) * vAux (runNetwork.swift:121-122,173-175) -- evaluated here, per workgroup,
     // instead of in a launch of its own.
-    const uint32_t pre = FUSED ? a.pre : (uint32_t)kPreNone;      // FUSED is a separate instantiation: the plain multiply pays nothing
+    const uint32_t pre = FUSED ? ((uint32_t)a.pre & 0xFFu) : (uint32_t)kPreNone;      // FUSED is a separate instantiation: the plain multiply pays nothing
     // A prologue's operands are ALL asked for here, in one memory round trip beside the stage loads: the first 4096 raw inputs,
     // their partners from vAux (the gate's x3 as f32, the norm weights as f16: kept as raw bits), the probes, and vAux for this
     // thread's element of the slice.  (Asked for where they were used -- vAux after the norm's reduction, the slice's vAux after
@@ -354,17 +395,17 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
         const bool gate = pre == (uint32_t)kPreSiluGate;
         if (needCutEarly || !gate) {
 #pragma unroll
-            for (int i = 0; i < VPT; i++) rawn[i] = a.v[tid + NT * i];
+            for (int i = 0; i < VPT; i++) rawn[i] = ld_dep<CHAIN>(a.v + tid + NT * i);
         }
         if (needCutEarly) {
 #pragma unroll
             for (int i = 0; i < VPT; i++) {
-                auxc[i] = gate ? __float_as_uint(reinterpret_cast<const float*>(a.vAux)[tid + NT * i]) : (uint32_t)reinterpret_cast<const uint16_t*>(a.vAux)[tid + NT * i];
+                auxc[i] = gate ? __float_as_uint(ld_dep<CHAIN>(reinterpret_cast<const float*>(a.vAux) + tid + NT * i)) : (uint32_t)reinterpret_cast<const uint16_t*>(a.vAux)[tid + NT * i];
                 prj[i] = pr[tid + NT * i];
             }
         }
         const uint32_t js = j0 + min((uint32_t)tid, nb - 1u);
-        auxS = gate ? __float_as_uint(reinterpret_cast<const float*>(a.vAux)[js]) : (uint32_t)reinterpret_cast<const uint16_t*>(a.vAux)[js];
+        auxS = gate ? __float_as_uint(ld_dep<CHAIN>(reinterpret_cast<const float*>(a.vAux) + js)) : (uint32_t)reinterpret_cast<const uint16_t*>(a.vAux)[js];
     }
     const uint32_t lg = g.sliceLog2;
     const uint32_t nSlots = FMT == kFp16 ? (g.rowsPerIn << lg) : (nb << 3);
@@ -385,7 +426,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 const uint32_t j = base + (uint32_t)(r * NT);
-                if (j < g.inDim) { const float x = a.v[j]; part[r] += x * x; }
+                if (j < g.inDim) { const float x = ld_dep<CHAIN>(a.v + j); part[r] += x * x; }
             }
         }
 #pragma unroll
@@ -412,7 +453,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
             for (int i = 0; i < VPT; i++) vj[i] = xform(rawn[i], auxc[i]);
         } else {
 #pragma unroll
-            for (int i = 0; i < VPT; i++) { vj[i] = a.v[tid + NT * i]; prj[i] = pr[tid + NT * i]; }
+            for (int i = 0; i < VPT; i++) { vj[i] = ld_dep<CHAIN>(a.v + tid + NT * i); prj[i] = pr[tid + NT * i]; }
         }
     };
     if (needCut && !viaJob) load_cut_inputs();
@@ -915,7 +956,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
                 for (int h = 0; h < 4; h++) {
                     const uint32_t oo = (uint32_t)o + h, lane2 = oo & 63u, sj = oo >> 6, j = sj % E, slot = sj / E;
                     const uint32_t c2 = t * (64u * E) + lane2 * E + j;
-                    if (c2 < g.cols) res[h] = a.resid[c2 * NACC + slot];
+                    if (c2 < g.cols) res[h] = ld_dep<CHAIN>(a.resid + c2 * NACC + slot);
                 }
             }
             float sm[4][4];                                // [tile slot of this thread][slice % 4]: fixed summation order
@@ -953,7 +994,13 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
                 const uint32_t oo = (uint32_t)o + h;
                 const uint32_t lane2 = oo & 63u, sj = oo >> 6, j = sj % E, slot = sj / E;
                 const uint32_t c2 = t * (64u * E) + lane2 * E + j;
-                if (c2 < g.cols) { const uint32_t oi = c2 * NACC + slot; a.out[oi] = (FUSED && a.resid) ? res[h] + tot[h] : tot[h]; }
+                if (c2 < g.cols) {
+                    const uint32_t oi = c2 * NACC + slot;
+                    const float val = (FUSED && a.resid) ? res[h] + tot[h] : tot[h];
+                    // (CHAIN: written through, so that a later stage's workgroup on another XCD reads it from memory)
+                    if constexpr (CHAIN) __hip_atomic_store(reinterpret_cast<uint32_t*>(a.out + oi), __float_as_uint(val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else a.out[oi] = val;
+                }
             }
         }
     };
@@ -964,6 +1011,12 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     // (G > 1: thread group 0 reads the partial sums in the accumulator region after reduce_tile's only barrier; a persistent
     //  workgroup's next item -- or cutoff job -- zeroes its count table there, so the region must be quiescent first)
     if (PERSIST && G > 1) __syncthreads();
+    if constexpr (CHAIN) {
+        // this tile of the call's output is written: once every thread's stores have left the CU, count it towards its stage
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(ga.queue + kStageDoneOff + ((uint32_t)a.pre >> 8) * 16u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (rstamp) GA_TSTAMP(ga)[24] = wall_clock64();
     if (tid == 0) {
         __hip_atomic_store(&a_counters[t], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next call
@@ -1019,7 +1072,11 @@ __device__ __forceinline__ void cutoff_job(const GroupKArgs& ga, uint32_t ci, ch
 // dispatcher only places ~40 workgroups/us chip-wide and spreads a large grid unevenly over the CUs (measured with
 // tools/microbench.hip: residency probe), so a group launch sizes its grid to the chip -- R workgroups per CU,
 // R fixed by the LDS each one asks for -- and balances the work itself.
-template <int FMT, int E, int W, bool FUSED, bool COMPACT = false, bool PERSIST = true>
+// CHAIN: the calls come in STAGES, and a stage's calls read what the stages before it wrote (the decode loop's wo -> w1|w3 -> w2 ->
+// wq|wk|wv of the next layer, glue folded in, as ONE launch): persistent workgroups, the queues hand out the stages in order, an item
+// waits for the stage before its own (mul_item, A), no cutoff jobs (every workgroup evaluates the cutoff of a call it works on, as
+// a plain grid's do).  E is then the LARGEST lane width in the launch; an item runs with its own call's (MulGeom::elems: 1 or 2).
+template <int FMT, int E, int W, bool FUSED, bool COMPACT = false, bool PERSIST = true, bool CHAIN = false>
 __global__ __launch_bounds__(64 * W, (W <= 8 ? EFFORT_MIN_WAVES_PER_EU : 4)) void bucket_mul_kernel(const GroupKArgs ga) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ uint32_t s_item;
@@ -1076,7 +1133,7 @@ __global__ __launch_bounds__(64 * W, (W <= 8 ? EFFORT_MIN_WAVES_PER_EU : 4)) voi
         }
         gen++;
         bool stagedNext = false;
-        mul_item<FMT, E, W, FUSED, COMPACT, PERSIST>(ga, item - GA_CUTJOBS(ga), ref, smem, lp, cachedCall, cachedCutoff, par, staged, gen == 1u && (GA_ABLATE(ga) & 512u) != 0u /* (measured: evaluating the first item's cutoff locally instead of waiting for the job is 1 us slower per 32-call launch; kept as an ablation) */, [&]() -> bool {
+        auto prefetch = [&]() -> bool {
             if (!GA_PERSISTENT(ga)) return true;
             if (threadIdx.x == 0)                                  // wave 0's first call: pull, publish (item and generation in one store)
                 __hip_atomic_store(&s_next, ((unsigned long long)gen << 32) | (unsigned long long)pull(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1091,7 +1148,13 @@ __global__ __launch_bounds__(64 * W, (W <= 8 ? EFFORT_MIN_WAVES_PER_EU : 4)) voi
                 stagedNext = true;
             }
             return true;
-        });
+        };
+        const bool firstOwn = gen == 1u && (GA_ABLATE(ga) & 512u) != 0u;     /* (measured: evaluating the first item's cutoff locally instead of waiting for the job is 1 us slower per 32-call launch; kept as an ablation) */
+        auto run = [&](auto ec) {
+            mul_item<FMT, decltype(ec)::value, W, FUSED, COMPACT, PERSIST, CHAIN>(ga, item - GA_CUTJOBS(ga), ref, smem, lp, cachedCall, cachedCutoff, par, staged, firstOwn, prefetch);
+        };
+        if (CHAIN && E > 1 && ga.geom[ga.call[__builtin_amdgcn_readfirstlane(ref.ci)].geom].elems == 1u) run(std::integral_constant<int, 1>{});   // (uniform)
+        else run(std::integral_constant<int, E>{});
         // (mul_item's barriers lie between wave 0's publication and this read)
         item = GA_PERSISTENT(ga) ? __builtin_amdgcn_readfirstlane((uint32_t)__hip_atomic_load(&s_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) : total;
         staged = stagedNext;
@@ -1102,6 +1165,7 @@ __global__ __launch_bounds__(64 * W, (W <= 8 ? EFFORT_MIN_WAVES_PER_EU : 4)) voi
         if (gone == gridDim.x - 1u) {
             for (int i = 0; i <= 8; i++) __hip_atomic_store(&ga.queue[i * 16], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             for (int i = 0; i < kMaxGroup; i++) __hip_atomic_store(&ga.queue[9 * 16 + i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (CHAIN) for (int i = 0; i < kMaxStages; i++) __hip_atomic_store(&ga.queue[kStageDoneOff + i * 16], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -1154,6 +1218,38 @@ static hipError_t launch_mul_t(const GroupKArgs& gaIn, hipStream_t st) {
 
 #define EFFORT_GEOMS(X) X(16, 1) X(16, 2) X(16, 4) X(8, 1) X(8, 2) X(8, 4) X(4, 1) X(4, 2) X(4, 4) X(2, 4)
 
+// ---- chain launches: FP16, 8 waves, lanes of one or two columns, prologues / residuals, compact means, persistent -----------
+constexpr int kChainE = 2, kChainW = 8;
+static const void* chain_kernel() { return reinterpret_cast<const void*>(&bucket_mul_kernel<kFp16, kChainE, kChainW, true, true, true, true>); }
+hipError_t launch_bucket_mul_chain(const GroupKArgs& gaIn, hipStream_t st) {
+    GroupKArgs ga = gaIn;
+    if (!(ga.split & 16u) || !(ga.split & 4u) || !ga.persistent || ga.cutJobs || ga.count < 1u) return hipErrorInvalidValue;
+    // the LDS plan over the launch's geometries: the tile of the widest lanes, every call's slots
+    const LdsPlan lp = ga.lp = plan_lds<kFp16, kChainE, kChainW>(ga.geom, kMaxGeoms);
+    if (lp.offA > 65536u) return hipErrorInvalidValue;
+    uint32_t stage = 0;
+    for (uint32_t i = 0; i < ga.count; i++) {
+        const MulGeom& g = ga.geom[ga.call[i].geom];
+        if (g.elems != 1u && g.elems != (uint32_t)kChainE) return hipErrorInvalidValue;
+        if (g.slots > (uint32_t)kRounds * 64 * kChainW || g.slots != (g.rowsPerIn << g.sliceLog2) || (1u << g.sliceLog2) > 64u * kChainW) return hipErrorInvalidValue;
+        if (g.tiles != (g.cols + 64u * g.elems - 1u) / (64u * g.elems)) return hipErrorInvalidValue;
+        if (((uint32_t)ga.wgEnd8[i] - (i ? (uint32_t)ga.wgEnd8[i - 1] : 0u)) * 8u != g.tiles * align_up(g.slices, 8)) return hipErrorInvalidValue;
+        const uint32_t sg = (uint32_t)ga.call[i].pre >> 8;          // stages in order, none skipped
+        if (sg < stage || sg > stage + 1u || sg >= (uint32_t)kMaxStages || (i == 0 && sg != 0u)) return hipErrorInvalidValue;
+        stage = sg;
+    }
+    if (ga.totalItems != (uint32_t)ga.wgEnd8[ga.count - 1] * 8u) return hipErrorInvalidValue;
+    // R workgroups per CU, exactly (as launch_mul_t does); never more workgroups than items
+    const uint32_t R = ga.persistent;
+    uint32_t grid = ga.numCU * R, lds = lp.total;
+    if (grid > ga.totalItems) grid = ga.totalItems;
+    const uint32_t force = (160u * 1024u) / (R + 1u) + 512u;
+    if (lds < force && force <= (160u * 1024u) / R) lds = force;
+    if (lds > kMaxLdsBytes) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((bucket_mul_kernel<kFp16, kChainE, kChainW, true, true, true, true>), dim3(grid), dim3(64 * kChainW), lds, st, ga);
+    return hipGetLastError();
+}
+
 // Lets every instantiation of the kernel ask for up to the whole LDS of a CU as dynamic shared memory, on the CURRENT device.
 // Done once per device when its first context is created (api.hip), not lazily at launch: a function attribute belongs to a
 // device, launches may come from several threads and devices, and a launch may sit inside a hipGraph capture.
@@ -1180,6 +1276,11 @@ static hipError_t prepare_t() {
 }
 hipError_t bucket_mul_prepare_device() {
     hipError_t err = hipSuccess;
+    {
+        hipFuncAttributes fa;
+        err = hipFuncGetAttributes(&fa, chain_kernel());
+        if (err == hipSuccess) err = hipFuncSetAttribute(chain_kernel(), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160u * 1024u - (uint32_t)fa.sharedSizeBytes));
+    }
 #define EFFORT_CASE(w, e) if (err == hipSuccess) err = prepare_t<kFp16, e, w>(); if (err == hipSuccess) err = prepare_t<kQ4, e, w>();
     EFFORT_GEOMS(EFFORT_CASE)
 #undef EFFORT_CASE

@@ -188,61 +188,61 @@ __device__ __forceinline__ float block_find_cutoff(const float (&vj)[4096 / NT],
                 // below the first cell: everything at or above it (zeros never count); beyond the last: `above`
                 return p < base ? allGE : (p > top ? above : c);
             };
-            // THE BISECTION WITHOUT ITS LOOKUPS.  A count enters a round of the reference's loop twice: through the comparison
-            // `countAbove < effort`, which steers the bounds, and through the exit tests (count == effort, |maxCount - minCount|
-            // < 3).  Counts are monotone in the threshold's cell, so the comparison is `cell >= P*`, P* = the first cell whose
-            // count is below the target -- found once, with two 64-lane probes of the table.  The rounds then run as a chain of a
-            // dozen VALU instructions each, no LDS round trip inside (it was ~330 cycles a round with the lookup on the chain:
-            // 1.4 us for 9 rounds, 2.7 for 29).  The count-driven exits are checked AFTERWARDS for all rounds at once: the loop
-            // is run divergently -- lane r leaves it after round r -- so lane r's registers hold the state after round r, three
-            // table lookups per lane give the counts the reference would have seen there, and the first lane that satisfies
-            // an exit test names the round the reference's loop ends in.  Same float operations in the same order: bit-identical.
-            // (All lanes of a round hold the same values; the state lives in VGPRs, as before.)
-            uint32_t pStar;
-            {
-                uint32_t c1 = tbl[(uint32_t)lane * 64u + 63u];                  // the last cell of each 64-cell segment (cells past `top` hold `above` < target)
-                const uint32_t seg = (uint32_t)__popcll(__ballot(c1 >= effort));
-                uint32_t c2 = tbl[min(seg, 63u) * 64u + (uint32_t)lane];
-                const uint32_t nge = seg >= 64u ? CAP : seg * 64u + (uint32_t)__popcll(__ballot(c2 >= effort));
-                pStar = allGE < effort ? 0u : base + nge;                          // cells below `base` count allGE
-            }
+            // THE BISECTION WITHOUT ITS LOOKUPS.  A count enters a round of the reference's loop in three places: the comparison
+            // `countAbove < effort` that steers the bounds, and the exit tests `countAbove == effort` and |maxCount - minCount| < 3.
+            // Counts are monotone in the threshold's bf16 cell, so each of them is a comparison of CELLS with a few order
+            // statistics of the values: with T(k) = the first cell whose count is below k (count(p) >= k  <=>  p < T(k)) and
+            // m = effort,
+            //     countAbove <  m                 <=>  p >= T(m)
+            //     countAbove == m                 <=>  T(m+1) <= p < T(m)
+            //     |maxCount - minCount| < 3       <=>  (count(hi) >= m-1 and count(lo) <= m+1) or (count(hi) >= m-2 and count(lo) <= m)
+            // (count(hi) < m <= count(lo) always; bounds never set yet count 0 / 4096, the reference's initial values).  The five
+            // cells T(m-2) .. T(m+2) are found ONCE, with two 64-lane probes of the table each (issued together); the rounds
+            // then run with no LDS round trip inside -- it was ~330 cycles a round with the lookup on the dependent chain, 1.4 us
+            // for 9 rounds and 2.7 for 29 -- as a chain of ~25 VALU instructions.  Same float operations in the same order, the
+            // same exits in the same round: bit-identical (tests/test_cutoff_trajectory_model.py restates this on the CPU).
+            constexpr uint32_t kSeg = CAP / 64u;                                 // cells per lane of the first probe
+            const uint32_t c1 = tbl[(uint32_t)lane * kSeg + kSeg - 1u];         // the last cell of each segment (cells past `top` hold `above`)
+            auto first_cell_below = [&](int k) -> uint32_t {                   // T(k)
+                if (k <= 0) return 0xFFFFFFFFu;                                 // every count is >= k
+                if (k > 4096 || allGE < (uint32_t)k) return 0u;                 // none is (cells below `base` count allGE, the largest count there is)
+                const uint32_t seg = (uint32_t)__popcll(__ballot(c1 >= (uint32_t)k));
+                if (seg >= 64u) return 0xFFFFFFFFu;                             // the whole table, hence every cell beyond it too (`above` >= k)
+                uint32_t n = seg * kSeg;
+#pragma unroll
+                for (uint32_t u = 0; u < (kSeg + 63u) / 64u; u++) {
+                    const uint32_t i = u * 64u + (uint32_t)lane;
+                    const uint32_t c2 = tbl[seg * kSeg + min(i, kSeg - 1u)];
+                    n += (uint32_t)__popcll(__ballot(i < kSeg && c2 >= (uint32_t)k));
+                }
+                return base + n;
+            };
+            const int m = (int)effort;
+            uint32_t tM2 = first_cell_below(m - 2), tM1 = first_cell_below(m - 1), tM = first_cell_below(m), tP1 = first_cell_below(m + 1), tP2 = first_cell_below(m + 2);
             float nb = newBound, lo = minBound, hi = maxBound;
             uint32_t pLo = patLo, pHi = patHi, nLoops = (uint32_t)loops;
-            for (;;) {
-                asm volatile("" : "+v"(nb), "+v"(lo), "+v"(hi), "+v"(pLo), "+v"(pHi), "+v"(nLoops));
-                uint32_t pT = 0;
-                bool finTraj = false, adj = false;
-                for (uint32_t r = 0; r <= (uint32_t)lane; r++) {                   // divergent on purpose: lane r keeps the state after round r
-                    const uint32_t p = __float_as_uint(nb) >> 16;
-                    const bool below = p >= pStar;                                 // == (count_above(p) < effort)
-                    nLoops += 1u;                                                  // :199-246, as `round` above
-                    hi = below ? nb : hi; pHi = below ? p : pHi;                   // :214-220
-                    lo = below ? lo : nb; pLo = below ? pLo : p;
-                    const float prev = nb;
-                    nb = (hi + lo) / 2;                                            // :222
-                    pT = p;
-                    finTraj = (hi - lo < 0.00001f) | (nLoops > 100u) | (nb == prev);   // :227-229 (the bounds), :236, fixed point
-                    adj = pHi == pLo + 1u;                                         // the while-condition: adjacent cells -> the tail
-                    if (finTraj | adj) break;                                      // (uniform among the lanes still in the loop)
-                }
-                // the counts the reference had in hand after this lane's round
-                const uint32_t cnt = count_above(pT);
-                const uint32_t maxC = pHi != kNoHi ? count_above(pHi) : (uint32_t)maxCount;     // count at the upper bound's cell (initial: maxCount)
-                const uint32_t minC = pLo != kNoLo ? count_above(pLo) : (uint32_t)minCount;
-                int d = (int)maxC - (int)minC; d = d < 0 ? -d : d;
-                const bool fin = (cnt == effort) | (d < 3) | finTraj;
-                const unsigned long long flagged = __ballot(fin | adj);
-                const int f = flagged ? (int)__builtin_ctzll(flagged) : 63;        // the round the loop ends in (none yet: go on from round 63's state)
-                nb = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(nb), f));
-                lo = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(lo), f));
-                hi = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(hi), f));
-                pLo = __builtin_amdgcn_readlane(pLo, f); pHi = __builtin_amdgcn_readlane(pHi, f); nLoops = __builtin_amdgcn_readlane(nLoops, f);
-                if (flagged) {
-                    done = (__builtin_amdgcn_readlane((uint32_t)fin, f) & 1u) != 0u;
-                    minCount = (int)__builtin_amdgcn_readlane(minC, f); maxCount = (int)__builtin_amdgcn_readlane(maxC, f);
-                    break;
-                }
+            // counts at the bounds, as the two comparisons each the third test needs; never-set bounds take the reference's initial counts
+            bool hiGeM1 = patHi != kNoHi ? patHi < tM1 : (uint32_t)maxCount >= (uint32_t)max(m - 1, 0), hiGeM2 = patHi != kNoHi ? patHi < tM2 : (uint32_t)maxCount >= (uint32_t)max(m - 2, 0);
+            bool loGeP1 = patLo != kNoLo ? patLo < tP1 : (uint32_t)minCount >= (uint32_t)(m + 1), loGeP2 = patLo != kNoLo ? patLo < tP2 : (uint32_t)minCount >= (uint32_t)(m + 2);
+            asm volatile("" : "+v"(nb), "+v"(lo), "+v"(hi), "+v"(pLo), "+v"(pHi), "+v"(nLoops), "+v"(tM2), "+v"(tM1), "+v"(tM), "+v"(tP1), "+v"(tP2));   // VGPRs: see above
+            bool fin = done;
+            while (!fin && pHi != pLo + 1u) {
+                const uint32_t p = __float_as_uint(nb) >> 16;
+                const bool below = p >= tM;                                        // countAbove < effort
+                nLoops += 1u;                                                      // :199-246, as `round` above
+                hi = below ? nb : hi; pHi = below ? p : pHi;                       // :214-220
+                lo = below ? lo : nb; pLo = below ? pLo : p;
+                hiGeM1 = below ? p < tM1 : hiGeM1; hiGeM2 = below ? p < tM2 : hiGeM2;
+                loGeP1 = below ? loGeP1 : p < tP1; loGeP2 = below ? loGeP2 : p < tP2;
+                const float prev = nb;
+                nb = (hi + lo) / 2;                                                // :222
+                const bool cntEq = (p >= tP1) & (p < tM);                          // countAbove == effort
+                const bool dLt3 = (hiGeM1 & !loGeP2) | (hiGeM2 & !loGeP1);         // |maxCount - minCount| < 3
+                fin = cntEq | (hi - lo < 0.00001f) | dLt3 | (nLoops > 100u) | (nb == prev);   // :227-229,236; fixed point
             }
+            done = fin;
+            if (pHi != kNoHi) maxCount = (int)count_above(pHi);                    // (reported state only; the tail below does not read counts)
+            if (pLo != kNoLo) minCount = (int)count_above(pLo);
             newBound = nb; minBound = lo; maxBound = hi; patLo = pLo; patHi = pHi; loops = (int)nLoops;
             if (!done) {
                 // tail: bounds in adjacent cells with known counts (below the target at and above X, not below it

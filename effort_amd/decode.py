@@ -21,7 +21,7 @@ from dataclasses import dataclass
 import torch
 
 from . import _lib
-from .bucket_mul import basicMul, bucketMul, bucketMulGroup
+from .bucket_mul import basicMul, bucketMul, bucketMulChain, bucketMulGroup
 from .runtime import gpu as _gpu
 from .weights import ExpertWeights
 
@@ -155,8 +155,12 @@ def _p(t):
 class Decoder:
     """State of one sequence (the globals of main.swift:78-140: h, xq, KV caches, scores ...) + the token step."""
 
-    def __init__(self, model: Model, maxTokens: int = 256, fused_attention: bool = True, fused_glue=True):
+    def __init__(self, model: Model, maxTokens: int = 256, fused_attention: bool = True, fused_glue=True, chain: bool = True):
         cfg = self.cfg = model.cfg
+        # chain: a layer's dependent multiplies -- wo -> w1|w3 -> w2 -> wq|wk|wv of the NEXT layer, glue folded in -- go out as ONE
+        # launch whose resident workgroups take the stages in order (effort_bucketmul_chain): two launches per layer (attention,
+        # chain) instead of five.  Needs all the glue folded (fused_glue=True) and a dense FFN.
+        self.chain = bool(chain)
         self.fused_attention = bool(fused_attention)      # rope + cache + attention in one launch per layer (else two)
         # rmsNorm, silu and the residual adds folded into the multiplies (effort_bucketmul_group_fused): 5 launches per layer
         # instead of 8.  Dense-FFN models only; the dense baseline keeps the separate glue kernels.  On by default since round 3:
@@ -207,6 +211,28 @@ class Decoder:
 
         ck(lib.effort_fetch_row(g.ctx, _p(m.tokEmbeddings), _p(self.tokId), _p(self.h), cfg.stateDim), "fetch_row")
         delta = None
+        if self.chain and self.fuse == {"norm", "gate", "resid"} and not dense:
+            # QKV of layer 0 alone; then per layer: attention, and ONE chain launch up to the next layer's QKV
+            an = lambda L: {"norm": L.attnNorm}                                                      # noqa: E731
+            L0 = m.layers[0]
+            bucketMulGroup([(self.h, L0.wq, None, self.xq_temp, effort, an(L0)), (self.h, L0.wk, None, self.xk_temp, effort, an(L0)),
+                            (self.h, L0.wv, None, self.xv_temp, effort, an(L0))])
+            for n, L in enumerate(m.layers):
+                ck(lib.effort_rope_attention(g.ctx, _p(self.xq_temp), _p(self.xk_temp), _p(self.xv_temp), _p(self.kCache[n]), _p(self.vCache[n]),
+                                             _p(self.pos), _p(self.attnOutput), cfg.numHeads, cfg.numHeadsKV, cfg.headDim, self.maxTokens,
+                                             C.c_float(cfg.ropeBase)), "rope_attention")
+                stages = [[(self.attnOutput, L.wo, None, self.h, effort, {"resid": self.h})],                                  # :170-172
+                          [(self.h, L.w1, None, self.x1, effort, {"norm": L.ffnNorm}), (self.h, L.w3, None, self.x3, effort, {"norm": L.ffnNorm})],   # :173-179
+                          [(self.x1, L.w2, None, self.h, effort, {"gate": self.x3, "resid": self.h})]]                        # :181-183
+                if n + 1 < len(m.layers):
+                    Ln = m.layers[n + 1]                                                                                       # :121-134 of the next layer
+                    stages.append([(self.h, Ln.wq, None, self.xq_temp, effort, an(Ln)), (self.h, Ln.wk, None, self.xk_temp, effort, an(Ln)),
+                                   (self.h, Ln.wv, None, self.xv_temp, effort, an(Ln))])
+                bucketMulChain(stages)
+            ck(lib.effort_add_rmsnorm_mul(g.ctx, _p(self.h), None, _p(m.norm), _p(self.outNormed), cfg.stateDim), "rmsnorm")
+            basicMul(self.outNormed, m.output, self.logits)                                           # :222
+            ck(lib.effort_argmax(g.ctx, _p(self.logits), cfg.vocab, _p(self.tokId), _p(self.pos), _p(self.history), int(self.history.numel())), "argmax")
+            return
         if self.fused_glue and not dense:
             fn, fg, fr = "norm" in self.fuse, "gate" in self.fuse, "resid" in self.fuse
             for n, L in enumerate(m.layers):

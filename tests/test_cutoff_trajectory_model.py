@@ -1,9 +1,9 @@
 """CPU model of the HIP cutoff's lookup-free bisection (effort_amd/csrc/cutoff_device.h, "THE BISECTION WITHOUT ITS
-LOOKUPS") against the oracle's findCutoff32.  The device code steers the reference's loop with `cell >= P*` instead of a
-count per round and checks the count-driven exits afterwards, one lane per round; this restates that control flow in
-numpy f32 arithmetic -- including the 64-round chunks, the hand-over to the closed-form tail and the ballot rounds for
-value ranges wider than the table -- and compares the float BITS with the C oracle over seeded inputs that leave the loop
-through every exit.  (The device code itself is compared with the oracle by the -m gpu tests: test_cutoff_*.)"""
+LOOKUPS") against the oracle's findCutoff32.  The device code replaces every use of a count inside the reference's loop --
+the steering comparison and the two count-driven exit tests -- with comparisons of the threshold's bf16 CELL against five
+order statistics of the values; this restates that control flow in numpy f32 arithmetic -- including the hand-over to the
+closed-form tail and the ballot rounds for value ranges wider than the table -- asserts every shortcut against the count
+it stands for, and compares the float BITS with the C oracle over seeded inputs that leave the loop through every exit.  (The device code itself is compared with the oracle by the -m gpu tests: test_cutoff_*.)"""
 import numpy as np
 import pytest
 
@@ -83,37 +83,43 @@ def model_cutoff(v, probes_u16, q):
             return above
         return int((vp > p).sum())
     tbl = [count_above(base + c) if base + c <= tp else above for c in range(CAP)]
-    nge = sum(1 for c in tbl if c >= effort)                                         # (monotone: a prefix)
-    assert all(tbl[c] >= effort for c in range(nge)) and all(tbl[c] < effort for c in range(nge, CAP))
-    pStar = 0 if allGE < effort else base + nge
-    while True:
-        recs = []
-        for r in range(64):                                                          # lane r keeps the state after round r
-            p = _pat(nb)
-            below = p >= pStar
-            assert below == (count_above(p) < effort)
-            loops += 1
-            if below:
-                hi, pHi = nb, p
-            else:
-                lo, pLo = nb, p
-            prev = nb
-            nb = F((hi + lo) / F(2))
-            finTraj = bool(F(hi - lo) < F(0.00001)) or loops > 100 or bool(nb == prev)
-            adj = pHi == pLo + 1
-            recs.append((p, nb, lo, hi, pLo, pHi, loops, finTraj, adj))
-            if finTraj or adj:
-                break
-        for (p, nb_r, lo_r, hi_r, pLo_r, pHi_r, loops_r, finTraj, adj) in recs:
-            cnt = count_above(p)
-            mx = count_above(pHi_r) if pHi_r != NO_HI else maxC
-            mn = count_above(pLo_r) if pLo_r != NO_LO else minC
-            fin = cnt == effort or abs(mx - mn) < 3 or finTraj
-            if fin or adj:
-                if fin:
-                    return nb_r
-                return _cell_edge_tail(nb_r, lo_r, hi_r, frompat(pHi_r), loops_r)
-        # 64 rounds without an exit: go on from round 63's state (the loop variables already hold it)
+    assert all(tbl[c] >= tbl[c + 1] for c in range(CAP - 1))
+
+    def first_cell_below(k):                                                         # T(k): count(p) >= k  <=>  p < T(k)
+        if k <= 0:
+            return 0xFFFFFFFF
+        if k > 4096 or allGE < k:
+            return 0
+        n = sum(1 for c in tbl if c >= k)
+        return 0xFFFFFFFF if n == CAP else base + n
+    m = effort
+    tM2, tM1, tM, tP1, tP2 = (first_cell_below(m + d) for d in (-2, -1, 0, 1, 2))
+    hiGeM1 = pHi < tM1 if pHi != NO_HI else maxC >= max(m - 1, 0)
+    hiGeM2 = pHi < tM2 if pHi != NO_HI else maxC >= max(m - 2, 0)
+    loGeP1 = pLo < tP1 if pLo != NO_LO else minC >= m + 1
+    loGeP2 = pLo < tP2 if pLo != NO_LO else minC >= m + 2
+    fin = False
+    while not fin and pHi != pLo + 1:
+        p = _pat(nb)
+        cnt = count_above(p)                                                         # (the model checks every shortcut against the count)
+        below = p >= tM
+        assert below == (cnt < m)
+        loops += 1
+        if below:
+            hi, pHi, hiGeM1, hiGeM2 = nb, p, p < tM1, p < tM2
+        else:
+            lo, pLo, loGeP1, loGeP2 = nb, p, p < tP1, p < tP2
+        prev = nb
+        nb = F((hi + lo) / F(2))
+        cntEq = tP1 <= p < tM
+        dLt3 = (hiGeM1 and not loGeP2) or (hiGeM2 and not loGeP1)
+        mx = count_above(pHi) if pHi != NO_HI else maxC
+        mn = count_above(pLo) if pLo != NO_LO else minC
+        assert cntEq == (cnt == m) and dLt3 == (abs(mx - mn) < 3), (cntEq, cnt, m, dLt3, mx, mn)
+        fin = cntEq or bool(F(hi - lo) < F(0.00001)) or dLt3 or loops > 100 or bool(nb == prev)
+    if fin:
+        return nb
+    return _cell_edge_tail(nb, lo, hi, frompat(pHi), loops)
 
 
 def _inputs(seed, kind):

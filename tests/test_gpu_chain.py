@@ -1,0 +1,152 @@
+"""GPU tests of the CHAIN launch (effort_bucketmul_chain): a decoder layer's dependent multiplies -- wo -> w1|w3 -> w2 ->
+wq|wk|wv of the next layer, rmsNorm / silu / residual folded in (runNetwork.swift:121-183) -- as ONE launch of resident
+workgroups taking the stages in order.  Against the same multiplies as launches of their own (bit for bit: same geometry,
+same arithmetic) and against the CPU oracle fed the GPU's own input vectors, call by call; through the C ABI."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from tests.test_gpu_parity import DEV, close, ea  # noqa: F401  (ea: module fixture)
+
+pytestmark = pytest.mark.gpu
+
+
+def _host(ew):
+    return (ew.buckets[0].contiguous().cpu().numpy().view(np.uint16), ew.stats[0].cpu().numpy().view(np.uint16),
+            ew.probes[0].cpu().numpy().view(np.uint16))
+
+
+@pytest.fixture(scope="module")
+def layers(ea):
+    from effort_amd.decode import MistralConfig, Model
+    cfg = MistralConfig(numLayers=2)                                          # Mistral-7B shapes: 4096 / 14336 / 1024
+    return Model.random(cfg, seed=11, keep_cores=False).layers
+
+
+def _buffers(seed):
+    gen = torch.Generator(device=DEV)
+    gen.manual_seed(seed)
+    f = lambda n, s=1.0: torch.randn(n, generator=gen, device=DEV) * s         # noqa: E731
+    return {"attn": f(4096), "h": f(4096), "x1": f(14336), "x3": f(14336), "xq": f(4096), "xk": f(1024), "xv": f(1024)}
+
+
+def _stages(L, Ln, B, e):
+    return [[(B["attn"], L.wo, None, B["h"], e, {"resid": B["h"]})],
+            [(B["h"], L.w1, None, B["x1"], e, {"norm": L.ffnNorm}), (B["h"], L.w3, None, B["x3"], e, {"norm": L.ffnNorm})],
+            [(B["x1"], L.w2, None, B["h"], e, {"gate": B["x3"], "resid": B["h"]})],
+            [(B["h"], Ln.wq, None, B["xq"], e, {"norm": Ln.attnNorm}), (B["h"], Ln.wk, None, B["xk"], e, {"norm": Ln.attnNorm}),
+             (B["h"], Ln.wv, None, B["xv"], e, {"norm": Ln.attnNorm})]]
+
+
+@pytest.mark.parametrize("effort", [0.25, 0.6])
+def test_chain_equals_separate_launches_and_oracle(ea, oracle_cpu, layers, effort):
+    L, Ln = layers
+    g = ea.gpu()
+    lib = ea.lib()
+    P = lambda t: C.c_void_p(t.data_ptr())                                      # noqa: E731
+    # --- the four launches of their own, keeping every intermediate
+    S = _buffers(3)
+    h0 = S["h"].clone()
+    snap, counts = {}, []
+    for k, st in enumerate(_stages(L, Ln, S, effort)):
+        ea.bucketMulGroup(st)
+        g.eval()
+        counts += [(g.last_dispatch_count(i), g.last_cutoff(i)) for i in range(len(st))]
+        snap[k] = {n: t.clone() for n, t in S.items()}
+    # --- the chain
+    Cb = _buffers(3)
+    ea.bucketMulChain(_stages(L, Ln, Cb, effort))
+    g.eval()
+    assert [(g.last_dispatch_count(i), g.last_cutoff(i)) for i in range(7)] == counts          # same rows, call by call
+    for n in Cb:
+        assert torch.equal(Cb[n], S[n]), n                                                        # same bits
+    # --- every call against the oracle on the GPU's own input
+    def oracle(ew, vin, want_out, resid=None):
+        want, n, cutoff = oracle_cpu.bucket_mul(vin.cpu().numpy(), *_host(ew), ew.inSize, ew.outSize, effort)
+        if resid is not None:
+            want = want + resid.cpu().numpy()
+        assert close(want_out.cpu().numpy(), want)
+        return n, cutoff
+    g._bind_stream()
+    got = [oracle(L.wo, S["attn"], snap[0]["h"], h0)]
+    hn = torch.zeros(4096, device=DEV)
+    g.check(lib.effort_add_rmsnorm_mul(g.ctx, P(snap[0]["h"].clone()), None, P(L.ffnNorm), P(hn), 4096), "rmsnorm")
+    got += [oracle(L.w1, hn, snap[1]["x1"]), oracle(L.w3, hn, snap[1]["x3"])]
+    x2 = torch.zeros(14336, device=DEV)
+    g.check(lib.effort_silu_mul(g.ctx, P(snap[1]["x1"]), P(snap[1]["x3"]), P(x2), 14336), "silu")
+    got += [oracle(L.w2, x2, snap[2]["h"], snap[1]["h"])]
+    g.check(lib.effort_add_rmsnorm_mul(g.ctx, P(snap[2]["h"].clone()), None, P(Ln.attnNorm), P(hn), 4096), "rmsnorm")
+    got += [oracle(Ln.wq, hn, snap[3]["xq"]), oracle(Ln.wk, hn, snap[3]["xk"]), oracle(Ln.wv, hn, snap[3]["xv"])]
+    assert got == counts                                                                          # dispatch.size and cutoff bits
+
+
+def test_chain_replays_are_race_free(ea, layers):
+    """The chain from a hipGraph, many replays back to back with the layers swapping roles (the buffers are rewritten every
+    replay, so a stale line in an L1 or an L2 of another XCD, or an item that ran ahead of its stage, shows up as a wrong
+    bit): every replay's outputs equal the first's."""
+    L, Ln = layers
+    g = ea.gpu()
+    B = _buffers(9)
+    init = {n: t.clone() for n, t in B.items()}
+
+    def step():
+        for n in B:
+            B[n].copy_(init[n])
+        ea.bucketMulChain(_stages(L, Ln, B, 0.25))
+        ea.bucketMulChain(_stages(Ln, L, B, 0.25))            # a second chain consuming the first one's h
+    step()
+    g.eval()
+    want = {n: t.clone() for n, t in B.items()}
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr, capture_error_mode="thread_local"):
+        step()
+    g._bind_stream()
+    for rep in range(60):
+        gr.replay()
+        if rep % 6 == 5:
+            g.eval()
+            for n in B:
+                assert torch.equal(B[n], want[n]), (rep, n)
+    # with launches in flight on other lanes beside it (uneven load)
+    g.set_overlap(4)
+    try:
+        junk = [torch.zeros(14336, device=DEV) for _ in range(8)]
+        for rep in range(10):
+            for j in junk:
+                ea.bucketMul(init["attn"], L.w1, None, j, 0.5)
+            step()
+            g.eval()
+            for n in B:
+                assert torch.equal(B[n], want[n]), (rep, n)
+    finally:
+        g.set_overlap(1)
+
+
+def test_decoder_chain_is_bit_identical(ea):
+    from effort_amd.decode import Decoder, MistralConfig, Model
+    cfg = MistralConfig(stateDim=4096, hiddenDim=4096, numLayers=3, numHeads=32, numHeadsKV=8, headDim=128, vocab=512)
+    model = Model.random(cfg, seed=5)
+    prompt, steps = [3, 77, 130, 9], 8
+    a = Decoder(model, maxTokens=16, chain=False)
+    b = Decoder(model, maxTokens=16, chain=True)
+    assert b.chain and not a.chain
+    for effort in (0.25, 1.0):
+        ids_a, _, lg_a = a.run(prompt, steps, effort=effort, collect_logits=True)
+        ids_b, _, lg_b = b.run(prompt, steps, effort=effort, collect_logits=True)
+        assert ids_a == ids_b and torch.equal(lg_a, lg_b), effort
+
+
+def test_chain_argument_checks(ea, layers):
+    L, Ln = layers
+    B = _buffers(1)
+    st = _stages(L, Ln, B, 0.25)
+    with pytest.raises(ea.EffortError):                       # w2 reads x1 / x3 in the stage that writes them
+        ea.bucketMulChain([st[0], st[1] + st[2]])
+    with pytest.raises(ea.EffortError):                       # two calls of one stage writing the same vector
+        ea.bucketMulChain([[(B["attn"], L.wo, None, B["h"], 0.25), (B["attn"], Ln.wo, None, B["h"], 0.25)]])
+    with pytest.raises(ValueError):
+        ea.bucketMulChain([])
+    ea.bucketMulChain([st[0]])                                # a chain of one stage is a group launch
+    ea.gpu().eval()

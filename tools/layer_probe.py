@@ -45,6 +45,13 @@ def main():
             ea.bucketMulGroup([(h, Lnext.wq, None, xq, e, {"norm": Lnext.attnNorm}), (h, Lnext.wk, None, xk, e, {"norm": Lnext.attnNorm}),
                                (h, Lnext.wv, None, xv, e, {"norm": Lnext.attnNorm})])
 
+    def chain(L, Lnext):              # the four dependent launches as ONE chain launch (effort_bucketmul_chain)
+        ea.bucketMulChain([[(attn, L.wo, None, h, e, {"resid": h})],
+                           [(h, L.w1, None, x1, e, {"norm": L.ffnNorm}), (h, L.w3, None, x3, e, {"norm": L.ffnNorm})],
+                           [(x1, L.w2, None, h, e, {"gate": x3, "resid": h})],
+                           [(h, Lnext.wq, None, xq, e, {"norm": Lnext.attnNorm}), (h, Lnext.wk, None, xk, e, {"norm": Lnext.attnNorm}),
+                            (h, Lnext.wv, None, xv, e, {"norm": Lnext.attnNorm})]])
+
     def seven(L, Lnext):              # the same seven multiplies as one launch of independent calls (plain inputs: no glue)
         ea.bucketMulGroup([(attn, L.wo, None, h, e), (h0, L.w1, None, x1, e), (h0, L.w3, None, x3, e), (x1, L.w2, None, attn, e),
                            (h0, Lnext.wq, None, xq, e), (h0, Lnext.wk, None, xk, e), (h0, Lnext.wv, None, xv, e)])
@@ -72,6 +79,7 @@ def main():
     res = {"effort": e}
     for name, which in (("wo", ("wo",)), ("w13", ("w13",)), ("w2", ("w2",)), ("qkv", ("qkv",)), ("four_dependent_launches", ("wo", "w13", "w2", "qkv"))):
         res[name + "_us"] = round(timed(lambda L, Ln, w=which: launches(L, Ln, w)), 2)
+    res["chain_one_launch_us"] = round(timed(chain), 2)
     res["seven_independent_calls_one_launch_us"] = round(timed(seven), 2)
     res["sum_of_lone_us"] = round(res["wo_us"] + res["w13_us"] + res["w2_us"] + res["qkv_us"], 2)
     print(json.dumps(res))
