@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("EFFORT_HIP_LIB") or os.path.join(_HERE, "libeffort_hi
 
 ERRORS = {
     -1: "EFFORT_ERR_ARG", -2: "EFFORT_ERR_SHAPE", -3: "EFFORT_ERR_EFFORT", -4: "EFFORT_ERR_HIP",
-    -5: "EFFORT_ERR_KIND", -6: "EFFORT_ERR_CONVERT", -7: "EFFORT_ERR_BLAS",
+    -5: "EFFORT_ERR_KIND", -6: "EFFORT_ERR_CONVERT", -7: "EFFORT_ERR_BLAS", -8: "EFFORT_ERR_COMM",
 }
 
 
@@ -52,6 +52,13 @@ _SIGS = {
     "effort_weights_row_pitch": (C.c_int, [_P]),
     "effort_weights_get_bound": (C.c_int, [_P, C.POINTER(C.c_float)]),
     "effort_weights_set_bound": (C.c_int, [_P, C.POINTER(C.c_float)]),
+    "effort_weights_column_shard": (_P, [_P, C.c_int, C.c_int]),
+    "effort_comm_unique_id": (C.c_int, [_P]),
+    "effort_comm_create": (C.c_int, [_P, C.c_int, C.c_int, _P]),
+    "effort_comm_destroy": (C.c_int, [_P]),
+    "effort_comm_rank": (C.c_int, [_P]),
+    "effort_comm_world": (C.c_int, [_P]),
+    "effort_allgather_outputs": (C.c_int, [_P, _P, _P, C.c_int]),
     "effort_bucketmul": (C.c_int, [_P, _P, _P, _P, _P, C.c_double]),
     "effort_bucketmul_q4": (C.c_int, [_P, _P, _P, _P, _P, C.c_double]),
     "effort_bucketmul_group": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P]),

@@ -1,6 +1,7 @@
 // C ABI of libeffort_hip.so (include/effort_hip.h): contexts, weight handles, launch orchestration.
 // Host-side equivalent of class BucketMul / BucketMulQ4 (bucketMul.swift:18-90, bucketMulQ4.swift:18-87)
 // and of the slice of class Gpu they use (helpers/gpu.swift:109-196).
+#include <rccl/rccl.h>
 #include <rocblas/rocblas.h>
 
 #include <cstdio>
@@ -60,6 +61,8 @@ struct effort_ctx {
     unsigned long long* d_tstamp = nullptr;   // device-clock stamps of the multiply kernel (timing mode)
     double wallClockKHz = 100000.0;
     rocblas_handle blas = nullptr;
+    ncclComm_t comm = nullptr;        // effort_comm_create: this rank's RCCL communicator (one process per GPU)
+    int commRank = 0, commWorld = 1;
     bool denseRocblas = false;        // effort_set_dense_backend: basicMul through rocBLAS instead of dense_gemv_kernel
     // tuning overrides (0 = heuristic)
     int tuneW = 0, tuneE = 0, tuneS = 0;
@@ -85,11 +88,13 @@ struct effort_w {
     const void* stats = nullptr;
     const uint16_t* probes = nullptr;
     uint32_t inDim = 0, outDim = 0, rowsPerIn = 0, numExperts = 1, cols = 0;
+    bool view = false;                // a column shard (effort_weights_column_shard): buckets and the outlier index point INTO the full handle's
     float* rankBound = nullptr;       // [numExperts] fixed-point bound of the multiply (see launch_rank_bound)
     uint16_t* means16 = nullptr;      // FP16: the row means alone (stats lane .w), one u16 per bucket row (launch_compact_means)
     // Q4 outliers
     uint64_t nOutliers = 0;
     uint32_t* olRowPtr = nullptr;     // by-output bounds (registration), then the per-64-output bounds the multiply reads
+    const uint32_t* olBound64 = nullptr;   // ... those: f32 bits per 64 outputs (olRowPtr + outDim + 1; a column shard's slice of the full handle's)
     uint32_t* olBlockPtr = nullptr;
     uint32_t* olEntry = nullptr;      // 4 bytes per outlier
 };
@@ -233,6 +238,7 @@ extern "C" void effort_destroy(effort_ctx* c) {
     hipSetDevice(c->device);
     for (int i = 0; i < effort_ctx::kMaxLanes; i++) if (c->lane[i].own) hipStreamSynchronize(c->lane[i].own);
     hipStreamSynchronize(c->stream);
+    if (c->comm) ncclCommDestroy(c->comm);
     if (c->blas) rocblas_destroy_handle(c->blas);
     if (c->ev) { for (int i = 0; i < effort_ctx::kMaxSamples * 4; i++) hipEventDestroy(c->ev[i]); delete[] c->ev; }
     for (int i = 0; i < effort_ctx::kMaxLanes; i++) lane_free(c->device, c->lane[i]);
@@ -351,6 +357,7 @@ extern "C" effort_w* effort_weights_q4(effort_ctx* c, const void* buckets, const
         uint32_t longest = 0;
         if (ok) ok = hipMemcpy(&longest, w->olRowPtr + (size_t)outDim + 1 + (outDim + 63) / 64, 4, hipMemcpyDeviceToHost) == hipSuccess;
         if (!ok) { fail(c, EFFORT_ERR_HIP, "effort_weights_q4: outlier index"); effort_weights_free(w); return nullptr; }
+        w->olBound64 = w->olRowPtr + (size_t)outDim + 1;
         if (longest >= (1u << 19)) { fail(c, EFFORT_ERR_SHAPE, "effort_weights_q4: more than 2^19 outliers on one output"); effort_weights_free(w); return nullptr; }
     }
     return w;
@@ -410,8 +417,76 @@ extern "C" int effort_weights_set_bound(effort_w* w, const float* host_in) {
 
 extern "C" void effort_weights_free(effort_w* w) {
     if (!w) return;
-    hipFree(w->olRowPtr); hipFree(w->olBlockPtr); hipFree(w->olEntry); hipFree(w->rankBound); hipFree(w->aligned); hipFree(w->means16);
+    if (!w->view) { hipFree(w->olRowPtr); hipFree(w->olBlockPtr); hipFree(w->olEntry); hipFree(w->aligned); }
+    hipFree(w->rankBound); hipFree(w->means16);
     delete w;
+}
+
+// ---- multi-GPU: one process per GPU, RCCL over xGMI (the reference is single-device, helpers/gpu.swift:36-38) --------------
+// Column shard of a registered bundle for rank `rank` of `world`: bucket columns [rank*C/world, (rank+1)*C/world) of every bucket
+// row -- outputs [rank*outDim/world, ...) -- as a VIEW of the full handle's buffers (rows stay rowPitch bytes apart: no copy),
+// stats and probes shared (they are row-global, convert.metal:105-119: every rank computes the same cutoff and selects the same
+// rows), the full matrix's fixed-point bound (every rank rounds on the same grid), and for Q4 the slice of the outlier index that
+// falls on these outputs (the index is grouped by blocks of outputs: a view too).
+extern "C" effort_w* effort_weights_column_shard(const effort_w* full, int rank, int world) {
+    if (!full || !full->ctx) return nullptr;
+    effort_ctx* c = full->ctx;
+    const uint32_t unit = full->fmt == kFp16 ? 16u : 32u;
+    if (world < 1 || rank < 0 || rank >= world || full->cols % (uint32_t)world || (full->cols / (uint32_t)world) % 2u) {
+        fail(c, EFFORT_ERR_SHAPE, "effort_weights_column_shard: the bucket columns must split evenly into an even number per rank"); return nullptr; }
+    const uint32_t per = full->cols / (uint32_t)world, outDim = per * unit;
+    if (check_shape(full->inDim, outDim) != EFFORT_OK) { fail(c, EFFORT_ERR_SHAPE, "effort_weights_column_shard: shard shape"); return nullptr; }
+    if (full->nOutliers && (outDim % (1u << (16u - ol_bits_in(full->inDim))) || outDim % 64u)) {
+        fail(c, EFFORT_ERR_SHAPE, "effort_weights_column_shard: the shard must hold whole blocks of the outlier index"); return nullptr; }
+    effort_w* w = new (std::nothrow) effort_w();
+    if (!w) return nullptr;
+    *w = *full;
+    w->view = true; w->aligned = nullptr; w->rankBound = nullptr; w->means16 = nullptr;
+    w->buckets = full->buckets + (size_t)rank * per;            // what the multiply reads (the full handle's own line-aligned copy, if it made one)
+    w->bucketsSrc = w->buckets; w->srcPitch = full->rowPitch;
+    w->cols = per; w->outDim = outDim;
+    if (register_bound(c, w) != EFFORT_OK) { effort_weights_free(w); return nullptr; }
+    if (hipMemcpy(w->rankBound, full->rankBound, (size_t)w->numExperts * 4, hipMemcpyDeviceToDevice) != hipSuccess) {
+        fail(c, EFFORT_ERR_HIP, "effort_weights_column_shard: bound"); effort_weights_free(w); return nullptr; }
+    if (full->nOutliers) {
+        const uint32_t bs = 1u << (16u - ol_bits_in(full->inDim));
+        w->olBlockPtr = full->olBlockPtr + (size_t)rank * outDim / bs;                        // block bounds index the SHARED entry array
+        w->olBound64 = full->olBound64 + (size_t)rank * outDim / 64u;
+    }
+    return w;
+}
+extern "C" int effort_comm_unique_id(void* id_out) {
+    if (!id_out) return EFFORT_ERR_ARG;
+    static_assert(sizeof(ncclUniqueId) == EFFORT_COMM_ID_BYTES, "effort_hip.h: EFFORT_COMM_ID_BYTES");
+    return ncclGetUniqueId(static_cast<ncclUniqueId*>(id_out)) == ncclSuccess ? EFFORT_OK : EFFORT_ERR_COMM;
+}
+extern "C" int effort_comm_create(effort_ctx* c, int rank, int world, const void* id) {
+    if (!c || !id || world < 1 || rank < 0 || rank >= world) return fail(c, EFFORT_ERR_ARG, "comm_create: bad argument");
+    if (c->comm) return fail(c, EFFORT_ERR_ARG, "comm_create: the context has a communicator already");
+    hipSetDevice(c->device);
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof(uid));
+    const ncclResult_t r = ncclCommInitRank(&c->comm, world, uid, rank);
+    if (r != ncclSuccess) { c->comm = nullptr; snprintf(c->err, sizeof(c->err), "ncclCommInitRank: %s", ncclGetErrorString(r)); return EFFORT_ERR_COMM; }
+    c->commRank = rank; c->commWorld = world;
+    return EFFORT_OK;
+}
+extern "C" int effort_comm_destroy(effort_ctx* c) {
+    if (!c) return EFFORT_ERR_ARG;
+    if (c->comm) { hipSetDevice(c->device); effort_sync(c); ncclCommDestroy(c->comm); c->comm = nullptr; c->commRank = 0; c->commWorld = 1; }
+    return EFFORT_OK;
+}
+extern "C" int effort_comm_rank(effort_ctx* c) { return c ? c->commRank : EFFORT_ERR_ARG; }
+extern "C" int effort_comm_world(effort_ctx* c) { return c ? c->commWorld : EFFORT_ERR_ARG; }
+// All-gather of the ranks' output slices on the context's stream, after the multiplies that wrote them (the lanes are joined):
+// recv = [world][count] f32.  send may be recv + rank*count (in place).
+extern "C" int effort_allgather_outputs(effort_ctx* c, const float* send, float* recv, int count) {
+    if (!c || !send || !recv || count < 1) return fail(c, EFFORT_ERR_ARG, "allgather_outputs: bad argument");
+    if (!c->comm) return fail(c, EFFORT_ERR_ARG, "allgather_outputs: no communicator (effort_comm_create)");
+    if (join_lanes(c) != EFFORT_OK) return EFFORT_ERR_HIP;
+    const ncclResult_t r = ncclAllGather(send, recv, (size_t)count, ncclFloat, c->comm, c->stream);
+    if (r != ncclSuccess) { snprintf(c->err, sizeof(c->err), "ncclAllGather: %s", ncclGetErrorString(r)); return EFFORT_ERR_COMM; }
+    return EFFORT_OK;
 }
 
 // ---- launch geometry ----------------------------------------------------------------------------
@@ -750,7 +825,7 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
             return fail(c, EFFORT_ERR_SHAPE, "bucketmul: group exceeds the context scratch");
         a.buckets = w->buckets; a.stats = w->stats; a.rankBound = w->rankBound; a.probes = w->probes; a.v = vs[i];
         a.expNo = expNos ? expNos[i] : nullptr; a.out = outs[i];
-        a.ol = OutlierIndex{fmt == kQ4 ? w->olBlockPtr : nullptr, w->olEntry, w->olRowPtr ? w->olRowPtr + w->outDim + 1 : nullptr};
+        a.ol = OutlierIndex{fmt == kQ4 ? w->olBlockPtr : nullptr, w->olEntry, w->olBound64};
         a.q = (uint32_t)(int)((double)(kProbes - 1) * (1.0 - efforts[i]));            // bucketMul.swift:39
         const int pre = prologues ? prologues[i] : 0;
         a.pre = (uint16_t)(pre | (curStage << 8)); a.vAux = pre ? vAux[i] : nullptr; a.resid = resids ? resids[i] : nullptr;

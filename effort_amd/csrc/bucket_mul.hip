@@ -904,8 +904,8 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
         if (GA_TRACE(ga) && item + GA_CUTJOBS(ga) < (uint32_t)kTraceItems) {           // one record per item: who / where / when
             unsigned long long* rec = GA_TSTAMP(ga) + kTraceOff + (size_t)(item + GA_CUTJOBS(ga)) * 8u;
             rec[0] = (unsigned long long)(item + GA_CUTJOBS(ga)) | ((unsigned long long)blockIdx.x << 32);
-            rec[1] = (unsigned long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xFu) | ((unsigned long long)(n & 0xFFFFu) << 8) | ((unsigned long long)(t & 0xFFu) << 24) |
-                     ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 32);   // XCC_ID | kept rows | tile | HW_ID
+            rec[1] = (unsigned long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xFu) | ((unsigned long long)(ci & 0xFu) << 4) | ((unsigned long long)(n & 0xFFFFu) << 8) | ((unsigned long long)(t & 0xFFu) << 24) |
+                     ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 32);   // XCC_ID | call (mod 16) | kept rows | tile | HW_ID
 #pragma unroll
             for (int i = 0; i < 6; i++) rec[2 + i] = ph[i];
         }

@@ -201,48 +201,54 @@ __device__ __forceinline__ float block_find_cutoff(const float (&vj)[4096 / NT],
             // then run with no LDS round trip inside -- it was ~330 cycles a round with the lookup on the dependent chain, 1.4 us
             // for 9 rounds and 2.7 for 29 -- as a chain of ~25 VALU instructions.  Same float operations in the same order, the
             // same exits in the same round: bit-identical (tests/test_cutoff_trajectory_model.py restates this on the CPU).
-            constexpr uint32_t kSeg = CAP / 64u;                                 // cells per lane of the first probe
+            // T(k) for the five k at once: ONE probe of the segment ends serves all five first levels, the five second-level
+            // probes are issued together, and the special cases are selects on the results -- no branch, two LDS latencies in all.
+            constexpr uint32_t kSeg = CAP / 64u, kSub = (kSeg + 63u) / 64u;     // cells per lane of the first probe; second-level probes per lane
             const uint32_t c1 = tbl[(uint32_t)lane * kSeg + kSeg - 1u];         // the last cell of each segment (cells past `top` hold `above`)
-            auto first_cell_below = [&](int k) -> uint32_t {                   // T(k)
-                if (k <= 0) return 0xFFFFFFFFu;                                 // every count is >= k
-                if (k > 4096 || allGE < (uint32_t)k) return 0u;                 // none is (cells below `base` count allGE, the largest count there is)
-                const uint32_t seg = (uint32_t)__popcll(__ballot(c1 >= (uint32_t)k));
-                if (seg >= 64u) return 0xFFFFFFFFu;                             // the whole table, hence every cell beyond it too (`above` >= k)
-                uint32_t n = seg * kSeg;
-#pragma unroll
-                for (uint32_t u = 0; u < (kSeg + 63u) / 64u; u++) {
-                    const uint32_t i = u * 64u + (uint32_t)lane;
-                    const uint32_t c2 = tbl[seg * kSeg + min(i, kSeg - 1u)];
-                    n += (uint32_t)__popcll(__ballot(i < kSeg && c2 >= (uint32_t)k));
-                }
-                return base + n;
-            };
             const int m = (int)effort;
-            uint32_t tM2 = first_cell_below(m - 2), tM1 = first_cell_below(m - 1), tM = first_cell_below(m), tP1 = first_cell_below(m + 1), tP2 = first_cell_below(m + 2);
+            uint32_t seg[5], c2[5][kSub], tk[5];
+#pragma unroll
+            for (int j = 0; j < 5; j++) {
+                const int k = m - 2 + j;
+                seg[j] = (uint32_t)__popcll(__ballot((int)c1 >= k));            // (counts <= 4096: the signed compare also serves k <= 0)
+#pragma unroll
+                for (uint32_t u = 0; u < kSub; u++) c2[j][u] = tbl[min(seg[j], 63u) * kSeg + min(u * 64u + (uint32_t)lane, kSeg - 1u)];
+            }
+#pragma unroll
+            for (int j = 0; j < 5; j++) {
+                const int k = m - 2 + j;
+                uint32_t n = seg[j] * kSeg;
+#pragma unroll
+                for (uint32_t u = 0; u < kSub; u++) n += (uint32_t)__popcll(__ballot(u * 64u + (uint32_t)lane < kSeg && (int)c2[j][u] >= k));
+                // every count is >= k (k <= 0, or the whole table and -- its last cell holds `above` -- everything beyond it): +inf;
+                // none is (k > 4096, or more than the values at or above the table's first cell): 0
+                tk[j] = (k <= 0 || seg[j] >= 64u) ? 0xFFFFFFFFu : ((k > 4096 || (int)allGE < k) ? 0u : base + n);
+            }
+            uint32_t tM2 = tk[0], tM1 = tk[1], tM = tk[2], tP1 = tk[3], tP2 = tk[4];
             float nb = newBound, lo = minBound, hi = maxBound;
             uint32_t pLo = patLo, pHi = patHi, nLoops = (uint32_t)loops;
-            // counts at the bounds, as the two comparisons each the third test needs; never-set bounds take the reference's initial counts
-            bool hiGeM1 = patHi != kNoHi ? patHi < tM1 : (uint32_t)maxCount >= (uint32_t)max(m - 1, 0), hiGeM2 = patHi != kNoHi ? patHi < tM2 : (uint32_t)maxCount >= (uint32_t)max(m - 2, 0);
-            bool loGeP1 = patLo != kNoLo ? patLo < tP1 : (uint32_t)minCount >= (uint32_t)(m + 1), loGeP2 = patLo != kNoLo ? patLo < tP2 : (uint32_t)minCount >= (uint32_t)(m + 2);
-            asm volatile("" : "+v"(nb), "+v"(lo), "+v"(hi), "+v"(pLo), "+v"(pHi), "+v"(nLoops), "+v"(tM2), "+v"(tM1), "+v"(tM), "+v"(tP1), "+v"(tP2));   // VGPRs: see above
+            // the third test needs count(hi) only as "how many of m-1, m-2 it reaches" and count(lo) as "how many of m+1, m+2":
+            //   |maxCount - minCount| < 3  <=>  catHi > catLo.   Bounds never set yet count 0 / 4096 (the reference's initial values).
+            uint32_t catHi = patHi != kNoHi ? (uint32_t)(patHi < tM1) + (uint32_t)(patHi < tM2) : (uint32_t)(maxCount >= m - 1) + (uint32_t)(maxCount >= m - 2);
+            uint32_t catLo = patLo != kNoLo ? (uint32_t)(patLo < tP1) + (uint32_t)(patLo < tP2) : (uint32_t)(minCount >= m + 1) + (uint32_t)(minCount >= m + 2);
+            asm volatile("" : "+v"(nb), "+v"(lo), "+v"(hi), "+v"(pLo), "+v"(pHi), "+v"(nLoops), "+v"(tM2), "+v"(tM1), "+v"(tM), "+v"(tP1), "+v"(tP2), "+v"(catHi), "+v"(catLo));   // VGPRs: see above
             bool fin = done;
-            while (!fin && pHi != pLo + 1u) {
-                const uint32_t p = __float_as_uint(nb) >> 16;
-                const bool below = p >= tM;                                        // countAbove < effort
-                nLoops += 1u;                                                      // :199-246, as `round` above
-                hi = below ? nb : hi; pHi = below ? p : pHi;                       // :214-220
-                lo = below ? lo : nb; pLo = below ? pLo : p;
-                hiGeM1 = below ? p < tM1 : hiGeM1; hiGeM2 = below ? p < tM2 : hiGeM2;
-                loGeP1 = below ? loGeP1 : p < tP1; loGeP2 = below ? loGeP2 : p < tP2;
-                const float prev = nb;
-                nb = (hi + lo) / 2;                                                // :222
-                const bool cntEq = (p >= tP1) & (p < tM);                          // countAbove == effort
-                const bool dLt3 = (hiGeM1 & !loGeP2) | (hiGeM2 & !loGeP1);         // |maxCount - minCount| < 3
-                fin = cntEq | (hi - lo < 0.00001f) | dLt3 | (nLoops > 100u) | (nb == prev);   // :227-229,236; fixed point
+            if (!fin && pHi != pLo + 1u) {
+                for (;;) {
+                    const uint32_t p = __float_as_uint(nb) >> 16;
+                    const bool below = p >= tM;                                        // countAbove < effort
+                    nLoops += 1u;                                                      // :199-246, as `round` above
+                    const uint32_t cH = (uint32_t)(p < tM1) + (uint32_t)(p < tM2), cL = (uint32_t)(p < tP1) + (uint32_t)(p < tP2);
+                    hi = below ? nb : hi; pHi = below ? p : pHi; catHi = below ? cH : catHi;     // :214-220
+                    lo = below ? lo : nb; pLo = below ? pLo : p; catLo = below ? catLo : cL;
+                    const float prev = nb;
+                    nb = (hi + lo) / 2;                                                // :222
+                    // :227-229 (countAbove == effort | the bounds | the counts), :236, and the fixed point
+                    fin = ((p >= tP1) & (p < tM)) | (hi - lo < 0.00001f) | (catHi > catLo) | (nLoops > 100u) | (nb == prev);
+                    if (__ballot(fin | (pHi == pLo + 1u)) != 0ull) break;              // (all lanes hold the same values: a scalar branch)
+                }
             }
             done = fin;
-            if (pHi != kNoHi) maxCount = (int)count_above(pHi);                    // (reported state only; the tail below does not read counts)
-            if (pLo != kNoLo) minCount = (int)count_above(pLo);
             newBound = nb; minBound = lo; maxBound = hi; patLo = pLo; patHi = pHi; loops = (int)nLoops;
             if (!done) {
                 // tail: bounds in adjacent cells with known counts (below the target at and above X, not below it

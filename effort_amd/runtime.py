@@ -23,6 +23,7 @@ class Gpu:
         with torch.cuda.device(self.device):
             stream = torch.cuda.current_stream(self.device).cuda_stream
             self.ctx = self._lib.effort_create(self.device, C.c_void_p(stream))
+        self.has_comm = False
         if not self.ctx:
             raise RuntimeError("effort_create failed: " + (self._lib.effort_last_error(None) or b"").decode())
         self._stream = stream
@@ -67,6 +68,46 @@ class Gpu:
 
     def join(self):
         self.check(self._lib.effort_join(self.ctx), "join")
+
+    # -- multi-GPU: one process per GPU, RCCL over xGMI (effort_comm_*) -----------------------------------------------------
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """Rank 0 makes the 128-byte id; the host program ships it to the other ranks (effort_comm_unique_id)."""
+        buf = (C.c_char * 128)()
+        rc = _lib.lib().effort_comm_unique_id(buf)
+        if rc != 0:
+            raise _lib.EffortError(rc, "comm_unique_id")
+        return bytes(buf)
+
+    def comm_create(self, rank: int, world: int, uid: bytes):
+        """This context's RCCL communicator (collective over the world: every rank calls it with the same id)."""
+        if len(uid) != 128:
+            raise ValueError("the communicator id is 128 bytes")
+        self._bind_stream()
+        self.check(self._lib.effort_comm_create(self.ctx, int(rank), int(world), C.c_char_p(uid)), "comm_create")
+        self.has_comm = True
+
+    def comm_destroy(self):
+        self.check(self._lib.effort_comm_destroy(self.ctx), "comm_destroy")
+        self.has_comm = False
+
+    @property
+    def comm_world(self) -> int:
+        return int(self._lib.effort_comm_world(self.ctx))
+
+    @property
+    def comm_rank(self) -> int:
+        return int(self._lib.effort_comm_rank(self.ctx))
+
+    def allgather_outputs(self, send: torch.Tensor, recv: torch.Tensor, count: int | None = None):
+        """recv f32 [world][count] = every rank's ``count`` outputs, enqueued on the context's stream after the multiplies
+        that wrote them (effort_allgather_outputs: ncclAllGather over xGMI)."""
+        n = int(send.numel() if count is None else count)
+        if not (send.is_cuda and recv.is_cuda and send.dtype == torch.float32 and recv.dtype == torch.float32 and send.is_contiguous()
+                and recv.is_contiguous() and send.numel() >= n and recv.numel() >= n * self.comm_world):
+            raise ValueError("allgather_outputs: contiguous f32 CUDA tensors, recv holding world * count elements")
+        self._bind_stream()
+        self.check(self._lib.effort_allgather_outputs(self.ctx, C.c_void_p(send.data_ptr()), C.c_void_p(recv.data_ptr()), n), "allgather_outputs")
 
     def hook_lane(self, lane: int):
         """Point last_dispatch_count / last_cutoff / slice_counts at lane ``lane``'s last launch (overlap mode; test hook)."""

@@ -9,6 +9,11 @@ result to the multiply's rounding (a shard takes the full matrix's fixed-point b
 grid its partial sums are rounded on -- may differ from the unsharded call's: |delta| <= 2e-5 max|out|).  The only exchange
 is an all-gather of outDim/G f32 per rank (KB-scale: latency-bound over xGMI, never bandwidth-bound), so
 matrices that share an input vector (Wq|Wk|Wv, W1|W3) are gathered together in ONE collective.
+
+The shards and the collective are the C ABI's (include/effort_hip.h: effort_weights_column_shard -- a view, no copy --,
+effort_comm_create, effort_allgather_outputs); this module is their host mirror.  ``init_comm`` uses torch.distributed only
+to ship the communicator id between the processes the launcher started; the CPU tests inject the multiply and gather
+through gloo.
 """
 from __future__ import annotations
 
@@ -102,10 +107,16 @@ def shardedExpertMulGroup(v: torch.Tensor, bys: Sequence[ShardedExpertWeights], 
     else:
         for b, piece in zip(bys, pieces):
             mul(v, b.local, piece, effort, expNo)
-    if world == 1:
+    g = None
+    if v.is_cuda and mul is _default_mul:
+        from .runtime import gpu as _gpu
+        g = _gpu(v.device.index)
+    if g is not None and g.has_comm and g.comm_world == world:
+        g.allgather_outputs(send, recv.view(-1), total)          # the C ABI's collective (effort_allgather_outputs: RCCL over xGMI)
+    elif world == 1:
         recv[0].copy_(send)
     else:
-        dist.all_gather_into_tensor(recv.view(-1), send, group=group)
+        dist.all_gather_into_tensor(recv.view(-1), send, group=group)     # (CPU tests: gloo, with the multiply injected)
     off = 0
     for b, out in zip(bys, outs):
         out.view(world, b.localOut).copy_(recv[:, off:off + b.localOut])
@@ -116,6 +127,18 @@ def shardedExpertMul(v: torch.Tensor, by: ShardedExpertWeights, out: torch.Tenso
                      expNo: torch.Tensor | None = None, group=None, mul: Callable = _default_mul):
     """Sharded drop-in for expertMul(v:by:out:effort:) (expertMul.swift:20-38)."""
     shardedExpertMulGroup(v, [by], [out], effort, expNo, group, mul)
+
+
+def init_comm(g=None, group=None):
+    """Give the device's context its RCCL communicator (effort_comm_create), with torch.distributed as the host program that ships
+    rank 0's 128-byte id to the other ranks.  One process per GPU; call once after dist.init_process_group."""
+    from .runtime import gpu as _gpu
+    g = g if g is not None else _gpu(torch.cuda.current_device())
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    box = [g.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0, group=group)
+    g.comm_create(rank, world, box[0])
+    return g
 
 
 _SCRATCH: dict = {}

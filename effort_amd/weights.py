@@ -141,17 +141,25 @@ class ExpertWeights:
         self._gpu.check(_lib.lib().effort_weights_set_bound(self.handle, buf), "ExpertWeights.set_rank_bound")
 
     def column_shard(self, rank: int, world: int) -> "ExpertWeights":
-        """Bucket-column (output) shard for multi-GPU: columns [rank*C/G, (rank+1)*C/G) of every bucket row,
-        stats and probes replicated (they are row-global), so every rank selects the same rows.  Any even split is
-        valid (the multiply masks a ragged last tile: 11008 outputs over 8 ranks = 86 columns each).  The shard takes
-        the full matrix's fixed-point bound, so its products are rounded on the same grid as the unsharded call's."""
-        from .sharded import shard_columns, shard_outliers
-        b = shard_columns(self.buckets, rank, world)
+        """Bucket-column (output) shard for multi-GPU (effort_weights_column_shard): columns [rank*C/G, (rank+1)*C/G) of every
+        bucket row as a VIEW of this bundle's buffers -- no copy --, stats and probes shared (they are row-global, so every rank
+        selects the same rows), the full matrix's fixed-point bound (every rank rounds on the same grid), and for Q4 the slice of
+        the outlier index on those outputs.  Any split into an even number of columns per rank is valid (the multiply masks a
+        ragged last tile: 11008 outputs over 8 ranks = 86 columns each).  Keep the full bundle alive while the shard is used."""
+        from .sharded import shard_outliers
+        lib = _lib.lib()
+        h = lib.effort_weights_column_shard(self.handle, int(rank), int(world))
+        if not h:
+            detail = lib.effort_last_error(self._gpu.ctx)
+            raise _lib.EffortError(-2, "ExpertWeights.column_shard", detail.decode() if detail else "")
         unit = 32 if self.q4 else 16
-        per = b.shape[2]
-        ol = shard_outliers(self.outliers, rank, world, self.outSize)
-        core = None if self.core is None else self.core[rank * per * unit:(rank + 1) * per * unit]
-        sh = ExpertWeights(b, self.stats, self.probes, self.inSize, per * unit, self.percentLoad, self.numExperts,
-                           outliers=ol, core=core, q4=self.q4)
-        sh.set_rank_bound(self.rank_bound())
+        per = self.buckets.shape[2] // world
+        sh = object.__new__(ExpertWeights)
+        sh.__dict__.update(self.__dict__)
+        sh.buckets = self.buckets[:, :, rank * per:(rank + 1) * per]              # (a strided view, like the handle's)
+        sh.outSize = per * unit
+        sh.outliers = shard_outliers(self.outliers, rank, world, self.outSize)
+        sh.core = None if self.core is None else self.core[rank * per * unit:(rank + 1) * per * unit]
+        sh._handle = h
+        sh._full = self                                                            # the view borrows the full bundle's buffers and index
         return sh

@@ -42,7 +42,8 @@ enum {
     EFFORT_ERR_HIP = -4,          /* a HIP runtime call failed (see effort_last_error)                 */
     EFFORT_ERR_KIND = -5,         /* FP16 weights passed to the Q4 call or vice versa                  */
     EFFORT_ERR_CONVERT = -6,      /* bucketize() preconditions (convert.swift:210-215,239)             */
-    EFFORT_ERR_BLAS = -7          /* rocBLAS failure in effort_dense_gemv                              */
+    EFFORT_ERR_BLAS = -7,         /* rocBLAS failure in effort_dense_gemv                              */
+    EFFORT_ERR_COMM = -8          /* an RCCL call failed (see effort_last_error)                       */
 };
 
 /* ---- context = class Gpu + the BucketMul / BucketMulQ4 singletons ------------------------------ */
@@ -203,6 +204,29 @@ EFFORT_API int effort_bucketmul_q4_group(effort_ctx* ctx, int n, const effort_w*
                               const uint32_t* const* expNos_dev, float* const* outs_dev, const double* efforts);
 EFFORT_API int effort_group_dispatch_count(effort_ctx* ctx, int idx, uint32_t* host_out);
 EFFORT_API int effort_group_cutoff(effort_ctx* ctx, int idx, float* host_out);
+
+/* ---- multi-GPU: one process per GPU, RCCL over xGMI ------------------------------------------------
+ * The reference is single-device (helpers/gpu.swift:36-38); this is what a host needs to spread the path over the GPUs of a
+ * node.  Two partitions: whole MATRICES on different ranks (nothing below but the communicator and the gather of the output
+ * vectors), or bucket COLUMNS of one matrix across the ranks:
+ *   effort_weights_column_shard(full, rank, world) -- rank's columns [rank*C/world, (rank+1)*C/world) of every bucket row of a
+ *     registered bundle, i.e. outputs [rank*outDim/world, ...), as a VIEW of the full handle's buffers (no copy; C/world must be
+ *     even); stats and probes are shared -- they are row-global, so every rank computes the same cutoff and selects the same rows
+ *     -- and the shard takes the full matrix's fixed-point bound.  Q4: with the slice of the outlier index on those outputs.
+ *     Multiply it like any handle; free it BEFORE the full handle.
+ *   effort_comm_unique_id: rank 0 makes the 128-byte id, the host program ships it to the other ranks by its own means;
+ *   effort_comm_create(ctx, rank, world, id): collective over the world (ncclCommInitRank); one communicator per context;
+ *   effort_allgather_outputs(ctx, send, recv, count): recv f32 [world][count] = every rank's `count` outputs, enqueued on the
+ *     context's stream after the multiplies that wrote them (send may be recv + rank*count).  Matrices sharing an input
+ *     vector put their shards' outputs side by side and gather ONCE (the messages are KB-scale: latency-bound over xGMI). */
+#define EFFORT_COMM_ID_BYTES 128
+EFFORT_API effort_w* effort_weights_column_shard(const effort_w* full, int rank, int world);
+EFFORT_API int effort_comm_unique_id(void* id_out_128_bytes);
+EFFORT_API int effort_comm_create(effort_ctx* ctx, int rank, int world, const void* id_128_bytes);
+EFFORT_API int effort_comm_destroy(effort_ctx* ctx);
+EFFORT_API int effort_comm_rank(effort_ctx* ctx);
+EFFORT_API int effort_comm_world(effort_ctx* ctx);
+EFFORT_API int effort_allgather_outputs(effort_ctx* ctx, const float* send_dev, float* recv_dev, int count);
 
 /* ---- reference-visible state / test hooks ------------------------------------------------------ */
 

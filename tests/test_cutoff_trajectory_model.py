@@ -94,10 +94,9 @@ def model_cutoff(v, probes_u16, q):
         return 0xFFFFFFFF if n == CAP else base + n
     m = effort
     tM2, tM1, tM, tP1, tP2 = (first_cell_below(m + d) for d in (-2, -1, 0, 1, 2))
-    hiGeM1 = pHi < tM1 if pHi != NO_HI else maxC >= max(m - 1, 0)
-    hiGeM2 = pHi < tM2 if pHi != NO_HI else maxC >= max(m - 2, 0)
-    loGeP1 = pLo < tP1 if pLo != NO_LO else minC >= m + 1
-    loGeP2 = pLo < tP2 if pLo != NO_LO else minC >= m + 2
+    # count(hi) as "how many of m-1, m-2 it reaches", count(lo) as "how many of m+1, m+2": |maxCount - minCount| < 3 <=> catHi > catLo
+    catHi = int(pHi < tM1) + int(pHi < tM2) if pHi != NO_HI else int(maxC >= m - 1) + int(maxC >= m - 2)
+    catLo = int(pLo < tP1) + int(pLo < tP2) if pLo != NO_LO else int(minC >= m + 1) + int(minC >= m + 2)
     fin = False
     while not fin and pHi != pLo + 1:
         p = _pat(nb)
@@ -106,13 +105,13 @@ def model_cutoff(v, probes_u16, q):
         assert below == (cnt < m)
         loops += 1
         if below:
-            hi, pHi, hiGeM1, hiGeM2 = nb, p, p < tM1, p < tM2
+            hi, pHi, catHi = nb, p, int(p < tM1) + int(p < tM2)
         else:
-            lo, pLo, loGeP1, loGeP2 = nb, p, p < tP1, p < tP2
+            lo, pLo, catLo = nb, p, int(p < tP1) + int(p < tP2)
         prev = nb
         nb = F((hi + lo) / F(2))
         cntEq = tP1 <= p < tM
-        dLt3 = (hiGeM1 and not loGeP2) or (hiGeM2 and not loGeP1)
+        dLt3 = catHi > catLo
         mx = count_above(pHi) if pHi != NO_HI else maxC
         mn = count_above(pLo) if pLo != NO_LO else minC
         assert cntEq == (cnt == m) and dLt3 == (abs(mx - mn) < 3), (cntEq, cnt, m, dLt3, mx, mn)

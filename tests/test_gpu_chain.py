@@ -150,3 +150,38 @@ def test_chain_argument_checks(ea, layers):
         ea.bucketMulChain([])
     ea.bucketMulChain([st[0]])                                # a chain of one stage is a group launch
     ea.gpu().eval()
+
+
+def test_c_abi_communicator_world_of_one(ea, oracle_cpu):
+    """The multi-GPU entry points of the C ABI as far as one GPU reaches: an RCCL communicator of one rank
+    (effort_comm_create), column shards as views of a registered bundle (effort_weights_column_shard: FP16, worlds 2 and 8),
+    their products gathered by effort_allgather_outputs -- ncclAllGather on the context's stream -- and the gathered vector
+    against the oracle's full product; selection bit-exact on every shard."""
+    from effort_amd.sharded import ShardedExpertWeights, shardedExpertMulGroup
+    from tests.test_gpu_parity import converted, devf, gpu_weights
+    from tests.util import make_v
+    inDim, outDim = 4096, 11008
+    W, b, s, p = converted(oracle_cpu, outDim, inDim)
+    ew = gpu_weights(ea, W, b, s, p)
+    g = ea.Gpu(0)
+    g.comm_create(0, 1, ea.Gpu.comm_unique_id())
+    assert g.has_comm and g.comm_world == 1 and g.comm_rank == 0
+    v = make_v(inDim, seed=31, heavy=True)
+    vd = devf(v)
+    want, n, cutoff = oracle_cpu.bucket_mul(v, b, s, p, inDim, outDim, 0.25)
+    for world in (2, 8):
+        got = torch.zeros(outDim, device=DEV)
+        send = torch.zeros(outDim, device=DEV)
+        per = outDim // world
+        shards = [ew.column_shard(r, world) for r in range(world)]
+        assert all(sh.outSize == per and sh.buckets.data_ptr() == ew.buckets.data_ptr() + r * per // 16 * 2 for r, sh in enumerate(shards))   # views
+        for r, sh in enumerate(shards):                                    # what rank r would run; here one after the other
+            ea.bucketMul(vd, sh, None, send[r * per:(r + 1) * per], 0.25, gpu=g)
+            g.eval()
+            assert g.last_dispatch_count() == n and g.last_cutoff() == cutoff
+        g.allgather_outputs(send, got)                                     # world of one: the whole vector through RCCL
+        g.eval()
+        assert close(got.cpu().numpy(), want)
+    g.comm_destroy()
+    assert not g.has_comm
+    g.close()
