@@ -28,6 +28,8 @@ struct Lane {
     float* d_cutoff = nullptr;        // BucketMul.cutoff
     uint32_t* d_count = nullptr;      // dispatch.size
     float* d_slabs = nullptr;         // partial tiles (replaces tmpMulVec)
+    float* d_slabsNamed = nullptr;    // ... of the launches that hand their tiles to a NAMED reducer (chain launches): every word holds the
+                                      // sentinel 0xFFFFFFFF between launches (bucket_mul.hip, E)
     uint32_t* d_counters = nullptr;   // per-tile arrival tickets (zero between calls)
     uint32_t* d_sliceCounts = nullptr;
     uint32_t* d_queue = nullptr;      // item queues of persistent launches
@@ -66,6 +68,7 @@ struct effort_ctx {
     bool denseRocblas = false;        // effort_set_dense_backend: basicMul through rocBLAS instead of dense_gemv_kernel
     // tuning overrides (0 = heuristic)
     int tuneW = 0, tuneE = 0, tuneS = 0;
+    int chainSliceMult = 1;       // chain launches: row slices per call = the heuristic's x this (effort_set_chain_tuning)
     bool splitCutoff = false;     // run findCutoff32 as its own 1-workgroup kernel instead of inside every workgroup
     // optional per-kernel timing
     bool timing = false;          // HIP events around each kernel
@@ -118,9 +121,10 @@ extern "C" const char* effort_last_error(effort_ctx* c) { return c ? c->err : g_
 
 static bool lane_alloc(effort_ctx* c, Lane& L) {
     bool ok = hipMalloc(&L.d_cutoff, 512) == hipSuccess && hipMalloc(&L.d_count, 16) == hipSuccess &&
-              hipMalloc(&L.d_slabs, c->slabBytes) == hipSuccess && hipMalloc(&L.d_counters, effort_ctx::kMaxTiles * 4) == hipSuccess &&
+              hipMalloc(&L.d_slabs, c->slabBytes) == hipSuccess && hipMalloc(&L.d_slabsNamed, c->slabBytes) == hipSuccess && hipMalloc(&L.d_counters, effort_ctx::kMaxTiles * 4) == hipSuccess &&
               hipMalloc(&L.d_sliceCounts, effort_ctx::kMaxSlices * 4) == hipSuccess && hipMalloc(&L.d_queue, kQueueWords * 4) == hipSuccess;
     if (!ok) return false;
+    hipMemset(L.d_slabsNamed, 0xFF, c->slabBytes);
     hipMemset(L.d_counters, 0, effort_ctx::kMaxTiles * 4);
     hipMemset(L.d_sliceCounts, 0, effort_ctx::kMaxSlices * 4);
     hipMemset(L.d_queue, 0, kQueueWords * 4);
@@ -157,7 +161,7 @@ static void pool_put(int device, hipEvent_t e) { if (e) { std::lock_guard<std::m
 static void lane_free(int device, Lane& L) {
     pool_put(device, L.own);
     pool_put(device, L.done);
-    hipFree(L.d_cutoff); hipFree(L.d_count); hipFree(L.d_slabs); hipFree(L.d_counters); hipFree(L.d_sliceCounts); hipFree(L.d_queue);
+    hipFree(L.d_cutoff); hipFree(L.d_count); hipFree(L.d_slabs); hipFree(L.d_slabsNamed); hipFree(L.d_counters); hipFree(L.d_sliceCounts); hipFree(L.d_queue);
     L = Lane();
 }
 
@@ -766,6 +770,7 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
         const int frc = fork_lane();
         if (frc != EFFORT_OK) return frc;
         if (chain) {
+            ga.slabs = L.d_slabsNamed;
             // persistent, no cutoff jobs (a job of a later stage would wait on the stage before it with everybody else: every
             // workgroup evaluates the cutoff of a call it works on, as a plain grid's do), compact means
             ga.persistent = R ? R : 2u; ga.cutJobs = 0u; ga.split = 4u | 16u;
@@ -803,7 +808,7 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
         }
 #endif
         // (a chain's stage is sliced as the launch of its own it replaces: its calls, its column tiles)
-        int rc = chain ? choose_geom(c, w, stageFirst[curStage + 1] - stageFirst[curStage], stageE[curStage], &g, &Wi, &Ei, mult, stageTilesAll[curStage])
+        int rc = chain ? choose_geom(c, w, stageFirst[curStage + 1] - stageFirst[curStage], stageE[curStage], &g, &Wi, &Ei, (uint32_t)c->chainSliceMult, stageTilesAll[curStage])
                        : choose_geom(c, w, n, groupE, &g, &Wi, &Ei, mult, groupTiles);
         if (rc != EFFORT_OK) return fail(c, rc, "bucketmul: no launch geometry for this shape/tuning");
         if (chain && (Wi != 8 || g.sliceRows % 2u)) return fail(c, EFFORT_ERR_SHAPE, "bucketmul_chain: 8-wave workgroups and slices of an even number of rows");
@@ -829,7 +834,10 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
         a.q = (uint32_t)(int)((double)(kProbes - 1) * (1.0 - efforts[i]));            // bucketMul.swift:39
         const int pre = prologues ? prologues[i] : 0;
         a.pre = (uint16_t)(pre | (curStage << 8)); a.vAux = pre ? vAux[i] : nullptr; a.resid = resids ? resids[i] : nullptr;
-        if (chain) ga.stageTiles[curStage] = (uint16_t)(ga.stageTiles[curStage] + g.tiles);
+        if (chain) {
+            ga.stageTiles[curStage] = (uint16_t)(ga.stageTiles[curStage] + g.tiles);
+            if (ga.stageTiles[curStage] > 64u) return fail(c, EFFORT_ERR_SHAPE, "bucketmul_chain: more than 64 column tiles in one stage");
+        }
         a.slabOff = (uint32_t)(slabOff / 256); a.tileOff = (uint16_t)tileOff; a.sliceOff = (uint16_t)sliceOff; a.geom = (uint16_t)gi;
         wg += g.tiles * ((g.slices + 7) / 8 * 8);
         if (wg / 8u > 0xFFFFu) return fail(c, EFFORT_ERR_SHAPE, "bucketmul: group exceeds the launch descriptor's item range");
@@ -1130,6 +1138,12 @@ extern "C" int effort_set_persistent(effort_ctx* c, int wgPerCU) {
 extern "C" int effort_debug_hook_lane(effort_ctx* c, int lane) {
     if (!c || lane < 0 || lane >= c->nLanes) return EFFORT_ERR_ARG;
     c->lastLane = lane;
+    return EFFORT_OK;
+}
+
+extern "C" int effort_set_chain_tuning(effort_ctx* c, int sliceMult) {
+    if (!c || sliceMult < 1 || sliceMult > 8) return EFFORT_ERR_ARG;
+    c->chainSliceMult = sliceMult;
     return EFFORT_OK;
 }
 

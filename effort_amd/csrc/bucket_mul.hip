@@ -94,6 +94,7 @@ constexpr int kRowAux = EFFORT_ROW_AUX;
 #define GA_TRACE(ga) (PERSIST ? (ga).trace : 0u)
 #endif
 constexpr uint32_t kMaxLdsBytes = 160u * 1024u - 1024u;     // dynamic LDS a launch may ask for: a gfx950 CU's 160 KB less the kernel's static words (rounded up generously)
+constexpr uint32_t kSlabSentinel = 0xFFFFFFFFu;      // NAMED hand-off: what every slab word holds between launches (a NaN no partial sum can be)
 constexpr int kSc1 = 16;     // buffer aux bit: sc1 = write-through store / L1-bypassing load (cross-XCD visible)
 
 template <int FMT> struct Fmt;
@@ -360,10 +361,14 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
         // those wait only on still earlier stages.  (A workgroup's second item of a call skips the poll.)
         const uint32_t stage = (uint32_t)a.pre >> 8;
         if (stage > 0u && cachedCall != ci) {
-            if (tid == 0) {
-                const uint32_t* const done = ga.queue + kStageDoneOff + (stage - 1u) * 16u;
+            if (wave == 0) {                                  // lane i watches the flag of tile i of the previous stage (<= 64 tiles), in this XCD's copy
                 const uint32_t need = ga.stageTiles[stage - 1u];
-                for (int spin = 0; spin < 400000 && __hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need; spin++) __builtin_amdgcn_s_sleep(4);
+                const uint32_t* const f = ga.queue + kStageFlagOff + ((stage - 1u) * 8u + (blockIdx.x & 7u)) * 64u + (uint32_t)lane;
+                for (int spin = 0; spin < 400000; spin++) {
+                    const uint32_t x = (uint32_t)lane < need ? __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1u;
+                    if (__ballot(x == 0u) == 0ull) break;
+                    __builtin_amdgcn_s_sleep(8);
+                }
             }
             __syncthreads();
         }
@@ -889,13 +894,24 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
         }
         return r;
     };
+    // NAMED (chain launches): the tile's reducer is known up front -- the workgroup that works the tile's LAST slice, the last
+    // of the tile's items the queues hand out.  The others store their slab and move on: no wait for the stores to drain, no
+    // ticket.  The reducer keeps its own tile in LDS and reads the other slabs until none of them shows the SENTINEL (an
+    // all-ones NaN no sum can take: slabs hold int -> float conversions times a power of two) that every slab holds between
+    // launches -- the reducer puts it back after reading, the lane's slab region starts out filled with it (api.hip).  One
+    // memory round trip from the last producer's store to the sum, where the ticket protocol has three (drain, ticket, read).
+    // Forward progress: the reducer waits only for items handed out BEFORE its own, by queues whose other workgroups never wait
+    // for it; the poll is bounded all the same (a slab that never arrives leaves NaNs in out[], loudly, not a hung GPU).
+    constexpr bool NAMED = CHAIN;
+    const bool reducer = NAMED && s == g.slices - 1u;
+    if (!reducer)
     for (int o = tid * 2; o < TILE_F; o += NT * 2) {
         const float s0 = tile_out(o), s1 = tile_out(o + 1);
         typedef uint32_t u2 __attribute__((ext_vector_type(2)));
         u2 pk; pk[0] = __float_as_uint(s0); pk[1] = __float_as_uint(s1);
         __builtin_amdgcn_raw_buffer_store_b64(pk, srs, (uint32_t)o * 4u, slabOff, kSc1);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's slab stores have left the CU
+    if (!NAMED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's slab stores have left the CU
     if (stamp) { GA_TSTAMP(ga)[21] = wall_clock64(); GA_TSTAMP(ga)[22] = n; }
     if (wstamp) ph[5] = wall_clock64();
     // the stamps are flushed off the critical path (after the ticket), spread over 32 cache lines
@@ -919,13 +935,17 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
         atomicMax(&GA_TSTAMP(ga)[29], ph[4] - ph[3]);                               // longest streaming phase
         atomicMax(&GA_TSTAMP(ga)[1], (unsigned long long)wall_clock64());
     };
-    __syncthreads();
-    if (tid == 0) {
-        const uint32_t ticket = __hip_atomic_fetch_add(&a_counters[t], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        flags[0] = (ticket == g.slices - 1u) ? 1u : 0u;
+    if constexpr (NAMED) {
+        if (!reducer) { flush_stamps(); return; }
+    } else {
+        __syncthreads();
+        if (tid == 0) {
+            const uint32_t ticket = __hip_atomic_fetch_add(&a_counters[t], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            flags[0] = (ticket == g.slices - 1u) ? 1u : 0u;
+        }
+        __syncthreads();
+        if (flags[0] == 0u) { flush_stamps(); return; }
     }
-    __syncthreads();
-    if (flags[0] == 0u) { flush_stamps(); return; }
     if (GA_ABLATE(ga) & 2u) { if (tid == 0) __hip_atomic_store(&a_counters[t], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
 
     // last arriver of tile t: every slab of the tile was stored write-through (sc1) and drained before its ticket;
@@ -940,7 +960,10 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     // group then has at most 16 slices = ONE round trip; the groups' partial sums meet in LDS and are added in group order.
     constexpr int kCols4 = TILE_F / 4;
     constexpr int G = NT / kCols4 >= 2 ? NT / kCols4 : 1;
-    float* const gpart = reinterpret_cast<float*>(smem + offA);     // [G][TILE_F]; the accumulator | list region is free by now
+    // [G][TILE_F] partial sums of the thread groups, BEHIND the accumulator tile (a named reducer still reads its own tile from
+    // there; the list and the rest of the cutoff table's region are free: G * TILE_F * 4 + the tile <= the table, see plan_lds)
+    float* const gpart = reinterpret_cast<float*>(smem + offA + (uint32_t)TILE_L * 4u);
+    static_assert(G == 1 || (uint32_t)TILE_L * 4u + (uint32_t)G * TILE_F * 4u <= cutoff_table_bytes(NT), "the thread groups' partial sums must fit behind the tile");
     auto reduce_tile = [&](auto kc) {
         constexpr int kRed = decltype(kc)::value;          // 16-byte slab loads in flight per thread
         const int grp = G > 1 ? tid / kCols4 : 0;
@@ -962,11 +985,40 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
             float sm[4][4];                                // [tile slot of this thread][slice % 4]: fixed summation order
 #pragma unroll
             for (int h = 0; h < 4; h++) { sm[h][0] = 0.0f; sm[h][1] = 0.0f; sm[h][2] = 0.0f; sm[h][3] = 0.0f; }
+            u4v own;                                       // NAMED: the reducer's own slice of these four outputs, straight from its LDS tile
+            if constexpr (NAMED) {
+#pragma unroll
+                for (int h = 0; h < 4; h++) own[h] = __float_as_uint(tile_out(o + h));
+            }
             for (uint32_t sl = sl0; sl < sl1; sl += kRed) {
                 u4v r[kRed];
+                if constexpr (NAMED) {
+                    // the slabs of the other slices: asked for together, again while any of them still shows the sentinel
+                    // (16 bytes = two 8-byte stores of one producer: every word is looked at), then the sentinel goes back
+                    // (fire and forget: the next launch finds the region as this one did)
+                    const uint32_t last = g.slices - 1u;
+                    for (uint32_t tries = 0;; tries++) {
+#pragma unroll
+                        for (int i = 0; i < kRed; i++)
+                            r[i] = __builtin_amdgcn_raw_buffer_load_b128(srs, vo, min(sl + i, last) * sliceStride, kSc1);
+                        bool bad = false;
+#pragma unroll
+                        for (int i = 0; i < kRed; i++)
+                            if (sl + i < sl1 && sl + i != last) bad |= (r[i][0] == kSlabSentinel) | (r[i][1] == kSlabSentinel) | (r[i][2] == kSlabSentinel) | (r[i][3] == kSlabSentinel);
+                        if (!bad || tries > (1u << 17)) break;
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                    u4v sent; sent[0] = sent[1] = sent[2] = sent[3] = kSlabSentinel;
+#pragma unroll
+                    for (int i = 0; i < kRed; i++) {
+                        if (sl + i < sl1 && sl + i != last) __builtin_amdgcn_raw_buffer_store_b128(sent, srs, vo, (sl + i) * sliceStride, kSc1);
+                        if (sl + i == last) r[i] = own;
+                    }
+                } else {
 #pragma unroll
                 for (int i = 0; i < kRed; i++)
                     r[i] = __builtin_amdgcn_raw_buffer_load_b128(srs, vo, min(sl + i, g.slices - 1u) * sliceStride, kSc1);
+                }
 #pragma unroll
                 for (int i = 0; i < kRed; i++) {
                     if (sl + i < sl1) {
@@ -1012,10 +1064,17 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     //  workgroup's next item -- or cutoff job -- zeroes its count table there, so the region must be quiescent first)
     if (PERSIST && G > 1) __syncthreads();
     if constexpr (CHAIN) {
-        // this tile of the call's output is written: once every thread's stores have left the CU, count it towards its stage
+        // this tile of the call's output is written: once every thread's stores have left the CU, raise the tile's flag of its
+        // stage -- eight copies, one per XCD, each on lines of its own: the next stage's workgroups poll the copy of THEIR XCD,
+        // 64 pollers a line instead of 500 on one counter (which queued the polls and the reducers' own traffic behind each other)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(ga.queue + kStageDoneOff + ((uint32_t)a.pre >> 8) * 16u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid < 8) {
+            const uint32_t stage = (uint32_t)a.pre >> 8;
+            uint32_t base = 0;
+            for (uint32_t k = 0; k < stage; k++) base += ga.stageTiles[k];
+            __hip_atomic_store(ga.queue + kStageFlagOff + (stage * 8u + (uint32_t)tid) * 64u + ((uint32_t)a.tileOff - base + t), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     if (rstamp) GA_TSTAMP(ga)[24] = wall_clock64();
     if (tid == 0) {
@@ -1160,13 +1219,19 @@ __global__ __launch_bounds__(64 * W, (W <= 8 ? EFFORT_MIN_WAVES_PER_EU : 4)) voi
         staged = stagedNext;
         par ^= 1u;
     }
+    if (CHAIN) { __syncthreads(); if (threadIdx.x == 0) s_item = 0u; }     // (s_item: every wave has read its last item by now)
     if (GA_PERSISTENT(ga) && threadIdx.x == 0) {               // the last workgroup out rewinds the queues (and flags) for the next launch
         const uint32_t gone = __hip_atomic_fetch_add(&ga.queue[8 * 16], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (gone == gridDim.x - 1u) {
             for (int i = 0; i <= 8; i++) __hip_atomic_store(&ga.queue[i * 16], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             for (int i = 0; i < kMaxGroup; i++) __hip_atomic_store(&ga.queue[9 * 16 + i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (CHAIN) for (int i = 0; i < kMaxStages; i++) __hip_atomic_store(&ga.queue[kStageDoneOff + i * 16], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (CHAIN) s_item = 0xFFFFFFFFu;                   // (the whole workgroup lowers the stage flags, below)
         }
+    }
+    if (CHAIN) {
+        __syncthreads();
+        if (s_item == 0xFFFFFFFFu)
+            for (uint32_t i = threadIdx.x; i < (uint32_t)(kMaxStages * 8 * 64); i += 64u * W) __hip_atomic_store(&ga.queue[kStageFlagOff + i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

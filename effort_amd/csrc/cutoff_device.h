@@ -182,12 +182,6 @@ __device__ __forceinline__ float block_find_cutoff(const float (&vj)[4096 / NT],
         if (wave == 0) {
             // ---- the bisection proper, one wave, one LDS lookup per round ------------------------------------
             const uint32_t allGE = s_all[0];
-            auto count_above = [&](uint32_t p) -> uint32_t {     // branch-free: the lookup is always issued (clamped)
-                uint32_t c = tbl[min(max(p, base), top) - base];
-                asm volatile("" : "+v"(c));                      // (... really always: hipcc otherwise sinks the read into two exec-masked branches)
-                // below the first cell: everything at or above it (zeros never count); beyond the last: `above`
-                return p < base ? allGE : (p > top ? above : c);
-            };
             // THE BISECTION WITHOUT ITS LOOKUPS.  A count enters a round of the reference's loop in three places: the comparison
             // `countAbove < effort` that steers the bounds, and the exit tests `countAbove == effort` and |maxCount - minCount| < 3.
             // Counts are monotone in the threshold's bf16 cell, so each of them is a comparison of CELLS with a few order

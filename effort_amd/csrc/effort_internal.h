@@ -53,7 +53,7 @@ __host__ __device__ inline uint32_t ol_bits_in(uint32_t inDim) { uint32_t b = 1;
 constexpr int kMaxGroup = EFFORT_MAX_GROUP;        // calls per launch (the macro: A/B builds of the kernel-argument size, tools/ only)
 constexpr int kMaxGeoms = 4;
 constexpr int kMaxStages = 8;                      // stages of a chain launch
-constexpr int kStageDoneOff = 11 * 16, kQueueWords = (11 + kMaxStages) * 16;   // layout of GroupKArgs::queue (words)
+constexpr int kStageFlagOff = 11 * 16, kQueueWords = 11 * 16 + kMaxStages * 8 * 64;   // layout of GroupKArgs::queue (words)
 constexpr int kTraceOff = 512, kTraceItems = 4096;   // per-item trace records: u64 index into the stamp buffer / capacity         // distinct (shape, slicing) geometries per launch
 enum Prologue : uint16_t { kPreNone = 0, kPreSiluGate = 1, kPreRmsNorm = 2 };
 struct CallDesc {                    // 112 bytes
@@ -95,15 +95,15 @@ struct GroupKArgs {
     uint32_t totalItems;           // = 8 * wgEnd8[count - 1]: items of the launch (without the cutoff jobs)
     uint32_t* groupDone;           // counter of finished tiles (zero between launches)
     uint32_t* queue;               // [9][16]: per-XCD item cursors (one cache line each), line 8 = exit counter;
-                                   // then [32] cutoff words (value | ready bit) of the calls; then, from word kStageDoneOff on, one
-                                   // line per chain stage: [0] tiles of the stage written so far; all zero between launches
+                                   // then [32] cutoff words (value | ready bit) of the calls; then, from word kStageFlagOff on, the
+                                   // chain launches' flags [stage][XCD copy][64]: tile i of the stage is written; all zero between launches
     float* slabs;                  // context scratch the calls index into
     uint32_t* counters;
     uint32_t* sliceCounts;
     float* cutoff;                 // [count]: BucketMul.cutoff of every call
     unsigned long long* tstamp;    // nullable profiling stamps: [0]=min start, [1]=max end, [2]=sum, [3]=launches, [16..] phases
     uint16_t wgEnd8[kMaxGroup];    // exclusive end of each call's item range, in units of 8 items (the ranges are multiples of 8)
-    uint16_t stageTiles[kMaxStages];   // chain launches: column tiles of each stage (all its calls)
+    uint16_t stageTiles[kMaxStages];   // chain launches: column tiles of each stage (all its calls; <= 64)
     MulGeom geom[kMaxGeoms];
     CallDesc call[kMaxGroup];
 };

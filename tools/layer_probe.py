@@ -19,6 +19,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--effort", type=float, default=0.25)
+    ap.add_argument("--slice-mult", type=int, default=1, help="chain launches: row slices per call x this")
     ap.add_argument("--layers", type=int, default=8, help="distinct weight sets rotated through (cache honesty)")
     ap.add_argument("--reps", type=int, default=200)
     args = ap.parse_args()
@@ -29,6 +30,7 @@ def main():
     cfg = MistralConfig(numLayers=args.layers)
     model = Model.random(cfg, seed=3, keep_cores=False)
     g = ea.gpu(0)
+    g.set_chain_tuning(args.slice_mult)
     e = args.effort
     f = lambda n: torch.randn(n, device=dev)                                    # noqa: E731
     h, attn, x1, x3, xq, xk, xv = f(4096), f(4096), f(14336), f(14336), f(4096), f(1024), f(1024)
