@@ -994,8 +994,9 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
                 u4v r[kRed];
                 if constexpr (NAMED) {
                     // the slabs of the other slices: asked for together, again while any of them still shows the sentinel
-                    // (16 bytes = two 8-byte stores of one producer: every word is looked at), then the sentinel goes back
-                    // (fire and forget: the next launch finds the region as this one did)
+                    // (16 bytes = two 8-byte stores of one producer: every word is looked at).  The sentinel goes back AFTER
+                    // out[] and the stage flag (below): 32 slabs of 4-8 KB are 128-256 KB of stores per reducer, 2-4 us that the
+                    // next stage must not wait for
                     const uint32_t last = g.slices - 1u;
                     for (uint32_t tries = 0;; tries++) {
 #pragma unroll
@@ -1008,12 +1009,8 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
                         if (!bad || tries > (1u << 17)) break;
                         __builtin_amdgcn_s_sleep(2);
                     }
-                    u4v sent; sent[0] = sent[1] = sent[2] = sent[3] = kSlabSentinel;
 #pragma unroll
-                    for (int i = 0; i < kRed; i++) {
-                        if (sl + i < sl1 && sl + i != last) __builtin_amdgcn_raw_buffer_store_b128(sent, srs, vo, (sl + i) * sliceStride, kSc1);
-                        if (sl + i == last) r[i] = own;
-                    }
+                    for (int i = 0; i < kRed; i++) if (sl + i == last) r[i] = own;
                 } else {
 #pragma unroll
                 for (int i = 0; i < kRed; i++)
@@ -1075,6 +1072,13 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
             for (uint32_t k = 0; k < stage; k++) base += ga.stageTiles[k];
             __hip_atomic_store(ga.queue + kStageFlagOff + (stage * 8u + (uint32_t)tid) * 64u + ((uint32_t)a.tileOff - base + t), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+    }
+    if constexpr (NAMED) {
+        // the slabs this reducer consumed hold the sentinel again when the launch ends (fire and forget)
+        u4v sent; sent[0] = sent[1] = sent[2] = sent[3] = kSlabSentinel;
+        for (uint32_t o4 = (uint32_t)tid; o4 < (uint32_t)(TILE_F / 4); o4 += (uint32_t)NT)
+            for (uint32_t sl = 0; sl + 1u < g.slices; sl++)
+                __builtin_amdgcn_raw_buffer_store_b128(sent, srs, t * (uint32_t)(TILE_F * 4) + o4 * 16u, sl * sliceStride, kSc1);
     }
     if (rstamp) GA_TSTAMP(ga)[24] = wall_clock64();
     if (tid == 0) {

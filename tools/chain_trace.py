@@ -19,6 +19,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--effort", type=float, default=0.25)
     ap.add_argument("--slice-mult", type=int, default=1, help="chain launches: row slices per call x this")
+    ap.add_argument("--persistent", type=int, default=-1, help="workgroups per CU of persistent launches (-1: heuristic = 2)")
     ap.add_argument("--out", default="gpurun_out/chain_trace.json")
     ap.add_argument("--separate", type=int, default=0, help="1: trace the four launches of their own instead (each one's records)")
     args = ap.parse_args()
@@ -30,6 +31,7 @@ def main():
     L, Ln = model.layers
     g = ea.gpu(0)
     g.set_chain_tuning(args.slice_mult)
+    g.set_persistent(args.persistent)
     e = args.effort
     f = lambda n: torch.randn(n, device=dev)                                    # noqa: E731
     h, attn, x1, x3, xq, xk, xv = f(4096), f(4096), f(14336), f(14336), f(4096), f(1024), f(1024)

@@ -20,6 +20,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--effort", type=float, default=0.25)
     ap.add_argument("--slice-mult", type=int, default=1, help="chain launches: row slices per call x this")
+    ap.add_argument("--persistent", type=int, default=-1, help="workgroups per CU of persistent launches (-1: heuristic = 2)")
     ap.add_argument("--layers", type=int, default=8, help="distinct weight sets rotated through (cache honesty)")
     ap.add_argument("--reps", type=int, default=200)
     args = ap.parse_args()
@@ -31,6 +32,7 @@ def main():
     model = Model.random(cfg, seed=3, keep_cores=False)
     g = ea.gpu(0)
     g.set_chain_tuning(args.slice_mult)
+    g.set_persistent(args.persistent)
     e = args.effort
     f = lambda n: torch.randn(n, device=dev)                                    # noqa: E731
     h, attn, x1, x3, xq, xk, xv = f(4096), f(4096), f(14336), f(14336), f(4096), f(1024), f(1024)
