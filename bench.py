@@ -60,7 +60,7 @@ IN_DIM, OUT_DIM = 4096, 11008
 N_MATS = 32
 SWEEP = [0.10, 0.15, 0.20, 0.25, 0.30, 0.40, 0.50, 0.60, 0.70, 0.80, 0.90, 1.00]
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PMC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r03_pmc_traffic.json", "r02_pmc_traffic.json")]   # rocprofv3 --pmc passes folded by tools/pmc_traffic.py
+PMC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")]   # rocprofv3 --pmc passes folded by tools/pmc_traffic.py
 
 
 def log(*a):
@@ -244,6 +244,117 @@ def cpu_baseline(ews, v, effort, inDim, outDim, budget_s=10.0, nmat=4):
                       f"{budget_s / 3:.0f} s each"}
 
 
+def measured_traffic(effort, group, budget_s=150):
+    """HBM-side bytes per launch of the timed configuration, MEASURED in this run: two rocprofv3 --pmc passes (FETCH_SIZE, then
+    WRITE_SIZE; counters in their own runs with --kernel-trace only, as MI355X_MICROARCH.md prescribes) of this script's
+    --headline-only job in a child process, folded by tools/pmc_traffic.py.  None if rocprofv3 is missing or a pass fails."""
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    if not shutil.which("rocprofv3"):
+        return None, "rocprofv3 not on PATH"
+    d = tempfile.mkdtemp(prefix="effort_pmc_", dir="/tmp")
+    try:
+        env = dict(os.environ, TMPDIR="/tmp")
+        for name in ("FETCH_SIZE", "WRITE_SIZE"):
+            cmd = ["rocprofv3", "--pmc", name, "--kernel-trace", "--output-format", "csv", "-d", os.path.join(d, name), "--",
+                   sys.executable, os.path.abspath(__file__), "--steps", "24", "--warmup", "4", "--headline-only", "--effort", str(effort), "--group", str(group)]
+            p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, start_new_session=True)
+            try:
+                _, err = p.communicate(timeout=budget_s)
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, signal.SIGKILL)
+                return None, f"rocprofv3 --pmc {name}: no result within {budget_s} s"
+            if p.returncode != 0:
+                return None, f"rocprofv3 --pmc {name} exited {p.returncode}: {(err or '')[-200:]}"
+        out = os.path.join(d, "traffic.json")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic.py"), "--fetch", os.path.join(d, "FETCH_SIZE"), "--write", os.path.join(d, "WRITE_SIZE"),
+                            "--group", str(group), "--effort", str(effort), "--out", out], capture_output=True, text=True, timeout=60)
+        if r.returncode != 0:
+            return None, "tools/pmc_traffic.py: " + (r.stderr or r.stdout)[-200:]
+        with open(out) as f:
+            return json.load(f), None
+    except Exception as ex:                                  # noqa: BLE001
+        return None, repr(ex)
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def timeit_protocol(ea, g, dev, efforts=(1.0, 0.7, 0.5, 0.25, 0.15), repeats=3000):
+    """The reference's own timing loop (helpers/timeit.swift:10-34 driven by benchmarks/benchmark.swift:245-257,
+    goQuickBucketPerformance): 1000 warm-up calls, eval, then `repeats` SINGLE bucketMul calls -- expertMul(v, layers[i % 32].w1,
+    out: test, effort) on 32 rotating 4096 -> 14336 matrices, one enqueue per call, one eval at the end; it prints
+    tpt = ms_per_call * 4 * 32 and spd = 1000 / tpt (projected tokens/s).  Here every call is one effort_bucketmul through the C
+    ABI (ctypes, arguments prebuilt: the host must not be what is timed; its enqueue time is reported beside the total).  Three
+    ways: the loop as written (every call writes the SAME output vector, so the calls are ordered whatever the lanes), the same
+    with effort_set_overlap(4), and with four rotating output vectors under overlap (calls independent: what a caller with more
+    than one vector in flight gets)."""
+    import ctypes as C
+    lib = ea.lib()
+    inDim, outDim = 4096, 14336
+    ws = make_weights(ea, 32, inDim, outDim, 777, dev, keep_core=False)
+    hs = [C.c_void_p(ew.handle) if not isinstance(ew.handle, C.c_void_p) else ew.handle for ew in ws]
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(43)
+    v = torch.randn(inDim, generator=gen, device=dev)
+    tests = [torch.zeros(outDim, device=dev) for _ in range(4)]
+    vp, tp = C.c_void_p(v.data_ptr()), [C.c_void_p(t.data_ptr()) for t in tests]
+    fn, ctx = lib.effort_bucketmul, g.ctx
+    g._bind_stream()
+    res = {"shape": f"{inDim}x{outDim}", "matrices": 32, "warmup_calls": 1000, "timed_calls": repeats,
+           "formula": "tpt_ms = ms_per_call * 4 * 32; spd_tps = 1000 / tpt_ms (helpers/timeit.swift:33-34)",
+           "reference_readoffs_tps": {"source": "docs/ryc/ryc0.1.png via BASELINE.md section 1 (Apple Silicon, hardware not stated)",
+                                      "mps_dense": 26, "1.0": 15, "0.5": 26, "0.25": 47, "0.2": 55, "0.1": 87}}
+
+    def loop(n, s, nout):
+        rc = 0
+        for i in range(n):
+            rc |= fn(ctx, hs[i & 31], vp, None, tp[i % nout], s)
+        return rc
+    for name, lanes, nout in (("as_written", 1, 1), ("as_written_overlap4", 4, 1), ("four_outputs_overlap4", 4, 4)):
+        g.set_overlap(lanes)
+        sec = {}
+        for s in efforts:
+            s = float(s)
+            assert loop(1000, s, nout) == 0
+            g.eval()
+            t0 = time.perf_counter()
+            assert loop(repeats, s, nout) == 0
+            t1 = time.perf_counter()
+            g.eval()
+            t2 = time.perf_counter()
+            epl = (t2 - t0) / repeats * 1e3                                   # ms per call
+            sec[str(s)] = {"us_per_call": round(epl * 1e3, 3), "tpt_ms": round(epl * 4 * 32, 3), "spd_tps": round(1000.0 / (epl * 4 * 32), 1),
+                           "host_enqueue_us_per_call": round((t1 - t0) / repeats * 1e6, 3)}
+        res[name] = sec
+    g.set_overlap(1)
+    # the MPS line of the same benchmark: three dense 4096 x 4096 multiplies per iteration, multiplier 4/3 (benchmark.swift:237-241)
+    cores = [(torch.randn((4096, 4096), generator=gen, device=dev) * 0.02).to(torch.float16) for _ in range(32)]
+    dfn = lib.effort_dense_gemv
+    cps = [C.c_void_p(c.data_ptr()) for c in cores]
+    ctl = torch.zeros(4096, device=dev)
+    cp = C.c_void_p(ctl.data_ptr())
+    for backend, rocblas in (("dense_hip_kernel", False), ("dense_rocblas", True)):
+        g.set_dense_backend(rocblas)
+
+        def dloop(n):
+            rc = 0
+            for i in range(n):
+                for _ in range(3):
+                    rc |= dfn(ctx, cps[i & 31], vp, cp, 4096, 4096)
+            return rc
+        assert dloop(1000) == 0
+        g.eval()
+        t0 = time.perf_counter()
+        assert dloop(repeats) == 0
+        g.eval()
+        epl = (time.perf_counter() - t0) / repeats * 1e3
+        res[backend + "_3x_wq"] = {"us_per_iteration": round(epl * 1e3, 3), "tpt_ms": round(epl * 4 * 32 * 4 / 3, 3), "spd_tps": round(1000.0 / (epl * 4 * 32 * 4 / 3), 1)}
+    g.set_dense_backend(False)
+    return res
+
+
 def oracle_outputs(ews, v, effort, inDim, outDim, idxs):
     """The CPU oracle's product for the matrices `idxs` (test infrastructure used as the CHECKER of the bench's outputs)."""
     import numpy as np
@@ -272,6 +383,7 @@ def main():
                     help="accepted for compatibility and ignored: N > 1 times both partitions (matrices = `value`, columns beside it in multi_gpu)")
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 --pmc passes (roofline.traffic then comes from the committed profile)")
     ap.add_argument("--no-decode", action="store_true", help="skip the end-to-end decode section (BASELINE.json configs[4])")
     ap.add_argument("--headline-only", action="store_true", help="only the timed job (for rocprofv3 passes: every bucket_mul_kernel dispatch is then the timed configuration)")
     ap.add_argument("--headline-shared", action="store_true", help="round 2's job: every step in flight on the SAME 32 matrices")
@@ -346,8 +458,12 @@ def main():
         # on one GPU) and ONE all-gather per round exchanges the round's output vectors.  Pipelined: round r's all-gather runs
         # on a communication stream while round r+1 computes into the other of two buffers.
         comm = torch.cuda.Stream(device=dev)
+        # the collective is the C ABI's (effort_comm_create / effort_allgather_outputs: ncclAllGather on a context's stream); a context of
+        # its own follows the communication stream.  torch.distributed only ships the communicator id between the ranks.
+        from effort_amd.sharded import init_comm
+        cg = init_comm(ea.Gpu(local))
 
-        def round_step(weights, send):
+        def round_step(weights, send, vec):
             """Step i of a round writes output set i of `send` ([R, 32, localOut]); Job hands out (ctx, slot = i % S)."""
             count = [0]
 
@@ -355,15 +471,16 @@ def main():
                 i = count[0]
                 count[0] += 1
                 ws = weights[slot % len(weights)] if isinstance(weights[0], list) else weights
-                items = [(v, ew, None, send[i % send.shape[0]][k], args.effort) for k, ew in enumerate(ws)]
+                items = [(vec, ew, None, send[i % send.shape[0]][k], args.effort) for k, ew in enumerate(ws)]
                 for ch in chunked(items, G):
                     ea.bucketMulGroup(ch, gpu=ctx)
             step.reset = lambda: count.__setitem__(0, 0)
             return step
 
         class Exchange:
-            def __init__(self, weights, localOut):
+            def __init__(self, weights, localOut, vec=None):
                 self.lo = localOut
+                self.vec = v if vec is None else vec
                 self.R = 16 * S                          # steps per round: sixteen per stream -- a round is one hipGraph whose launches drain at its end, so long rounds
                 self.send = [torch.zeros((self.R, N_MATS, localOut), device=dev) for _ in range(2)]
                 self.recv = [torch.zeros(world * self.R * N_MATS * localOut, device=dev) for _ in range(2)]
@@ -372,7 +489,7 @@ def main():
 
             def graph(self, b, n):                       # n steps (<= R) into buffer b: step i -> stream i % S, output set i
                 if (b, n) not in self.graphs:
-                    self.graphs[(b, n)] = job.capture(round_step(self.weights, self.send[b]), n)
+                    self.graphs[(b, n)] = job.capture(round_step(self.weights, self.send[b], self.vec), n)
                 return self.graphs[(b, n)]
 
             def run(self, nsteps, exchange=True):
@@ -388,7 +505,7 @@ def main():
                         with torch.cuda.stream(comm):
                             comm.wait_event(self.ev[b][0])
                             cnt = n * N_MATS * self.lo
-                            dist.all_gather_into_tensor(self.recv[b][:world * cnt], self.send[b].view(-1)[:cnt])
+                            cg.allgather_outputs(self.send[b].view(-1)[:cnt], self.recv[b][:world * cnt], cnt)
                             self.ev[b][1].record(comm)
                 main.wait_stream(comm)
 
@@ -492,6 +609,51 @@ def main():
             del shards, exc
         except Exception as ex2:
             result["multi_gpu"]["columns"] = {"error": repr(ex2)}
+        # ---- both partitions at both of north_star's shapes, per rank: kernel-only and with-gather times, fraction of the HBM roofline
+        def partitions(iD, oD, sets, full):
+            """sets: this rank's own S x 32 matrices (matrix partition); full: the 32 matrices every rank shards by columns."""
+            out = {}
+            exm = Exchange(sets, oD)
+            exm.timed(False)
+            n = args.steps * reps
+            exm.timed(False, n)
+            km, am = exm.timed(False, n), exm.timed(True, n)
+            Dm = job.ctxs[0].last_dispatch_count((N_MATS - 1) % G)
+            bm = mul_kernel_bytes(Dm, iD, oD)
+            out["matrices"] = {"ms_per_step_kernel_only": round(km * 1e3, 5), "ms_per_step_with_all_gather": round(am * 1e3, 5),
+                               "per_rank_achieved_GBps": round(N_MATS * bm / km / 1e9, 1), "per_rank_frac_of_hbm_peak": round(N_MATS * bm / km / 1e9 / HBM_PEAK_GBPS, 4),
+                               "whole_job_effective_GBps": round(world * N_MATS * 2 * iD * oD / am / 1e9, 1), "scaling": "weak"}
+            del exm
+            shs = []
+            for e in full:
+                sh = e.column_shard(rank, world)
+                sh.handle
+                shs.append(sh)
+            exs = Exchange(shs, oD // world)
+            exs.timed(False)
+            exs.timed(False, n)
+            kc, ac = exs.timed(False, n), exs.timed(True, n)
+            Dc = job.ctxs[0].last_dispatch_count((N_MATS - 1) % G)
+            bc = Dc * (oD // 16 // world) * 2 + 16 * iD * 8 + 4096 * 2 + 4 * iD + 4 * (oD // world)      # a rank's algorithmic bytes per call: its columns of the kept rows, all the stats
+            out["columns"] = {"ms_per_step_kernel_only": round(kc * 1e3, 5), "ms_per_step_with_all_gather": round(ac * 1e3, 5),
+                              "per_rank_achieved_GBps": round(N_MATS * bc / kc / 1e9, 1), "per_rank_frac_of_hbm_peak": round(N_MATS * bc / kc / 1e9 / HBM_PEAK_GBPS, 4),
+                              "whole_job_effective_GBps": round(N_MATS * 2 * iD * oD / ac / 1e9, 1), "scaling": "strong",
+                              "columns_per_rank": oD // 16 // world}
+            del exs, shs
+            return out
+        try:
+            per_shape = {}
+            full_11008 = ews if seed0 == 1234 else make_weights(ea, N_MATS, inDim, outDim, 1234, dev, keep_core=False)
+            per_shape[f"{inDim}x{outDim}"] = partitions(inDim, outDim, ew_sets, full_11008)
+            sq_sets = [make_weights(ea, N_MATS, 4096, 4096, 5000 + rank * N_MATS * S + k * N_MATS, dev, keep_core=False) for k in range(S)]
+            sq_full = make_weights(ea, N_MATS, 4096, 4096, 5000, dev, keep_core=False) if rank or world > 1 else sq_sets[0]
+            per_shape["4096x4096"] = partitions(4096, 4096, sq_sets, sq_full)
+            result["multi_gpu"]["per_shape"] = per_shape
+            result["multi_gpu"]["per_shape_note"] = ("per rank and N: `matrices` = every rank its own 32 matrices per step (weak scaling, the headline), `columns` = every rank "
+                                                     "its bucket columns of the SAME 32 matrices (strong scaling); kernel-only and with the round's RCCL all-gather "
+                                                     "(effort_allgather_outputs) under the next round's compute; fractions against 8 TB/s per GPU")
+        except Exception as ex3:
+            result["multi_gpu"]["per_shape"] = {"error": repr(ex3)}
 
     if rank == 0 and world == 1 and not args.headline_only:
         # ---------------- roofline of the dominant kernel, in the timed configuration -----------------
@@ -505,13 +667,28 @@ def main():
                     break
             except Exception:
                 pass
+        traffic_src = (f"static: a committed rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE pass of this command on another run ({pmc_src}), "
+                       "corrected as MI355X_MICROARCH.md prescribes; NOT measured in this run") if traffic else None
+        if not args.no_pmc:
+            log("roofline.traffic: two rocprofv3 --pmc passes of the headline job in a child process ...")
+            mt, why = measured_traffic(args.effort, G)
+            if mt and mt.get("hbm_bytes_per_launch"):
+                static = traffic
+                traffic = mt["hbm_bytes_per_launch"]
+                traffic_src = (f"measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes (own child processes, --kernel-trace only) of "
+                               f"`bench.py --headline-only` on this box, {mt['dispatches_averaged']} dispatches averaged; FETCH_SIZE x2 as MI355X_MICROARCH.md "
+                               f"prescribes for gfx950, WRITE_SIZE as reported" + (f"; the committed pass of an earlier run reads {static}" if static else ""))
+            else:
+                log(f"roofline.traffic: not measured ({why}); falling back to the committed pass")
+                if traffic_src:
+                    traffic_src += f" (the in-run pass failed: {why})"
         t_launch = dt / launches_per_step                # the timed region's share per launch
         mb = moved_bytes(D, inDim, outDim)
         result["roofline"] = {
             "bound": "hbm", "kernel": "bucket_mul_kernel", "achieved": round(G * kb / t_launch / 1e9, 1), "peak": HBM_PEAK_GBPS,
             "unit": "GB/s", "frac": round(G * kb / t_launch / 1e9 / HBM_PEAK_GBPS, 4), "traffic": traffic,
-            "traffic_source": (f"static: a committed rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE pass of this command on another run ({pmc_src}), "
-                               "corrected as MI355X_MICROARCH.md prescribes; NOT measured in this run") if traffic else None,
+            "traffic_source": traffic_src,
+            "traffic_over_algorithmic": round(traffic / (G * kb), 4) if traffic else None,
             "calls_per_launch": G, "bytes_per_launch": G * kb, "bytes_per_call": kb, "launches_in_flight": in_flight,
             "bytes_per_call_note": "SURVEY 8d formula (8-byte stats entries); the persistent launch stages 2-byte compact means instead: frac_moved_bytes",
             "frac_moved_bytes": round(G * mb / t_launch / 1e9 / HBM_PEAK_GBPS, 4),
@@ -559,6 +736,11 @@ def main():
                           "achieved_GBps": round(kb / tn / 1e9, 1), "tokens_per_s": round(1.0 / (tn * 4 * 32), 1)}
             del gn
         result["by_group_size"] = by
+        if not args.no_sweep:
+            try:
+                result["timeit_protocol"] = timeit_protocol(ea, ea.Gpu(local), dev)
+            except Exception as ex:                              # noqa: BLE001
+                result["timeit_protocol"] = {"error": repr(ex)}
         bs = {}
 
         def rate(tn):

@@ -155,11 +155,15 @@ def _p(t):
 class Decoder:
     """State of one sequence (the globals of main.swift:78-140: h, xq, KV caches, scores ...) + the token step."""
 
-    def __init__(self, model: Model, maxTokens: int = 256, fused_attention: bool = True, fused_glue=True, chain: bool = True):
+    def __init__(self, model: Model, maxTokens: int = 256, fused_attention: bool = True, fused_glue=True, chain: bool = False):
         cfg = self.cfg = model.cfg
         # chain: a layer's dependent multiplies -- wo -> w1|w3 -> w2 -> wq|wk|wv of the NEXT layer, glue folded in -- go out as ONE
         # launch whose resident workgroups take the stages in order (effort_bucketmul_chain): two launches per layer (attention,
-        # chain) instead of five.  Needs all the glue folded (fused_glue=True) and a dense FFN.
+        # chain) instead of five.  Needs all the glue folded (fused_glue=True) and a dense FFN.  OFF by default: measured SLOWER than
+        # the launches of their own (round 4: 252 against 308 tokens/s at 25 %; a layer's four multiplies 112 us as a chain against
+        # 91 us as launches) -- a stage hand-over inside the launch is as many dependent memory round trips (out[] written through
+        # and acknowledged, flag, poll, input loads) as a kernel boundary plus a cold start, and the stage's late starters -- the
+        # workgroups that reduced the previous stage's tiles -- lengthen its tail.  DESIGN.md section 8 has the per-item trace.
         self.chain = bool(chain)
         self.fused_attention = bool(fused_attention)      # rope + cache + attention in one launch per layer (else two)
         # rmsNorm, silu and the residual adds folded into the multiplies (effort_bucketmul_group_fused): 5 launches per layer

@@ -26,7 +26,7 @@ def main():
                                                       "+ shards) instead of random-init weights")
     ap.add_argument("--model-name", default="buckets-FP16")
     ap.add_argument("--percent-load", type=int, default=16)
-    ap.add_argument("--chain", type=int, default=1, help="0: every multiply group a launch of its own (round 3's loop); 1: a layer's dependent multiplies as one chain launch")
+    ap.add_argument("--chain", type=int, default=0, help="0: every multiply group a launch of its own (round 3's loop); 1: a layer's dependent multiplies as one chain launch")
     a = ap.parse_args()
     torch.cuda.set_device(0)
     cfg = MistralConfig(numLayers=a.layers)
