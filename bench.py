@@ -84,6 +84,18 @@ def moved_bytes(D: int, inDim: int, outDim: int) -> int:
     return D * (outDim // 16) * 2 + 16 * inDim * 2 + 4096 * 2 + 4 * inDim + 4 * outDim
 
 
+def _lds_atomic_peak():
+    """Chip-wide ds_add_u32 rate in G atomics/s: the microbenchmark's elements per ns and CU x 256 CUs."""
+    try:
+        for line in open(os.path.join(ROOT, "profiles", "r04_q4_microbench_scatter.txt")):
+            if "ds_add_u32" in line:
+                return float(line.split("elem/ns/CU")[0].split()[-1]) * 256, "profiles/r04_q4_microbench_scatter.txt (tools/microbench.hip on an MI355X)"
+    except Exception:                                        # noqa: BLE001
+        pass
+    return 13 * 2.4 * 256, "13 ds_add_u32 per clock and CU (DESIGN 4.1) x 2.4 GHz x 256 CUs"
+
+
+LDS_ATOMIC_PEAK, LDS_ATOMIC_SRC = _lds_atomic_peak()
 ALIGN_ROWS = True    # (--no-align) the converter writes the bucket rows on whole 128-byte lines (effort_convert_fp16_pitched): no second copy
 
 
@@ -870,6 +882,13 @@ def main():
                 if q4:       # SURVEY 8d prices an outlier at the reference's 16 bytes; the registered index holds 4: the bytes actually moved
                     r["achieved_GBps_4B_outliers"] = round((ab - 12 * nol) / tx / 1e9, 1)
                     r["frac_of_hbm_peak_4B_outliers"] = round((ab - 12 * nol) / tx / 1e9 / HBM_PEAK_GBPS, 4)
+                    # what bounds the Q4 multiply is its LDS scatter, not memory: four integer LDS atomics per 16-bit word of a kept row
+                    # (one per nibble) plus two per outlier, against the measured ds_add_u32 rate of the chip (tools/microbench.hip:
+                    # elements per ns and CU, profiles/r04_q4_microbench_scatter.txt; 13 per clock and CU at 2.4 GHz when that file is absent)
+                    atomics = Dx * (outDim_x // 32) * 4 + 2 * nol
+                    r["roofline_lds_atomic"] = {"bound": "lds_atomic", "atomics_per_call": atomics, "achieved_Gatomics_per_s": round(atomics / tx / 1e9, 1),
+                                                "peak_Gatomics_per_s": round(LDS_ATOMIC_PEAK, 1), "frac": round(atomics / tx / 1e9 / LDS_ATOMIC_PEAK, 4),
+                                                "peak_source": LDS_ATOMIC_SRC}
                 return r
 
             def three(sets_w, outDim_x, inDim_x, effort, q4=False):

@@ -33,6 +33,7 @@ struct Lane {
     uint32_t* d_counters = nullptr;   // per-tile arrival tickets (zero between calls)
     uint32_t* d_sliceCounts = nullptr;
     uint32_t* d_queue = nullptr;      // item queues of persistent launches
+    unsigned long long* d_named = nullptr;   // per tile: launches that consumed it | producers that gave up << 32 (plain grids' hand-off; never reset)
     // where each call of the lane's last (group) launch keeps its per-slice counts; slices == 0: dispatch.size is d_count
     uint32_t lastCalls = 1, lastSliceOff[effort::kMaxGroup] = {0}, lastSlices[effort::kMaxGroup] = {0};
     // address ranges the launches enqueued since the last join read / write (hazard check of the next launch)
@@ -122,12 +123,14 @@ extern "C" const char* effort_last_error(effort_ctx* c) { return c ? c->err : g_
 static bool lane_alloc(effort_ctx* c, Lane& L) {
     bool ok = hipMalloc(&L.d_cutoff, 512) == hipSuccess && hipMalloc(&L.d_count, 16) == hipSuccess &&
               hipMalloc(&L.d_slabs, c->slabBytes) == hipSuccess && hipMalloc(&L.d_slabsNamed, c->slabBytes) == hipSuccess && hipMalloc(&L.d_counters, effort_ctx::kMaxTiles * 4) == hipSuccess &&
-              hipMalloc(&L.d_sliceCounts, effort_ctx::kMaxSlices * 4) == hipSuccess && hipMalloc(&L.d_queue, kQueueWords * 4) == hipSuccess;
+              hipMalloc(&L.d_sliceCounts, effort_ctx::kMaxSlices * 4) == hipSuccess && hipMalloc(&L.d_queue, kQueueWords * 4) == hipSuccess &&
+              hipMalloc(&L.d_named, effort_ctx::kMaxTiles * 8) == hipSuccess;
     if (!ok) return false;
     hipMemset(L.d_slabsNamed, 0xFF, c->slabBytes);
     hipMemset(L.d_counters, 0, effort_ctx::kMaxTiles * 4);
     hipMemset(L.d_sliceCounts, 0, effort_ctx::kMaxSlices * 4);
     hipMemset(L.d_queue, 0, kQueueWords * 4);
+    hipMemset(L.d_named, 0, effort_ctx::kMaxTiles * 8);
     hipMemset(L.d_cutoff, 0, 512);
     hipMemset(L.d_count, 0, 16);
     return true;
@@ -161,7 +164,7 @@ static void pool_put(int device, hipEvent_t e) { if (e) { std::lock_guard<std::m
 static void lane_free(int device, Lane& L) {
     pool_put(device, L.own);
     pool_put(device, L.done);
-    hipFree(L.d_cutoff); hipFree(L.d_count); hipFree(L.d_slabs); hipFree(L.d_slabsNamed); hipFree(L.d_counters); hipFree(L.d_sliceCounts); hipFree(L.d_queue);
+    hipFree(L.d_cutoff); hipFree(L.d_count); hipFree(L.d_slabs); hipFree(L.d_slabsNamed); hipFree(L.d_counters); hipFree(L.d_sliceCounts); hipFree(L.d_queue); hipFree(L.d_named);
     L = Lane();
 }
 
@@ -730,7 +733,7 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
         ga.slabs = L.d_slabs; ga.counters = L.d_counters; ga.sliceCounts = L.d_sliceCounts; ga.cutoff = L.d_cutoff + firstCall;
         ga.tstamp = c->clock ? c->d_tstamp : nullptr;
         ga.ablate = ablate; ga.split = c->splitCutoff ? 1u : 0u; ga.trace = (c->clock && c->trace) ? 1u : 0u;
-        ga.numCU = (uint32_t)c->numCU; ga.queue = L.d_queue;
+        ga.numCU = (uint32_t)c->numCU; ga.queue = L.d_queue; ga.named = L.d_named;
         nGeoms = 0; wg = 0; first = firstCall;
     };
     auto flush = [&]() -> int {                        // one kernel launch for the calls gathered so far
@@ -767,6 +770,8 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
             for (uint32_t i = 0; i < ga.count; i++) ga.call[i].stats = ws[first + i]->means16;
             ga.split |= 4u;
         }
+        // plain grids of the lean instantiation hand their tiles to a NAMED reducer: the slabs live in the lane's sentinel region
+        if (leanGrid && !chain) { ga.slabs = L.d_slabsNamed; ga.split |= 8u; }
         const int frc = fork_lane();
         if (frc != EFFORT_OK) return frc;
         if (chain) {

@@ -347,6 +347,9 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     const uint32_t j0 = s * B;
     const uint32_t nb = min(B, g.inDim - j0);
     const uint32_t e = a.expNo ? a.expNo[0] : 0u;
+    // (plain grids' hand-off, see E: the tile's consumption counter as this launch finds it; asked for here, used at the end)
+    uint32_t namedC0 = 0u;
+    if constexpr (!PERSIST) { if (tid == 0) namedC0 = (uint32_t)__hip_atomic_load(ga.named + (a.tileOff + t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
     // ---- A. everything the selection needs lands in LDS (stage_issue): the row means of the candidate slots, the slice of v
     if (!staged) stage_issue<FMT, W, COMPACT, CHAIN>(ga, ref, tid, smem, lp, par, CHAIN ? 1u : 3u);
@@ -902,8 +905,20 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     // memory round trip from the last producer's store to the sum, where the ticket protocol has three (drain, ticket, read).
     // Forward progress: the reducer waits only for items handed out BEFORE its own, by queues whose other workgroups never wait
     // for it; the poll is bounded all the same (a slab that never arrives leaves NaNs in out[], loudly, not a hung GPU).
-    constexpr bool NAMED = CHAIN;
+    // Plain grids (the LEAN instantiation: lone calls, the decode loop's small groups) use the same hand-off, with the sentinel
+    // put back by the PRODUCERS instead of the reducer (BY_PRODUCER): a plain grid's kernel ends when its last store has drained,
+    // so 32 slabs reset by one reducer would lengthen the very call the ticket was removed from; a producer's own slab is 4-8 KB.
+    // The tile has a 64-bit word in the lane's scratch: low half = a counter of launches that consumed the tile (never reset),
+    // high half = producers that gave up waiting.  Every workgroup reads the counter when it starts (c0); the reducer adds 1 once
+    // it holds every slab; a producer waits for the counter to move, then stores the sentinel over its slab and leaves.  The wait
+    // is bounded by the device clock (100 us: e.g. the reducer's block found no free slot because other launches' producers hold
+    // them); a producer that gives up adds 1 to the HIGH half with a returning atomic -- one word, so either it sees the reducer's
+    // increment in the value returned (and resets its slab after all), or the reducer sees the producer's in ITS returned value and
+    // resets the tile's slabs itself at the end.  No path leaves a slab without the sentinel, none waits without bound.
+    constexpr bool NAMED = CHAIN || !PERSIST;
+    constexpr bool BY_PRODUCER = NAMED && !PERSIST;
     const bool reducer = NAMED && s == g.slices - 1u;
+    unsigned long long* const tileWord = ga.named + (a.tileOff + t);
     if (!reducer)
     for (int o = tid * 2; o < TILE_F; o += NT * 2) {
         const float s0 = tile_out(o), s1 = tile_out(o + 1);
@@ -936,7 +951,30 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
         atomicMax(&GA_TSTAMP(ga)[1], (unsigned long long)wall_clock64());
     };
     if constexpr (NAMED) {
-        if (!reducer) { flush_stamps(); return; }
+        if (!reducer) {
+            if constexpr (BY_PRODUCER) {
+                if (tid == 0) {
+                    const unsigned long long t0 = wall_clock64();
+                    uint32_t ok = 0u;
+                    do {
+                        if ((uint32_t)__hip_atomic_load(tileWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != namedC0) { ok = 1u; break; }
+                        __builtin_amdgcn_s_sleep(8);
+                    } while (wall_clock64() - t0 < 10000ull);                    // 100 us of the 100 MHz device clock
+                    if (!ok) {                                                   // gave up: say so -- unless the reducer got there meanwhile
+                        const unsigned long long old = __hip_atomic_fetch_add(tileWord, 1ull << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((uint32_t)old != namedC0) { ok = 1u; __hip_atomic_fetch_add(tileWord, ~(1ull << 32) + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                    }
+                    flags[1] = ok;
+                }
+                __syncthreads();
+                if (flags[1]) {
+                    typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+                    u2 sent; sent[0] = sent[1] = kSlabSentinel;
+                    for (int o = tid * 2; o < TILE_F; o += NT * 2) __builtin_amdgcn_raw_buffer_store_b64(sent, srs, (uint32_t)o * 4u, slabOff, kSc1);
+                }
+            }
+            flush_stamps(); return;
+        }
     } else {
         __syncthreads();
         if (tid == 0) {
@@ -1074,11 +1112,27 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
         }
     }
     if constexpr (NAMED) {
-        // the slabs this reducer consumed hold the sentinel again when the launch ends (fire and forget)
-        u4v sent; sent[0] = sent[1] = sent[2] = sent[3] = kSlabSentinel;
-        for (uint32_t o4 = (uint32_t)tid; o4 < (uint32_t)(TILE_F / 4); o4 += (uint32_t)NT)
-            for (uint32_t sl = 0; sl + 1u < g.slices; sl++)
-                __builtin_amdgcn_raw_buffer_store_b128(sent, srs, t * (uint32_t)(TILE_F * 4) + o4 * 16u, sl * sliceStride, kSc1);
+        bool resetAll = !BY_PRODUCER;
+        if constexpr (BY_PRODUCER) {
+            // every thread holds its sums: the producers may put the sentinel back (the counter moves on); the value returned tells
+            // whether one of them gave up waiting -- then the tile's slabs are reset here
+            __syncthreads();
+            if (tid == 0) {
+                const unsigned long long old = __hip_atomic_fetch_add(tileWord, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t gaveUp = (uint32_t)(old >> 32);
+                if (gaveUp) __hip_atomic_fetch_add(tileWord, ~((unsigned long long)gaveUp << 32) + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                flags[1] = gaveUp;
+            }
+            __syncthreads();
+            resetAll = flags[1] != 0u;
+        }
+        if (resetAll) {
+            // the slabs this reducer consumed hold the sentinel again when the launch ends (fire and forget)
+            u4v sent; sent[0] = sent[1] = sent[2] = sent[3] = kSlabSentinel;
+            for (uint32_t o4 = (uint32_t)tid; o4 < (uint32_t)(TILE_F / 4); o4 += (uint32_t)NT)
+                for (uint32_t sl = 0; sl + 1u < g.slices; sl++)
+                    __builtin_amdgcn_raw_buffer_store_b128(sent, srs, t * (uint32_t)(TILE_F * 4) + o4 * 16u, sl * sliceStride, kSc1);
+        }
     }
     if (rstamp) GA_TSTAMP(ga)[24] = wall_clock64();
     if (tid == 0) {
@@ -1271,6 +1325,7 @@ static hipError_t launch_mul_t(const GroupKArgs& gaIn, hipStream_t st) {
     if (lds > kMaxLdsBytes) return hipErrorInvalidValue;
     const bool compact = (ga.split & 4u) != 0u;                   // (api.hip: persistent FP16 launches of plain calls)
     const bool lean = kLean && !ga.persistent && !ga.tstamp && !ga.ablate;
+    if (lean != ((ga.split & 8u) != 0u)) return hipErrorInvalidValue;      // (the lean kernels' hand-off needs the sentinel slabs: api.hip decides with the same test)
     if (compact && (FMT != kFp16 || (fusedAny && !lean))) return hipErrorInvalidValue;
     const dim3 gd(grid), bd(64 * W);
     if constexpr (kLean) {

@@ -88,6 +88,7 @@ struct GroupKArgs {
     uint32_t ablate;               // profiling only (env EFFORT_ABLATE): 2 = no last-arriver reduce, 4 = no row streaming, 8 = no selection, 32 = never wait for a cutoff job
     uint32_t split;                // bit 0: the cutoffs were evaluated by find_cutoff_group_kernel (split mode), else in the multiply kernel;
                                    // bit 2: FP16 calls' `stats` point at the compact row means (u16 per bucket row), not at the f16x4 stats;
+                                   // bit 3: the launch's slabs are the lane's SENTINEL region (plain grids of the lean kernels: named reducer);
                                    // bit 4: CHAIN launch -- the calls come in stages, a stage's calls read what earlier stages wrote
     uint32_t cutJobs;              // persistent launches: the first cutJobs items (a multiple of 8 >= count) are cutoff jobs, one per call
     uint32_t trace;                // profiling only: 1 = every item leaves a 64-byte record (who ran it, where, its phase stamps) at tstamp + kTraceOff
@@ -101,6 +102,7 @@ struct GroupKArgs {
     uint32_t* counters;
     uint32_t* sliceCounts;
     float* cutoff;                 // [count]: BucketMul.cutoff of every call
+    unsigned long long* named;     // [kMaxTiles] per tile of the launch: launches that consumed it | producers that gave up << 32 (plain grids' hand-off, bucket_mul.hip E)
     unsigned long long* tstamp;    // nullable profiling stamps: [0]=min start, [1]=max end, [2]=sum, [3]=launches, [16..] phases
     uint16_t wgEnd8[kMaxGroup];    // exclusive end of each call's item range, in units of 8 items (the ranges are multiples of 8)
     uint16_t stageTiles[kMaxStages];   // chain launches: column tiles of each stage (all its calls; <= 64)

@@ -146,13 +146,23 @@ class ExpertWeights:
         selects the same rows), the full matrix's fixed-point bound (every rank rounds on the same grid), and for Q4 the slice of
         the outlier index on those outputs.  Any split into an even number of columns per rank is valid (the multiply masks a
         ragged last tile: 11008 outputs over 8 ranks = 86 columns each).  Keep the full bundle alive while the shard is used."""
-        from .sharded import shard_outliers
+        from .sharded import shard_columns, shard_outliers
         lib = _lib.lib()
+        unit = 32 if self.q4 else 16
+        if (self.buckets.shape[2] // world) % 2:
+            # an ODD number of columns per rank (Q4 only: 11008 outputs over 8 ranks = 43 words): a view would start rows on odd
+            # 16-bit words, which the dword row loads cannot take -- this rank gets its own dense copy of its columns instead
+            b = shard_columns(self.buckets, rank, world)
+            per = b.shape[2]
+            sh = ExpertWeights(b, self.stats, self.probes, self.inSize, per * unit, self.percentLoad, self.numExperts,
+                               outliers=shard_outliers(self.outliers, rank, world, self.outSize),
+                               core=None if self.core is None else self.core[rank * per * unit:(rank + 1) * per * unit], q4=self.q4)
+            sh.set_rank_bound(self.rank_bound())
+            return sh
         h = lib.effort_weights_column_shard(self.handle, int(rank), int(world))
         if not h:
             detail = lib.effort_last_error(self._gpu.ctx)
             raise _lib.EffortError(-2, "ExpertWeights.column_shard", detail.decode() if detail else "")
-        unit = 32 if self.q4 else 16
         per = self.buckets.shape[2] // world
         sh = object.__new__(ExpertWeights)
         sh.__dict__.update(self.__dict__)
