@@ -93,6 +93,7 @@ _SIGS = {
     "effort_cosine": (C.c_int, [_P, _P, _P, C.c_int, C.POINTER(C.c_float)]),
     "effort_set_split_cutoff": (C.c_int, [_P, C.c_int]),
     "effort_set_chain_tuning": (C.c_int, [_P, C.c_int]),
+    "effort_set_q4_byte_acc": (C.c_int, [_P, C.c_int]),
     "effort_set_tuning": (C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
     "effort_enable_kernel_timing": (C.c_int, [_P, C.c_int]),
     "effort_debug_stamps": (C.c_int, [_P, C.POINTER(C.c_ulonglong)]),

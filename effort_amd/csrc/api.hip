@@ -69,6 +69,7 @@ struct effort_ctx {
     bool denseRocblas = false;        // effort_set_dense_backend: basicMul through rocBLAS instead of dense_gemv_kernel
     // tuning overrides (0 = heuristic)
     int tuneW = 0, tuneE = 0, tuneS = 0;
+    bool q4ByteAcc = false;       // Q4 launches accumulate per byte (Format kQ4B; effort_set_q4_byte_acc)
     int chainSliceMult = 1;       // chain launches: row slices per call = the heuristic's x this (effort_set_chain_tuning)
     bool splitCutoff = false;     // run findCutoff32 as its own 1-workgroup kernel instead of inside every workgroup
     // optional per-kernel timing
@@ -530,6 +531,7 @@ static uint32_t pick_slices(const effort_ctx* c, const effort_w* w, int groupSiz
 // 4096x11008: 8 calls 7.9 vs 8.4 us/call, 16 calls 7.2 vs 6.6, 32 calls 5.7 vs 6.3).  Q4 (a word = 4 sub-buckets): 1, or 2 from 8 calls on.
 static int pick_elems(const effort_ctx* c, Format fmt, int n, const effort_w* const* ws) {
     if (c->tuneE) return c->tuneE;
+    if (fmt != kFp16 && c->q4ByteAcc) return 1;     // (byte-indexed accumulators: 128 KB for a 64-column tile)
     if (fmt != kFp16) return n >= 8 ? 2 : 1;        // measured, 4096x11008 Q4: 32 calls 5.3 vs 6.4 us/call, 8 calls 8.3 vs 8.3, 2 calls 20.8 vs 18.8
     if (c->tuneS) return 2;
     auto group_tiles = [&](int E) {
@@ -568,8 +570,9 @@ static int pick_elems(const effort_ctx* c, Format fmt, int n, const effort_w* co
 }
 
 static int choose_geom(const effort_ctx* c, const effort_w* w, int groupSize, int E, MulGeom* g, int* Wout, int* Eout, uint32_t sliceMult = 1, uint32_t groupTiles = 0) {
-    const int W = c->tuneW ? c->tuneW : 8;                 // 8 waves per workgroup
-    if (!supported(W, E)) return EFFORT_ERR_ARG;
+    const Format lfmt = (w->fmt == kQ4 && c->q4ByteAcc) ? kQ4B : w->fmt;      // the launch's variant of the format
+    const int W = c->tuneW ? c->tuneW : (lfmt == kQ4B ? 16 : 8);               // 8 waves per workgroup (byte-indexed Q4: one 16-wave workgroup per CU)
+    if (!supported(W, E) || (lfmt == kQ4B && (E != 1 || (W != 8 && W != 16)))) return EFFORT_ERR_ARG;
     const uint32_t nacc = w->fmt == kFp16 ? 16 : 32;
     g->inDim = w->inDim; g->outDim = w->outDim; g->cols = w->cols; g->rowsPerIn = w->rowsPerIn;
     g->expertRows = w->rowsPerIn * w->inDim; g->numExperts = w->numExperts;
@@ -593,7 +596,7 @@ static int choose_geom(const effort_ctx* c, const effort_w* w, int groupSize, in
         g->slices = (w->inDim + g->sliceRows - 1) / g->sliceRows;
         g->sliceLog2 = 0; while ((1u << g->sliceLog2) < g->sliceRows) g->sliceLog2++;
         g->slots = w->fmt == kFp16 ? (g->rowsPerIn << g->sliceLog2) : g->sliceRows * 8u;
-        const size_t lds = bucket_mul_lds_bytes(w->fmt, W, E, *g);
+        const size_t lds = bucket_mul_lds_bytes(lfmt, W, E, *g);
         const bool fits = lds <= ldsMax && g->slots <= maxCand && (size_t)g->slots * 4 + (size_t)g->sliceRows * 8 + 1024 <= 65536 &&   // staged regions below 64 KB
                           (w->fmt == kFp16 ? (1u << g->sliceLog2) <= 64u * (uint32_t)W : g->sliceRows <= 128u * (uint32_t)W);   // a thread stages one (Q4: two) inputs of the slice
         const size_t slab = (size_t)g->slices * g->tiles * tileFloats * 4;
@@ -738,7 +741,8 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
     };
     auto flush = [&]() -> int {                        // one kernel launch for the calls gathered so far
         // grid: persistent workgroups once the items outnumber what the chip holds at R per CU
-        const uint32_t R = c->persistent < 0 ? 2u : (uint32_t)c->persistent;
+        const Format lfmt = (fmt == kQ4 && c->q4ByteAcc) ? kQ4B : fmt;
+        const uint32_t R = c->persistent < 0 ? (lfmt == kQ4B ? 1u : 2u) : (uint32_t)c->persistent;
         ga.persistent = (R && wg > ga.numCU * R) ? R : 0u;
         // persistent launches evaluate every call's cutoff ONCE, in a job of its own at the head of the item queues, instead
         // of once per workgroup and call (measured: 6.8 of the ~90 us of an item at 32 calls per launch)
@@ -770,8 +774,8 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
             for (uint32_t i = 0; i < ga.count; i++) ga.call[i].stats = ws[first + i]->means16;
             ga.split |= 4u;
         }
-        // plain grids of the lean instantiation hand their tiles to a NAMED reducer: the slabs live in the lane's sentinel region
-        if (leanGrid && !chain) { ga.slabs = L.d_slabsNamed; ga.split |= 8u; }
+        // (A/B builds only -- EFFORT_LEAN_NAMED, measured slower: bucket_mul.hip, E)
+        if (leanGrid && !chain && bucket_mul_lean_named()) { ga.slabs = L.d_slabsNamed; ga.split |= 8u; }
         const int frc = fork_lane();
         if (frc != EFFORT_OK) return frc;
         if (chain) {
@@ -787,7 +791,7 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
             return EFFORT_OK;
         }
         if (c->splitCutoff && !(ablate & 1u)) HIP_TRY(c, launch_find_cutoff_group(ga, st));
-        HIP_TRY(c, launch_bucket_mul(fmt, W, E, ga, st));
+        HIP_TRY(c, launch_bucket_mul(lfmt, W, E, ga, st));
         return EFFORT_OK;
     };
     uint32_t groupTiles = 0;
@@ -1146,6 +1150,12 @@ extern "C" int effort_set_persistent(effort_ctx* c, int wgPerCU) {
 extern "C" int effort_debug_hook_lane(effort_ctx* c, int lane) {
     if (!c || lane < 0 || lane >= c->nLanes) return EFFORT_ERR_ARG;
     c->lastLane = lane;
+    return EFFORT_OK;
+}
+
+extern "C" int effort_set_q4_byte_acc(effort_ctx* c, int on) {
+    if (!c) return EFFORT_ERR_ARG;
+    c->q4ByteAcc = on != 0;
     return EFFORT_OK;
 }
 

@@ -94,6 +94,10 @@ constexpr int kRowAux = EFFORT_ROW_AUX;
 #define GA_TRACE(ga) (PERSIST ? (ga).trace : 0u)
 #endif
 constexpr uint32_t kMaxLdsBytes = 160u * 1024u - 1024u;     // dynamic LDS a launch may ask for: a gfx950 CU's 160 KB less the kernel's static words (rounded up generously)
+#ifndef EFFORT_LEAN_NAMED
+#define EFFORT_LEAN_NAMED 0
+#endif
+constexpr bool kLeanNamed = EFFORT_LEAN_NAMED != 0;   // plain grids hand their tiles to a named reducer too (A/B builds; see mul_item, E: measured slower)
 constexpr uint32_t kSlabSentinel = 0xFFFFFFFFu;      // NAMED hand-off: what every slab word holds between launches (a NaN no partial sum can be)
 constexpr int kSc1 = 16;     // buffer aux bit: sc1 = write-through store / L1-bypassing load (cross-XCD visible)
 
@@ -102,12 +106,19 @@ template <int FMT> struct Fmt;
 // Q4 keeps TWO accumulators per output, one for each sign nibble (slot = sub-bucket*16 + the whole 4-bit nibble): every
 // nibble then adds the same +d and the address comes straight out of the nibble -- 3 instructions per nibble instead of
 // 6 (no sign select) -- and the hand-off subtracts the planes.
-template <> struct Fmt<kFp16> { static constexpr int kAcc = 16, kSlots = 16; };
-template <> struct Fmt<kQ4> { static constexpr int kAcc = 32, kSlots = 64; };
+// kStream: LDS accumulators per u16 column WHILE the rows stream (= kSlots, except for the byte-indexed Q4 variant).
+template <> struct Fmt<kFp16> { static constexpr int kAcc = 16, kSlots = 16, kStream = 16; };
+template <> struct Fmt<kQ4> { static constexpr int kAcc = 32, kSlots = 64, kStream = 64; };
+// kQ4B -- ONE LDS atomic per BYTE of a word instead of one per nibble: the two nibbles of a byte share an accumulator indexed by
+// the byte's value (2 x 256 slots per column: 128 KB for a 64-column tile, one workgroup per CU), and after the last row the 512
+// byte sums are FOLDED into the 64 nibble sums the rest of the item works with: slot(nibble position qi, value n) = the sum over
+// the sixteen values m of the byte's other nibble.  Half the atomics of kQ4 for 2 x 16 LDS reads per output at the end.
+template <> struct Fmt<kQ4B> { static constexpr int kAcc = 32, kSlots = 64, kStream = 512; };
 
 template <int FMT> struct MeanT;                       // what the staged row means are kept as in LDS
 template <> struct MeanT<kFp16> { typedef uint16_t type; };    // f16 bits (stats lane .w)
 template <> struct MeanT<kQ4> { typedef float type; };        // f32 (stats lane .y)
+template <> struct MeanT<kQ4B> { typedef float type; };
 
 // One lane's piece of a bucket row: E u16 words.
 template <int E> struct Piece;
@@ -159,7 +170,7 @@ __host__ __device__ inline LdsPlan plan_lds(const MulGeom* geoms, int nGeoms) {
         slots = slots > g.slots ? slots : g.slots;
         const uint32_t vr = align_up(g.sliceRows, 64);      // the loads land a whole wave (64 dwords) at a time
         vrows = vrows > vr ? vrows : vr;
-        if (FMT == kQ4) { const uint32_t x = ol_scratch_bytes<E>(g); ol = ol > x ? ol : x; }
+        if (FMT != kFp16) { const uint32_t x = ol_scratch_bytes<E>(g); ol = ol > x ? ol : x; }
     }
     LdsPlan p;
     uint32_t o = 0;
@@ -167,8 +178,8 @@ __host__ __device__ inline LdsPlan plan_lds(const MulGeom* geoms, int nGeoms) {
     p.offV[0] = o; o += vrows * 4;
     p.offV[1] = FMT == kFp16 ? o : p.offV[0];
     if (FMT == kFp16) o += vrows * 4;
-    if (FMT == kQ4 && o < ol) o = align_up(ol, 16);
-    p.offA = o; o += (uint32_t)Fmt<FMT>::kSlots * E * 64 * 4;
+    if (FMT != kFp16 && o < ol) o = align_up(ol, 16);
+    p.offA = o; o += (uint32_t)Fmt<FMT>::kStream * E * 64 * 4;
     p.offL = o; o += align_up(slots * 2, 16);
     const uint32_t tbl = cutoff_table_bytes(64 * W);        // (>= the tile reduction's [G][tileFloats] partial sums)
     if (o < p.offA + tbl) o = p.offA + tbl;
@@ -305,7 +316,8 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
                                          float& cachedCutoff, const uint32_t par, const bool staged, const bool firstItem, Prefetch prefetch) {
     constexpr int NACC = Fmt<FMT>::kAcc;
     constexpr int TILE_F = NACC * E * 64;                    // outputs of a tile (slab / out[] granularity)
-    constexpr int TILE_L = Fmt<FMT>::kSlots * E * 64;        // LDS accumulators of a tile
+    constexpr int TILE_L = Fmt<FMT>::kStream * E * 64;       // LDS accumulators of a tile while the rows stream
+    constexpr int TILE_LF = Fmt<FMT>::kSlots * E * 64;       // ... once they are in (kQ4B folds 512 byte slots per column into 64)
     constexpr int NT = 64 * W;
     constexpr int VPT = 4096 / NT;
     constexpr int KB = batch_rows<E>();                      // bucket rows per batch; two batches in flight per wave
@@ -349,7 +361,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     const uint32_t e = a.expNo ? a.expNo[0] : 0u;
     // (plain grids' hand-off, see E: the tile's consumption counter as this launch finds it; asked for here, used at the end)
     uint32_t namedC0 = 0u;
-    if constexpr (!PERSIST) { if (tid == 0) namedC0 = (uint32_t)__hip_atomic_load(ga.named + (a.tileOff + t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    if constexpr (kLeanNamed && !PERSIST) { if (tid == 0) namedC0 = (uint32_t)__hip_atomic_load(ga.named + (a.tileOff + t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
     // ---- A. everything the selection needs lands in LDS (stage_issue): the row means of the candidate slots, the slice of v
     if (!staged) stage_issue<FMT, W, COMPACT, CHAIN>(ga, ref, tid, smem, lp, par, CHAIN ? 1u : 3u);
@@ -525,6 +537,10 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
         cutoff = a_cutoff[0];
         __syncthreads();                                             // publishes vblk / wbound / the list length
     }
+    if constexpr (FMT == kQ4B) {                                     // (128 KB: sixteen bytes a store)
+        uint4* const acc4 = reinterpret_cast<uint4*>(acc);
+        for (int i = tid; i < TILE_L / 4; i += NT) acc4[i] = make_uint4(0, 0, 0, 0);
+    } else
     for (int i = tid; i < TILE_L; i += NT) acc[i] = 0;               // the table is dead: zero the tile (barrier in C)
     // Fixed-point scale of this workgroup's tile.  Every product is |v_j| * |w| with |w| <= (max |w| of its rank), so
     // every partial sum is bounded by L = (sum over the slice of |v_j|) * (sum over ranks of that rank's max |w|)
@@ -576,7 +592,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
         for (int u = 0; u < 4; u++) {
             const uint32_t c = min((uint32_t)((blk * 4 + u) * NT + tid), slotCap);
             if constexpr (COMPACT && FMT == kFp16) { mraw[u] = (uint32_t)m16[c] << 16; vq[u] = 0.0f; }      // compact means: u16 per slot, kept in the high half
-            else { mraw[u] = m32[c]; vq[u] = FMT == kQ4 ? vblk[min(c >> 3, nb - 1u)] : 0.0f; }
+            else { mraw[u] = m32[c]; vq[u] = FMT != kFp16 ? vblk[min(c >> 3, nb - 1u)] : 0.0f; }
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -677,6 +693,17 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
                 else asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[0,1,0]\n\tv_cvt_rpi_i32_f32 %0, %0" : "=v"(qv) : "v"(dd), "v"(dw));
                 __hip_atomic_fetch_add((lds_i*)(size_t)a2 + j * 64, qv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
+        } else if (FMT == kQ4B) {
+            // one atomic per BYTE: slot = byte index (0 low, 1 high) * 256 + the byte's value; the second byte's plane lies 64 KB
+            // above the first -- beyond a DS instruction's 16-bit offset, hence a base of its own
+            static_assert(FMT != kQ4B || E == 1, "byte-indexed Q4: 64-column tiles");
+            const int di = __float_as_int(dd);
+            const uint32_t x = pc.word(0);
+            uint32_t a0, a1;
+            asm("v_bfe_u32 %0, %1, 0, 8\n\tv_lshl_add_u32 %0, %0, 8, %2" : "=&v"(a0) : "v"(x), "v"(accB));
+            asm("v_bfe_u32 %0, %1, 8, 8\n\tv_lshl_add_u32 %0, %0, 8, %2" : "=&v"(a1) : "v"(x), "v"(accB + 65536u));
+            __hip_atomic_fetch_add((lds_i*)(size_t)a0, di, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add((lds_i*)(size_t)a1, di, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         } else {
             // bucketMulQ4.metal:76-81: low nibble first <-> sub-bucket 3,2,1,0; out += (n&8) ? -d : d.  Here: plane
             // (n&8) of slot (sub-bucket, n&7) += d; the planes are subtracted at the hand-off.
@@ -740,6 +767,30 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     // (measured too: everything BUT this loop at raised priority -- no effect, 173.9 vs 173.5 us per 32-call launch)
     if (!asked) asked = prefetch();            // (a wave without rows; wave 0 always gets an answer: it is the one that pulls)
     __syncthreads();                           // every wave's atomics have landed in the tile
+    if constexpr (FMT == kQ4B) {
+        // fold: the nibble at position qi (0 = lowest) of a word with value n collected, spread over the sixteen values m of its
+        // byte's other nibble, in the byte slots (qi >> 1) * 256 + (qi odd ? n << 4 | m : m << 4 | n); its sum goes where the
+        // nibble-indexed scatter of kQ4 would have put it: slot (3 - qi) * 16 + n.  Every thread holds its sums across the barrier
+        // (the folded tile overwrites the first 16 KB of the byte tile).
+        constexpr int PER = 64 * 64 / NT;
+        int res[PER];
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            const int s64 = (tid >> 6) + (NT / 64) * k, qi = s64 >> 4, nn = s64 & 15;
+            const int* const src = acc + ((qi >> 1) * 256) * 64 + lane;
+            int sum = 0;
+#pragma unroll
+            for (int m = 0; m < 16; m++) sum += src[((qi & 1) ? (nn << 4 | m) : (m << 4 | nn)) * 64];
+            res[k] = sum;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            const int s64 = (tid >> 6) + (NT / 64) * k, qi = s64 >> 4, nn = s64 & 15;
+            acc[((3 - qi) * 16 + nn) * 64 + lane] = res[k];
+        }
+        __syncthreads();
+    }
     if (stamp) GA_TSTAMP(ga)[20] = wall_clock64();
     if (wstamp) ph[4] = wall_clock64();
 
@@ -759,7 +810,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     const uint32_t olPer = ol_outputs_per_item<E>(g), olLoOff = align_up(olPer * 4u, 16u) / 4u;
     bool olAny = false;
     float olUnscale = 0.0f;
-    if constexpr (FMT == kQ4) {
+    if constexpr (FMT != kFp16) {
         olAny = a.ol.blockPtr != nullptr;                                                  // uniform per call
         if (olAny) {
             const OutlierIndex& ol = a.ol;
@@ -915,7 +966,13 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     // them); a producer that gives up adds 1 to the HIGH half with a returning atomic -- one word, so either it sees the reducer's
     // increment in the value returned (and resets its slab after all), or the reducer sees the producer's in ITS returned value and
     // resets the tile's slabs itself at the end.  No path leaves a slab without the sentinel, none waits without bound.
-    constexpr bool NAMED = CHAIN || !PERSIST;
+    // MEASURED, AND OFF (EFFORT_LEAN_NAMED = 0): correct -- the whole -m gpu suite passes with it -- but every plain-grid launch got
+    // 2.3-3.6 us SLOWER (round 4, one box: 4096 -> 4096 lone 18.4 -> 20.7 us, w1|w3 27.3 -> 29.9, the decode loop 315 -> 288
+    // tokens/s at 25 %): the kernel now ends when the last PRODUCER has seen the counter move and drained its reset stores, two
+    // dependent round trips after the reducer's slab loads, where the ticket protocol ends one round trip after them (out[]
+    // drained); what the ticket and the drain cost before the reduction is paid by the last arriver only and was smaller than
+    // that.  Plain grids keep the ticket; chain launches (persistent: nobody waits to leave) keep the named reducer.
+    constexpr bool NAMED = CHAIN || (kLeanNamed && !PERSIST);
     constexpr bool BY_PRODUCER = NAMED && !PERSIST;
     const bool reducer = NAMED && s == g.slices - 1u;
     unsigned long long* const tileWord = ga.named + (a.tileOff + t);
@@ -1000,8 +1057,9 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     constexpr int G = NT / kCols4 >= 2 ? NT / kCols4 : 1;
     // [G][TILE_F] partial sums of the thread groups, BEHIND the accumulator tile (a named reducer still reads its own tile from
     // there; the list and the rest of the cutoff table's region are free: G * TILE_F * 4 + the tile <= the table, see plan_lds)
-    float* const gpart = reinterpret_cast<float*>(smem + offA + (uint32_t)TILE_L * 4u);
-    static_assert(G == 1 || (uint32_t)TILE_L * 4u + (uint32_t)G * TILE_F * 4u <= cutoff_table_bytes(NT), "the thread groups' partial sums must fit behind the tile");
+    float* const gpart = reinterpret_cast<float*>(smem + offA + (uint32_t)TILE_LF * 4u);
+    static_assert(G == 1 || (uint32_t)TILE_LF * 4u + (uint32_t)G * TILE_F * 4u <= (cutoff_table_bytes(NT) > (uint32_t)TILE_L * 4u ? cutoff_table_bytes(NT) : (uint32_t)TILE_L * 4u),
+                  "the thread groups' partial sums must fit behind the tile");
     auto reduce_tile = [&](auto kc) {
         constexpr int kRed = decltype(kc)::value;          // 16-byte slab loads in flight per thread
         const int grp = G > 1 ? tid / kCols4 : 0;
@@ -1325,7 +1383,7 @@ static hipError_t launch_mul_t(const GroupKArgs& gaIn, hipStream_t st) {
     if (lds > kMaxLdsBytes) return hipErrorInvalidValue;
     const bool compact = (ga.split & 4u) != 0u;                   // (api.hip: persistent FP16 launches of plain calls)
     const bool lean = kLean && !ga.persistent && !ga.tstamp && !ga.ablate;
-    if (lean != ((ga.split & 8u) != 0u)) return hipErrorInvalidValue;      // (the lean kernels' hand-off needs the sentinel slabs: api.hip decides with the same test)
+    if ((lean && kLeanNamed) != ((ga.split & 8u) != 0u)) return hipErrorInvalidValue;      // (a named hand-off needs the sentinel slabs: api.hip decides with the same test)
     if (compact && (FMT != kFp16 || (fusedAny && !lean))) return hipErrorInvalidValue;
     const dim3 gd(grid), bd(64 * W);
     if constexpr (kLean) {
@@ -1398,6 +1456,7 @@ static hipError_t prepare_t() {
     }
     return err;
 }
+bool bucket_mul_lean_named() { return kLeanNamed; }
 hipError_t bucket_mul_prepare_device() {
     hipError_t err = hipSuccess;
     {
@@ -1408,6 +1467,8 @@ hipError_t bucket_mul_prepare_device() {
 #define EFFORT_CASE(w, e) if (err == hipSuccess) err = prepare_t<kFp16, e, w>(); if (err == hipSuccess) err = prepare_t<kQ4, e, w>();
     EFFORT_GEOMS(EFFORT_CASE)
 #undef EFFORT_CASE
+    if (err == hipSuccess) err = prepare_t<kQ4B, 1, 16>();
+    if (err == hipSuccess) err = prepare_t<kQ4B, 1, 8>();
     return err;
 }
 
@@ -1420,10 +1481,16 @@ static hipError_t launch_mul_fmt(int W, int E, const GroupKArgs& a, hipStream_t 
 }
 
 hipError_t launch_bucket_mul(Format fmt, int W, int E, const GroupKArgs& a, hipStream_t st) {
+    if (fmt == kQ4B) {                                       // byte-indexed Q4: 64-column tiles, 16 or 8 waves
+        if (E == 1 && W == 16) return launch_mul_t<kQ4B, 1, 16>(a, st);
+        if (E == 1 && W == 8) return launch_mul_t<kQ4B, 1, 8>(a, st);
+        return hipErrorInvalidValue;
+    }
     return fmt == kFp16 ? launch_mul_fmt<kFp16>(W, E, a, st) : launch_mul_fmt<kQ4>(W, E, a, st);
 }
 
 size_t bucket_mul_lds_bytes(Format fmt, int W, int E, const MulGeom& g) {
+    if (fmt == kQ4B) return E != 1 ? 0 : W == 16 ? plan_lds<kQ4B, 1, 16>(&g, 1).total : W == 8 ? plan_lds<kQ4B, 1, 8>(&g, 1).total : 0;
 #define EFFORT_CASE(w, e)                                                                     \
     if (W == w && E == e)                                                                     \
         return fmt == kFp16 ? plan_lds<kFp16, e, w>(&g, 1).total : plan_lds<kQ4, e, w>(&g, 1).total;

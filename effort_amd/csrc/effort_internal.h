@@ -10,7 +10,9 @@ constexpr int kWave = 64;            // CDNA4 wavefront
 constexpr int kProbes = 4096;        // bucketMul.swift:17
 constexpr float kCutoffScale = 100000.0f;   // CUTOFF_SCALE, bucketMul.metal:33
 
-enum Format : int { kFp16 = 0, kQ4 = 1 };
+enum Format : int { kFp16 = 0, kQ4 = 1,
+                    kQ4B = 2 };     // a LAUNCH variant of Q4 (handles are kQ4): the streaming phase accumulates per BYTE (two nibbles, one LDS atomic) into 512
+                                    // slots per column and folds them to the 64 nibble slots afterwards (bucket_mul.hip; effort_set_q4_byte_acc)
 
 // Geometry of one multiply launch (see DESIGN.md "bucket_mul kernel").
 struct MulGeom {
@@ -180,6 +182,7 @@ hipError_t launch_find_cutoff(const float* v, const uint16_t* probes, const uint
 
 // Returns hipErrorInvalidValue for unsupported (fmt, W, E).
 hipError_t launch_bucket_mul(Format fmt, int wavesPerGroup, int elemsPerLane, const GroupKArgs& ga, hipStream_t st);
+bool bucket_mul_lean_named();               // A/B builds (EFFORT_LEAN_NAMED): plain grids use the named-reducer hand-off
 hipError_t bucket_mul_prepare_device();     // once per device: the kernels may use the whole LDS (hipFuncSetAttribute)
 hipError_t launch_bucket_mul_chain(const GroupKArgs& ga, hipStream_t st);   // FP16 calls in stages (GroupKArgs::split bit 4)
 hipError_t launch_find_cutoff_group(const GroupKArgs& ga, hipStream_t st);    // ga.cutoff[i] of every call
