@@ -381,6 +381,7 @@ static int copy_aligned(effort_w* w) {
 }
 extern "C" int effort_weights_refresh(effort_w* w) {
     if (!w || !w->ctx) return EFFORT_ERR_ARG;
+    if (w->view) return fail(w->ctx, EFFORT_ERR_ARG, "effort_weights_refresh: a column shard takes its bound from the full handle -- refresh that one and shard again");
     hipSetDevice(w->ctx->device);
     int rc = join_lanes(w->ctx);                 // multiplies still in flight on the lanes read what is recomputed here
     if (rc == EFFORT_OK) rc = register_bound(w->ctx, w);          // in place: graphs captured earlier keep valid pointers

@@ -1009,7 +1009,11 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     };
     if constexpr (NAMED) {
         if (!reducer) {
+#ifdef EFFORT_NAMED_NO_RESET        // (timing-only A/B build: nobody puts the sentinel back -- WRONG results from the second launch on; the upper bound of what a named reducer can gain)
+            if constexpr (false) {
+#else
             if constexpr (BY_PRODUCER) {
+#endif
                 if (tid == 0) {
                     const unsigned long long t0 = wall_clock64();
                     uint32_t ok = 0u;
@@ -1171,7 +1175,11 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     }
     if constexpr (NAMED) {
         bool resetAll = !BY_PRODUCER;
+#ifdef EFFORT_NAMED_NO_RESET
+        if constexpr (false) {
+#else
         if constexpr (BY_PRODUCER) {
+#endif
             // every thread holds its sums: the producers may put the sentinel back (the counter moves on); the value returned tells
             // whether one of them gave up waiting -- then the tile's slabs are reset here
             __syncthreads();

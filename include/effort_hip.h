@@ -213,7 +213,8 @@ EFFORT_API int effort_group_cutoff(effort_ctx* ctx, int idx, float* host_out);
  *     registered bundle, i.e. outputs [rank*outDim/world, ...), as a VIEW of the full handle's buffers (no copy; C/world must be
  *     even); stats and probes are shared -- they are row-global, so every rank computes the same cutoff and selects the same rows
  *     -- and the shard takes the full matrix's fixed-point bound.  Q4: with the slice of the outlier index on those outputs.
- *     Multiply it like any handle; free it BEFORE the full handle.
+ *     Multiply it like any handle; free it BEFORE the full handle; after rewriting weights in place refresh the FULL handle and
+ *     shard again (effort_weights_refresh refuses a shard).
  *   effort_comm_unique_id: rank 0 makes the 128-byte id, the host program ships it to the other ranks by its own means;
  *   effort_comm_create(ctx, rank, world, id): collective over the world (ncclCommInitRank); one communicator per context;
  *   effort_allgather_outputs(ctx, send, recv, count): recv f32 [world][count] = every rank's `count` outputs, enqueued on the
