@@ -166,12 +166,10 @@ hipError_t launch_convert_fp16(const uint16_t* W, uint32_t outDim, uint32_t inDi
     uint32_t P = 1; while (P < outDim) P <<= 1;
     const uint32_t C = outDim / kB;
     const uint32_t lds = P * 4 + C * (kB + 1) * 2 + outDim * 2 + 16;
-    static uint32_t maxSet = 0;
-    if (lds > maxSet) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sort_bucketize_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 160u * 1024u - 64u) return hipErrorInvalidValue;
+    {
+        hipError_t e = allow_full_lds(reinterpret_cast<const void*>(&sort_bucketize_kernel));
         if (e != hipSuccess) return e;
-        maxSet = lds;
     }
     hipLaunchKernelGGL(sort_bucketize_kernel, dim3(inDim), dim3(1024), lds, st, scratchVals, buckets, pitchCols, outDim, inDim, P, status);
     hipLaunchKernelGGL(make_stats_kernel, dim3((inDim * kB + 255) / 256), dim3(256), 0, st, buckets, stats, inDim * kB, C, pitchCols);

@@ -37,30 +37,22 @@ __global__ __launch_bounds__(1024) void find_cutoff_group_kernel(const GroupKArg
     if (threadIdx.x == 0) ga.cutoff[blockIdx.x] = c;
 }
 
-static hipError_t cutoff_attr(const void* fn) {
-    return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kCutoffLdsBytes + cutoff_table_bytes(1024)));
+static hipError_t cutoff_prepare() {       // (both kernels ask for kCutoffLdsBytes + the table of dynamic LDS)
+    hipError_t e = allow_full_lds(reinterpret_cast<const void*>(&find_cutoff_group_kernel));
+    return e != hipSuccess ? e : allow_full_lds(reinterpret_cast<const void*>(&find_cutoff_kernel));
 }
 
 hipError_t launch_find_cutoff_group(const GroupKArgs& ga, hipStream_t st) {
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = cutoff_attr(reinterpret_cast<const void*>(&find_cutoff_group_kernel));
-        if (e != hipSuccess) return e;
-        attr = true;
-    }
+    hipError_t e = cutoff_prepare();
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(find_cutoff_group_kernel, dim3(ga.count), dim3(1024), kCutoffLdsBytes + cutoff_table_bytes(1024), st, ga);
     return hipGetLastError();
 }
 
 hipError_t launch_find_cutoff(const float* v, const uint16_t* probes, const uint32_t* expNo, uint32_t q,
                               float* cutoff, uint32_t* dispatchCount, unsigned long long* tstamp, hipStream_t st) {
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&find_cutoff_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kCutoffLdsBytes + cutoff_table_bytes(1024)));
-        if (e != hipSuccess) return e;
-        attr = true;
-    }
+    hipError_t e = cutoff_prepare();
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(find_cutoff_kernel, dim3(1), dim3(1024), kCutoffLdsBytes + cutoff_table_bytes(1024), st, v, probes, expNo, q, cutoff, dispatchCount, tstamp);
     return hipGetLastError();
 }

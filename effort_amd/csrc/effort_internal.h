@@ -4,6 +4,10 @@
 #include <hip/hip_fp16.h>
 #include <stdint.h>
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 namespace effort {
 
 constexpr int kWave = 64;            // CDNA4 wavefront
@@ -172,6 +176,25 @@ __device__ __forceinline__ float row16_sum_f32(float x) {
     v = EFFORT_FADD_(v, __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false));
 #undef EFFORT_FADD_
     return __int_as_float(v);
+}
+
+// A kernel may ask for up to a CU's whole LDS (less its static words) as dynamic shared memory: set ONCE per (kernel, device) --
+// a function attribute belongs to a device, launches may come from several host threads and devices -- not lazily behind a
+// per-process static.
+inline hipError_t allow_full_lds(const void* fn) {
+    static std::mutex m;
+    static std::map<std::pair<const void*, int>, bool> done;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lk(m);
+    bool& d = done[std::make_pair(fn, dev)];
+    if (d) return hipSuccess;
+    hipFuncAttributes fa;
+    e = hipFuncGetAttributes(&fa, fn);
+    if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160u * 1024u - (uint32_t)fa.sharedSizeBytes));
+    if (e == hipSuccess) d = true;
+    return e;
 }
 
 // ---- launchers (one per translation unit) ---------------------------------------------------

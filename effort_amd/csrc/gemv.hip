@@ -93,11 +93,9 @@ bool dense_gemv_supported(uint32_t inDim, uint32_t outDim) {
 template <int ROWS>
 static hipError_t launch_dense_gemv_t(const uint16_t* W, const float* v, float* out, uint32_t inDim, uint32_t outDim, hipStream_t st) {
     const uint32_t lds = (inDim + 511u) / 512u * 512u * 2u;
-    static uint32_t maxSet = 48u * 1024u;          // per instantiation
-    if (lds > maxSet) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_gemv_kernel<ROWS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 48u * 1024u) {
+        hipError_t e = allow_full_lds(reinterpret_cast<const void*>(&dense_gemv_kernel<ROWS>));
         if (e != hipSuccess) return e;
-        maxSet = lds;
     }
     const uint32_t rowsPerWg = kGemvWaves * ROWS;
     hipLaunchKernelGGL(dense_gemv_kernel<ROWS>, dim3((outDim + rowsPerWg - 1) / rowsPerWg), dim3(64 * kGemvWaves), lds, st, W, v, out, inDim, outDim);
