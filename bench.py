@@ -340,6 +340,27 @@ def timeit_protocol(ea, g, dev, efforts=(1.0, 0.7, 0.5, 0.25, 0.15), repeats=300
             sec[str(s)] = {"us_per_call": round(epl * 1e3, 3), "tpt_ms": round(epl * 4 * 32, 3), "spd_tps": round(1000.0 / (epl * 4 * 32), 1),
                            "host_enqueue_us_per_call": round((t1 - t0) / repeats * 1e6, 3)}
         res[name] = sec
+    # the same loop with the host taken out: 320 calls (ten rotations) captured into ONE hipGraph, replayed ten times
+    g.set_overlap(1)
+    sec = {}
+    for s in efforts:
+        s = float(s)
+        assert loop(64, s, 1) == 0
+        g.eval()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, capture_error_mode="thread_local"):
+            assert loop(320, s, 1) == 0
+        g._bind_stream()
+        gr.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            gr.replay()
+        torch.cuda.synchronize()
+        epl = (time.perf_counter() - t0) / 3200 * 1e3
+        sec[str(s)] = {"us_per_call": round(epl * 1e3, 3), "tpt_ms": round(epl * 4 * 32, 3), "spd_tps": round(1000.0 / (epl * 4 * 32), 1)}
+        del gr
+    res["as_written_from_a_graph"] = sec
     g.set_overlap(1)
     # the MPS line of the same benchmark: three dense 4096 x 4096 multiplies per iteration, multiplier 4/3 (benchmark.swift:237-241)
     cores = [(torch.randn((4096, 4096), generator=gen, device=dev) * 0.02).to(torch.float16) for _ in range(32)]
