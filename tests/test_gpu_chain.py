@@ -40,7 +40,7 @@ def _stages(L, Ln, B, e):
              (B["h"], Ln.wv, None, B["xv"], e, {"norm": Ln.attnNorm})]]
 
 
-@pytest.mark.parametrize("effort", [0.25, 0.6])
+@pytest.mark.parametrize("effort", [0.0, 0.25, 0.6, 1.0])
 def test_chain_equals_separate_launches_and_oracle(ea, oracle_cpu, layers, effort):
     L, Ln = layers
     g = ea.gpu()
@@ -182,6 +182,10 @@ def test_c_abi_communicator_world_of_one(ea, oracle_cpu):
         g.allgather_outputs(send, got)                                     # world of one: the whole vector through RCCL
         g.eval()
         assert close(got.cpu().numpy(), want)
+    with pytest.raises(ea.EffortError):                                       # a shard's bound is the full handle's: refresh that one
+        shards[0].refresh()
+    with pytest.raises((ValueError, ea.EffortError)):                         # 688 columns do not split over 3 ranks
+        ew.column_shard(0, 3)
     g.comm_destroy()
     assert not g.has_comm
     g.close()
