@@ -349,6 +349,7 @@ def timeit_protocol(ea, g, dev, efforts=(1.0, 0.7, 0.5, 0.25, 0.15), repeats=300
         g.eval()
         gr = torch.cuda.CUDAGraph()
         with torch.cuda.graph(gr, capture_error_mode="thread_local"):
+            g._bind_stream()                                                  # (the raw ABI calls go to the context's stream: the capturing one)
             assert loop(320, s, 1) == 0
         g._bind_stream()
         gr.replay()
