@@ -820,13 +820,8 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
             if (tailMult >= 4 && i >= n - tc && i < n - tc / 2) mult = (uint32_t)tailMult / 2;      // two steps: ... x2 x2 x4 x4
         }
 #endif
-        // A lone narrow matrix at high effort is sliced twice as thin: its stream phase, not its fixed work, is then most of the call, and
-        // 256 workgroups pull it faster than 128 (measured round 4, 4096 -> 4096 lone, 32 against 64 slices: 17.2 / 18.0 us at 25 %,
-        // 20.6 / 19.7 at 50 %, 27.8 / 24.3 at 100 %; wider or taller matrices and groups already fill the chip: gpurun_out/r4r)
-        const int stageN = chain ? stageFirst[curStage + 1] - stageFirst[curStage] : n;
-        if (fmt == kFp16 && stageN == 1 && !c->tuneS && (chain ? stageE[curStage] : groupE) == 1 && w->cols <= 256u && w->inDim <= 4096u && efforts[i] >= 0.45) mult *= 2u;
         // (a chain's stage is sliced as the launch of its own it replaces: its calls, its column tiles)
-        int rc = chain ? choose_geom(c, w, stageFirst[curStage + 1] - stageFirst[curStage], stageE[curStage], &g, &Wi, &Ei, mult * (uint32_t)c->chainSliceMult, stageTilesAll[curStage])
+        int rc = chain ? choose_geom(c, w, stageFirst[curStage + 1] - stageFirst[curStage], stageE[curStage], &g, &Wi, &Ei, (uint32_t)c->chainSliceMult, stageTilesAll[curStage])
                        : choose_geom(c, w, n, groupE, &g, &Wi, &Ei, mult, groupTiles);
         if (rc != EFFORT_OK) return fail(c, rc, "bucketmul: no launch geometry for this shape/tuning");
         if (chain && (Wi != 8 || g.sliceRows % 2u)) return fail(c, EFFORT_ERR_SHAPE, "bucketmul_chain: 8-wave workgroups and slices of an even number of rows");
