@@ -132,3 +132,15 @@ def test_product_fails_loudly_without_gpu():
     import effort_amd
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         effort_amd.gpu()
+
+
+def test_bench_imports_and_prices_the_headline_launch():
+    """bench.py must at least import on a machine without a GPU (the driver runs it unattended), and its byte model is the
+    SURVEY 8d formula: 4096 x 11008 at 16 737 kept rows = 23 623 008 bytes per call."""
+    import importlib
+    bench = importlib.import_module("bench")
+    assert bench.algorithmic_bytes(16737, 4096, 11008) == 16737 * 688 * 2 + 524288 + 8192 + 16384 + 44032 == 23623008
+    assert bench.moved_bytes(16737, 4096, 11008) < bench.algorithmic_bytes(16737, 4096, 11008)
+    for fn in ("timeit_protocol", "measured_traffic", "cpu_baseline", "oracle_outputs", "main"):
+        assert callable(getattr(bench, fn))
+    assert bench.LDS_ATOMIC_PEAK > 1000
