@@ -526,10 +526,10 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     } else if (needCut) {
         cutoff = block_find_cutoff<NT>(vj, prj, a.q, smem + offC, tbl, []() {}, stamp ? GA_TSTAMP(ga) + 8 : nullptr);
         cachedCall = ci; cachedCutoff = cutoff;
-        if (b == 0 && tid == 0 && !GA_CUTJOBS(ga)) a_cutoff[0] = cutoff;             // BucketMul.cutoff (bucketMul.swift:22)
+        // (BucketMul.cutoff, bucketMul.swift:22, is stored with the slab, in E: a store here sits in front of the `s_waitcnt vmcnt(0)` that
+        //  rankBound's consumer needs, and the call's first workgroup waited a microsecond for its acknowledgement)
     } else if (fused) {
         cutoff = cachedCutoff;
-        if (b == 0 && tid == 0 && !GA_CUTJOBS(ga)) a_cutoff[0] = cutoff;
         __syncthreads();                                             // publishes vblk / wbound / the list length
     } else {
         // split mode: the standalone cutoff kernel ran first on this stream (cheaper in aggregate when several
@@ -972,6 +972,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     // dependent round trips after the reducer's slab loads, where the ticket protocol ends one round trip after them (out[]
     // drained); what the ticket and the drain cost before the reduction is paid by the last arriver only and was smaller than
     // that.  Plain grids keep the ticket; chain launches (persistent: nobody waits to leave) keep the named reducer.
+    if (fused && b == 0 && tid == 0 && !GA_CUTJOBS(ga)) a_cutoff[0] = cutoff;       // BucketMul.cutoff (bucketMul.swift:22) of a call without a cutoff job
     constexpr bool NAMED = CHAIN || (kLeanNamed && !PERSIST);
     constexpr bool BY_PRODUCER = NAMED && !PERSIST;
     const bool reducer = NAMED && s == g.slices - 1u;
