@@ -144,3 +144,39 @@ def test_bench_imports_and_prices_the_headline_launch():
     for fn in ("timeit_protocol", "measured_traffic", "cpu_baseline", "oracle_outputs", "main"):
         assert callable(getattr(bench, fn))
     assert bench.LDS_ATOMIC_PEAK > 1000
+
+
+def test_bench_compact_line_fits_the_driver_tail():
+    """The driver keeps about 8 KB of stdout tail and parses the LAST line (round 4's single 23 KB line left BENCH_r04.parsed =
+    null).  bench.compact_line() must turn a full record -- round 4's own, and one bloated far beyond it -- into a line below 4 KB
+    that round-trips through json.loads and still carries the contract keys, `roofline` and `cpu_baseline`."""
+    import importlib
+    import json
+    import os
+    bench = importlib.import_module("bench")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "profiles", "r04_bench_driver_style.json")) as f:
+        full = json.load(f)
+    bloated = json.loads(json.dumps(full))
+    bloated["config"]["workload"] = "x" * 5000
+    bloated["roofline"]["traffic_source"] = "y" * 5000
+    bloated["cpu_baseline"]["sample"] = "z" * 5000
+    bloated["multi_gpu"] = {"ms_per_step_kernel_only": 1.0, "ms_per_step_with_all_gather": 1.1, "per_shape": {"a": "b" * 9000},
+                            "columns": {"ms_per_step_kernel_only": 0.5, "partition": "c" * 3000},
+                            "layer_latency": {"effort": 0.5, "us_per_layer_kernel_only": 80.0, "us_per_layer_with_gathers": 120.0, "note": "n" * 3000}}
+    for rec in (full, bloated, {"metric": "m", "value": 1.0}):
+        line = bench.compact_line(rec)
+        assert "\n" not in line and len(line) < bench.COMPACT_LIMIT <= 4096
+        got = json.loads(line)
+        for k in ("metric", "value"):
+            assert got[k] == rec[k]
+    got = json.loads(bench.compact_line(full))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline"):
+        assert k in got, k
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_us", "bytes_per_launch"):
+        assert k in got["roofline"], k
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in got["cpu_baseline"], k
+    assert abs(got["roofline"]["frac"] - got["roofline"]["achieved"] / got["roofline"]["peak"]) < 1e-3
+    assert "workload" in got["config"] and "model" not in got["config"]
