@@ -117,7 +117,7 @@ def compact_line(result: dict) -> str:
         cfg["workload"] = str(cfg["workload"])[:197] + "..."
     cfg.pop("kernel_geometry(waves,elems,slices)", None)
     out["config"] = cfg
-    out.update(_pick(result, ("us_per_call", "tokens_per_s", "timed_region_ms", "timed_steps")))
+    out.update(_pick(result, ("us_per_call", "tokens_per_s", "timed_region_ms", "timed_steps", "bytes_per_launch")))
     rf = result.get("roofline")
     if isinstance(rf, dict):
         r = _pick(rf, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "traffic_measured_in_run",
@@ -157,6 +157,11 @@ def compact_line(result: dict) -> str:
         d = result["decode"]
         extra["decode_tps"] = {"dense_rocblas": d["dense_rocblas_tokens_per_s"], "dense_hip_kernel": d["dense_hip_kernel_tokens_per_s"],
                                **{e: x["tokens_per_s"] for e, x in d["effort"].items()}}
+    except Exception:                                        # noqa: BLE001
+        pass
+    try:
+        ll = result["layer_latency"]
+        extra["layer_latency_us_effort_0.5"] = _pick(ll, ("us_per_layer_unsharded", "us_per_layer_with_gathers", "projected_kernel_only", "error"))
     except Exception:                                        # noqa: BLE001
         pass
     try:
@@ -476,6 +481,82 @@ def timeit_protocol(ea, g, dev, efforts=(1.0, 0.7, 0.5, 0.25, 0.15), repeats=300
     return res
 
 
+def layer_latency(ea, g, dev, rank=0, world=1, effort=0.5, n_layers=8, reps=60, project=(2, 4, 8)):
+    """BASELINE config 4's LATENCY case ("all 32 layers' Wq/Wk/Wv/Wo + FFN matrices sharded across 8 x MI355X, RCCL all-gather over
+    xGMI, effort 50 %"): one Mistral-7B layer's seven matrices column-sharded, in the decode loop's dependent order with the glue
+    folded in -- wo -> w1|w3 -> w2 -> wq|wk|wv of the next layer (runNetwork.swift:121-183) -- ONE grouped launch of this rank's
+    shards and ONE effort_allgather_outputs per group (in place on h for wo / w2): effort_amd.sharded.ColumnShardedGroups, what
+    Decoder(world=G) runs.  `n_layers` weight sets are rotated (3.4 GB: no set finds its rows in the Infinity Cache); the chain
+    is one hipGraph, us per LAYER = replay time / n_layers.  Reported per rank: kernel-only (no collectives) and with the
+    gathers; plus, on this GPU alone, rank 0's kernel-only chain of a world of 2 / 4 / 8 (`projected_kernel_only`: what a rank of
+    such a world launches, without its collectives)."""
+    from effort_amd.decode import MistralConfig, Model
+    from effort_amd.sharded import ColumnShardedGroups
+    model = Model.random(MistralConfig(numLayers=n_layers), seed=3, keep_cores=False)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(5)
+    f = lambda n: torch.randn(n, generator=gen, device=dev)                      # noqa: E731
+    B = {"h": f(4096), "attn": f(4096), "x1": f(14336), "x3": f(14336), "xq": f(4096), "xk": f(1024), "xv": f(1024)}
+    h0 = B["h"].clone()
+
+    def chain(G):
+        for n in range(n_layers):
+            L, Ln = model.layers[n], model.layers[(n + 1) % n_layers]
+            an, fnw = {"norm": Ln.attnNorm}, {"norm": L.ffnNorm}
+            G.mul(B["attn"], [(L.wo, B["h"], {"resid": B["h"]})], effort)
+            G.mul(B["h"], [(L.w1, B["x1"], fnw), (L.w3, B["x3"], fnw)], effort)
+            G.mul(B["x1"], [(L.w2, B["h"], {"gate": B["x3"], "resid": B["h"]})], effort)
+            G.mul(B["h"], [(Ln.wq, B["xq"], an), (Ln.wk, B["xk"], an), (Ln.wv, B["xv"], an)], effort)
+        B["h"].copy_(h0)                                                          # (the state stays bounded from replay to replay)
+
+    def timed(G, graph=True):
+        chain(G)                                                                  # warm: shards registered, kernel attributes
+        torch.cuda.synchronize()
+        if graph:
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, capture_error_mode="thread_local"):
+                chain(G)
+            g._bind_stream()
+            run = gr.replay
+        else:
+            run = lambda: chain(G)                                                # noqa: E731
+        for _ in range(3):
+            run()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            run()
+        torch.cuda.synchronize()
+        return round((time.perf_counter() - t0) / reps / n_layers * 1e6, 2)
+
+    res = {"effort": effort, "layers_rotated": n_layers, "world": world, "rank": rank,
+           "order": "wo -> w1|w3 -> w2 -> wq|wk|wv (next layer), glue folded in, one gather per group (in place on h for wo / w2)",
+           "us_per_layer_unsharded": timed(ColumnShardedGroups(1, 0, emulate=True, gpu=g))}
+    res["us_per_layer_kernel_only"] = timed(ColumnShardedGroups(world, rank, gpu=g, gather=False)) if world > 1 else res["us_per_layer_unsharded"]
+    if g.has_comm and g.comm_world == world:
+        try:
+            res["us_per_layer_with_gathers"] = timed(ColumnShardedGroups(world, rank, gpu=g))
+            res["with_gathers_from"] = "one hipGraph (collectives captured)"
+        except Exception as ex:                                                   # noqa: BLE001  (a runtime that cannot capture the collective)
+            res["with_gathers_graph_error"] = repr(ex)[:200]
+            try:
+                torch.cuda.synchronize()
+                res["us_per_layer_with_gathers"] = timed(ColumnShardedGroups(world, rank, gpu=g), graph=False)
+                res["with_gathers_from"] = "eager enqueues (host in the loop)"
+            except Exception as ex2:                                              # noqa: BLE001
+                res["error"] = repr(ex2)[:200]
+    if world == 1:
+        proj = {}
+        for Gw in project:
+            try:
+                proj[str(Gw)] = timed(ColumnShardedGroups(Gw, 0, gpu=g, gather=False))
+            except Exception as ex:                                               # noqa: BLE001
+                proj[str(Gw)] = repr(ex)[:120]
+        res["projected_kernel_only"] = proj
+        res["projected_kernel_only_note"] = "rank 0's launches of a world of G on THIS GPU, no collectives: us per layer"
+    return res
+
+
 def oracle_outputs(ews, v, effort, inDim, outDim, idxs):
     """The CPU oracle's product for the matrices `idxs` (test infrastructure used as the CHECKER of the bench's outputs)."""
     import numpy as np
@@ -710,29 +791,34 @@ def main():
         # bucket-column sharding: every rank multiplies ITS columns of the same 32 matrices (seed 1234 on every
         # rank), one all-gather per round of [world, S * 32 * outDim/world] floats; strong scaling
         try:
-            from effort_amd.sharded import ShardedExpertWeights
-            full = ews if seed0 == 1234 else make_weights(ea, N_MATS, inDim, outDim, 1234, dev, keep_core=False)
+            # every step in flight shards ITS OWN 32 matrices (S disjoint sets, the same on every rank: seeds 1234 + 32 k), like the
+            # headline: with one set, four launches in flight streamed the SAME matrices and a rank's 25 % working set (90 MB at
+            # G = 8) sat in the 256 MB Infinity Cache -- round 4's `columns` read 0.83-0.87 of "HBM" for that reason
+            full_sets = ew_sets if seed0 == 1234 else [make_weights(ea, N_MATS, inDim, outDim, 1234 + k * N_MATS, dev, keep_core=False) for k in range(n_sets)]
             shards = []
-            for e in full:
-                sh = ShardedExpertWeights.from_full(e, rank, world).local
-                sh.handle
-                if ALIGN_ROWS:
-                    sh.align_rows()
-                shards.append(sh)
+            for fs in full_sets:
+                row = []
+                for e in fs:
+                    sh = e.column_shard(rank, world)
+                    sh.handle
+                    row.append(sh)
+                shards.append(row)
             exc = Exchange(shards, outDim // world)
             exc.timed(False)                                 # (uploads the graphs)
             exc.timed(False, args.steps * reps)
             ck, ca = exc.timed(False, args.steps * reps), exc.timed(True, args.steps * reps)
             result["multi_gpu"]["columns"] = {
-                "partition": f"bucket columns: {outDim // 16 // world} of {outDim // 16} columns per rank, stats / probes replicated (strong scaling: the same 32 matrices on every N)",
+                "partition": f"bucket columns: {outDim // 16 // world} of {outDim // 16} columns per rank, stats / probes replicated (strong scaling: the same {n_sets} x 32 matrices on every N, every step in flight on its own set)",
                 "ms_per_step_kernel_only": round(ck * 1e3, 5), "ms_per_step_with_all_gather": round(ca * 1e3, 5),
                 "effective_GBps_whole_job": round(N_MATS * eff_bytes / ca / 1e9, 1), "all_gather_bytes_per_rank_per_round": 16 * S * N_MATS * (outDim // world) * 4}
             del shards, exc
+            if full_sets is not ew_sets:
+                del full_sets
         except Exception as ex2:
             result["multi_gpu"]["columns"] = {"error": repr(ex2)}
         # ---- both partitions at both of north_star's shapes, per rank: kernel-only and with-gather times, fraction of the HBM roofline
         def partitions(iD, oD, sets, full):
-            """sets: this rank's own S x 32 matrices (matrix partition); full: the 32 matrices every rank shards by columns."""
+            """sets: this rank's own S x 32 matrices (matrix partition); full: the S x 32 matrices every rank shards by columns."""
             out = {}
             exm = Exchange(sets, oD)
             exm.timed(False)
@@ -746,10 +832,13 @@ def main():
                                "whole_job_effective_GBps": round(world * N_MATS * 2 * iD * oD / am / 1e9, 1), "scaling": "weak"}
             del exm
             shs = []
-            for e in full:
-                sh = e.column_shard(rank, world)
-                sh.handle
-                shs.append(sh)
+            for fs in full:                                  # (S disjoint sets: every step in flight on its own matrices)
+                row = []
+                for e in fs:
+                    sh = e.column_shard(rank, world)
+                    sh.handle
+                    row.append(sh)
+                shs.append(row)
             exs = Exchange(shs, oD // world)
             exs.timed(False)
             exs.timed(False, n)
@@ -764,17 +853,25 @@ def main():
             return out
         try:
             per_shape = {}
-            full_11008 = ews if seed0 == 1234 else make_weights(ea, N_MATS, inDim, outDim, 1234, dev, keep_core=False)
+            full_11008 = ew_sets if seed0 == 1234 else [make_weights(ea, N_MATS, inDim, outDim, 1234 + k * N_MATS, dev, keep_core=False) for k in range(n_sets)]
             per_shape[f"{inDim}x{outDim}"] = partitions(inDim, outDim, ew_sets, full_11008)
+            del full_11008
             sq_sets = [make_weights(ea, N_MATS, 4096, 4096, 5000 + rank * N_MATS * S + k * N_MATS, dev, keep_core=False) for k in range(S)]
-            sq_full = make_weights(ea, N_MATS, 4096, 4096, 5000, dev, keep_core=False) if rank or world > 1 else sq_sets[0]
+            sq_full = [make_weights(ea, N_MATS, 4096, 4096, 5000 + k * N_MATS, dev, keep_core=False) for k in range(S)] if rank else sq_sets
             per_shape["4096x4096"] = partitions(4096, 4096, sq_sets, sq_full)
+            del sq_sets, sq_full
             result["multi_gpu"]["per_shape"] = per_shape
             result["multi_gpu"]["per_shape_note"] = ("per rank and N: `matrices` = every rank its own 32 matrices per step (weak scaling, the headline), `columns` = every rank "
                                                      "its bucket columns of the SAME 32 matrices (strong scaling); kernel-only and with the round's RCCL all-gather "
                                                      "(effort_allgather_outputs) under the next round's compute; fractions against 8 TB/s per GPU")
         except Exception as ex3:
             result["multi_gpu"]["per_shape"] = {"error": repr(ex3)}
+        # ---- config 4's latency case: a layer's dependent chain, column-sharded, one gather per group, effort 0.5
+        try:
+            torch.cuda.empty_cache()
+            result["multi_gpu"]["layer_latency"] = layer_latency(ea, cg, dev, rank, world)
+        except Exception as ex4:
+            result["multi_gpu"]["layer_latency"] = {"error": repr(ex4)[:300]}
 
     if rank == 0 and world == 1 and not args.headline_only:
         # ---------------- roofline of the dominant kernel, in the timed configuration -----------------
@@ -1032,7 +1129,8 @@ def main():
                         finally:
                             one.S = 1
                         Dx = jb.last_dispatch_count(nst, (nm - 1) % per_launch)
-                        tx = time_graph(gx, None, reps=4) / nst            # per step = per rank per step
+                        est = time_graph(gx, None, reps=2)
+                        tx = time_graph(gx, None, reps=max(4, int(0.05 / max(est, 1e-6)) + 1)) / nst     # per step = per rank per step; timed over >= 50 ms like the headline (a 5 ms region read 7-9 % slow)
                         del gx
                         ab = nm * algorithmic_bytes(Dx, inD, lo)
                         r[nm_] = {"us_per_step_per_rank": round(tx * 1e6, 2), "frac_of_hbm_peak": round(ab / tx / 1e9 / HBM_PEAK_GBPS, 4)}
@@ -1121,6 +1219,17 @@ def main():
                 del dec, model
             except Exception as ex:
                 result.setdefault("decode", {})["error"] = repr(ex)
+        # ---------------- BASELINE config 4's latency case on ONE GPU: a world of one through RCCL + projected ranks ------
+        if not args.no_sweep:
+            try:
+                torch.cuda.empty_cache()
+                lg = ea.Gpu(local)
+                lg.comm_create(0, 1, ea.Gpu.comm_unique_id())
+                result["layer_latency"] = layer_latency(ea, lg, dev, 0, 1)
+                lg.comm_destroy()
+                del lg
+            except Exception as ex:                                              # noqa: BLE001
+                result["layer_latency"] = {"error": repr(ex)[:300]}
         # ---------------- CPU baseline + every output of the timed step against the oracle -------------
         if not args.no_cpu:
             try:

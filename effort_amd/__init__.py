@@ -18,7 +18,7 @@ def __getattr__(name):
     if name in ("ExpertWeights",):
         from . import weights as _w
         return getattr(_w, name)
-    if name in ("bucketMul", "bucketMulQ4", "bucketMulGroup", "bucketMulChain", "expertMul", "basicMul", "BucketMul", "BucketMulQ4", "cosineSimilarityTo"):
+    if name in ("bucketMul", "bucketMulQ4", "bucketMulGroup", "expertMul", "basicMul", "BucketMul", "BucketMulQ4", "cosineSimilarityTo"):
         from . import bucket_mul as _b
         return getattr(_b, name)
     if name == "bucketize":

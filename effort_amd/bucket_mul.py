@@ -109,25 +109,6 @@ def bucketMulGroup(calls, gpu=None):
     g.check(fn(g.ctx, n, ws, vs, es, outs, eff), "bucketMulGroup")
 
 
-def bucketMulChain(stages, gpu=None):
-    """A chain of dependent groups in ONE launch (effort_bucketmul_chain): ``stages`` = [[call, ...], [call, ...], ...], calls as
-    in ``bucketMulGroup`` (FP16 bundles); a call may read -- as its input, its gate partner or its residual -- what calls of
-    EARLIER stages write; the calls of one stage are independent.  The decode loop's wo -> w1|w3 -> w2 -> wq|wk|wv of the next
-    layer (runNetwork.swift:121-183) is such a chain: one launch instead of four."""
-    stages = [[tuple(c) for c in st] for st in stages]
-    calls = [c for st in stages for c in st]
-    if not stages or any(not st for st in stages) or len(stages) > 8 or len(calls) > 32:
-        raise ValueError("a chain holds 1..8 non-empty stages and at most 32 calls")
-    bm = BucketMul.shared() if gpu is None else BucketMul(gpu.device, gpu)
-    for c in calls:
-        bm._validate(c[0], c[1], c[2], c[3])
-    n, ws, vs, es, outs, eff, pre, aux, res = _marshal(calls, False)
-    g = bm.gpu
-    g._bind_stream()
-    counts = (C.c_int * len(stages))(*[len(st) for st in stages])
-    g.check(_lib.lib().effort_bucketmul_chain(g.ctx, len(stages), counts, ws, vs, es, outs, eff, pre, aux, res), "bucketMulChain")
-
-
 def basicMul(v: torch.Tensor, by: torch.Tensor, out: torch.Tensor, gpu=None):
     """Dense f16 GEMV, ``by`` = core matrix [outDim, inDim]; asserts of helpers/mps.swift:15-18."""
     assert by.shape[0] == out.numel() and by.shape[1] == v.numel() and by.shape[1] % 16 == 0

@@ -1,7 +1,8 @@
 // C ABI of libeffort_hip.so (include/effort_hip.h): contexts, weight handles, launch orchestration.
 // Host-side equivalent of class BucketMul / BucketMulQ4 (bucketMul.swift:18-90, bucketMulQ4.swift:18-87)
 // and of the slice of class Gpu they use (helpers/gpu.swift:109-196).
-#include <rccl/rccl.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>          // types only: the library is opened when the first communicator is asked for (rccl(), below)
 #include <rocblas/rocblas.h>
 
 #include <cstdio>
@@ -28,12 +29,9 @@ struct Lane {
     float* d_cutoff = nullptr;        // BucketMul.cutoff
     uint32_t* d_count = nullptr;      // dispatch.size
     float* d_slabs = nullptr;         // partial tiles (replaces tmpMulVec)
-    float* d_slabsNamed = nullptr;    // ... of the launches that hand their tiles to a NAMED reducer (chain launches): every word holds the
-                                      // sentinel 0xFFFFFFFF between launches (bucket_mul.hip, E)
     uint32_t* d_counters = nullptr;   // per-tile arrival tickets (zero between calls)
     uint32_t* d_sliceCounts = nullptr;
     uint32_t* d_queue = nullptr;      // item queues of persistent launches
-    unsigned long long* d_named = nullptr;   // per tile: launches that consumed it | producers that gave up << 32 (plain grids' hand-off; never reset)
     // where each call of the lane's last (group) launch keeps its per-slice counts; slices == 0: dispatch.size is d_count
     uint32_t lastCalls = 1, lastSliceOff[effort::kMaxGroup] = {0}, lastSlices[effort::kMaxGroup] = {0};
     // address ranges the launches enqueued since the last join read / write (hazard check of the next launch)
@@ -69,8 +67,6 @@ struct effort_ctx {
     bool denseRocblas = false;        // effort_set_dense_backend: basicMul through rocBLAS instead of dense_gemv_kernel
     // tuning overrides (0 = heuristic)
     int tuneW = 0, tuneE = 0, tuneS = 0;
-    bool q4ByteAcc = false;       // Q4 launches accumulate per byte (Format kQ4B; effort_set_q4_byte_acc)
-    int chainSliceMult = 1;       // chain launches: row slices per call = the heuristic's x this (effort_set_chain_tuning)
     bool splitCutoff = false;     // run findCutoff32 as its own 1-workgroup kernel instead of inside every workgroup
     // optional per-kernel timing
     bool timing = false;          // HIP events around each kernel
@@ -93,7 +89,11 @@ struct effort_w {
     const void* stats = nullptr;
     const uint16_t* probes = nullptr;
     uint32_t inDim = 0, outDim = 0, rowsPerIn = 0, numExperts = 1, cols = 0;
-    bool view = false;                // a column shard (effort_weights_column_shard): buckets and the outlier index point INTO the full handle's
+    bool view = false;                // a column shard (effort_weights_column_shard): buckets, row means and the outlier index point INTO the full handle's
+    effort_w* parent = nullptr;       // ... that handle; it stays alive (its buffers, that is) until its last view is freed
+    uint32_t viewTrim = 0;            // ... bytes `buckets` lies behind the full handle's: the multiply's buffer descriptor ends at the END of the full allocation
+    int views = 0;                    // live views of this (full) handle
+    bool dead = false;                // effort_weights_free was called while views were alive: freed with the last of them
     float* rankBound = nullptr;       // [numExperts] fixed-point bound of the multiply (see launch_rank_bound)
     uint16_t* means16 = nullptr;      // FP16: the row means alone (stats lane .w), one u16 per bucket row (launch_compact_means)
     // Q4 outliers
@@ -117,21 +117,49 @@ static int fail(effort_ctx* c, int code, const char* what, hipError_t e = hipSuc
         if (e_ != hipSuccess) return fail((ctx), EFFORT_ERR_HIP, #call, e_); \
     } while (0)
 
+// RCCL is bound at RUN time, when the first communicator is asked for: a single-GPU host needs no librccl to load this library,
+// and a process that has one mapped already (PyTorch-ROCm brings its own copy) gets THAT one -- dlopen by soname returns the copy
+// already in the process -- so two RCCLs never meet in one address space; a plain C / Swift host gets the system ROCm's.
+struct RcclApi {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+};
+static const RcclApi& rccl() {
+    static RcclApi api = [] {
+        RcclApi a;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+            a.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (a.lib) break;
+        }
+        if (!a.lib) return a;
+        a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(dlsym(a.lib, "ncclGetUniqueId"));
+        a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(a.lib, "ncclCommInitRank"));
+        a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(a.lib, "ncclCommDestroy"));
+        a.AllGather = reinterpret_cast<decltype(a.AllGather)>(dlsym(a.lib, "ncclAllGather"));
+        a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(a.lib, "ncclGetErrorString"));
+        a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllGather && a.GetErrorString;
+        return a;
+    }();
+    return api;
+}
+
 extern "C" const char* effort_version(void) { return "effort-hip 0.1 (gfx950)"; }
 static char g_createErr[256] = "null context";       // effort_last_error(NULL): why the last effort_create failed, if one did
 extern "C" const char* effort_last_error(effort_ctx* c) { return c ? c->err : g_createErr; }
 
 static bool lane_alloc(effort_ctx* c, Lane& L) {
     bool ok = hipMalloc(&L.d_cutoff, 512) == hipSuccess && hipMalloc(&L.d_count, 16) == hipSuccess &&
-              hipMalloc(&L.d_slabs, c->slabBytes) == hipSuccess && hipMalloc(&L.d_slabsNamed, c->slabBytes) == hipSuccess && hipMalloc(&L.d_counters, effort_ctx::kMaxTiles * 4) == hipSuccess &&
-              hipMalloc(&L.d_sliceCounts, effort_ctx::kMaxSlices * 4) == hipSuccess && hipMalloc(&L.d_queue, kQueueWords * 4) == hipSuccess &&
-              hipMalloc(&L.d_named, effort_ctx::kMaxTiles * 8) == hipSuccess;
+              hipMalloc(&L.d_slabs, c->slabBytes) == hipSuccess && hipMalloc(&L.d_counters, effort_ctx::kMaxTiles * 4) == hipSuccess &&
+              hipMalloc(&L.d_sliceCounts, effort_ctx::kMaxSlices * 4) == hipSuccess && hipMalloc(&L.d_queue, kQueueWords * 4) == hipSuccess;
     if (!ok) return false;
-    hipMemset(L.d_slabsNamed, 0xFF, c->slabBytes);
     hipMemset(L.d_counters, 0, effort_ctx::kMaxTiles * 4);
     hipMemset(L.d_sliceCounts, 0, effort_ctx::kMaxSlices * 4);
     hipMemset(L.d_queue, 0, kQueueWords * 4);
-    hipMemset(L.d_named, 0, effort_ctx::kMaxTiles * 8);
     hipMemset(L.d_cutoff, 0, 512);
     hipMemset(L.d_count, 0, 16);
     return true;
@@ -165,7 +193,7 @@ static void pool_put(int device, hipEvent_t e) { if (e) { std::lock_guard<std::m
 static void lane_free(int device, Lane& L) {
     pool_put(device, L.own);
     pool_put(device, L.done);
-    hipFree(L.d_cutoff); hipFree(L.d_count); hipFree(L.d_slabs); hipFree(L.d_slabsNamed); hipFree(L.d_counters); hipFree(L.d_sliceCounts); hipFree(L.d_queue); hipFree(L.d_named);
+    hipFree(L.d_cutoff); hipFree(L.d_count); hipFree(L.d_slabs); hipFree(L.d_counters); hipFree(L.d_sliceCounts); hipFree(L.d_queue);
     L = Lane();
 }
 
@@ -246,7 +274,7 @@ extern "C" void effort_destroy(effort_ctx* c) {
     hipSetDevice(c->device);
     for (int i = 0; i < effort_ctx::kMaxLanes; i++) if (c->lane[i].own) hipStreamSynchronize(c->lane[i].own);
     hipStreamSynchronize(c->stream);
-    if (c->comm) ncclCommDestroy(c->comm);
+    if (c->comm) rccl().CommDestroy(c->comm);
     if (c->blas) rocblas_destroy_handle(c->blas);
     if (c->ev) { for (int i = 0; i < effort_ctx::kMaxSamples * 4; i++) hipEventDestroy(c->ev[i]); delete[] c->ev; }
     for (int i = 0; i < effort_ctx::kMaxLanes; i++) lane_free(c->device, c->lane[i]);
@@ -426,7 +454,15 @@ extern "C" int effort_weights_set_bound(effort_w* w, const float* host_in) {
 
 extern "C" void effort_weights_free(effort_w* w) {
     if (!w) return;
-    if (!w->view) { hipFree(w->olRowPtr); hipFree(w->olBlockPtr); hipFree(w->olEntry); }
+    if (w->view) {                               // a column shard owns its bound only; the last view of a freed parent takes the parent along
+        effort_w* const par = w->parent;
+        hipFree(w->rankBound);
+        delete w;
+        if (par && --par->views == 0 && par->dead) { par->dead = false; effort_weights_free(par); }
+        return;
+    }
+    if (w->views > 0) { w->dead = true; return; }   // views still read these buffers (the header says: free the shards first -- but do not dangle if not)
+    hipFree(w->olRowPtr); hipFree(w->olBlockPtr); hipFree(w->olEntry);
     hipFree(w->aligned); hipFree(w->rankBound); hipFree(w->means16);
     delete w;
 }
@@ -449,14 +485,21 @@ extern "C" effort_w* effort_weights_column_shard(const effort_w* full, int rank,
         fail(c, EFFORT_ERR_SHAPE, "effort_weights_column_shard: the shard must hold whole blocks of the outlier index"); return nullptr; }
     effort_w* w = new (std::nothrow) effort_w();
     if (!w) return nullptr;
+    if (full->view || full->dead) { fail(c, EFFORT_ERR_ARG, "effort_weights_column_shard: shard a full, live handle"); delete w; return nullptr; }
     *w = *full;
-    w->view = true; w->aligned = nullptr; w->rankBound = nullptr; w->means16 = nullptr;
+    w->view = true; w->parent = const_cast<effort_w*>(full); w->views = 0; w->dead = false;
+    w->aligned = nullptr; w->rankBound = nullptr;
     w->buckets = full->buckets + (size_t)rank * per;            // what the multiply reads (the full handle's own line-aligned copy, if it made one)
+    w->viewTrim = (uint32_t)((size_t)rank * per * 2u);          // < rowPitch <= 2048: the descriptor stops where the full buffer does
     w->bucketsSrc = w->buckets; w->srcPitch = full->rowPitch;
     w->cols = per; w->outDim = outDim;
-    if (register_bound(c, w) != EFFORT_OK) { effort_weights_free(w); return nullptr; }
-    if (hipMemcpy(w->rankBound, full->rankBound, (size_t)w->numExperts * 4, hipMemcpyDeviceToDevice) != hipSuccess) {
-        fail(c, EFFORT_ERR_HIP, "effort_weights_column_shard: bound"); effort_weights_free(w); return nullptr; }
+    // the row means are row-global: the view reads the full handle's compact copy (means16 stays the parent's); the fixed-point bound is
+    // the FULL matrix's -- every rank rounds on the same grid -- in a word of the view's own (effort_weights_set_bound may change it)
+    hipSetDevice(c->device);
+    if (hipMalloc(&w->rankBound, (size_t)w->numExperts * 4) != hipSuccess ||
+        hipMemcpy(w->rankBound, full->rankBound, (size_t)w->numExperts * 4, hipMemcpyDeviceToDevice) != hipSuccess) {
+        fail(c, EFFORT_ERR_HIP, "effort_weights_column_shard: bound"); hipFree(w->rankBound); delete w; return nullptr; }
+    w->parent->views++;
     if (full->nOutliers) {
         const uint32_t bs = 1u << (16u - ol_bits_in(full->inDim));
         w->olBlockPtr = full->olBlockPtr + (size_t)rank * outDim / bs;                        // block bounds index the SHARED entry array
@@ -467,7 +510,8 @@ extern "C" effort_w* effort_weights_column_shard(const effort_w* full, int rank,
 extern "C" int effort_comm_unique_id(void* id_out) {
     if (!id_out) return EFFORT_ERR_ARG;
     static_assert(sizeof(ncclUniqueId) == EFFORT_COMM_ID_BYTES, "effort_hip.h: EFFORT_COMM_ID_BYTES");
-    return ncclGetUniqueId(static_cast<ncclUniqueId*>(id_out)) == ncclSuccess ? EFFORT_OK : EFFORT_ERR_COMM;
+    if (!rccl().ok) return EFFORT_ERR_COMM;
+    return rccl().GetUniqueId(static_cast<ncclUniqueId*>(id_out)) == ncclSuccess ? EFFORT_OK : EFFORT_ERR_COMM;
 }
 extern "C" int effort_comm_create(effort_ctx* c, int rank, int world, const void* id) {
     if (!c || !id || world < 1 || rank < 0 || rank >= world) return fail(c, EFFORT_ERR_ARG, "comm_create: bad argument");
@@ -475,14 +519,15 @@ extern "C" int effort_comm_create(effort_ctx* c, int rank, int world, const void
     hipSetDevice(c->device);
     ncclUniqueId uid;
     memcpy(&uid, id, sizeof(uid));
-    const ncclResult_t r = ncclCommInitRank(&c->comm, world, uid, rank);
-    if (r != ncclSuccess) { c->comm = nullptr; snprintf(c->err, sizeof(c->err), "ncclCommInitRank: %s", ncclGetErrorString(r)); return EFFORT_ERR_COMM; }
+    if (!rccl().ok) return fail(c, EFFORT_ERR_COMM, "comm_create: librccl.so could not be opened (dlopen) -- multi-GPU needs RCCL");
+    const ncclResult_t r = rccl().CommInitRank(&c->comm, world, uid, rank);
+    if (r != ncclSuccess) { c->comm = nullptr; snprintf(c->err, sizeof(c->err), "ncclCommInitRank: %s", rccl().GetErrorString(r)); return EFFORT_ERR_COMM; }
     c->commRank = rank; c->commWorld = world;
     return EFFORT_OK;
 }
 extern "C" int effort_comm_destroy(effort_ctx* c) {
     if (!c) return EFFORT_ERR_ARG;
-    if (c->comm) { hipSetDevice(c->device); effort_sync(c); ncclCommDestroy(c->comm); c->comm = nullptr; c->commRank = 0; c->commWorld = 1; }
+    if (c->comm) { hipSetDevice(c->device); effort_sync(c); rccl().CommDestroy(c->comm); c->comm = nullptr; c->commRank = 0; c->commWorld = 1; }
     return EFFORT_OK;
 }
 extern "C" int effort_comm_rank(effort_ctx* c) { return c ? c->commRank : EFFORT_ERR_ARG; }
@@ -493,8 +538,8 @@ extern "C" int effort_allgather_outputs(effort_ctx* c, const float* send, float*
     if (!c || !send || !recv || count < 1) return fail(c, EFFORT_ERR_ARG, "allgather_outputs: bad argument");
     if (!c->comm) return fail(c, EFFORT_ERR_ARG, "allgather_outputs: no communicator (effort_comm_create)");
     if (join_lanes(c) != EFFORT_OK) return EFFORT_ERR_HIP;
-    const ncclResult_t r = ncclAllGather(send, recv, (size_t)count, ncclFloat, c->comm, c->stream);
-    if (r != ncclSuccess) { snprintf(c->err, sizeof(c->err), "ncclAllGather: %s", ncclGetErrorString(r)); return EFFORT_ERR_COMM; }
+    const ncclResult_t r = rccl().AllGather(send, recv, (size_t)count, ncclFloat, c->comm, c->stream);
+    if (r != ncclSuccess) { snprintf(c->err, sizeof(c->err), "ncclAllGather: %s", rccl().GetErrorString(r)); return EFFORT_ERR_COMM; }
     return EFFORT_OK;
 }
 
@@ -532,7 +577,6 @@ static uint32_t pick_slices(const effort_ctx* c, const effort_w* w, int groupSiz
 // 4096x11008: 8 calls 7.9 vs 8.4 us/call, 16 calls 7.2 vs 6.6, 32 calls 5.7 vs 6.3).  Q4 (a word = 4 sub-buckets): 1, or 2 from 8 calls on.
 static int pick_elems(const effort_ctx* c, Format fmt, int n, const effort_w* const* ws) {
     if (c->tuneE) return c->tuneE;
-    if (fmt != kFp16 && c->q4ByteAcc) return 1;     // (byte-indexed accumulators: 128 KB for a 64-column tile)
     if (fmt != kFp16) return n >= 8 ? 2 : 1;        // measured, 4096x11008 Q4: 32 calls 5.3 vs 6.4 us/call, 8 calls 8.3 vs 8.3, 2 calls 20.8 vs 18.8
     if (c->tuneS) return 2;
     auto group_tiles = [&](int E) {
@@ -571,9 +615,8 @@ static int pick_elems(const effort_ctx* c, Format fmt, int n, const effort_w* co
 }
 
 static int choose_geom(const effort_ctx* c, const effort_w* w, int groupSize, int E, MulGeom* g, int* Wout, int* Eout, uint32_t sliceMult = 1, uint32_t groupTiles = 0) {
-    const Format lfmt = (w->fmt == kQ4 && c->q4ByteAcc) ? kQ4B : w->fmt;      // the launch's variant of the format
-    const int W = c->tuneW ? c->tuneW : (lfmt == kQ4B ? 16 : 8);               // 8 waves per workgroup (byte-indexed Q4: one 16-wave workgroup per CU)
-    if (!supported(W, E) || (lfmt == kQ4B && (E != 1 || (W != 8 && W != 16)))) return EFFORT_ERR_ARG;
+    const int W = c->tuneW ? c->tuneW : 8;                 // 8 waves per workgroup
+    if (!supported(W, E)) return EFFORT_ERR_ARG;
     const uint32_t nacc = w->fmt == kFp16 ? 16 : 32;
     g->inDim = w->inDim; g->outDim = w->outDim; g->cols = w->cols; g->rowsPerIn = w->rowsPerIn;
     g->expertRows = w->rowsPerIn * w->inDim; g->numExperts = w->numExperts;
@@ -597,7 +640,7 @@ static int choose_geom(const effort_ctx* c, const effort_w* w, int groupSize, in
         g->slices = (w->inDim + g->sliceRows - 1) / g->sliceRows;
         g->sliceLog2 = 0; while ((1u << g->sliceLog2) < g->sliceRows) g->sliceLog2++;
         g->slots = w->fmt == kFp16 ? (g->rowsPerIn << g->sliceLog2) : g->sliceRows * 8u;
-        const size_t lds = bucket_mul_lds_bytes(lfmt, W, E, *g);
+        const size_t lds = bucket_mul_lds_bytes(w->fmt, W, E, *g);
         const bool fits = lds <= ldsMax && g->slots <= maxCand && (size_t)g->slots * 4 + (size_t)g->sliceRows * 8 + 1024 <= 65536 &&   // staged regions below 64 KB
                           (w->fmt == kFp16 ? (1u << g->sliceLog2) <= 64u * (uint32_t)W : g->sliceRows <= 128u * (uint32_t)W);   // a thread stages one (Q4: two) inputs of the slice
         const size_t slab = (size_t)g->slices * g->tiles * tileFloats * 4;
@@ -620,10 +663,7 @@ static int ensure_timing(effort_ctx* c) {
 // One launch for a group of independent calls (a lone call is a group of one).
 static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws, const float* const* vs,
                     const uint32_t* const* expNos, float* const* outs, const double* efforts,
-                    const int* prologues = nullptr, const void* const* vAux = nullptr, const float* const* resids = nullptr,
-                    const int* stages = nullptr) {
-    // `stages` (chain launches, effort_bucketmul_chain): the stage of every call, non-decreasing from 0; a stage's calls may read
-    // what the calls of earlier stages write.  ONE persistent launch (bucket_mul.hip: CHAIN).
+                    const int* prologues = nullptr, const void* const* vAux = nullptr, const float* const* resids = nullptr) {
     if (!c || !ws || !vs || !outs || !efforts) return fail(c, EFFORT_ERR_ARG, "bucketmul: null argument");
     if (n < 1 || n > kMaxGroup) return fail(c, EFFORT_ERR_ARG, "bucketmul: group size outside 1..32");
     // The A/B switches below read the environment in LAB builds only (-DEFFORT_LAB: tools/build_variant*.sh); the shipped
@@ -641,37 +681,7 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
         if (pre < 0 || pre > 2 || (pre && (!vAux || !vAux[i]))) return fail(c, EFFORT_ERR_ARG, "bucketmul: bad input prologue");
         if (pre && (fmt != kFp16 || c->splitCutoff)) return fail(c, EFFORT_ERR_KIND, "bucketmul: input prologues need FP16 weights and the fused cutoff");
     }
-    const bool chain = stages != nullptr;
-    int stageFirst[kMaxStages + 1] = {0}, nStages = 0;         // calls [stageFirst[k], stageFirst[k+1]) make up stage k
-    if (chain) {
-        if (fmt != kFp16 || c->splitCutoff) return fail(c, EFFORT_ERR_KIND, "bucketmul_chain: FP16 weights and the fused cutoff");
-        for (int i = 0; i < n; i++) {
-            if (stages[i] != nStages - 1) {
-                if (stages[i] != nStages || nStages == kMaxStages) return fail(c, EFFORT_ERR_ARG, "bucketmul_chain: stages must count up from 0 without gaps (at most 8)");
-                stageFirst[nStages++] = i;
-            }
-            if (!ws[i]->means16 || ws[i]->inDim % 2u) return fail(c, EFFORT_ERR_SHAPE, "bucketmul_chain: an even inDim is needed");
-        }
-        stageFirst[nStages] = n;
-        // calls of ONE stage run concurrently: none may write what another one of them reads or writes
-        auto hit = [](const void* p, size_t pb, const void* q, size_t qb) { return p && q && (uintptr_t)p < (uintptr_t)q + qb && (uintptr_t)q < (uintptr_t)p + pb; };
-        for (int k = 0; k < nStages; k++)
-            for (int i = stageFirst[k]; i < stageFirst[k + 1]; i++)
-                for (int j = stageFirst[k]; j < stageFirst[k + 1]; j++) {
-                    const size_t ob = (size_t)ws[i]->outDim * 4, ib = (size_t)ws[j]->inDim * 4;
-                    const bool aliasOwnResid = i == j && resids && resids[j] == outs[i];       // h += product in place
-                    if (hit(outs[i], ob, vs[j], ib) || (vAux && prologues && prologues[j] == EFFORT_PRE_SILU_GATE && hit(outs[i], ob, vAux[j], ib)) ||
-                        (resids && !aliasOwnResid && hit(outs[i], ob, resids[j], (size_t)ws[j]->outDim * 4)) || (i != j && hit(outs[i], ob, outs[j], (size_t)ws[j]->outDim * 4)))
-                        return fail(c, EFFORT_ERR_ARG, "bucketmul_chain: a call writes what a call of the same stage reads or writes");
-                }
-    }
-    // columns per lane: one choice for a group launch; per STAGE in a chain (what the stage would get as a launch of its own)
-    int stageE[kMaxStages] = {0};
-    for (int k = 0; k < nStages; k++) {
-        stageE[k] = pick_elems(c, fmt, stageFirst[k + 1] - stageFirst[k], ws + stageFirst[k]);
-        if (stageE[k] > 2) stageE[k] = 2;
-    }
-    const int groupE = chain ? stageE[0] : pick_elems(c, fmt, n, ws);
+    const int groupE = pick_elems(c, fmt, n, ws);         // columns per lane: one choice for a group launch
     const bool tm = c->timing && c->nSamples < effort_ctx::kMaxSamples;
     hipEvent_t* ev = tm ? c->ev + 4 * c->nSamples : nullptr;
     // ---- which lane (overlap mode): the launch may run beside the launches in flight on the OTHER lanes unless it reads or
@@ -716,8 +726,26 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
     } guard{L, st};
     auto fork_lane = [&]() -> int {                    // before the group's first launch
         if (!laned || guard.forked) return EFFORT_OK;
-        HIP_TRY(c, hipEventRecord(c->forkEv, c->stream));
-        HIP_TRY(c, hipStreamWaitEvent(L.own, c->forkEv, 0));
+        // "after everything enqueued on the context's stream before this call": an event recorded there, the lane waits -- UNLESS the
+        // stream is idle: then everything enqueued on it has completed and there is nothing to wait for.  That is the state of a
+        // caller who enqueues multiply after multiply and evaluates once (helpers/gpu.swift:109-119; the reference's own timing
+        // loop, benchmarks/benchmark.swift:245-257): all its work sits on the lanes, and the two HIP calls plus the cross-stream
+        // edge per call made that loop 45 % SLOWER with lanes than without (round 4: 32.5 against 22.5 us per call).  A capturing
+        // stream cannot be queried (and "idle" means nothing inside a capture): there the fork is a graph edge, as before.
+        bool wait = true;
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusActive;
+        if (hipStreamIsCapturing(c->stream, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) {
+            const hipError_t q = hipStreamQuery(c->stream);
+            if (q == hipSuccess) wait = false;
+            else {
+                (void)hipGetLastError();                    // ("not ready" must not linger as the thread's last error: the launchers read it after their kernels)
+                if (q != hipErrorNotReady) return fail(c, EFFORT_ERR_HIP, "hipStreamQuery", q);
+            }
+        } else (void)hipGetLastError();
+        if (wait) {
+            HIP_TRY(c, hipEventRecord(c->forkEv, c->stream));
+            HIP_TRY(c, hipStreamWaitEvent(L.own, c->forkEv, 0));
+        }
         guard.forked = true;
         for (int k = 0; k < nh; k++) if (hazard[k] != li) HIP_TRY(c, hipStreamWaitEvent(L.own, c->lane[hazard[k]].done, 0));
         if (!nh) c->nextLane = (c->nextLane + 1) % c->nLanes;
@@ -737,13 +765,12 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
         ga.slabs = L.d_slabs; ga.counters = L.d_counters; ga.sliceCounts = L.d_sliceCounts; ga.cutoff = L.d_cutoff + firstCall;
         ga.tstamp = c->clock ? c->d_tstamp : nullptr;
         ga.ablate = ablate; ga.split = c->splitCutoff ? 1u : 0u; ga.trace = (c->clock && c->trace) ? 1u : 0u;
-        ga.numCU = (uint32_t)c->numCU; ga.queue = L.d_queue; ga.named = L.d_named;
+        ga.numCU = (uint32_t)c->numCU; ga.queue = L.d_queue;
         nGeoms = 0; wg = 0; first = firstCall;
     };
     auto flush = [&]() -> int {                        // one kernel launch for the calls gathered so far
         // grid: persistent workgroups once the items outnumber what the chip holds at R per CU
-        const Format lfmt = (fmt == kQ4 && c->q4ByteAcc) ? kQ4B : fmt;
-        const uint32_t R = c->persistent < 0 ? (lfmt == kQ4B ? 1u : 2u) : (uint32_t)c->persistent;
+        const uint32_t R = c->persistent < 0 ? 2u : (uint32_t)c->persistent;
         ga.persistent = (R && wg > ga.numCU * R) ? R : 0u;
         // persistent launches evaluate every call's cutoff ONCE, in a job of its own at the head of the item queues, instead
         // of once per workgroup and call (measured: 6.8 of the ~90 us of an item at 32 calls per launch)
@@ -775,36 +802,17 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
             for (uint32_t i = 0; i < ga.count; i++) ga.call[i].stats = ws[first + i]->means16;
             ga.split |= 4u;
         }
-        // (A/B builds only -- EFFORT_LEAN_NAMED, measured slower: bucket_mul.hip, E)
-        if (leanGrid && !chain && bucket_mul_lean_named()) { ga.slabs = L.d_slabsNamed; ga.split |= 8u; }
         const int frc = fork_lane();
         if (frc != EFFORT_OK) return frc;
-        if (chain) {
-            ga.slabs = L.d_slabsNamed;
-            // persistent, no cutoff jobs (a job of a later stage would wait on the stage before it with everybody else: every
-            // workgroup evaluates the cutoff of a call it works on, as a plain grid's do), compact means
-            // ONE workgroup per CU unless told otherwise (measured, a Mistral-7B layer's chain at 25 %: 112 us against 125 with two:
-            // a stage has fewer items than the chip has CUs, and two co-resident workgroups that both got one share the CU's pull rate
-            // while other CUs idle -- the stage then ends on them)
-            ga.persistent = c->persistent > 0 ? (uint32_t)c->persistent : 1u; ga.cutJobs = 0u; ga.split = 4u | 16u;
-            for (uint32_t i = 0; i < ga.count; i++) ga.call[i].stats = ws[first + i]->means16;
-            HIP_TRY(c, launch_bucket_mul_chain(ga, st));
-            return EFFORT_OK;
-        }
         if (c->splitCutoff && !(ablate & 1u)) HIP_TRY(c, launch_find_cutoff_group(ga, st));
-        HIP_TRY(c, launch_bucket_mul(lfmt, W, E, ga, st));
+        HIP_TRY(c, launch_bucket_mul(fmt, W, E, ga, st));
         return EFFORT_OK;
     };
     uint32_t groupTiles = 0;
     for (int i = 0; i < n; i++) groupTiles += (ws[i]->cols + 64 * groupE - 1) / (64 * groupE);
-    uint32_t stageTilesAll[kMaxStages] = {0};
-    for (int k = 0; k < nStages; k++)
-        for (int i = stageFirst[k]; i < stageFirst[k + 1]; i++) stageTilesAll[k] += (ws[i]->cols + 64 * stageE[k] - 1) / (64 * stageE[k]);
     begin(0);
-    int curStage = 0;
     for (int i = 0; i < n; i++) {
         const effort_w* w = ws[i];
-        if (chain) curStage = stages[i];
         MulGeom g;
         memset(&g, 0, sizeof(g));
         int Wi, Ei;
@@ -820,17 +828,13 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
             if (tailMult >= 4 && i >= n - tc && i < n - tc / 2) mult = (uint32_t)tailMult / 2;      // two steps: ... x2 x2 x4 x4
         }
 #endif
-        // (a chain's stage is sliced as the launch of its own it replaces: its calls, its column tiles)
-        int rc = chain ? choose_geom(c, w, stageFirst[curStage + 1] - stageFirst[curStage], stageE[curStage], &g, &Wi, &Ei, (uint32_t)c->chainSliceMult, stageTilesAll[curStage])
-                       : choose_geom(c, w, n, groupE, &g, &Wi, &Ei, mult, groupTiles);
+        int rc = choose_geom(c, w, n, groupE, &g, &Wi, &Ei, mult, groupTiles);
         if (rc != EFFORT_OK) return fail(c, rc, "bucketmul: no launch geometry for this shape/tuning");
-        if (chain && (Wi != 8 || g.sliceRows % 2u)) return fail(c, EFFORT_ERR_SHAPE, "bucketmul_chain: 8-wave workgroups and slices of an even number of rows");
         if (i == 0) { W = Wi; E = Ei; }
-        else if (Wi != W || (!chain && Ei != E)) return fail(c, EFFORT_ERR_SHAPE, "bucketmul: the calls of a group must agree on the kernel variant");
+        else if (Wi != W || Ei != E) return fail(c, EFFORT_ERR_SHAPE, "bucketmul: the calls of a group must agree on the kernel variant");
         uint32_t gi = 0;
         while (gi < nGeoms && memcmp(&ga.geom[gi], &g, sizeof(g)) != 0) gi++;
         if (gi == nGeoms && nGeoms == kMaxGeoms) {     // a launch carries kMaxGeoms distinct shapes: this call opens the next one
-            if (chain) return fail(c, EFFORT_ERR_SHAPE, "bucketmul_chain: more than four distinct launch geometries in one chain");
             rc = flush();
             if (rc != EFFORT_OK) return rc;
             begin((uint32_t)i);
@@ -844,13 +848,10 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
         a.buckets = w->buckets; a.stats = w->stats; a.rankBound = w->rankBound; a.probes = w->probes; a.v = vs[i];
         a.expNo = expNos ? expNos[i] : nullptr; a.out = outs[i];
         a.ol = OutlierIndex{fmt == kQ4 ? w->olBlockPtr : nullptr, w->olEntry, w->olBound64};
-        a.q = (uint32_t)(int)((double)(kProbes - 1) * (1.0 - efforts[i]));            // bucketMul.swift:39
+        a.q = (uint16_t)(int)((double)(kProbes - 1) * (1.0 - efforts[i]));            // bucketMul.swift:39
+        a.bucketsTrim = (uint16_t)w->viewTrim;
         const int pre = prologues ? prologues[i] : 0;
-        a.pre = (uint16_t)(pre | (curStage << 8)); a.vAux = pre ? vAux[i] : nullptr; a.resid = resids ? resids[i] : nullptr;
-        if (chain) {
-            ga.stageTiles[curStage] = (uint16_t)(ga.stageTiles[curStage] + g.tiles);
-            if (ga.stageTiles[curStage] > 64u) return fail(c, EFFORT_ERR_SHAPE, "bucketmul_chain: more than 64 column tiles in one stage");
-        }
+        a.pre = (uint16_t)pre; a.vAux = pre ? vAux[i] : nullptr; a.resid = resids ? resids[i] : nullptr;
         a.slabOff = (uint32_t)(slabOff / 256); a.tileOff = (uint16_t)tileOff; a.sliceOff = (uint16_t)sliceOff; a.geom = (uint16_t)gi;
         wg += g.tiles * ((g.slices + 7) / 8 * 8);
         if (wg / 8u > 0xFFFFu) return fail(c, EFFORT_ERR_SHAPE, "bucketmul: group exceeds the launch descriptor's item range");
@@ -881,17 +882,6 @@ extern "C" int effort_bucketmul_group_fused(effort_ctx* c, int n, const effort_w
                                             const uint32_t* const* expNos, float* const* outs, const double* efforts,
                                             const int* prologues, const void* const* vAux, const float* const* resids) {
     return do_group(c, kFp16, n, ws, vs, expNos, outs, efforts, prologues, vAux, resids);
-}
-extern "C" int effort_bucketmul_chain(effort_ctx* c, int nStages, const int* stageCalls, const effort_w* const* ws, const float* const* vs,
-                                      const uint32_t* const* expNos, float* const* outs, const double* efforts,
-                                      const int* prologues, const void* const* vAux, const float* const* resids) {
-    if (!c || !stageCalls || nStages < 1 || nStages > kMaxStages) return fail(c, EFFORT_ERR_ARG, "bucketmul_chain: 1..8 stages");
-    int stages[kMaxGroup], n = 0;
-    for (int k = 0; k < nStages; k++) {
-        if (stageCalls[k] < 1 || n + stageCalls[k] > kMaxGroup) return fail(c, EFFORT_ERR_ARG, "bucketmul_chain: a stage holds at least one call, a chain at most 32");
-        for (int i = 0; i < stageCalls[k]; i++) stages[n++] = k;
-    }
-    return do_group(c, kFp16, n, ws, vs, expNos, outs, efforts, prologues, vAux, resids, stages);
 }
 extern "C" int effort_bucketmul_q4_group(effort_ctx* c, int n, const effort_w* const* ws, const float* const* vs,
                                          const uint32_t* const* expNos, float* const* outs, const double* efforts) {
@@ -1151,18 +1141,6 @@ extern "C" int effort_set_persistent(effort_ctx* c, int wgPerCU) {
 extern "C" int effort_debug_hook_lane(effort_ctx* c, int lane) {
     if (!c || lane < 0 || lane >= c->nLanes) return EFFORT_ERR_ARG;
     c->lastLane = lane;
-    return EFFORT_OK;
-}
-
-extern "C" int effort_set_q4_byte_acc(effort_ctx* c, int on) {
-    if (!c) return EFFORT_ERR_ARG;
-    c->q4ByteAcc = on != 0;
-    return EFFORT_OK;
-}
-
-extern "C" int effort_set_chain_tuning(effort_ctx* c, int sliceMult) {
-    if (!c || sliceMult < 1 || sliceMult > 8) return EFFORT_ERR_ARG;
-    c->chainSliceMult = sliceMult;
     return EFFORT_OK;
 }
 

@@ -94,11 +94,6 @@ constexpr int kRowAux = EFFORT_ROW_AUX;
 #define GA_TRACE(ga) (PERSIST ? (ga).trace : 0u)
 #endif
 constexpr uint32_t kMaxLdsBytes = 160u * 1024u - 1024u;     // dynamic LDS a launch may ask for: a gfx950 CU's 160 KB less the kernel's static words (rounded up generously)
-#ifndef EFFORT_LEAN_NAMED
-#define EFFORT_LEAN_NAMED 0
-#endif
-constexpr bool kLeanNamed = EFFORT_LEAN_NAMED != 0;   // plain grids hand their tiles to a named reducer too (A/B builds; see mul_item, E: measured slower)
-constexpr uint32_t kSlabSentinel = 0xFFFFFFFFu;      // NAMED hand-off: what every slab word holds between launches (a NaN no partial sum can be)
 constexpr int kSc1 = 16;     // buffer aux bit: sc1 = write-through store / L1-bypassing load (cross-XCD visible)
 
 template <int FMT> struct Fmt;
@@ -106,19 +101,14 @@ template <int FMT> struct Fmt;
 // Q4 keeps TWO accumulators per output, one for each sign nibble (slot = sub-bucket*16 + the whole 4-bit nibble): every
 // nibble then adds the same +d and the address comes straight out of the nibble -- 3 instructions per nibble instead of
 // 6 (no sign select) -- and the hand-off subtracts the planes.
-// kStream: LDS accumulators per u16 column WHILE the rows stream (= kSlots, except for the byte-indexed Q4 variant).
-template <> struct Fmt<kFp16> { static constexpr int kAcc = 16, kSlots = 16, kStream = 16; };
-template <> struct Fmt<kQ4> { static constexpr int kAcc = 32, kSlots = 64, kStream = 64; };
-// kQ4B -- ONE LDS atomic per BYTE of a word instead of one per nibble: the two nibbles of a byte share an accumulator indexed by
-// the byte's value (2 x 256 slots per column: 128 KB for a 64-column tile, one workgroup per CU), and after the last row the 512
-// byte sums are FOLDED into the 64 nibble sums the rest of the item works with: slot(nibble position qi, value n) = the sum over
-// the sixteen values m of the byte's other nibble.  Half the atomics of kQ4 for 2 x 16 LDS reads per output at the end.
-template <> struct Fmt<kQ4B> { static constexpr int kAcc = 32, kSlots = 64, kStream = 512; };
+// (A byte-indexed variant -- one atomic per BYTE into 512 slots per column, folded afterwards -- was built and measured slower in
+//  round 4: branch `chain-launch`)
+template <> struct Fmt<kFp16> { static constexpr int kAcc = 16, kSlots = 16; };
+template <> struct Fmt<kQ4> { static constexpr int kAcc = 32, kSlots = 64; };
 
 template <int FMT> struct MeanT;                       // what the staged row means are kept as in LDS
 template <> struct MeanT<kFp16> { typedef uint16_t type; };    // f16 bits (stats lane .w)
 template <> struct MeanT<kQ4> { typedef float type; };        // f32 (stats lane .y)
-template <> struct MeanT<kQ4B> { typedef float type; };
 
 // One lane's piece of a bucket row: E u16 words.
 template <int E> struct Piece;
@@ -179,7 +169,7 @@ __host__ __device__ inline LdsPlan plan_lds(const MulGeom* geoms, int nGeoms) {
     p.offV[1] = FMT == kFp16 ? o : p.offV[0];
     if (FMT == kFp16) o += vrows * 4;
     if (FMT != kFp16 && o < ol) o = align_up(ol, 16);
-    p.offA = o; o += (uint32_t)Fmt<FMT>::kStream * E * 64 * 4;
+    p.offA = o; o += (uint32_t)Fmt<FMT>::kSlots * E * 64 * 4;
     p.offL = o; o += align_up(slots * 2, 16);
     const uint32_t tbl = cutoff_table_bytes(64 * W);        // (>= the tile reduction's [G][tileFloats] partial sums)
     if (o < p.offA + tbl) o = p.offA + tbl;
@@ -223,26 +213,10 @@ __device__ __forceinline__ bool locate_item(const GroupKArgs& ga, const uint32_t
 // as its own youngest ones, so the first wait after an issue drains the wave's batches in flight once.  Completion is
 // awaited explicitly (s_waitcnt vmcnt(0)) where the data is read.
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-// SC1: the load bypasses this CU's L1 and is coherent at device scope -- for data another workgroup of the SAME launch wrote
-// (chain launches: the input vector of a later stage).
-template <bool SC1 = false>
 __device__ __forceinline__ void lds_dma_dword(const u32x4 rsrc, const uint32_t voff, const uint32_t ldsAddr) {
     uint32_t keep;
-    if constexpr (SC1)
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dword %1, %3, 0 offen sc1 lds\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(voff), "s"(ldsAddr), "s"(rsrc) : "memory");
-    else
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dword %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(voff), "s"(ldsAddr), "s"(rsrc) : "memory");
-}
-// A load of data written earlier in the same launch by another workgroup (CHAIN), or an ordinary load.
-template <bool CHAIN, typename T>
-__device__ __forceinline__ T ld_dep(const T* p) {
-    if constexpr (CHAIN) {
-        static_assert(sizeof(T) == 4, "ld_dep: dwords");
-        const uint32_t u = __hip_atomic_load(reinterpret_cast<const uint32_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        T r; __builtin_memcpy(&r, &u, 4); return r;
-    } else return *p;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dword %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(ldsAddr), "s"(rsrc) : "memory");
 }
 __device__ __forceinline__ u32x4 make_rsrc(const void* base, uint32_t bytes) {
     const uint64_t p = (uint64_t)(size_t)base;
@@ -252,10 +226,8 @@ __device__ __forceinline__ u32x4 make_rsrc(const void* base, uint32_t bytes) {
     return r;
 }
 
-// `parts`: bit 0 = the row means (weights only), bit 1 = the slice of v.  A CHAIN item asks for the means first and for v only once
-// the stage that writes v is complete.
-template <int FMT, int W, bool COMPACT, bool CHAIN = false>
-__device__ __forceinline__ void stage_issue(const GroupKArgs& ga, const ItemRef& r, const int tid, char* smem, const LdsPlan& lp, const uint32_t par, const uint32_t parts = 3u) {
+template <int FMT, int W, bool COMPACT>
+__device__ __forceinline__ void stage_issue(const GroupKArgs& ga, const ItemRef& r, const int tid, char* smem, const LdsPlan& lp, const uint32_t par) {
     constexpr int NT = 64 * W;
     using lds_v = __attribute__((address_space(3))) void;
     const CallDesc& a = ga.call[__builtin_amdgcn_readfirstlane(r.ci)];
@@ -271,7 +243,6 @@ __device__ __forceinline__ void stage_issue(const GroupKArgs& ga, const ItemRef&
     const u32x4 rv = make_rsrc(a.v, inDim * 4u);
     const uint32_t ldsM = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(lds_v*)(smem + lp.offM));
     const uint32_t ldsV = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(lds_v*)(smem + ((par & 1u) ? lp.offV[1] : lp.offV[0])));
-    if (parts & 1u) {
     if constexpr (compact) {
         // one dword = the means of candidate slots 2d and 2d+1 (rows j and j+1 of one rank: neighbours in memory; every slice
         // starts on an even row -- the host checks -- so the dword is aligned): half the loads, means[] holds u16 per slot
@@ -297,13 +268,10 @@ __device__ __forceinline__ void stage_issue(const GroupKArgs& ga, const ItemRef&
         }
         lds_dma_dword(rs, voff, ldsM + ((uint32_t)(rr * NT) + wave * 64u) * 4u);
     }
-    }
-    if (parts & 2u) {
 #pragma unroll
     for (int u = 0; u < (FMT == kFp16 ? 1 : 2); u++) {
         if ((uint32_t)(u * NT) + wave * 64u >= nb) continue;    // uniform per wave (reads past inDim return 0; past the slice, a neighbour's input nobody looks at)
-        lds_dma_dword<CHAIN>(rv, (j0 + (uint32_t)(u * NT + tid)) * 4u, ldsV + ((uint32_t)(u * NT) + wave * 64u) * 4u);
-    }
+        lds_dma_dword(rv, (j0 + (uint32_t)(u * NT + tid)) * 4u, ldsV + ((uint32_t)(u * NT) + wave * 64u) * 4u);
     }
 }
 
@@ -311,13 +279,12 @@ __device__ __forceinline__ void stage_issue(const GroupKArgs& ga, const ItemRef&
 // `staged` (per wave): this wave's share of the item's stage loads was issued while the previous item streamed (into vblk
 // buffer `par`).  `prefetch` is polled by every wave near the end of its streaming loop until it returns true: there the
 // caller pulls the next item from the queue (wave 0) and issues the wave's share of its stage loads (into buffer par ^ 1).
-template <int FMT, int E, int W, bool FUSED, bool COMPACT, bool PERSIST, bool CHAIN, typename Prefetch>
+template <int FMT, int E, int W, bool FUSED, bool COMPACT, bool PERSIST, typename Prefetch>
 __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t item, const ItemRef& ref, char* smem, const LdsPlan& lp, uint32_t& cachedCall,
                                          float& cachedCutoff, const uint32_t par, const bool staged, const bool firstItem, Prefetch prefetch) {
     constexpr int NACC = Fmt<FMT>::kAcc;
     constexpr int TILE_F = NACC * E * 64;                    // outputs of a tile (slab / out[] granularity)
-    constexpr int TILE_L = Fmt<FMT>::kStream * E * 64;       // LDS accumulators of a tile while the rows stream
-    constexpr int TILE_LF = Fmt<FMT>::kSlots * E * 64;       // ... once they are in (kQ4B folds 512 byte slots per column into 64)
+    constexpr int TILE_L = Fmt<FMT>::kSlots * E * 64;        // LDS accumulators of a tile
     constexpr int NT = 64 * W;
     constexpr int VPT = 4096 / NT;
     constexpr int KB = batch_rows<E>();                      // bucket rows per batch; two batches in flight per wave
@@ -359,36 +326,10 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     const uint32_t j0 = s * B;
     const uint32_t nb = min(B, g.inDim - j0);
     const uint32_t e = a.expNo ? a.expNo[0] : 0u;
-    // (plain grids' hand-off, see E: the tile's consumption counter as this launch finds it; asked for here, used at the end)
-    uint32_t namedC0 = 0u;
-    if constexpr (kLeanNamed && !PERSIST) { if (tid == 0) namedC0 = (uint32_t)__hip_atomic_load(ga.named + (a.tileOff + t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
     // ---- A. everything the selection needs lands in LDS (stage_issue): the row means of the candidate slots, the slice of v
-    if (!staged) stage_issue<FMT, W, COMPACT, CHAIN>(ga, ref, tid, smem, lp, par, CHAIN ? 1u : 3u);
+    if (!staged) stage_issue<FMT, W, COMPACT>(ga, ref, tid, smem, lp, par);
     const float rankBound = a.rankBound[e];                       // (asked for here: its round trip runs under the staged loads')
-    if constexpr (CHAIN) {
-        // CHAIN launch: this call's inputs (v, the gate's partner, the residual) are outputs of the calls of the previous
-        // stage.  The row means -- weights only -- are on their way into LDS already; thread 0 polls the previous stage's
-        // count of written column tiles (the last arriver of a tile raises it after its stores to out[] have left the CU, see
-        // E), the barrier hands the verdict to the workgroup, and only then the slice of v is asked for.  Every load of such
-        // data bypasses L1 (sc1: ld_dep, lds_dma_dword<true>): this CU may hold the buffer's lines of an earlier token.  Forward
-        // progress: the queues hand out a stage's items after all items of the stages before it, and the workgroups that took
-        // those wait only on still earlier stages.  (A workgroup's second item of a call skips the poll.)
-        const uint32_t stage = (uint32_t)a.pre >> 8;
-        if (stage > 0u && cachedCall != ci) {
-            if (wave == 0) {                                  // lane i watches the flag of tile i of the previous stage (<= 64 tiles), in this XCD's copy
-                const uint32_t need = ga.stageTiles[stage - 1u];
-                const uint32_t* const f = ga.queue + kStageFlagOff + ((stage - 1u) * 8u + (blockIdx.x & 7u)) * 64u + (uint32_t)lane;
-                for (int spin = 0; spin < 400000; spin++) {
-                    const uint32_t x = (uint32_t)lane < need ? __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1u;
-                    if (__ballot(x == 0u) == 0ull) break;
-                    __builtin_amdgcn_s_sleep(8);
-                }
-            }
-            __syncthreads();
-        }
-        stage_issue<FMT, W, COMPACT, CHAIN>(ga, ref, tid, smem, lp, par, 2u);
-    }
     float vj[VPT]; uint16_t prj[VPT];
     const uint16_t* pr = a.probes + (size_t)e * kProbes;
     const bool fused = (ga.split & 1u) == 0u;                    // uniform
@@ -401,7 +342,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     // Input prologue (uniform per call): the multiply's input is v itself, or silu(v) * vAux (the FFN gate,
     // runNetwork.swift:181), or rmsNorm(v) * vAux (runNetwork.swift:121-122,173-175) -- evaluated here, per workgroup,
     // instead of in a launch of its own.
-    const uint32_t pre = FUSED ? ((uint32_t)a.pre & 0xFFu) : (uint32_t)kPreNone;      // FUSED is a separate instantiation: the plain multiply pays nothing
+    const uint32_t pre = FUSED ? (uint32_t)a.pre : (uint32_t)kPreNone;      // FUSED is a separate instantiation: the plain multiply pays nothing
     // A prologue's operands are ALL asked for here, in one memory round trip beside the stage loads: the first 4096 raw inputs,
     // their partners from vAux (the gate's x3 as f32, the norm weights as f16: kept as raw bits), the probes, and vAux for this
     // thread's element of the slice.  (Asked for where they were used -- vAux after the norm's reduction, the slice's vAux after
@@ -415,17 +356,17 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
         const bool gate = pre == (uint32_t)kPreSiluGate;
         if (needCutEarly || !gate) {
 #pragma unroll
-            for (int i = 0; i < VPT; i++) rawn[i] = ld_dep<CHAIN>(a.v + tid + NT * i);
+            for (int i = 0; i < VPT; i++) rawn[i] = *(a.v + tid + NT * i);
         }
         if (needCutEarly) {
 #pragma unroll
             for (int i = 0; i < VPT; i++) {
-                auxc[i] = gate ? __float_as_uint(ld_dep<CHAIN>(reinterpret_cast<const float*>(a.vAux) + tid + NT * i)) : (uint32_t)reinterpret_cast<const uint16_t*>(a.vAux)[tid + NT * i];
+                auxc[i] = gate ? __float_as_uint(*(reinterpret_cast<const float*>(a.vAux) + tid + NT * i)) : (uint32_t)reinterpret_cast<const uint16_t*>(a.vAux)[tid + NT * i];
                 prj[i] = pr[tid + NT * i];
             }
         }
         const uint32_t js = j0 + min((uint32_t)tid, nb - 1u);
-        auxS = gate ? __float_as_uint(ld_dep<CHAIN>(reinterpret_cast<const float*>(a.vAux) + js)) : (uint32_t)reinterpret_cast<const uint16_t*>(a.vAux)[js];
+        auxS = gate ? __float_as_uint(*(reinterpret_cast<const float*>(a.vAux) + js)) : (uint32_t)reinterpret_cast<const uint16_t*>(a.vAux)[js];
     }
     const uint32_t lg = g.sliceLog2;
     const uint32_t nSlots = FMT == kFp16 ? (g.rowsPerIn << lg) : (nb << 3);
@@ -446,7 +387,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 const uint32_t j = base + (uint32_t)(r * NT);
-                if (j < g.inDim) { const float x = ld_dep<CHAIN>(a.v + j); part[r] += x * x; }
+                if (j < g.inDim) { const float x = *(a.v + j); part[r] += x * x; }
             }
         }
 #pragma unroll
@@ -473,7 +414,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
             for (int i = 0; i < VPT; i++) vj[i] = xform(rawn[i], auxc[i]);
         } else {
 #pragma unroll
-            for (int i = 0; i < VPT; i++) { vj[i] = ld_dep<CHAIN>(a.v + tid + NT * i); prj[i] = pr[tid + NT * i]; }
+            for (int i = 0; i < VPT; i++) { vj[i] = *(a.v + tid + NT * i); prj[i] = pr[tid + NT * i]; }
         }
     };
     if (needCut && !viaJob) load_cut_inputs();
@@ -537,10 +478,6 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
         cutoff = a_cutoff[0];
         __syncthreads();                                             // publishes vblk / wbound / the list length
     }
-    if constexpr (FMT == kQ4B) {                                     // (128 KB: sixteen bytes a store)
-        uint4* const acc4 = reinterpret_cast<uint4*>(acc);
-        for (int i = tid; i < TILE_L / 4; i += NT) acc4[i] = make_uint4(0, 0, 0, 0);
-    } else
     for (int i = tid; i < TILE_L; i += NT) acc[i] = 0;               // the table is dead: zero the tile (barrier in C)
     // Fixed-point scale of this workgroup's tile.  Every product is |v_j| * |w| with |w| <= (max |w| of its rank), so
     // every partial sum is bounded by L = (sum over the slice of |v_j|) * (sum over ranks of that rank's max |w|)
@@ -628,7 +565,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     const uint32_t col = t * (64u * E) + (uint32_t)lane * E;
     const bool colOK = col < g.cols;                               // a piece past the last column is skipped whole
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint16_t*>(a.buckets), 0, (int)min((size_t)0xFFFFFFFFu, (size_t)g.numExperts * g.expertRows * g.rowPitch), 0x00020000);
+        const_cast<uint16_t*>(a.buckets), 0, (int)min((size_t)0xFFFFFFFFu, (size_t)g.numExperts * g.expertRows * g.rowPitch - (size_t)a.bucketsTrim), 0x00020000);
     // lanes past the last column re-read the row's LAST piece -- the line their neighbours are fetching anyway.  (They used to
     // re-read column 0: one more 128-byte line per kept row for the ragged last tile, 68 MB of a 32-call launch's 824.)
     const uint32_t voff = (colOK ? col : (g.cols - 1u) / (uint32_t)E * (uint32_t)E) * 2u;
@@ -693,17 +630,6 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
                 else asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[0,1,0]\n\tv_cvt_rpi_i32_f32 %0, %0" : "=v"(qv) : "v"(dd), "v"(dw));
                 __hip_atomic_fetch_add((lds_i*)(size_t)a2 + j * 64, qv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
-        } else if (FMT == kQ4B) {
-            // one atomic per BYTE: slot = byte index (0 low, 1 high) * 256 + the byte's value; the second byte's plane lies 64 KB
-            // above the first -- beyond a DS instruction's 16-bit offset, hence a base of its own
-            static_assert(FMT != kQ4B || E == 1, "byte-indexed Q4: 64-column tiles");
-            const int di = __float_as_int(dd);
-            const uint32_t x = pc.word(0);
-            uint32_t a0, a1;
-            asm("v_bfe_u32 %0, %1, 0, 8\n\tv_lshl_add_u32 %0, %0, 8, %2" : "=&v"(a0) : "v"(x), "v"(accB));
-            asm("v_bfe_u32 %0, %1, 8, 8\n\tv_lshl_add_u32 %0, %0, 8, %2" : "=&v"(a1) : "v"(x), "v"(accB + 65536u));
-            __hip_atomic_fetch_add((lds_i*)(size_t)a0, di, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_add((lds_i*)(size_t)a1, di, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         } else {
             // bucketMulQ4.metal:76-81: low nibble first <-> sub-bucket 3,2,1,0; out += (n&8) ? -d : d.  Here: plane
             // (n&8) of slot (sub-bucket, n&7) += d; the planes are subtracted at the hand-off.
@@ -767,30 +693,6 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     // (measured too: everything BUT this loop at raised priority -- no effect, 173.9 vs 173.5 us per 32-call launch)
     if (!asked) asked = prefetch();            // (a wave without rows; wave 0 always gets an answer: it is the one that pulls)
     __syncthreads();                           // every wave's atomics have landed in the tile
-    if constexpr (FMT == kQ4B) {
-        // fold: the nibble at position qi (0 = lowest) of a word with value n collected, spread over the sixteen values m of its
-        // byte's other nibble, in the byte slots (qi >> 1) * 256 + (qi odd ? n << 4 | m : m << 4 | n); its sum goes where the
-        // nibble-indexed scatter of kQ4 would have put it: slot (3 - qi) * 16 + n.  Every thread holds its sums across the barrier
-        // (the folded tile overwrites the first 16 KB of the byte tile).
-        constexpr int PER = 64 * 64 / NT;
-        int res[PER];
-#pragma unroll
-        for (int k = 0; k < PER; k++) {
-            const int s64 = (tid >> 6) + (NT / 64) * k, qi = s64 >> 4, nn = s64 & 15;
-            const int* const src = acc + ((qi >> 1) * 256) * 64 + lane;
-            int sum = 0;
-#pragma unroll
-            for (int m = 0; m < 16; m++) sum += src[((qi & 1) ? (nn << 4 | m) : (m << 4 | nn)) * 64];
-            res[k] = sum;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < PER; k++) {
-            const int s64 = (tid >> 6) + (NT / 64) * k, qi = s64 >> 4, nn = s64 & 15;
-            acc[((3 - qi) * 16 + nn) * 64 + lane] = res[k];
-        }
-        __syncthreads();
-    }
     if (stamp) GA_TSTAMP(ga)[20] = wall_clock64();
     if (wstamp) ph[4] = wall_clock64();
 
@@ -948,43 +850,16 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
         }
         return r;
     };
-    // NAMED (chain launches): the tile's reducer is known up front -- the workgroup that works the tile's LAST slice, the last
-    // of the tile's items the queues hand out.  The others store their slab and move on: no wait for the stores to drain, no
-    // ticket.  The reducer keeps its own tile in LDS and reads the other slabs until none of them shows the SENTINEL (an
-    // all-ones NaN no sum can take: slabs hold int -> float conversions times a power of two) that every slab holds between
-    // launches -- the reducer puts it back after reading, the lane's slab region starts out filled with it (api.hip).  One
-    // memory round trip from the last producer's store to the sum, where the ticket protocol has three (drain, ticket, read).
-    // Forward progress: the reducer waits only for items handed out BEFORE its own, by queues whose other workgroups never wait
-    // for it; the poll is bounded all the same (a slab that never arrives leaves NaNs in out[], loudly, not a hung GPU).
-    // Plain grids (the LEAN instantiation: lone calls, the decode loop's small groups) use the same hand-off, with the sentinel
-    // put back by the PRODUCERS instead of the reducer (BY_PRODUCER): a plain grid's kernel ends when its last store has drained,
-    // so 32 slabs reset by one reducer would lengthen the very call the ticket was removed from; a producer's own slab is 4-8 KB.
-    // The tile has a 64-bit word in the lane's scratch: low half = a counter of launches that consumed the tile (never reset),
-    // high half = producers that gave up waiting.  Every workgroup reads the counter when it starts (c0); the reducer adds 1 once
-    // it holds every slab; a producer waits for the counter to move, then stores the sentinel over its slab and leaves.  The wait
-    // is bounded by the device clock (100 us: e.g. the reducer's block found no free slot because other launches' producers hold
-    // them); a producer that gives up adds 1 to the HIGH half with a returning atomic -- one word, so either it sees the reducer's
-    // increment in the value returned (and resets its slab after all), or the reducer sees the producer's in ITS returned value and
-    // resets the tile's slabs itself at the end.  No path leaves a slab without the sentinel, none waits without bound.
-    // MEASURED, AND OFF (EFFORT_LEAN_NAMED = 0): correct -- the whole -m gpu suite passes with it -- but every plain-grid launch got
-    // 2.3-3.6 us SLOWER (round 4, one box: 4096 -> 4096 lone 18.4 -> 20.7 us, w1|w3 27.3 -> 29.9, the decode loop 315 -> 288
-    // tokens/s at 25 %): the kernel now ends when the last PRODUCER has seen the counter move and drained its reset stores, two
-    // dependent round trips after the reducer's slab loads, where the ticket protocol ends one round trip after them (out[]
-    // drained); what the ticket and the drain cost before the reduction is paid by the last arriver only and was smaller than
-    // that.  Plain grids keep the ticket; chain launches (persistent: nobody waits to leave) keep the named reducer.
     if (fused && b == 0 && tid == 0 && !GA_CUTJOBS(ga)) a_cutoff[0] = cutoff;       // BucketMul.cutoff (bucketMul.swift:22) of a call without a cutoff job
-    constexpr bool NAMED = CHAIN || (kLeanNamed && !PERSIST);
-    constexpr bool BY_PRODUCER = NAMED && !PERSIST;
-    const bool reducer = NAMED && s == g.slices - 1u;
-    unsigned long long* const tileWord = ga.named + (a.tileOff + t);
-    if (!reducer)
+    // (Round 4 built this hand-off WITHOUT ticket and drain -- a reducer named up front polling sentinel slabs -- and measured it
+    //  slower on plain grids: branch `chain-launch`)
     for (int o = tid * 2; o < TILE_F; o += NT * 2) {
         const float s0 = tile_out(o), s1 = tile_out(o + 1);
         typedef uint32_t u2 __attribute__((ext_vector_type(2)));
         u2 pk; pk[0] = __float_as_uint(s0); pk[1] = __float_as_uint(s1);
         __builtin_amdgcn_raw_buffer_store_b64(pk, srs, (uint32_t)o * 4u, slabOff, kSc1);
     }
-    if (!NAMED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's slab stores have left the CU
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          // this wave's slab stores have left the CU
     if (stamp) { GA_TSTAMP(ga)[21] = wall_clock64(); GA_TSTAMP(ga)[22] = n; }
     if (wstamp) ph[5] = wall_clock64();
     // the stamps are flushed off the critical path (after the ticket), spread over 32 cache lines
@@ -1008,36 +883,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
         atomicMax(&GA_TSTAMP(ga)[29], ph[4] - ph[3]);                               // longest streaming phase
         atomicMax(&GA_TSTAMP(ga)[1], (unsigned long long)wall_clock64());
     };
-    if constexpr (NAMED) {
-        if (!reducer) {
-#ifdef EFFORT_NAMED_NO_RESET        // (timing-only A/B build: nobody puts the sentinel back -- WRONG results from the second launch on; the upper bound of what a named reducer can gain)
-            if constexpr (false) {
-#else
-            if constexpr (BY_PRODUCER) {
-#endif
-                if (tid == 0) {
-                    const unsigned long long t0 = wall_clock64();
-                    uint32_t ok = 0u;
-                    do {
-                        if ((uint32_t)__hip_atomic_load(tileWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != namedC0) { ok = 1u; break; }
-                        __builtin_amdgcn_s_sleep(8);
-                    } while (wall_clock64() - t0 < 10000ull);                    // 100 us of the 100 MHz device clock
-                    if (!ok) {                                                   // gave up: say so -- unless the reducer got there meanwhile
-                        const unsigned long long old = __hip_atomic_fetch_add(tileWord, 1ull << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if ((uint32_t)old != namedC0) { ok = 1u; __hip_atomic_fetch_add(tileWord, ~(1ull << 32) + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-                    }
-                    flags[1] = ok;
-                }
-                __syncthreads();
-                if (flags[1]) {
-                    typedef uint32_t u2 __attribute__((ext_vector_type(2)));
-                    u2 sent; sent[0] = sent[1] = kSlabSentinel;
-                    for (int o = tid * 2; o < TILE_F; o += NT * 2) __builtin_amdgcn_raw_buffer_store_b64(sent, srs, (uint32_t)o * 4u, slabOff, kSc1);
-                }
-            }
-            flush_stamps(); return;
-        }
-    } else {
+    {
         __syncthreads();
         if (tid == 0) {
             const uint32_t ticket = __hip_atomic_fetch_add(&a_counters[t], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1060,10 +906,10 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     // group then has at most 16 slices = ONE round trip; the groups' partial sums meet in LDS and are added in group order.
     constexpr int kCols4 = TILE_F / 4;
     constexpr int G = NT / kCols4 >= 2 ? NT / kCols4 : 1;
-    // [G][TILE_F] partial sums of the thread groups, BEHIND the accumulator tile (a named reducer still reads its own tile from
-    // there; the list and the rest of the cutoff table's region are free: G * TILE_F * 4 + the tile <= the table, see plan_lds)
-    float* const gpart = reinterpret_cast<float*>(smem + offA + (uint32_t)TILE_LF * 4u);
-    static_assert(G == 1 || (uint32_t)TILE_LF * 4u + (uint32_t)G * TILE_F * 4u <= (cutoff_table_bytes(NT) > (uint32_t)TILE_L * 4u ? cutoff_table_bytes(NT) : (uint32_t)TILE_L * 4u),
+    // [G][TILE_F] partial sums of the thread groups, BEHIND the accumulator tile (the list and the rest of the cutoff table's
+    // region are free: G * TILE_F * 4 + the tile <= the table, see plan_lds)
+    float* const gpart = reinterpret_cast<float*>(smem + offA + (uint32_t)TILE_L * 4u);
+    static_assert(G == 1 || (uint32_t)TILE_L * 4u + (uint32_t)G * TILE_F * 4u <= (cutoff_table_bytes(NT) > (uint32_t)TILE_L * 4u ? cutoff_table_bytes(NT) : (uint32_t)TILE_L * 4u),
                   "the thread groups' partial sums must fit behind the tile");
     auto reduce_tile = [&](auto kc) {
         constexpr int kRed = decltype(kc)::value;          // 16-byte slab loads in flight per thread
@@ -1080,43 +926,17 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
                 for (int h = 0; h < 4; h++) {
                     const uint32_t oo = (uint32_t)o + h, lane2 = oo & 63u, sj = oo >> 6, j = sj % E, slot = sj / E;
                     const uint32_t c2 = t * (64u * E) + lane2 * E + j;
-                    if (c2 < g.cols) res[h] = ld_dep<CHAIN>(a.resid + c2 * NACC + slot);
+                    if (c2 < g.cols) res[h] = *(a.resid + c2 * NACC + slot);
                 }
             }
             float sm[4][4];                                // [tile slot of this thread][slice % 4]: fixed summation order
 #pragma unroll
             for (int h = 0; h < 4; h++) { sm[h][0] = 0.0f; sm[h][1] = 0.0f; sm[h][2] = 0.0f; sm[h][3] = 0.0f; }
-            u4v own;                                       // NAMED: the reducer's own slice of these four outputs, straight from its LDS tile
-            if constexpr (NAMED) {
-#pragma unroll
-                for (int h = 0; h < 4; h++) own[h] = __float_as_uint(tile_out(o + h));
-            }
             for (uint32_t sl = sl0; sl < sl1; sl += kRed) {
                 u4v r[kRed];
-                if constexpr (NAMED) {
-                    // the slabs of the other slices: asked for together, again while any of them still shows the sentinel
-                    // (16 bytes = two 8-byte stores of one producer: every word is looked at).  The sentinel goes back AFTER
-                    // out[] and the stage flag (below): 32 slabs of 4-8 KB are 128-256 KB of stores per reducer, 2-4 us that the
-                    // next stage must not wait for
-                    const uint32_t last = g.slices - 1u;
-                    for (uint32_t tries = 0;; tries++) {
-#pragma unroll
-                        for (int i = 0; i < kRed; i++)
-                            r[i] = __builtin_amdgcn_raw_buffer_load_b128(srs, vo, min(sl + i, last) * sliceStride, kSc1);
-                        bool bad = false;
-#pragma unroll
-                        for (int i = 0; i < kRed; i++)
-                            if (sl + i < sl1 && sl + i != last) bad |= (r[i][0] == kSlabSentinel) | (r[i][1] == kSlabSentinel) | (r[i][2] == kSlabSentinel) | (r[i][3] == kSlabSentinel);
-                        if (!bad || tries > (1u << 17)) break;
-                        __builtin_amdgcn_s_sleep(2);
-                    }
-#pragma unroll
-                    for (int i = 0; i < kRed; i++) if (sl + i == last) r[i] = own;
-                } else {
 #pragma unroll
                 for (int i = 0; i < kRed; i++)
                     r[i] = __builtin_amdgcn_raw_buffer_load_b128(srs, vo, min(sl + i, g.slices - 1u) * sliceStride, kSc1);
-                }
 #pragma unroll
                 for (int i = 0; i < kRed; i++) {
                     if (sl + i < sl1) {
@@ -1147,9 +967,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
                 if (c2 < g.cols) {
                     const uint32_t oi = c2 * NACC + slot;
                     const float val = (FUSED && a.resid) ? res[h] + tot[h] : tot[h];
-                    // (CHAIN: written through, so that a later stage's workgroup on another XCD reads it from memory)
-                    if constexpr (CHAIN) __hip_atomic_store(reinterpret_cast<uint32_t*>(a.out + oi), __float_as_uint(val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    else a.out[oi] = val;
+                    a.out[oi] = val;
                 }
             }
         }
@@ -1161,46 +979,6 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     // (G > 1: thread group 0 reads the partial sums in the accumulator region after reduce_tile's only barrier; a persistent
     //  workgroup's next item -- or cutoff job -- zeroes its count table there, so the region must be quiescent first)
     if (PERSIST && G > 1) __syncthreads();
-    if constexpr (CHAIN) {
-        // this tile of the call's output is written: once every thread's stores have left the CU, raise the tile's flag of its
-        // stage -- eight copies, one per XCD, each on lines of its own: the next stage's workgroups poll the copy of THEIR XCD,
-        // 64 pollers a line instead of 500 on one counter (which queued the polls and the reducers' own traffic behind each other)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid < 8) {
-            const uint32_t stage = (uint32_t)a.pre >> 8;
-            uint32_t base = 0;
-            for (uint32_t k = 0; k < stage; k++) base += ga.stageTiles[k];
-            __hip_atomic_store(ga.queue + kStageFlagOff + (stage * 8u + (uint32_t)tid) * 64u + ((uint32_t)a.tileOff - base + t), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    if constexpr (NAMED) {
-        bool resetAll = !BY_PRODUCER;
-#ifdef EFFORT_NAMED_NO_RESET
-        if constexpr (false) {
-#else
-        if constexpr (BY_PRODUCER) {
-#endif
-            // every thread holds its sums: the producers may put the sentinel back (the counter moves on); the value returned tells
-            // whether one of them gave up waiting -- then the tile's slabs are reset here
-            __syncthreads();
-            if (tid == 0) {
-                const unsigned long long old = __hip_atomic_fetch_add(tileWord, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t gaveUp = (uint32_t)(old >> 32);
-                if (gaveUp) __hip_atomic_fetch_add(tileWord, ~((unsigned long long)gaveUp << 32) + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                flags[1] = gaveUp;
-            }
-            __syncthreads();
-            resetAll = flags[1] != 0u;
-        }
-        if (resetAll) {
-            // the slabs this reducer consumed hold the sentinel again when the launch ends (fire and forget)
-            u4v sent; sent[0] = sent[1] = sent[2] = sent[3] = kSlabSentinel;
-            for (uint32_t o4 = (uint32_t)tid; o4 < (uint32_t)(TILE_F / 4); o4 += (uint32_t)NT)
-                for (uint32_t sl = 0; sl + 1u < g.slices; sl++)
-                    __builtin_amdgcn_raw_buffer_store_b128(sent, srs, t * (uint32_t)(TILE_F * 4) + o4 * 16u, sl * sliceStride, kSc1);
-        }
-    }
     if (rstamp) GA_TSTAMP(ga)[24] = wall_clock64();
     if (tid == 0) {
         __hip_atomic_store(&a_counters[t], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next call
@@ -1256,11 +1034,9 @@ __device__ __forceinline__ void cutoff_job(const GroupKArgs& ga, uint32_t ci, ch
 // dispatcher only places ~40 workgroups/us chip-wide and spreads a large grid unevenly over the CUs (measured with
 // tools/microbench.hip: residency probe), so a group launch sizes its grid to the chip -- R workgroups per CU,
 // R fixed by the LDS each one asks for -- and balances the work itself.
-// CHAIN: the calls come in STAGES, and a stage's calls read what the stages before it wrote (the decode loop's wo -> w1|w3 -> w2 ->
-// wq|wk|wv of the next layer, glue folded in, as ONE launch): persistent workgroups, the queues hand out the stages in order, an item
-// waits for the stage before its own (mul_item, A), no cutoff jobs (every workgroup evaluates the cutoff of a call it works on, as
-// a plain grid's do).  E is then the LARGEST lane width in the launch; an item runs with its own call's (MulGeom::elems: 1 or 2).
-template <int FMT, int E, int W, bool FUSED, bool COMPACT = false, bool PERSIST = true, bool CHAIN = false>
+// (Round 4's CHAIN instantiation -- a layer's dependent multiplies as stages of ONE launch, measured 22 % slower than the launches of
+//  their own -- lives on branch `chain-launch`: DESIGN.md 4.5.)
+template <int FMT, int E, int W, bool FUSED, bool COMPACT = false, bool PERSIST = true>
 __global__ __launch_bounds__(64 * W, (W <= 8 ? EFFORT_MIN_WAVES_PER_EU : 4)) void bucket_mul_kernel(const GroupKArgs ga) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ uint32_t s_item;
@@ -1334,29 +1110,18 @@ __global__ __launch_bounds__(64 * W, (W <= 8 ? EFFORT_MIN_WAVES_PER_EU : 4)) voi
             return true;
         };
         const bool firstOwn = gen == 1u && (GA_ABLATE(ga) & 512u) != 0u;     /* (measured: evaluating the first item's cutoff locally instead of waiting for the job is 1 us slower per 32-call launch; kept as an ablation) */
-        auto run = [&](auto ec) {
-            mul_item<FMT, decltype(ec)::value, W, FUSED, COMPACT, PERSIST, CHAIN>(ga, item - GA_CUTJOBS(ga), ref, smem, lp, cachedCall, cachedCutoff, par, staged, firstOwn, prefetch);
-        };
-        if (CHAIN && E > 1 && ga.geom[ga.call[__builtin_amdgcn_readfirstlane(ref.ci)].geom].elems == 1u) run(std::integral_constant<int, 1>{});   // (uniform)
-        else run(std::integral_constant<int, E>{});
+        mul_item<FMT, E, W, FUSED, COMPACT, PERSIST>(ga, item - GA_CUTJOBS(ga), ref, smem, lp, cachedCall, cachedCutoff, par, staged, firstOwn, prefetch);
         // (mul_item's barriers lie between wave 0's publication and this read)
         item = GA_PERSISTENT(ga) ? __builtin_amdgcn_readfirstlane((uint32_t)__hip_atomic_load(&s_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) : total;
         staged = stagedNext;
         par ^= 1u;
     }
-    if (CHAIN) { __syncthreads(); if (threadIdx.x == 0) s_item = 0u; }     // (s_item: every wave has read its last item by now)
     if (GA_PERSISTENT(ga) && threadIdx.x == 0) {               // the last workgroup out rewinds the queues (and flags) for the next launch
         const uint32_t gone = __hip_atomic_fetch_add(&ga.queue[8 * 16], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (gone == gridDim.x - 1u) {
             for (int i = 0; i <= 8; i++) __hip_atomic_store(&ga.queue[i * 16], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             for (int i = 0; i < kMaxGroup; i++) __hip_atomic_store(&ga.queue[9 * 16 + i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (CHAIN) s_item = 0xFFFFFFFFu;                   // (the whole workgroup lowers the stage flags, below)
         }
-    }
-    if (CHAIN) {
-        __syncthreads();
-        if (s_item == 0xFFFFFFFFu)
-            for (uint32_t i = threadIdx.x; i < (uint32_t)(kMaxStages * 8 * 64); i += 64u * W) __hip_atomic_store(&ga.queue[kStageFlagOff + i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -1392,7 +1157,6 @@ static hipError_t launch_mul_t(const GroupKArgs& gaIn, hipStream_t st) {
     if (lds > kMaxLdsBytes) return hipErrorInvalidValue;
     const bool compact = (ga.split & 4u) != 0u;                   // (api.hip: persistent FP16 launches of plain calls)
     const bool lean = kLean && !ga.persistent && !ga.tstamp && !ga.ablate;
-    if ((lean && kLeanNamed) != ((ga.split & 8u) != 0u)) return hipErrorInvalidValue;      // (a named hand-off needs the sentinel slabs: api.hip decides with the same test)
     if (compact && (FMT != kFp16 || (fusedAny && !lean))) return hipErrorInvalidValue;
     const dim3 gd(grid), bd(64 * W);
     if constexpr (kLean) {
@@ -1408,38 +1172,6 @@ static hipError_t launch_mul_t(const GroupKArgs& gaIn, hipStream_t st) {
 }
 
 #define EFFORT_GEOMS(X) X(16, 1) X(16, 2) X(16, 4) X(8, 1) X(8, 2) X(8, 4) X(4, 1) X(4, 2) X(4, 4) X(2, 4)
-
-// ---- chain launches: FP16, 8 waves, lanes of one or two columns, prologues / residuals, compact means, persistent -----------
-constexpr int kChainE = 2, kChainW = 8;
-static const void* chain_kernel() { return reinterpret_cast<const void*>(&bucket_mul_kernel<kFp16, kChainE, kChainW, true, true, true, true>); }
-hipError_t launch_bucket_mul_chain(const GroupKArgs& gaIn, hipStream_t st) {
-    GroupKArgs ga = gaIn;
-    if (!(ga.split & 16u) || !(ga.split & 4u) || !ga.persistent || ga.cutJobs || ga.count < 1u) return hipErrorInvalidValue;
-    // the LDS plan over the launch's geometries: the tile of the widest lanes, every call's slots
-    const LdsPlan lp = ga.lp = plan_lds<kFp16, kChainE, kChainW>(ga.geom, kMaxGeoms);
-    if (lp.offA > 65536u) return hipErrorInvalidValue;
-    uint32_t stage = 0;
-    for (uint32_t i = 0; i < ga.count; i++) {
-        const MulGeom& g = ga.geom[ga.call[i].geom];
-        if (g.elems != 1u && g.elems != (uint32_t)kChainE) return hipErrorInvalidValue;
-        if (g.slots > (uint32_t)kRounds * 64 * kChainW || g.slots != (g.rowsPerIn << g.sliceLog2) || (1u << g.sliceLog2) > 64u * kChainW) return hipErrorInvalidValue;
-        if (g.tiles != (g.cols + 64u * g.elems - 1u) / (64u * g.elems)) return hipErrorInvalidValue;
-        if (((uint32_t)ga.wgEnd8[i] - (i ? (uint32_t)ga.wgEnd8[i - 1] : 0u)) * 8u != g.tiles * align_up(g.slices, 8)) return hipErrorInvalidValue;
-        const uint32_t sg = (uint32_t)ga.call[i].pre >> 8;          // stages in order, none skipped
-        if (sg < stage || sg > stage + 1u || sg >= (uint32_t)kMaxStages || (i == 0 && sg != 0u)) return hipErrorInvalidValue;
-        stage = sg;
-    }
-    if (ga.totalItems != (uint32_t)ga.wgEnd8[ga.count - 1] * 8u) return hipErrorInvalidValue;
-    // R workgroups per CU, exactly (as launch_mul_t does); never more workgroups than items
-    const uint32_t R = ga.persistent;
-    uint32_t grid = ga.numCU * R, lds = lp.total;
-    if (grid > ga.totalItems) grid = ga.totalItems;
-    const uint32_t force = (160u * 1024u) / (R + 1u) + 512u;
-    if (lds < force && force <= (160u * 1024u) / R) lds = force;
-    if (lds > kMaxLdsBytes) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((bucket_mul_kernel<kFp16, kChainE, kChainW, true, true, true, true>), dim3(grid), dim3(64 * kChainW), lds, st, ga);
-    return hipGetLastError();
-}
 
 // Lets every instantiation of the kernel ask for up to the whole LDS of a CU as dynamic shared memory, on the CURRENT device.
 // Done once per device when its first context is created (api.hip), not lazily at launch: a function attribute belongs to a
@@ -1465,19 +1197,11 @@ static hipError_t prepare_t() {
     }
     return err;
 }
-bool bucket_mul_lean_named() { return kLeanNamed; }
 hipError_t bucket_mul_prepare_device() {
     hipError_t err = hipSuccess;
-    {
-        hipFuncAttributes fa;
-        err = hipFuncGetAttributes(&fa, chain_kernel());
-        if (err == hipSuccess) err = hipFuncSetAttribute(chain_kernel(), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160u * 1024u - (uint32_t)fa.sharedSizeBytes));
-    }
 #define EFFORT_CASE(w, e) if (err == hipSuccess) err = prepare_t<kFp16, e, w>(); if (err == hipSuccess) err = prepare_t<kQ4, e, w>();
     EFFORT_GEOMS(EFFORT_CASE)
 #undef EFFORT_CASE
-    if (err == hipSuccess) err = prepare_t<kQ4B, 1, 16>();
-    if (err == hipSuccess) err = prepare_t<kQ4B, 1, 8>();
     return err;
 }
 
@@ -1490,16 +1214,10 @@ static hipError_t launch_mul_fmt(int W, int E, const GroupKArgs& a, hipStream_t 
 }
 
 hipError_t launch_bucket_mul(Format fmt, int W, int E, const GroupKArgs& a, hipStream_t st) {
-    if (fmt == kQ4B) {                                       // byte-indexed Q4: 64-column tiles, 16 or 8 waves
-        if (E == 1 && W == 16) return launch_mul_t<kQ4B, 1, 16>(a, st);
-        if (E == 1 && W == 8) return launch_mul_t<kQ4B, 1, 8>(a, st);
-        return hipErrorInvalidValue;
-    }
     return fmt == kFp16 ? launch_mul_fmt<kFp16>(W, E, a, st) : launch_mul_fmt<kQ4>(W, E, a, st);
 }
 
 size_t bucket_mul_lds_bytes(Format fmt, int W, int E, const MulGeom& g) {
-    if (fmt == kQ4B) return E != 1 ? 0 : W == 16 ? plan_lds<kQ4B, 1, 16>(&g, 1).total : W == 8 ? plan_lds<kQ4B, 1, 8>(&g, 1).total : 0;
 #define EFFORT_CASE(w, e)                                                                     \
     if (W == w && E == e)                                                                     \
         return fmt == kFp16 ? plan_lds<kFp16, e, w>(&g, 1).total : plan_lds<kQ4, e, w>(&g, 1).total;

@@ -14,9 +14,7 @@ constexpr int kWave = 64;            // CDNA4 wavefront
 constexpr int kProbes = 4096;        // bucketMul.swift:17
 constexpr float kCutoffScale = 100000.0f;   // CUTOFF_SCALE, bucketMul.metal:33
 
-enum Format : int { kFp16 = 0, kQ4 = 1,
-                    kQ4B = 2 };     // a LAUNCH variant of Q4 (handles are kQ4): the streaming phase accumulates per BYTE (two nibbles, one LDS atomic) into 512
-                                    // slots per column and folds them to the 64 nibble slots afterwards (bucket_mul.hip; effort_set_q4_byte_acc)
+enum Format : int { kFp16 = 0, kQ4 = 1 };
 
 // Geometry of one multiply launch (see DESIGN.md "bucket_mul kernel").
 struct MulGeom {
@@ -32,7 +30,7 @@ struct MulGeom {
     uint32_t slots;        // candidate slots per slice: rowsPerIn << sliceLog2 (FP16) or 8*B (Q4)
     uint32_t rowPitch;     // bytes from one bucket row to the next: 2*cols as converted, or padded to whole 128-byte lines (effort_weights_align_rows)
     uint32_t numExperts;   // experts stacked in the buffers (bounds of the buffer descriptor)
-    uint32_t elems;        // E: u16 columns per lane of this call's tiles (a CHAIN launch mixes 1 and 2; otherwise the launch's template parameter)
+    uint32_t elems;        // E: u16 columns per lane of this call's tiles (= the launch's template parameter)
 };
 
 // The Q4 outliers, indexed at registration (dispatch.hip): FOUR bytes per outlier.  An entry packs the f16 value (the table
@@ -58,8 +56,7 @@ __host__ __device__ inline uint32_t ol_bits_in(uint32_t inDim) { uint32_t b = 1;
 #endif
 constexpr int kMaxGroup = EFFORT_MAX_GROUP;        // calls per launch (the macro: A/B builds of the kernel-argument size, tools/ only)
 constexpr int kMaxGeoms = 4;
-constexpr int kMaxStages = 8;                      // stages of a chain launch
-constexpr int kStageFlagOff = 11 * 16, kQueueWords = 11 * 16 + kMaxStages * 8 * 64;   // layout of GroupKArgs::queue (words)
+constexpr int kQueueWords = 11 * 16;               // layout of GroupKArgs::queue (words)
 constexpr int kTraceOff = 512, kTraceItems = 4096;   // per-item trace records: u64 index into the stamp buffer / capacity         // distinct (shape, slicing) geometries per launch
 enum Prologue : uint16_t { kPreNone = 0, kPreSiluGate = 1, kPreRmsNorm = 2 };
 struct CallDesc {                    // 112 bytes
@@ -71,12 +68,14 @@ struct CallDesc {                    // 112 bytes
     const uint32_t* expNo;     // nullable
     float* out;                // f32 [outDim]
     OutlierIndex ol;
-    uint32_t q;                // Int(4095*(1-effort)), bucketMul.swift:39
+    uint16_t q;                // Int(4095*(1-effort)), bucketMul.swift:39
+    uint16_t bucketsTrim;      // a column shard's `buckets` points rank*cols*2 bytes INTO the full handle's rows: the buffer descriptor ends that many bytes early,
+                               // at the end of the full allocation (a ragged last tile of the last row must not read past it)
     uint32_t slabOff;          // this call's partial-tile slabs [slices][tiles][tileFloats]: offset into GroupKArgs::slabs, in units of 64 floats
     uint16_t tileOff;          // ... arrival tickets [tiles]: offset into GroupKArgs::counters
     uint16_t sliceOff;         // ... kept rows per slice [slices] (sum = dispatch.size): offset into GroupKArgs::sliceCounts
     uint16_t geom;             // index into GroupKArgs::geom
-    uint16_t pre;              // low byte: Prologue, how the kernel derives its input from v (and vAux); high byte: the call's STAGE in a chain launch
+    uint16_t pre;              // Prologue: how the kernel derives its input from v (and vAux)
     const void* vAux;          // kPreSiluGate: x3 f32 [inDim], input = x3 * v / (1 + exp(-v)) (silu(x1, x3), matrix.metal:25-35);
                                // kPreRmsNorm: norm weights f16 [inDim], input = v / sqrt(mean(v^2) + 1e-5) * w (rmsNormFast + mul(by:))
     const float* resid;        // nullable epilogue: out = resid + product (h.add(by:), runNetwork.swift:172,183); may alias out
@@ -93,25 +92,20 @@ struct GroupKArgs {
     uint32_t numCU;
     uint32_t ablate;               // profiling only (env EFFORT_ABLATE): 2 = no last-arriver reduce, 4 = no row streaming, 8 = no selection, 32 = never wait for a cutoff job
     uint32_t split;                // bit 0: the cutoffs were evaluated by find_cutoff_group_kernel (split mode), else in the multiply kernel;
-                                   // bit 2: FP16 calls' `stats` point at the compact row means (u16 per bucket row), not at the f16x4 stats;
-                                   // bit 3: the launch's slabs are the lane's SENTINEL region (plain grids of the lean kernels: named reducer);
-                                   // bit 4: CHAIN launch -- the calls come in stages, a stage's calls read what earlier stages wrote
+                                   // bit 2: FP16 calls' `stats` point at the compact row means (u16 per bucket row), not at the f16x4 stats
     uint32_t cutJobs;              // persistent launches: the first cutJobs items (a multiple of 8 >= count) are cutoff jobs, one per call
     uint32_t trace;                // profiling only: 1 = every item leaves a 64-byte record (who ran it, where, its phase stamps) at tstamp + kTraceOff
     LdsPlan lp;                    // of the instantiation launched, over geom[] (launch_mul_t)
     uint32_t totalItems;           // = 8 * wgEnd8[count - 1]: items of the launch (without the cutoff jobs)
     uint32_t* groupDone;           // counter of finished tiles (zero between launches)
     uint32_t* queue;               // [9][16]: per-XCD item cursors (one cache line each), line 8 = exit counter;
-                                   // then [32] cutoff words (value | ready bit) of the calls; then, from word kStageFlagOff on, the
-                                   // chain launches' flags [stage][XCD copy][64]: tile i of the stage is written; all zero between launches
+                                   // then [32] cutoff words (value | ready bit) of the calls; all zero between launches
     float* slabs;                  // context scratch the calls index into
     uint32_t* counters;
     uint32_t* sliceCounts;
     float* cutoff;                 // [count]: BucketMul.cutoff of every call
-    unsigned long long* named;     // [kMaxTiles] per tile of the launch: launches that consumed it | producers that gave up << 32 (plain grids' hand-off, bucket_mul.hip E)
     unsigned long long* tstamp;    // nullable profiling stamps: [0]=min start, [1]=max end, [2]=sum, [3]=launches, [16..] phases
     uint16_t wgEnd8[kMaxGroup];    // exclusive end of each call's item range, in units of 8 items (the ranges are multiples of 8)
-    uint16_t stageTiles[kMaxStages];   // chain launches: column tiles of each stage (all its calls; <= 64)
     MulGeom geom[kMaxGeoms];
     CallDesc call[kMaxGroup];
 };
@@ -205,9 +199,7 @@ hipError_t launch_find_cutoff(const float* v, const uint16_t* probes, const uint
 
 // Returns hipErrorInvalidValue for unsupported (fmt, W, E).
 hipError_t launch_bucket_mul(Format fmt, int wavesPerGroup, int elemsPerLane, const GroupKArgs& ga, hipStream_t st);
-bool bucket_mul_lean_named();               // A/B builds (EFFORT_LEAN_NAMED): plain grids use the named-reducer hand-off
 hipError_t bucket_mul_prepare_device();     // once per device: the kernels may use the whole LDS (hipFuncSetAttribute)
-hipError_t launch_bucket_mul_chain(const GroupKArgs& ga, hipStream_t st);   // FP16 calls in stages (GroupKArgs::split bit 4)
 hipError_t launch_find_cutoff_group(const GroupKArgs& ga, hipStream_t st);    // ga.cutoff[i] of every call
 size_t bucket_mul_lds_bytes(Format fmt, int wavesPerGroup, int elemsPerLane, const MulGeom& g);
 uint32_t bucket_mul_max_candidates(int wavesPerGroup);

@@ -21,7 +21,7 @@ from dataclasses import dataclass
 import torch
 
 from . import _lib
-from .bucket_mul import basicMul, bucketMul, bucketMulChain, bucketMulGroup
+from .bucket_mul import basicMul, bucketMul, bucketMulGroup
 from .runtime import gpu as _gpu
 from .weights import ExpertWeights
 
@@ -155,16 +155,11 @@ def _p(t):
 class Decoder:
     """State of one sequence (the globals of main.swift:78-140: h, xq, KV caches, scores ...) + the token step."""
 
-    def __init__(self, model: Model, maxTokens: int = 256, fused_attention: bool = True, fused_glue=True, chain: bool = False):
+    def __init__(self, model: Model, maxTokens: int = 256, fused_attention: bool = True, fused_glue=True,
+                 world: int = 1, rank: int = 0, sharded: bool | None = None, emulate_world: bool = False):
         cfg = self.cfg = model.cfg
-        # chain: a layer's dependent multiplies -- wo -> w1|w3 -> w2 -> wq|wk|wv of the NEXT layer, glue folded in -- go out as ONE
-        # launch whose resident workgroups take the stages in order (effort_bucketmul_chain): two launches per layer (attention,
-        # chain) instead of five.  Needs all the glue folded (fused_glue=True) and a dense FFN.  OFF by default: measured SLOWER than
-        # the launches of their own (round 4: 252 against 308 tokens/s at 25 %; a layer's four multiplies 112 us as a chain against
-        # 91 us as launches) -- a stage hand-over inside the launch is as many dependent memory round trips (out[] written through
-        # and acknowledged, flag, poll, input loads) as a kernel boundary plus a cold start, and the stage's late starters -- the
-        # workgroups that reduced the previous stage's tiles -- lengthen its tail.  DESIGN.md section 8 has the per-item trace.
-        self.chain = bool(chain)
+        # (Round 4's `chain=True` -- a layer's dependent multiplies as ONE launch of resident workgroups -- measured 252 against 308
+        #  tokens/s and lives on branch `chain-launch`: DESIGN.md 4.5.)
         self.fused_attention = bool(fused_attention)      # rope + cache + attention in one launch per layer (else two)
         # rmsNorm, silu and the residual adds folded into the multiplies (effort_bucketmul_group_fused): 5 launches per layer
         # instead of 8.  Dense-FFN models only; the dense baseline keeps the separate glue kernels.  On by default since round 3:
@@ -179,6 +174,25 @@ class Decoder:
         self.model, self.maxTokens = model, int(maxTokens)
         dev = model.norm.device
         self.g = _gpu(dev.index)
+        # Column-sharded decode (BASELINE config 4: "all 32 layers' Wq/Wk/Wv/Wo + FFN matrices sharded across 8 x MI355X, RCCL
+        # all-gather"; the reference is single-device, runNetwork.swift:121-183 is what this wraps): every bundle becomes this rank's
+        # column shard, every launch group is followed by ONE effort_allgather_outputs (in place on h for wo / w2), the state vectors
+        # stay replicated, and the glue (attention, the LM head) runs replicated on every rank.  ``sharded=True`` with world 1 runs
+        # the same path through a communicator of one rank; ``emulate_world`` computes every rank's launches in THIS process (no
+        # collective): how the split is validated, and its launches timed, on one GPU.
+        self.world, self.rank = int(world), int(rank)
+        self.sharded = bool(sharded) if sharded is not None else (self.world > 1)
+        self.groups = None
+        if self.sharded or emulate_world:
+            if self.fuse != {"norm", "gate", "resid"}:
+                raise ValueError("the column-sharded decode loop needs the glue folded into the multiplies (fused_glue=True, dense FFN)")
+            if not emulate_world and not self.g.has_comm:
+                raise RuntimeError("Decoder(sharded=True): give the device's context its communicator first (effort_amd.sharded.init_comm / Gpu.comm_create)")
+            if not emulate_world and (self.g.comm_world != self.world or self.g.comm_rank != self.rank):
+                raise ValueError("Decoder: world / rank differ from the context's communicator")
+            from .sharded import ColumnShardedGroups
+            self.sharded = True
+            self.groups = ColumnShardedGroups(self.world, self.rank, emulate=emulate_world, gpu=self.g)
         f = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)      # noqa: E731
         q, kv = cfg.numHeads * cfg.headDim, cfg.numHeadsKV * cfg.headDim
         self.h, self.h_norm, self.fxn, self.outNormed = f(cfg.stateDim), f(cfg.stateDim), f(cfg.stateDim), f(cfg.stateDim)
@@ -215,26 +229,19 @@ class Decoder:
 
         ck(lib.effort_fetch_row(g.ctx, _p(m.tokEmbeddings), _p(self.tokId), _p(self.h), cfg.stateDim), "fetch_row")
         delta = None
-        if self.chain and self.fuse == {"norm", "gate", "resid"} and not dense:
-            # QKV of layer 0 alone; then per layer: attention, and ONE chain launch up to the next layer's QKV
-            an = lambda L: {"norm": L.attnNorm}                                                      # noqa: E731
-            L0 = m.layers[0]
-            bucketMulGroup([(self.h, L0.wq, None, self.xq_temp, effort, an(L0)), (self.h, L0.wk, None, self.xk_temp, effort, an(L0)),
-                            (self.h, L0.wv, None, self.xv_temp, effort, an(L0))])
+        if self.sharded and not dense:
+            G = self.groups
             for n, L in enumerate(m.layers):
+                an, fnw = {"norm": L.attnNorm}, {"norm": L.ffnNorm}
+                G.mul(self.h, [(L.wq, self.xq_temp, an), (L.wk, self.xk_temp, an), (L.wv, self.xv_temp, an)], effort)      # :121-134
                 ck(lib.effort_rope_attention(g.ctx, _p(self.xq_temp), _p(self.xk_temp), _p(self.xv_temp), _p(self.kCache[n]), _p(self.vCache[n]),
                                              _p(self.pos), _p(self.attnOutput), cfg.numHeads, cfg.numHeadsKV, cfg.headDim, self.maxTokens,
                                              C.c_float(cfg.ropeBase)), "rope_attention")
-                stages = [[(self.attnOutput, L.wo, None, self.h, effort, {"resid": self.h})],                                  # :170-172
-                          [(self.h, L.w1, None, self.x1, effort, {"norm": L.ffnNorm}), (self.h, L.w3, None, self.x3, effort, {"norm": L.ffnNorm})],   # :173-179
-                          [(self.x1, L.w2, None, self.h, effort, {"gate": self.x3, "resid": self.h})]]                        # :181-183
-                if n + 1 < len(m.layers):
-                    Ln = m.layers[n + 1]                                                                                       # :121-134 of the next layer
-                    stages.append([(self.h, Ln.wq, None, self.xq_temp, effort, an(Ln)), (self.h, Ln.wk, None, self.xk_temp, effort, an(Ln)),
-                                   (self.h, Ln.wv, None, self.xv_temp, effort, an(Ln))])
-                bucketMulChain(stages)
+                G.mul(self.attnOutput, [(L.wo, self.h, {"resid": self.h})], effort)                                     # :170-172, in place on h
+                G.mul(self.h, [(L.w1, self.x1, fnw), (L.w3, self.x3, fnw)], effort)                                      # :173-179
+                G.mul(self.x1, [(L.w2, self.h, {"gate": self.x3, "resid": self.h})], effort)                             # :181-183, in place on h
             ck(lib.effort_add_rmsnorm_mul(g.ctx, _p(self.h), None, _p(m.norm), _p(self.outNormed), cfg.stateDim), "rmsnorm")
-            basicMul(self.outNormed, m.output, self.logits)                                           # :222
+            basicMul(self.outNormed, m.output, self.logits)                                           # :222 (replicated: every rank picks the same token)
             ck(lib.effort_argmax(g.ctx, _p(self.logits), cfg.vocab, _p(self.tokId), _p(self.pos), _p(self.history), int(self.history.numel())), "argmax")
             return
         if self.fused_glue and not dense:

@@ -117,12 +117,6 @@ class Gpu:
     def set_tuning(self, waves: int = 0, elems: int = 0, slices: int = 0):
         self.check(self._lib.effort_set_tuning(self.ctx, waves, elems, slices), "set_tuning")
 
-    def set_q4_byte_acc(self, on: bool = True):
-        self.check(self._lib.effort_set_q4_byte_acc(self.ctx, int(bool(on))), "set_q4_byte_acc")
-
-    def set_chain_tuning(self, slice_mult: int = 1):
-        self.check(self._lib.effort_set_chain_tuning(self.ctx, int(slice_mult)), "set_chain_tuning")
-
     def set_split_cutoff(self, split: bool = True):
         self.check(self._lib.effort_set_split_cutoff(self.ctx, int(split)), "set_split_cutoff")
 

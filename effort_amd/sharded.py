@@ -141,4 +141,91 @@ def init_comm(g=None, group=None):
     return g
 
 
+class ColumnShardedGroups:
+    """The decode loop's launch groups with every matrix column-sharded over ``world`` ranks (BASELINE config 4): a group
+    = the matrices that share an input vector (Wq|Wk|Wv, W1|W3; Wo and W2 alone -- runNetwork.swift:121-183), ONE grouped launch of
+    this rank's shards and ONE all-gather (effort_allgather_outputs) per group.  The glue folded into the launches stays folded:
+    the input prologues read full, replicated vectors; a residual epilogue adds this rank's SLICE of the residual, and when the
+    output IS the residual vector (h += wo(attn), h += w2(...)) the gather runs in place on it -- no staging, no copies.
+
+    ``ranks``: the ranks this process computes -- ``[rank]`` in a real run; ALL of them to EMULATE a world on one GPU (every rank's
+    launch one after the other, their slices written where the gather would put them, no collective): identical results, and the
+    way a column split's decode is validated and its per-rank launches timed where there is one GPU (``gather=False`` with one
+    rank: that rank's kernels alone)."""
+
+    def __init__(self, world: int, rank: int = 0, emulate: bool = False, gpu=None, gather: bool = True, mul_group=None, allgather=None):
+        """``mul_group(calls)`` / ``allgather(send, recv_flat, count)``: the launch and the collective (default: bucketMulGroup on the
+        context and its effort_allgather_outputs); the CPU tests inject a CPU multiply and gloo here."""
+        self.world, self.rank, self.emulate, self.gather = int(world), int(rank), bool(emulate), bool(gather)
+        self.ranks = list(range(self.world)) if emulate else [self.rank]
+        self.g = gpu
+        self._mul_group, self._allgather = mul_group, allgather
+        self._shards: dict = {}
+        self._bufs: dict = {}
+
+    def _ctx(self, v):
+        if self.g is None:
+            from .runtime import gpu as _gpu
+            self.g = _gpu(v.device.index)
+        return self.g
+
+    def shards(self, ew):
+        """{rank: column shard} of a full bundle, made once (views: effort_weights_column_shard)."""
+        k = id(ew)
+        if k not in self._shards:
+            self._shards[k] = (ew, {r: ew.column_shard(r, self.world) for r in self.ranks})
+            for sh in self._shards[k][1].values():
+                getattr(sh, "handle", None)                       # (registered now, not inside a graph capture)
+        return self._shards[k][1]
+
+    def _launch(self, v, calls):
+        if self._mul_group is not None:
+            return self._mul_group(calls)
+        from .bucket_mul import bucketMulGroup
+        bucketMulGroup(calls, gpu=self._ctx(v))
+
+    def _collect(self, v, send, recv_flat, count):
+        if self._allgather is not None:
+            return self._allgather(send, recv_flat, count)
+        self._ctx(v).allgather_outputs(send, recv_flat, count)
+
+    def mul(self, v, items, effort):
+        """items = [(full bundle, out (f32 [outSize], full), extras dict or None), ...] sharing the input ``v``."""
+        W = self.world
+        los = [ew.outSize // W for ew, _, _ in items]
+        inplace = len(items) == 1 and bool(items[0][2]) and items[0][2].get("resid") is items[0][1]
+        if inplace:                                               # h += product: every rank its slice of h, the gather in place on h
+            ew, out, kw = items[0]
+            lo = los[0]
+            for r in self.ranks:
+                sl = out[r * lo:(r + 1) * lo]
+                self._launch(v, [(v, self.shards(ew)[r], None, sl, effort, dict(kw, resid=sl))])
+            if not self.emulate and self.gather:
+                self._collect(v, out[self.rank * lo:(self.rank + 1) * lo], out, lo)
+            return
+        total = sum(los)
+        key = (v.device, tuple(los))
+        if key not in self._bufs:
+            self._bufs[key] = (torch.zeros(total, dtype=torch.float32, device=v.device), torch.zeros((W, total), dtype=torch.float32, device=v.device))
+        send, recv = self._bufs[key]
+        for r in self.ranks:
+            calls, off = [], 0
+            for (ew, out, kw), lo in zip(items, los):
+                piece = recv[r, off:off + lo] if self.emulate else send[off:off + lo]
+                kw2 = dict(kw) if kw else None
+                if kw2 and "resid" in kw2:
+                    kw2["resid"] = kw2["resid"][r * lo:(r + 1) * lo]
+                calls.append((v, self.shards(ew)[r], None, piece, effort, kw2) if kw2 else (v, self.shards(ew)[r], None, piece, effort))
+                off += lo
+            self._launch(v, calls)
+        if not self.emulate:
+            if not self.gather:
+                return
+            self._collect(v, send, recv.view(-1), total)
+        off = 0
+        for (ew, out, kw), lo in zip(items, los):
+            out.view(W, lo).copy_(recv[:, off:off + lo])
+            off += lo
+
+
 _SCRATCH: dict = {}

@@ -188,18 +188,6 @@ EFFORT_API int effort_bucketmul_group(effort_ctx* ctx, int n, const effort_w* co
 EFFORT_API int effort_bucketmul_group_fused(effort_ctx* ctx, int n, const effort_w* const* ws, const float* const* vs_dev,
                                  const uint32_t* const* expNos_dev, float* const* outs_dev, const double* efforts,
                                  const int* prologues, const void* const* v_aux_dev, const float* const* resids_dev);
-/* A CHAIN of dependent groups in ONE launch: the decode loop is a chain of multiplies each consuming the previous one's output --
- * h += wo(attn); x1|x3 = w1|w3(norm(h)); h += w2(silu(x1)*x3); q|k|v = wq|wk|wv(norm(h)) of the next layer (runNetwork.swift:
- * 121-183) -- and as launches of their own every one of them pays a kernel boundary, a dispatch ramp and a cold start, four to
- * five times per layer, for a few microseconds of streaming.  Here the calls come in nStages STAGES of stageCalls[k] calls each
- * (the arrays list them stage after stage, sum <= 32, FP16 bundles); a call may read (v, the gate's x3, the residual) what calls
- * of EARLIER stages write; calls of one stage are independent of each other.  The workgroups stay resident, take the stages'
- * work items in order, and an item waits for the stage before its own -- while its row means are already on their way.  Same row
- * selection as the separate launches, exactly; outputs within the rounding of the per-slice sums.  Prologues / residuals as in
- * effort_bucketmul_group_fused (arrays may be NULL).  At most four distinct (shape, slicing) geometries per chain. */
-EFFORT_API int effort_bucketmul_chain(effort_ctx* ctx, int nStages, const int* stageCalls, const effort_w* const* ws, const float* const* vs_dev,
-                           const uint32_t* const* expNos_dev, float* const* outs_dev, const double* efforts,
-                           const int* prologues, const void* const* v_aux_dev, const float* const* resids_dev);
 EFFORT_API int effort_bucketmul_q4_group(effort_ctx* ctx, int n, const effort_w* const* ws, const float* const* vs_dev,
                               const uint32_t* const* expNos_dev, float* const* outs_dev, const double* efforts);
 EFFORT_API int effort_group_dispatch_count(effort_ctx* ctx, int idx, uint32_t* host_out);

@@ -20,14 +20,6 @@ EFFORT_API int effort_set_tuning(effort_ctx* ctx, int wavesPerGroup, int elemsPe
 /* split = 1: evaluate findCutoff32 in its own one-workgroup launch ahead of the multiply kernel instead of
  * inside it.  Costs a kernel boundary per call.  Results are bit-identical.  Default 0 (fused). */
 EFFORT_API int effort_set_split_cutoff(effort_ctx* ctx, int split);
-/* Chain launches (effort_bucketmul_chain): row slices per call = the heuristic's choice x sliceMult (1..8; capped at one round of
- * resident workgroups).  Thinner slices shorten a stage's streaming phase -- every workgroup is resident anyway -- at the price
- * of more slabs per tile. */
-EFFORT_API int effort_set_chain_tuning(effort_ctx* ctx, int sliceMult);
-/* Q4 multiplies accumulate per BYTE while the rows stream -- one LDS atomic for the two nibbles of a byte, 2 x 256 slots per column
- * (128 KB for a 64-column tile: one 16-wave workgroup per CU), folded into the 64 nibble sums afterwards -- instead of one atomic
- * per nibble.  Same results bit for bit (integer sums).  Default 0: measured in round 4, see DESIGN.md 4.1 "Q4". */
-EFFORT_API int effort_set_q4_byte_acc(effort_ctx* ctx, int on);
 
 /* Group launches with more work items than wgPerCU workgroups per CU run as that many PERSISTENT workgroups pulling
  * items from per-XCD queues.  -1 = heuristic (default), 0 = always one workgroup per item. */

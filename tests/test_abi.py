@@ -115,6 +115,25 @@ def test_shipped_library_reads_no_environment(hip_lib_built):
             assert "getenv" not in syms, obj
 
 
+def test_shipped_library_has_no_measured_dead_ends(hip_lib_built):
+    """What round 4 built and measured SLOWER -- chain launches, the named reducer, byte-indexed Q4 accumulators -- lives on branch
+    `chain-launch`, not in the drop-in header or the shipped library; and the library loads without RCCL (multi-GPU binds it at run
+    time: a single-GPU host needs no librccl) and without gcc-built extras."""
+    import subprocess
+    fns = _header_functions()
+    assert not [f for f in fns if "chain" in f or "byte_acc" in f], fns
+    syms = subprocess.run(["nm", "-D", "--defined-only", hip_lib_built], capture_output=True, text=True, check=True).stdout
+    assert "effort_bucketmul_chain" not in syms and "effort_set_q4_byte_acc" not in syms
+    kernels = subprocess.run(["nm", "-C", hip_lib_built], capture_output=True, text=True, check=True).stdout
+    inst = [l for l in kernels.splitlines() if "bucket_mul_kernel<" in l]
+    assert inst, "no multiply kernel in the library?"
+    assert all(l.count(",") <= 6 for l in inst), "a CHAIN instantiation (seventh template argument) is back"      # <FMT, E, W, FUSED, COMPACT, PERSIST>
+    needed = subprocess.run(["readelf", "-d", hip_lib_built], capture_output=True, text=True, check=True).stdout
+    assert "librccl" not in needed, "libeffort_hip.so must not hard-link RCCL (it is opened by effort_comm_*)"
+    und = subprocess.run(["nm", "-D", "--undefined-only", hip_lib_built], capture_output=True, text=True, check=True).stdout
+    assert "nccl" not in und
+
+
 def test_product_has_no_oracle_dependency():
     """The product package must never import or link the oracle (it is test infrastructure)."""
     pkg = os.path.join(ROOT, "effort_amd")

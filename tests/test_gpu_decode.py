@@ -233,3 +233,38 @@ def test_in_graph_multiplies_match_the_oracle(small_model, oracle_cpu):
         fus = Decoder(small_model, maxTokens=16, fused_glue=("norm", "resid"))
         fus.run([3, 77, 130, 9], 4, effort=effort, forced=True)
         assert torch.equal(fus.x1, dec.x1) and torch.equal(fus.x3, dec.x3) and torch.equal(fus.logits, dec.logits)   # same input bits, same everything
+
+
+def test_column_sharded_decoder(small_model):
+    """BASELINE config 4's product path as far as one GPU reaches: the decode loop with every bundle column-sharded
+    (Decoder(world=G): ColumnShardedGroups, one effort_allgather_outputs per launch group, in place on h for wo / w2).
+    (a) a world of ONE through RCCL (effort_comm_create on the device's context): shards are whole-matrix views, the launch
+    geometry is the unsharded one -- logits bit-identical with the plain decoder, from a hipGraph with the collectives in it;
+    (b) worlds of 2 and 8 EMULATED in this process (every rank's launches, their slices written where the gather puts them):
+    same tokens on teacher-forced inputs, logits within the multiply's bar (a shard's slicing -- its rounding grid -- differs,
+    and a 2e-5 difference can flip a row selection downstream: hence 2e-3 on the logits, the bar of the other decode tests)."""
+    import effort_amd as ea
+    from effort_amd.decode import Decoder
+    prompt, steps = [3, 77, 130], 8
+    plain = Decoder(small_model, maxTokens=16)
+    ids_p, _, lg_p = plain.run(prompt, steps, effort=0.5, collect_logits=True)
+    forced = prompt + ids_p[len(prompt) - 1:-1]
+    g = ea.gpu(0)
+    with pytest.raises(RuntimeError):
+        Decoder(small_model, maxTokens=16, sharded=True)                                # no communicator yet
+    g.comm_create(0, 1, ea.Gpu.comm_unique_id())
+    try:
+        one = Decoder(small_model, maxTokens=16, world=1, rank=0, sharded=True)
+        assert one.sharded and one.groups is not None
+        ids_1, _, lg_1 = one.run(prompt, steps, effort=0.5, collect_logits=True)
+        assert ids_1 == ids_p and torch.equal(lg_1, lg_p)
+        assert one.status() == 0
+    finally:
+        g.comm_destroy()
+    for world in (2, 8):
+        emu = Decoder(small_model, maxTokens=16, world=world, emulate_world=True)
+        _, _, lg_e = emu.run(forced, steps, effort=0.5, forced=True, collect_logits=True)
+        assert float((lg_e - lg_p).abs().max() / lg_p.abs().max()) < 2e-3, world
+        assert lg_e.argmax(-1).tolist() == lg_p.argmax(-1).tolist(), world
+    with pytest.raises(ValueError):
+        Decoder(small_model, maxTokens=16, world=2, emulate_world=True, fused_glue=("norm",))

@@ -1,7 +1,7 @@
-"""GPU tests of the CHAIN launch (effort_bucketmul_chain): a decoder layer's dependent multiplies -- wo -> w1|w3 -> w2 ->
-wq|wk|wv of the next layer, rmsNorm / silu / residual folded in (runNetwork.swift:121-183) -- as ONE launch of resident
-workgroups taking the stages in order.  Against the same multiplies as launches of their own (bit for bit: same geometry,
-same arithmetic) and against the CPU oracle fed the GPU's own input vectors, call by call; through the C ABI."""
+"""GPU tests at the decode loop's full layer shapes (Mistral-7B: 4096 / 14336 / 1024): a decoder layer's dependent multiplies -- wo ->
+w1|w3 -> w2 -> wq|wk|wv of the next layer, rmsNorm / silu / residual folded in (runNetwork.swift:121-183) -- as the four launches
+the decode loop issues, every call against the CPU oracle fed the GPU's own input vectors; and the multi-GPU entry points of the C
+ABI as far as one GPU reaches.  (Round 4's one-chain-launch variant of the same seven calls lives on branch `chain-launch`.)"""
 import ctypes as C
 
 import numpy as np
@@ -41,12 +41,12 @@ def _stages(L, Ln, B, e):
 
 
 @pytest.mark.parametrize("effort", [0.0, 0.25, 0.6, 1.0])
-def test_chain_equals_separate_launches_and_oracle(ea, oracle_cpu, layers, effort):
+def test_layer_launches_match_the_oracle(ea, oracle_cpu, layers, effort):
     L, Ln = layers
     g = ea.gpu()
     lib = ea.lib()
     P = lambda t: C.c_void_p(t.data_ptr())                                      # noqa: E731
-    # --- the four launches of their own, keeping every intermediate
+    # --- the four launches, keeping every intermediate
     S = _buffers(3)
     h0 = S["h"].clone()
     snap, counts = {}, []
@@ -55,13 +55,6 @@ def test_chain_equals_separate_launches_and_oracle(ea, oracle_cpu, layers, effor
         g.eval()
         counts += [(g.last_dispatch_count(i), g.last_cutoff(i)) for i in range(len(st))]
         snap[k] = {n: t.clone() for n, t in S.items()}
-    # --- the chain
-    Cb = _buffers(3)
-    ea.bucketMulChain(_stages(L, Ln, Cb, effort))
-    g.eval()
-    assert [(g.last_dispatch_count(i), g.last_cutoff(i)) for i in range(7)] == counts          # same rows, call by call
-    for n in Cb:
-        assert torch.equal(Cb[n], S[n]), n                                                        # same bits
     # --- every call against the oracle on the GPU's own input
     def oracle(ew, vin, want_out, resid=None):
         want, n, cutoff = oracle_cpu.bucket_mul(vin.cpu().numpy(), *_host(ew), ew.inSize, ew.outSize, effort)
@@ -82,10 +75,10 @@ def test_chain_equals_separate_launches_and_oracle(ea, oracle_cpu, layers, effor
     assert got == counts                                                                          # dispatch.size and cutoff bits
 
 
-def test_chain_replays_are_race_free(ea, layers):
-    """The chain from a hipGraph, many replays back to back with the layers swapping roles (the buffers are rewritten every
-    replay, so a stale line in an L1 or an L2 of another XCD, or an item that ran ahead of its stage, shows up as a wrong
-    bit): every replay's outputs equal the first's."""
+def test_layer_replays_are_race_free(ea, layers):
+    """The layer's four launches from a hipGraph, many replays back to back with the layers swapping roles (the buffers are
+    rewritten every replay, so a stale line in an L1 or in another XCD's L2 shows up as a wrong bit): every replay's outputs
+    equal the first's -- also with launches in flight on other lanes beside them."""
     L, Ln = layers
     g = ea.gpu()
     B = _buffers(9)
@@ -94,8 +87,8 @@ def test_chain_replays_are_race_free(ea, layers):
     def step():
         for n in B:
             B[n].copy_(init[n])
-        ea.bucketMulChain(_stages(L, Ln, B, 0.25))
-        ea.bucketMulChain(_stages(Ln, L, B, 0.25))            # a second chain consuming the first one's h
+        for st in _stages(L, Ln, B, 0.25) + _stages(Ln, L, B, 0.25):       # a second layer consuming the first one's h
+            ea.bucketMulGroup(st)
     step()
     g.eval()
     want = {n: t.clone() for n, t in B.items()}
@@ -103,17 +96,16 @@ def test_chain_replays_are_race_free(ea, layers):
     with torch.cuda.graph(gr, capture_error_mode="thread_local"):
         step()
     g._bind_stream()
-    for rep in range(60):
+    for rep in range(30):
         gr.replay()
         if rep % 6 == 5:
             g.eval()
             for n in B:
                 assert torch.equal(B[n], want[n]), (rep, n)
-    # with launches in flight on other lanes beside it (uneven load)
     g.set_overlap(4)
     try:
         junk = [torch.zeros(14336, device=DEV) for _ in range(8)]
-        for rep in range(10):
+        for rep in range(6):
             for j in junk:
                 ea.bucketMul(init["attn"], L.w1, None, j, 0.5)
             step()
@@ -122,34 +114,6 @@ def test_chain_replays_are_race_free(ea, layers):
                 assert torch.equal(B[n], want[n]), (rep, n)
     finally:
         g.set_overlap(1)
-
-
-def test_decoder_chain_is_bit_identical(ea):
-    from effort_amd.decode import Decoder, MistralConfig, Model
-    cfg = MistralConfig(stateDim=4096, hiddenDim=4096, numLayers=3, numHeads=32, numHeadsKV=8, headDim=128, vocab=512)
-    model = Model.random(cfg, seed=5)
-    prompt, steps = [3, 77, 130, 9], 8
-    a = Decoder(model, maxTokens=16, chain=False)
-    b = Decoder(model, maxTokens=16, chain=True)
-    assert b.chain and not a.chain
-    for effort in (0.25, 1.0):
-        ids_a, _, lg_a = a.run(prompt, steps, effort=effort, collect_logits=True)
-        ids_b, _, lg_b = b.run(prompt, steps, effort=effort, collect_logits=True)
-        assert ids_a == ids_b and torch.equal(lg_a, lg_b), effort
-
-
-def test_chain_argument_checks(ea, layers):
-    L, Ln = layers
-    B = _buffers(1)
-    st = _stages(L, Ln, B, 0.25)
-    with pytest.raises(ea.EffortError):                       # w2 reads x1 / x3 in the stage that writes them
-        ea.bucketMulChain([st[0], st[1] + st[2]])
-    with pytest.raises(ea.EffortError):                       # two calls of one stage writing the same vector
-        ea.bucketMulChain([[(B["attn"], L.wo, None, B["h"], 0.25), (B["attn"], Ln.wo, None, B["h"], 0.25)]])
-    with pytest.raises(ValueError):
-        ea.bucketMulChain([])
-    ea.bucketMulChain([st[0]])                                # a chain of one stage is a group launch
-    ea.gpu().eval()
 
 
 def test_c_abi_communicator_world_of_one(ea, oracle_cpu):
@@ -188,4 +152,38 @@ def test_c_abi_communicator_world_of_one(ea, oracle_cpu):
         ew.column_shard(0, 3)
     g.comm_destroy()
     assert not g.has_comm
+    g.close()
+
+
+def test_column_shard_views_outlive_a_freed_parent(ea, oracle_cpu):
+    """effort_weights_free on a full handle with live column-shard views must not leave them dangling (the header asks for the
+    shards to be freed first; the library keeps the parent's registration data until its last view is gone), and a view's
+    buffer descriptor ends at the END of the full allocation: the last rank's ragged last tile of the LAST row reads nothing
+    past it (a 4096 x 11008 shard of a world of 8 has 86 columns: a 128-column tile's lanes 43..63 lie beyond the row)."""
+    import ctypes as C
+    from tests.test_gpu_parity import converted, dev16, devf
+    from tests.util import make_v
+    lib = ea.lib()
+    g = ea.Gpu(0)
+    inDim, outDim, world = 4096, 11008, 8
+    W, b, s, p = converted(oracle_cpu, outDim, inDim)
+    bd, sd, pd = dev16(b), dev16(s), dev16(p)
+    full = lib.effort_weights_fp16(g.ctx, C.c_void_p(bd.data_ptr()), C.c_void_p(sd.data_ptr()), C.c_void_p(pd.data_ptr()), inDim, outDim, 16, 1)
+    assert full
+    views = [lib.effort_weights_column_shard(full, r, world) for r in range(world)]
+    assert all(views)
+    assert not lib.effort_weights_column_shard(views[0], 0, 2)                 # a view of a view is refused
+    lib.effort_weights_free(full)                                                # deferred: the views still read its row means
+    v = make_v(inDim, seed=5)
+    vd = devf(v)
+    want, n, cutoff = oracle_cpu.bucket_mul(v, b, s, p, inDim, outDim, 1.0)      # effort 1.0: the last row of the buffer is streamed
+    per = outDim // world
+    got = torch.zeros(outDim, device=DEV)
+    for r in range(world):
+        g.check(lib.effort_bucketmul(g.ctx, views[r], C.c_void_p(vd.data_ptr()), None, C.c_void_p(got[r * per:].data_ptr()), 1.0), "bucketmul")
+        g.eval()
+        assert g.last_dispatch_count() == n
+    assert close(got.cpu().numpy(), want)
+    for vw in views:
+        lib.effort_weights_free(vw)                                              # the last one frees the parent too
     g.close()

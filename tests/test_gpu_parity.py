@@ -873,54 +873,6 @@ def test_q4_config3_full_size(ea, oracle_cpu, q4_11008):
         assert close(outs[i].cpu().numpy(), want), i
 
 
-def test_q4_byte_indexed_accumulators(ea, oracle_cpu, q4_11008, q4_case):
-    """effort_set_q4_byte_acc: the streaming phase adds per BYTE of a word (two nibbles, one LDS atomic, 512 slots per column)
-    and folds to the nibble sums afterwards.  Integer sums: with the same slicing the outputs are the nibble-indexed launch's
-    bit for bit where the geometry agrees, and the oracle's within the bar everywhere -- lone, 16 per launch (persistent, one
-    16-wave workgroup per CU), with outliers and without, on 8-wave workgroups too."""
-    g = ea.Gpu(0)
-    try:
-        for (W, L, inDim, outDim) in (q4_11008, q4_case):
-            ew = ea.ExpertWeights(dev16(L["buckets"]), devf(L["bucket.stats"]), dev16(L["probes"]), inSize=inDim, outSize=outDim,
-                                  outliers=devf(L["outliers"]), q4=True)
-            bare = ea.ExpertWeights(dev16(L["buckets"]), devf(L["bucket.stats"]), dev16(L["probes"]), inSize=inDim, outSize=outDim, q4=True)
-            v = make_v(inDim, seed=12, heavy=True)
-            vd = devf(v)
-            for effort in (0.1, 0.25, 1.0):
-                want, n, cutoff = oracle_cpu.bucket_mul_q4(v, L["buckets"], L["bucket.stats"], L["probes"], L["outliers"], inDim, outDim, effort)
-                want0, n0, _ = oracle_cpu.bucket_mul_q4(v, L["buckets"], L["bucket.stats"], L["probes"], None, inDim, outDim, effort)
-                for tune in ((0, 0, 0), (8, 1, 0)):
-                    g.set_tuning(*tune)
-                    g.set_q4_byte_acc(True)
-                    o, o0 = torch.full((outDim,), float("nan"), device=DEV), torch.full((outDim,), float("nan"), device=DEV)
-                    ea.bucketMulQ4(vd, ew, None, o, effort, gpu=g)
-                    g.eval()
-                    assert g.last_dispatch_count() == n and g.last_cutoff() == cutoff, (outDim, effort, tune)
-                    ea.bucketMulQ4(vd, bare, None, o0, effort, gpu=g)
-                    g.eval()
-                    assert close(o.cpu().numpy(), want) and close(o0.cpu().numpy(), want0), (outDim, effort, tune)
-                    if tune == (8, 1, 0):                              # the same geometry with nibble slots: the same integers
-                        g.set_q4_byte_acc(False)
-                        o1 = torch.full((outDim,), float("nan"), device=DEV)
-                        ea.bucketMulQ4(vd, ew, None, o1, effort, gpu=g)
-                        g.eval()
-                        assert torch.equal(o, o1), (outDim, effort)
-            g.set_tuning(0, 0, 0)
-            g.set_q4_byte_acc(True)
-            hv = [make_v(inDim, seed=400 + i, heavy=bool(i & 1)) for i in range(16)]       # 16 calls per launch
-            outs = [torch.full((outDim,), float("nan"), device=DEV) for _ in range(16)]
-            efforts = (0.1, 0.25, 0.5, 1.0)
-            for rep in range(2):                                       # (twice: persistent queues and scratch left clean)
-                ea.bucketMulGroup([(devf(hv[i]), ew, None, outs[i], efforts[i % 4]) for i in range(16)], gpu=g)
-                g.eval()
-                for i in range(16):
-                    want, n, cutoff = oracle_cpu.bucket_mul_q4(hv[i], L["buckets"], L["bucket.stats"], L["probes"], L["outliers"], inDim, outDim, efforts[i % 4])
-                    assert g.last_dispatch_count(i) == n and g.last_cutoff(i) == cutoff, (rep, i)
-                    assert close(outs[i].cpu().numpy(), want), (rep, i)
-    finally:
-        g.close()
-
-
 def test_bench_geometry_32_matrices_from_graph(ea, oracle_cpu):
     """The bench's 32-call launch: 32 DISTINCT converted 4096 x 11008 matrices, one call each at 25 % effort, one heuristic
     group (persistent workgroups, cutoff jobs), replayed from a hipGraph -- every output, dispatch count and cutoff against

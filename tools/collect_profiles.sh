@@ -42,13 +42,10 @@ python tools/decode_bench.py --tokens 64 > $O/${R}_decode_bench.json 2> $O/decod
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_dec -- python tools/decode_bench.py --tokens 64 --efforts 0.25 > $O/prof_dec.log 2>&1
 cp "$(ls -t $O/prof_dec/*/*kernel_stats.csv | head -1)" $O/${R}_rocprofv3_kernel_stats_decode.csv
 rm -rf $O/prof_dec
-# 7. round 4: the cutoff's phases, a layer's multiplies as launches / as one chain launch (+ its per-item trace), decode with the chain
+# 7. the cutoff's phases, a layer's multiplies as launches of their own
 python tools/cutprof.py 2>&1 | grep "effort" > $O/${R}_cutprof.txt
 python tools/layer_probe.py > $O/${R}_layer_probe_effort25.json 2>> $O/probe.log
 python tools/layer_probe.py --effort 0.5 > $O/${R}_layer_probe_effort50.json 2>> $O/probe.log
-python tools/chain_trace.py --out $O/chain_trace.json 2>&1 | tail -8 > $O/${R}_chain_trace_p1_m1.txt
-python tools/chain_trace.py --persistent 2 --out $O/chain_trace2.json 2>&1 | tail -8 > $O/${R}_chain_trace_p2_m1.txt
-python tools/decode_bench.py --tokens 64 --efforts 0.5,0.25 --chain 1 > $O/${R}_decode_bench_chain.json 2>> $O/decode.log
 [ -x build/rowbench ] && build/rowbench | grep "^mode" > $O/${R}_rowbench.txt
 [ -x build/rampbench ] && build/rampbench > $O/${R}_rampbench.txt
 ls -la $O | grep ${R}_

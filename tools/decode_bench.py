@@ -26,7 +26,6 @@ def main():
                                                       "+ shards) instead of random-init weights")
     ap.add_argument("--model-name", default="buckets-FP16")
     ap.add_argument("--percent-load", type=int, default=16)
-    ap.add_argument("--chain", type=int, default=0, help="0: every multiply group a launch of its own (round 3's loop); 1: a layer's dependent multiplies as one chain launch")
     a = ap.parse_args()
     torch.cuda.set_device(0)
     cfg = MistralConfig(numLayers=a.layers)
@@ -38,7 +37,7 @@ def main():
         model = Model.random(cfg, seed=1)
     torch.cuda.synchronize()
     print(f"model: {a.layers} layers, 7 bucketized matrices each, {'loaded' if a.model_dir else 'built + converted'} in {time.time() - t0:.1f} s", file=sys.stderr)
-    dec = Decoder(model, maxTokens=max(64, a.tokens + 8), chain=bool(a.chain))
+    dec = Decoder(model, maxTokens=max(64, a.tokens + 8))
     prompt = [1, 733, 16289, 28793, 22557]
     dec.g.set_dense_backend(True)                  # dense through rocBLAS' hssgemv, then through the package's own GEMV (the default)
     _, dt_r, _ = dec.run(prompt, a.tokens, dense=True)

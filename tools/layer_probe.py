@@ -1,9 +1,9 @@
 #!/usr/bin/env python
 """What a decoder layer's multiplies cost as the decode loop issues them -- four dependent launches (wo -> w1|w3 -> w2 ->
 wq|wk|wv of the next layer, glue folded in) -- against each launch alone and against the same seven calls as ONE independent
-group launch (the bound a resident chain could approach: no boundaries, no ramps, no dependency stalls).
+group launch (the bound: no boundaries, no ramps, no dependency stalls).  (The one-chain-launch variant of round 4: branch chain-launch.)
 
-    python tools/layer_probe.py [--effort 0.25] [--layers 8] [--chain 0|1]
+    python tools/layer_probe.py [--effort 0.25] [--layers 8]
 """
 import argparse
 import json
@@ -19,7 +19,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--effort", type=float, default=0.25)
-    ap.add_argument("--slice-mult", type=int, default=1, help="chain launches: row slices per call x this")
     ap.add_argument("--persistent", type=int, default=-1, help="workgroups per CU of persistent launches (-1: heuristic = 2)")
     ap.add_argument("--layers", type=int, default=8, help="distinct weight sets rotated through (cache honesty)")
     ap.add_argument("--reps", type=int, default=200)
@@ -31,7 +30,6 @@ def main():
     cfg = MistralConfig(numLayers=args.layers)
     model = Model.random(cfg, seed=3, keep_cores=False)
     g = ea.gpu(0)
-    g.set_chain_tuning(args.slice_mult)
     g.set_persistent(args.persistent)
     e = args.effort
     f = lambda n: torch.randn(n, device=dev)                                    # noqa: E731
@@ -48,13 +46,6 @@ def main():
         if "qkv" in which:
             ea.bucketMulGroup([(h, Lnext.wq, None, xq, e, {"norm": Lnext.attnNorm}), (h, Lnext.wk, None, xk, e, {"norm": Lnext.attnNorm}),
                                (h, Lnext.wv, None, xv, e, {"norm": Lnext.attnNorm})])
-
-    def chain(L, Lnext):              # the four dependent launches as ONE chain launch (effort_bucketmul_chain)
-        ea.bucketMulChain([[(attn, L.wo, None, h, e, {"resid": h})],
-                           [(h, L.w1, None, x1, e, {"norm": L.ffnNorm}), (h, L.w3, None, x3, e, {"norm": L.ffnNorm})],
-                           [(x1, L.w2, None, h, e, {"gate": x3, "resid": h})],
-                           [(h, Lnext.wq, None, xq, e, {"norm": Lnext.attnNorm}), (h, Lnext.wk, None, xk, e, {"norm": Lnext.attnNorm}),
-                            (h, Lnext.wv, None, xv, e, {"norm": Lnext.attnNorm})]])
 
     def seven(L, Lnext):              # the same seven multiplies as one launch of independent calls (plain inputs: no glue)
         ea.bucketMulGroup([(attn, L.wo, None, h, e), (h0, L.w1, None, x1, e), (h0, L.w3, None, x3, e), (x1, L.w2, None, attn, e),
@@ -83,7 +74,6 @@ def main():
     res = {"effort": e}
     for name, which in (("wo", ("wo",)), ("w13", ("w13",)), ("w2", ("w2",)), ("qkv", ("qkv",)), ("four_dependent_launches", ("wo", "w13", "w2", "qkv"))):
         res[name + "_us"] = round(timed(lambda L, Ln, w=which: launches(L, Ln, w)), 2)
-    res["chain_one_launch_us"] = round(timed(chain), 2)
     res["seven_independent_calls_one_launch_us"] = round(timed(seven), 2)
     res["sum_of_lone_us"] = round(res["wo_us"] + res["w13_us"] + res["w2_us"] + res["qkv_us"], 2)
     print(json.dumps(res))

@@ -31,7 +31,6 @@ def main():
     ap.add_argument("--overlap", type=int, default=1, help="K > 1: ONE context with effort_set_overlap(K); the steps of a graph write K rotating output sets")
     ap.add_argument("--no-outliers", type=int, default=0, help="Q4: register the bundles without their outlier tables")
     ap.add_argument("--fused", default="", help="comma list of gate,norm,resid: every call derives its input / adds its residual in the launch (effort_bucketmul_group_fused)")
-    ap.add_argument("--byte-acc", type=int, default=0, help="Q4: accumulate per byte (effort_set_q4_byte_acc)")
     ap.add_argument("--split", type=int, default=0, help="1: the cutoffs in a kernel of their own before the multiply (the device-clock span then covers the multiply alone)")
     args = ap.parse_args()
     inDim, outDim = (int(x) for x in args.shape.split("x"))
@@ -39,8 +38,6 @@ def main():
     from bench import make_weights
     dev = torch.device("cuda", 0)
     g = ea.gpu(0)
-    if args.byte_acc:
-        g.set_q4_byte_acc(True)
     ews = make_weights(ea, args.mats, inDim, outDim, 1234, dev, keep_core=False, q4=bool(args.q4))
     if args.q4 and args.no_outliers:
         ews = [ea.ExpertWeights(e.buckets, e.stats, e.probes, inSize=inDim, outSize=outDim, q4=True) for e in ews]
