@@ -610,6 +610,7 @@ def main():
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")        # (BENCH_FORCE_DIST on a bare box: the launcher sets it otherwise)
         if rank != 0:
             os.dup2(2, 1)        # only rank 0 owns stdout (RCCL prints banners there); the others' goes to stderr
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -1089,9 +1090,9 @@ def main():
                     r["achieved_GBps_4B_outliers"] = round((ab - 12 * nol) / tx / 1e9, 1)
                     r["frac_of_hbm_peak_4B_outliers"] = round((ab - 12 * nol) / tx / 1e9 / HBM_PEAK_GBPS, 4)
                     # what bounds the Q4 multiply is its LDS scatter, not memory: four integer LDS atomics per 16-bit word of a kept row
-                    # (one per nibble) plus two per outlier, against the measured ds_add_u32 rate of the chip (tools/microbench.hip:
+                    # (one per nibble), against the measured ds_add_u32 rate of the chip (tools/microbench.hip:
                     # elements per ns and CU, profiles/r04_q4_microbench_scatter.txt; 13 per clock and CU at 2.4 GHz when that file is absent)
-                    atomics = Dx * (outDim_x // 32) * 4 + 2 * nol
+                    atomics = Dx * (outDim_x // 32) * 4          # (the outlier phase has none since round 5: a lane sums its output in a register)
                     r["roofline_lds_atomic"] = {"bound": "lds_atomic", "atomics_per_call": atomics, "achieved_Gatomics_per_s": round(atomics / tx / 1e9, 1),
                                                 "peak_Gatomics_per_s": round(LDS_ATOMIC_PEAK, 1), "frac": round(atomics / tx / 1e9 / LDS_ATOMIC_PEAK, 4),
                                                 "peak_source": LDS_ATOMIC_SRC}

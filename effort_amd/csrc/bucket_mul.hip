@@ -138,9 +138,10 @@ __host__ __device__ inline uint32_t align_up(uint32_t x, uint32_t a) { return (x
 constexpr int kOlBatch = 16;                               // outlier entries in flight per lane
 constexpr uint32_t kOlLdsFloats = 16384;                   // v is staged whole in LDS up to this inDim (64 KB), else gathered from memory
 template <int E> __host__ __device__ inline uint32_t ol_outputs_per_item(const MulGeom& g) { return align_up((32u * E * 64u + g.slices - 1u) / g.slices, 64u); }   // whole interleave blocks
+constexpr uint32_t kOlSumFloats = 1024;                    // partial sums of a thin share split among the waves: [parts][share] <= 64 * waves floats
 template <int E> __host__ __device__ inline uint32_t ol_scratch_bytes(const MulGeom& g) {
-    return 2u * align_up(ol_outputs_per_item<E>(g) * 4u, 16u) + (g.inDim <= kOlLdsFloats ? g.inDim * 4u : 0u) +     // sums hi | lo | v
-           align_up((ol_outputs_per_item<E>(g) + 1u) * 4u, 16u);                                                       // | block bounds of the share (at most one block per output)
+    const uint32_t per = ol_outputs_per_item<E>(g);
+    return (per > kOlSumFloats ? per : kOlSumFloats) * 4u + (g.inDim <= kOlLdsFloats ? g.inDim * 4u : 0u);           // sums | v
 }
 
 // LDS carve (bytes), one plan for the whole launch (the largest of its geometries, so that a persistent workgroup can stage
@@ -173,7 +174,7 @@ __host__ __device__ inline LdsPlan plan_lds(const MulGeom* geoms, int nGeoms) {
     p.offL = o; o += align_up(slots * 2, 16);
     const uint32_t tbl = cutoff_table_bytes(64 * W);        // (>= the tile reduction's [G][tileFloats] partial sums)
     if (o < p.offA + tbl) o = p.offA + tbl;
-    p.offC = o; o += 2048;           // [0..kCutoffLdsBytes) cutoff scratch, [1280] flags, [1344..1407] wave bounds, [1408..1471] Q4 outlier bounds
+    p.offC = o; o += 2048;           // [0..kCutoffLdsBytes) cutoff scratch, [1280] flags, [1344..1407] wave bounds
     static_assert(kCutoffLdsBytes <= 1280, "the cutoff scratch must end below the flags of the misc region");
     p.total = o;
     return p;
@@ -697,139 +698,99 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     if (wstamp) ph[4] = wall_clock64();
 
     // ---- O. Q4 outliers (calcOutliers, bucketMulQ4.metal:13-21: out[o] += v[in]*value per outlier; the reference fires
-    //         one f32 atomic per outlier in table order).  Registration packed the table into FOUR bytes per outlier (f16
-    //         value | output within its block | input), grouped by blocks of 2^(16 - bits of inDim) outputs and
-    //         interleaved inside a block (dispatch.hip).  The tile's outputs are shared out among its slice items in
-    //         whole runs of 64; the waves of this item take the blocks of its share in turn and stream their entries --
-    //         coalesced, kOlBatch per lane in flight -- gather v from LDS (a 64-address gather from memory costs the L1
-    //         one line per lane) and add the products to fixed-point LDS sums like the tile's own (scale from max|v| * the
-    //         largest sum of |value| over an output of the share, known per 64 outputs since registration; integer adds
-    //         commute, so the result is deterministic), which join its slab below.  Measured, 4096x11008 with 901 775
-    //         outliers, per call at 32 calls per launch / alone: a kernel of its own with a wave per output 8.3 / 33.5 us;
-    //         eight lanes per output 5.2 / 32.5; this phase with 8-byte entries 4.6 / 29.0 -- the entries were 7.2 MB per
-    //         call then, more bytes than the 25 %-effort bucket rows (5.6 MB); 3.6 MB now. --------------------------
-    int* const olacc = reinterpret_cast<int*>(smem + offM);            // (means | vblk are dead by now)
-    const uint32_t olPer = ol_outputs_per_item<E>(g), olLoOff = align_up(olPer * 4u, 16u) / 4u;
+    //         one f32 atomic per outlier in table order).  Registration laid the table out per block of 64 outputs in
+    //         jagged-diagonal order, FOUR bytes per outlier (f16 value | input; dispatch.hip): ONE LANE OWNS AN OUTPUT and sums its
+    //         products in a register -- no atomics, no fixed point: out[o] += v[in] * value, entry after entry in the table's
+    //         order, as the reference's loop reads -- while step k of a wave (the k-th entry of every output of the block that
+    //         has one) is one contiguous load.  The tile's outputs are shared out among its slice items in whole blocks; the
+    //         waves of an item take the blocks of its share in turn, a thin share (a lone call's: one block) splits every
+    //         block's steps among `parts` waves, whose partial sums meet in LDS.  v is gathered from an LDS copy.  Round 4's
+    //         form -- interleaved entries, two LDS atomics per outlier on two-level fixed-point sums -- moved 3.6 MB per call at
+    //         2.4 TB/s (24 of the 80 us of a 16-call launch): DESIGN.md 4.1.
+    float* const olsum = reinterpret_cast<float*>(smem + offM);        // (means | vblk are dead by now) [parts][olPer]
+    const uint32_t olPer = ol_outputs_per_item<E>(g);
     bool olAny = false;
-    float olUnscale = 0.0f;
+    uint32_t olParts = 1u;
     if constexpr (FMT != kFp16) {
         olAny = a.ol.blockPtr != nullptr;                                                  // uniform per call
         if (olAny) {
             const OutlierIndex& ol = a.ol;
-            int* const ollo = olacc + align_up(olPer * 4u, 16u) / 4u;                        // low parts of the sums (see below)
-            float* const vfull = reinterpret_cast<float*>(ollo + align_up(olPer * 4u, 16u) / 4u);
-            uint32_t* const sPtr = reinterpret_cast<uint32_t*>(vfull + (g.inDim <= kOlLdsFloats ? g.inDim : 0u));   // the share's block bounds
+            float* const vfull = olsum + (olPer > kOlSumFloats ? olPer : kOlSumFloats);
             const bool vLds = g.inDim <= kOlLdsFloats;
             const uint32_t oBeg = min(t * (uint32_t)TILE_F + s * olPer, g.outDim);
             const uint32_t oEnd = max(oBeg, min(min(t * (uint32_t)TILE_F + (s + 1u) * olPer, (t + 1u) * (uint32_t)TILE_F), g.outDim));
-            const uint32_t bitsIn = ol_bits_in(g.inDim), bsLog = 16u - bitsIn, inMask = (1u << bitsIn) - 1u;
-            const uint32_t bFirst = oBeg >> bsLog, nB = ((oEnd + (1u << bsLog) - 1u) >> bsLog) - bFirst;     // (oBeg is a multiple of 64 >= the block size)
-            for (uint32_t i = tid; i <= nB; i += NT) sPtr[i] = ol.blockPtr[bFirst + i];
-            // bound of this share's sums: max over its runs of 64 outputs of (max over the outputs of sum |value|), from registration
-            const uint32_t nBlk = (oEnd - oBeg + 63u) / 64u;
-            float olBound = 0.0f;
-            for (uint32_t bq = tid; bq < nBlk; bq += NT) olBound = fmaxf(olBound, __uint_as_float(ol.bound64[oBeg / 64u + bq]));
-            float vm = 0.0f;
-            for (uint32_t i0 = 0; i0 < g.inDim; i0 += NT * 8u) {                           // eight loads in flight (clamped, branch-free)
-                float x[8];
+            const uint32_t bFirst = oBeg >> 6, nB = ((oEnd + 63u) >> 6) - bFirst;               // (oBeg is a multiple of 64)
+            if (vLds)
+                for (uint32_t i0 = 0; i0 < g.inDim; i0 += NT * 8u) {                           // eight loads in flight (clamped, branch-free)
+                    float x[8];
 #pragma unroll
-                for (int u = 0; u < 8; u++) x[u] = a.v[min(i0 + u * NT + tid, g.inDim - 1u)];
+                    for (int u = 0; u < 8; u++) x[u] = a.v[min(i0 + u * NT + tid, g.inDim - 1u)];
 #pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const uint32_t i = i0 + u * NT + tid;
-                    if (vLds && i < g.inDim) vfull[i] = x[u];
-                    vm = fmaxf(vm, fabsf(x[u]));
+                    for (int u = 0; u < 8; u++) {
+                        const uint32_t i = i0 + u * NT + tid;
+                        if (i < g.inDim) vfull[i] = x[u];
+                    }
                 }
-            }
-            for (uint32_t i = tid; i < olPer; i += NT) { olacc[i] = 0; ollo[i] = 0; }
-            float* const wmax = reinterpret_cast<float*>(smem + offC + 1408);              // [W] per-wave max of the block bounds
-            vm = __uint_as_float(wave_max_u32(__float_as_uint(vm))); olBound = __uint_as_float(wave_max_u32(__float_as_uint(olBound)));   // (non-negative floats order like their bit patterns)
-            if (lane == 0) { wbound[wave] = vm; wmax[wave] = olBound; }                    // (the slice bounds are dead by now)
-            __syncthreads();
-            vm = 0.0f; olBound = 0.0f;
-#pragma unroll
-            for (int w2 = 0; w2 < W; w2++) { vm = fmaxf(vm, wbound[w2]); olBound = fmaxf(olBound, wmax[w2]); }
-            // 2^k * (max|v| * olBound) < 2^29: no sum can leave int32; powers of two scale exactly
-            const int ex = (int)((__float_as_uint(vm * olBound) >> 23) & 0xFFu);
-            const int kk2 = min(max(155 - ex, -100), 100);
-            const float olScale = __uint_as_float((uint32_t)(kk2 + 127) << 23);
-            olUnscale = __uint_as_float((uint32_t)(127 - kk2) << 23);
-            // uniform per wave: the blocks of the share in turn; a share with fewer blocks than the workgroup has waves (a lone
-            // call's thin slices) splits every block's entries among `parts` waves.  (Measured, 4096x11008 / 901 775
-            // outliers, us per call alone / 16 per launch / 16 per launch x 4 launches in flight: 8-byte entries
-            // 27.3 / 5.52 / 3.28; this 27.3 / 5.51 / 3.27 -- half the outlier bytes at the same speed: the Q4 multiply is
-            // bound by its LDS atomics (four per 16-bit word of a bucket row), not by HBM.)
+            // a share with fewer blocks than the workgroup has waves splits every block's steps among `parts` waves
             const uint32_t parts = (nB && nB < (uint32_t)W) ? (uint32_t)W / nB : 1u;
-            // The wave's work, flattened into UNITS of up to 64 * kOlBatch entries of one (part of a) block, and software-pipelined:
-            // the entries of the next unit are asked for before the current one's are added.  (Measured before: a unit's loads
-            // are a full memory round trip each, ~2.5 us, and a wave had eight of them in a row -- 28 of the 87 us of a 16-call
-            // launch went here, at 2 TB/s.)
-            uint32_t q = (uint32_t)wave, kPos = 0, kEnd = 0, oB = 0;
-            auto advance = [&]() -> bool {                       // (uniform) moves to the wave's next non-empty unit
-                for (;;) {
-                    if (kPos < kEnd) return true;
-                    if (q >= nB * parts) return false;
-                    const uint32_t bq = q / parts, part = q % parts;
-                    const uint32_t kB0 = __builtin_amdgcn_readfirstlane(sPtr[bq]), kE0 = __builtin_amdgcn_readfirstlane(sPtr[bq + 1u]);
-                    const uint32_t chunk = align_up((kE0 - kB0 + parts - 1u) / parts, 64u);
-                    kPos = min(kE0, kB0 + part * chunk); kEnd = min(kE0, kPos + chunk);
-                    oB = ((bFirst + bq) << bsLog) - oBeg;
-                    q += W;
-                }
-            };
-            struct Unit { uint32_t k0, kE, outBase; };
-            auto fetch = [&](uint32_t (&ent)[kOlBatch], Unit& un) {  // the unit at the cursor: its entries asked for (clamped, branch-free), the cursor moved on
-                un.k0 = kPos; un.kE = kEnd; un.outBase = oB;
-#pragma unroll
-                for (int u = 0; u < kOlBatch; u++) ent[u] = ol.entry[min(un.k0 + u * 64u + (uint32_t)lane, un.kE - 1u)];
-                kPos = min(kEnd, kPos + 64u * kOlBatch);
-            };
-            // (Measured and dropped: units whose entries sit regularly on their block's outputs -- lane l on output l % 16, four
-            //  fifths of them -- summed in registers and folded with shuffles, two conflict-free atomics per unit instead of 32
-            //  four-way conflicted ones: 94.8 against 85.1 us per 16-call launch.  The phase is bound by its VALU work per entry,
-            //  not by the LDS atomics.)
-            // v is gathered from its LDS copy (inDim <= 16384) or from memory -- two instantiations of the loop, NOT one loop
-            // reading through `vLds ? vfull : a.v`: hipcc turns that select into a generic pointer and every gather into a FLAT
-            // load followed by s_waitcnt vmcnt(0) lgkmcnt(0) -- one gather at a time, ~430 cycles each, and the wait drains the
-            // next unit's prefetch as well (that was 26 of the 87 us of a 16-call launch).
+            olParts = parts;
+            __syncthreads();                                                               // vfull is whole
             using lds_f = __attribute__((address_space(3))) float;
             const lds_f* const vfullL = (const lds_f*)(size_t)(uint32_t)(size_t)(__attribute__((address_space(3))) void*)vfull;
-            auto add = [&](auto fromLds, const uint32_t (&ent)[kOlBatch], const Unit& un) {
-                float x[kOlBatch];
+            // (v from its LDS copy or from memory: two instantiations of the loop, NOT one loop reading through `vLds ? vfull : a.v`
+            //  -- hipcc turns that select into a generic pointer and every gather into a FLAT load behind s_waitcnt vmcnt(0) lgkmcnt(0))
+            auto run_blocks = [&](auto fromLds) {
+                for (uint32_t q = (uint32_t)wave; q < nB * parts; q += (uint32_t)W) {     // uniform per wave
+                    const uint32_t bq = q / parts, part = q % parts;
+                    const uint32_t meta = ol.meta[(size_t)(bFirst + bq) * 64u + (uint32_t)lane];
+                    const uint32_t myLen = meta >> 8, myOut = meta & 63u;                  // lane i <-> the output of rank i: counts descend with the lane
+                    const uint32_t maxLen = (uint32_t)__builtin_amdgcn_readfirstlane((int)myLen);
+                    const uint32_t chunk = (maxLen + parts - 1u) / parts, k0 = min(maxLen, part * chunk), k1 = min(maxLen, k0 + chunk);
+                    const uint32_t bBeg = __builtin_amdgcn_readfirstlane(ol.blockPtr[bFirst + bq]), bEnd = __builtin_amdgcn_readfirstlane(ol.blockPtr[bFirst + bq + 1u]);
+                    // entries of the steps before k0 = sum over the outputs of min(count, k0)
+                    uint32_t cur = bBeg + wave_sum_u32(min(myLen, k0));
+                    float acc = 0.0f;
+                    auto fetch = [&](uint32_t (&ent)[kOlBatch], uint32_t kk) {             // the entries of steps kk .. kk + kOlBatch - 1 asked for (clamped, branch-free)
 #pragma unroll
-                for (int u = 0; u < kOlBatch; u++) {                              // all the gathers of the unit go out together
-                    const uint32_t in = ent[u] & inMask;
-                    if constexpr (decltype(fromLds)::value) x[u] = vfullL[in]; else x[u] = a.v[in];
-                }
+                        for (int u = 0; u < kOlBatch; u++) {
+                            ent[u] = ol.entry[min(cur + (uint32_t)lane, bEnd - 1u)];
+                            cur += (kk + (uint32_t)u < k1) ? (uint32_t)__popcll(__ballot(myLen > kk + (uint32_t)u)) : 0u;
+                        }
+                    };
+                    auto add = [&](const uint32_t (&ent)[kOlBatch], uint32_t kk) {
+                        float x[kOlBatch];
 #pragma unroll
-                for (int u = 0; u < kOlBatch; u++) {
-                    const uint32_t o = un.outBase + ((ent[u] & 0xFFFFu) >> bitsIn);
-                    // two-level fixed point: the bound can sit far above the sums (one huge input), so the rounding
-                    // remainder of every product -- exact in f32 -- is summed too, 2^12 times finer (|ql| <= 2^11: an
-                    // output may have 2^19 entries before that sum could leave int32; registration refuses more)
-                    const float cs = (x[u] * half_bits_to_float((uint16_t)(ent[u] >> 16))) * olScale;
-                    const int qh = __float2int_rn(cs);
-                    const int ql = __float2int_rn((cs - (float)qh) * 4096.0f);
-                    if (un.k0 + u * 64u + (uint32_t)lane < un.kE) { atomicAdd(&olacc[o], qh); atomicAdd(&ollo[o], ql); }
+                        for (int u = 0; u < kOlBatch; u++) {                              // all the gathers of the unit go out together
+                            const uint32_t in = ent[u] & 0xFFFFu;
+                            if constexpr (decltype(fromLds)::value) x[u] = vfullL[in]; else x[u] = a.v[in];
+                        }
+#pragma unroll
+                        for (int u = 0; u < kOlBatch; u++) {
+                            const float pr = x[u] * half_bits_to_float((uint16_t)(ent[u] >> 16));      // bucketMulQ4.metal:19: v[o.y] * o.x
+                            if (myLen > kk + (uint32_t)u && kk + (uint32_t)u < k1) acc += pr;           //                      out[o.z] +=
+                        }
+                    };
+                    if (k0 < k1 && bEnd > bBeg) {
+                        uint32_t entA[kOlBatch], entB[kOlBatch];
+                        uint32_t kk = k0;
+                        fetch(entA, kk);
+                        for (;;) {
+                            const bool more = kk + (uint32_t)kOlBatch < k1;
+                            if (more) fetch(entB, kk + (uint32_t)kOlBatch);
+                            add(entA, kk);
+                            if (!more) break;
+                            kk += (uint32_t)kOlBatch;
+                            const bool more2 = kk + (uint32_t)kOlBatch < k1;
+                            if (more2) fetch(entA, kk + (uint32_t)kOlBatch);
+                            add(entB, kk);
+                            if (!more2) break;
+                            kk += (uint32_t)kOlBatch;
+                        }
+                    }
+                    olsum[part * olPer + bq * 64u + myOut] = acc;                           // every (part, output of the share) is written exactly once
                 }
             };
-            auto run_units = [&](auto fromLds) {
-                if (!advance()) return;
-                uint32_t entA[kOlBatch], entB[kOlBatch];
-                Unit ua, ub;
-                fetch(entA, ua);
-                for (;;) {
-                    bool more = advance();
-                    if (more) fetch(entB, ub);
-                    add(fromLds, entA, ua);
-                    if (!more) break;
-                    more = advance();
-                    if (more) fetch(entA, ua);
-                    add(fromLds, entB, ub);
-                    if (!more) break;
-                }
-            };
-            if (vLds) run_units(std::true_type{}); else run_units(std::false_type{});
+            if (vLds) run_blocks(std::true_type{}); else run_blocks(std::false_type{});
             __syncthreads();
         }
     }
@@ -846,7 +807,11 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
         float r = (float)(acc[p] - acc[p + 8 * E * 64]) * unscale;
         if (olAny) {                                                 // this item's share of the tile's outputs: + their outliers
             const uint32_t ol_o = (uint32_t)((rem & 63) * E + (rem >> 6)) * 32u + (uint32_t)slot - s * olPer;      // tile-local output, from the share's start
-            if (ol_o < olPer && (uint32_t)(t * TILE_F) + s * olPer + ol_o < g.outDim) r += ((float)olacc[ol_o] + (float)olacc[olLoOff + ol_o] * (1.0f / 4096.0f)) * olUnscale;
+            if (ol_o < olPer && (uint32_t)(t * TILE_F) + s * olPer + ol_o < g.outDim) {
+                float so = olsum[ol_o];
+                for (uint32_t pp = 1; pp < olParts; pp++) so += olsum[pp * olPer + ol_o];     // (a thin share's partial sums, in wave order)
+                r += so;
+            }
         }
         return r;
     };

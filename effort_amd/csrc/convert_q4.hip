@@ -196,4 +196,21 @@ hipError_t launch_convert_q4(const uint16_t* core2, uint32_t inDim, uint32_t out
     return done(e);
 }
 
+// Stable radix sort of (key, value) pairs by key -- the Q4 outlier index's by-output order (dispatch.hip) -- kept in THIS
+// translation unit: it is the one that carries rocPRIM (whose own getenv import tests/test_abi.py allows here only).
+hipError_t launch_sort_pairs_u32(const uint32_t* keysIn, uint32_t* keysOut, const uint32_t* valsIn, uint32_t* valsOut, uint64_t n, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    if (n >= (1ull << 31)) return hipErrorInvalidValue;
+    size_t tmpBytes = 0;
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs(nullptr, tmpBytes, keysIn, keysOut, valsIn, valsOut, (int)n, 0, 32, st);
+    if (e != hipSuccess) return e;
+    void* cubTmp = nullptr;
+    e = hipMalloc(&cubTmp, tmpBytes ? tmpBytes : 16);
+    if (e != hipSuccess) return e;
+    e = hipcub::DeviceRadixSort::SortPairs(cubTmp, tmpBytes, keysIn, keysOut, valsIn, valsOut, (int)n, 0, 32, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);           // (the scratch is freed below)
+    hipFree(cubTmp);
+    return e;
+}
+
 }  // namespace effort

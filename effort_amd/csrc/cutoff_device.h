@@ -225,21 +225,61 @@ __device__ __forceinline__ float block_find_cutoff(const float (&vj)[4096 / NT],
             //   |maxCount - minCount| < 3  <=>  catHi > catLo.   Bounds never set yet count 0 / 4096 (the reference's initial values).
             uint32_t catHi = patHi != kNoHi ? (uint32_t)(patHi < tM1) + (uint32_t)(patHi < tM2) : (uint32_t)(maxCount >= m - 1) + (uint32_t)(maxCount >= m - 2);
             uint32_t catLo = patLo != kNoLo ? (uint32_t)(patLo < tP1) + (uint32_t)(patLo < tP2) : (uint32_t)(minCount >= m + 1) + (uint32_t)(minCount >= m + 2);
-            asm volatile("" : "+v"(nb), "+v"(lo), "+v"(hi), "+v"(pLo), "+v"(pHi), "+v"(nLoops), "+v"(tM2), "+v"(tM1), "+v"(tM), "+v"(tP1), "+v"(tP2), "+v"(catHi), "+v"(catLo));   // VGPRs: see above
+            // THE ROUNDS, kBlk AT A TIME, THEIR EXIT TESTS IN PARALLEL (round 5).  What makes a round depend on the one before it is
+            // the bounds alone: newBound = (hi + lo) / 2, and which bound it replaces -- `countAbove < effort`, i.e. the midpoint's
+            // bits against the first float of cell T(m) (non-negative floats order like their bit patterns).  That recurrence is six
+            // VALU instructions.  Everything else a round does -- the three count-driven exit tests, the 1e-5 test, the 100-round
+            // cap, the fixed point, the hand-over to the closed-form tail at adjacent cells -- only decides WHERE the loop stops, and
+            // rounds run past that point have no side effect.  So a block of kBlk rounds runs the bare recurrence, identical in every
+            // lane, round r leaving the midpoint it tested in lane r; then lane r reconstructs round r on its own -- the bounds
+            // after the round are the latest midpoints at or before r that went each way (two bpermutes), their cells and count
+            // categories follow -- and evaluates the reference's exits for it; the first lane that stops (a ballot) hands its state
+            // to the wave.  Same float operations on the same operands, the same exit taken in the same round: bit-identical
+            // (tests/test_cutoff_trajectory_model.py restates the block form on the CPU against the count-by-count loop).  It was a
+            // chain of ~38 instructions and a branch per round (~260 cycles: 1.0 us for 9 rounds, 3.2 for 29); a block of 16 rounds
+            // is ~100 + ~70 instructions.
+            constexpr int kBlk = 16;
+            const uint32_t tMs0 = tM >= 0x10000u ? 0xFFFFFFFFu : (tM << 16);        // (T(m) is a cell, 0, or +inf)
             bool fin = done;
             if (!fin && pHi != pLo + 1u) {
                 for (;;) {
-                    const uint32_t p = __float_as_uint(nb) >> 16;
-                    const bool below = p >= tM;                                        // countAbove < effort
-                    nLoops += 1u;                                                      // :199-246, as `round` above
-                    const uint32_t cH = (uint32_t)(p < tM1) + (uint32_t)(p < tM2), cL = (uint32_t)(p < tP1) + (uint32_t)(p < tP2);
-                    hi = below ? nb : hi; pHi = below ? p : pHi; catHi = below ? cH : catHi;     // :214-220
-                    lo = below ? lo : nb; pLo = below ? pLo : p; catLo = below ? catLo : cL;
-                    const float prev = nb;
-                    nb = (hi + lo) / 2;                                                // :222
+                    float a = nb, l = lo, h = hi, rec = 0.0f;
+                    uint32_t tMs = tMs0;
+                    asm volatile("" : "+v"(a), "+v"(l), "+v"(h), "+v"(tMs));          // VGPRs: left uniform, hipcc splits every round between SALU and VALU
+#pragma unroll
+                    for (int r = 0; r < kBlk; r++) {
+                        rec = lane == r ? a : rec;                                    // the midpoint round r tests
+                        const bool below = __float_as_uint(a) >= tMs;                 // countAbove < effort
+                        h = below ? a : h;                                            // :214-220
+                        l = below ? l : a;
+                        a = (h + l) / 2;                                              // :222
+                    }
+                    // lane r < kBlk: round r of the block
+                    const uint32_t lr = (uint32_t)lane & (uint32_t)(kBlk - 1);
+                    const uint32_t p = __float_as_uint(rec) >> 16;
+                    const bool wentHi = __float_as_uint(rec) >= tMs;                  // this round's midpoint became the upper bound
+                    const uint32_t kmask = (1u << kBlk) - 1u;
+                    const uint32_t hb = (uint32_t)__ballot(wentHi) & kmask, lb = ~hb & kmask;      // (uniform) which rounds went which way
+                    const uint32_t upto = (2u << lr) - 1u;
+                    const uint32_t hSeen = hb & upto, lSeen = lb & upto;
+                    const float hFrom = __shfl(rec, hSeen ? 31 - __clz(hSeen) : 0), lFrom = __shfl(rec, lSeen ? 31 - __clz(lSeen) : 0);
+                    const float hr = hSeen ? hFrom : hi, lor = lSeen ? lFrom : lo;   // the bounds AFTER round r
+                    const uint32_t pHr = hSeen ? __float_as_uint(hr) >> 16 : pHi, pLr = lSeen ? __float_as_uint(lor) >> 16 : pLo;
+                    const uint32_t cHr = hSeen ? (uint32_t)(pHr < tM1) + (uint32_t)(pHr < tM2) : catHi;
+                    const uint32_t cLr = lSeen ? (uint32_t)(pLr < tP1) + (uint32_t)(pLr < tP2) : catLo;
+                    const float nbr = (hr + lor) / 2;                                 // :222
                     // :227-229 (countAbove == effort | the bounds | the counts), :236, and the fixed point
-                    fin = ((p >= tP1) & (p < tM)) | (hi - lo < 0.00001f) | (catHi > catLo) | (nLoops > 100u) | (nb == prev);
-                    if (__ballot(fin | (pHi == pLo + 1u)) != 0ull) break;              // (all lanes hold the same values: a scalar branch)
+                    const bool finr = ((p >= tP1) & (p < tM)) | (hr - lor < 0.00001f) | (cHr > cLr) | (nLoops + lr + 1u > 100u) | (nbr == rec);
+                    const bool stopr = finr | (pHr == pLr + 1u);                      // ... or the bounds sit in adjacent cells: the closed-form tail
+                    const uint32_t sm = (uint32_t)__ballot(stopr) & kmask;
+                    const int e = sm ? __builtin_ctz(sm) : kBlk - 1;                  // (uniform) the round the loop stops in, or the block's last
+                    nb = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(nbr), e));
+                    lo = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(lor), e));
+                    hi = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(hr), e));
+                    pLo = __builtin_amdgcn_readlane(pLr, e); pHi = __builtin_amdgcn_readlane(pHr, e);
+                    catLo = __builtin_amdgcn_readlane(cLr, e); catHi = __builtin_amdgcn_readlane(cHr, e);
+                    nLoops += (uint32_t)e + 1u;
+                    if (sm) { fin = (__builtin_amdgcn_readlane((uint32_t)finr, e) & 1u) != 0u; break; }
                 }
             }
             done = fin;

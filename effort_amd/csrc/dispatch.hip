@@ -175,14 +175,14 @@ hipError_t launch_cosine(const float* a, const float* b, uint32_t n, float* out3
 }
 
 // ---- Q4 outliers -> index (registration time) -------------------------------------------------------------------
-// outliers float4 = (value, inIdx, outIdx, 0) (q4_draft.py:58-67).  Pass 1 counts per output, a one-block scan makes
-// rowPtr, pass 2 places each outlier in its output's segment (atomic cursor: arbitrary order inside a segment -- the
-// multiply adds the products as integers, so the order does not matter), pass 3 packs the segments of every block of
-// 2^(16 - bitsIn) consecutive outputs into 4-byte entries (f16 value | output in block | input), interleaved -- first
-// entry of each output, then the second of each ... -- so that neighbouring lanes of the multiply's coalesced stream
-// mostly hold different outputs (their LDS atomics collide 64 / blockOutputs ways instead of 64).
-// entries the format does not allow: an index outside the matrix (or NaN) -- e.g. a full-matrix table handed to a column
-// shard -- or a value that is not an f16 number (the table comes from an f16 matrix; the 4-byte entry keeps 16 bits of it)
+// outliers float4 = (value, inIdx, outIdx, 0) (q4_draft.py:58-67).  The multiply's outlier phase (bucket_mul.hip, O) gives every
+// OUTPUT to one lane, which sums that output's products in a register -- no atomics -- while the wave's loads stay coalesced: the
+// index is a jagged-diagonal layout per block of 64 consecutive outputs.  The table is sorted by output, stably (a radix sort by
+// key: an output's entries keep the TABLE's order, so the sums are added in a defined order whatever the registration's atomics
+// did); within a block the 64 outputs are ranked by entry count, descending (ties: lower output first); entry k of the output of
+// rank i sits at block start + sum over k' < k of #{outputs with more than k' entries} + i -- step k of the multiply reads the k-th
+// entry of every output that has one with ONE contiguous load, lane i <-> rank i, and no padding exists.  Per rank a meta word
+// (entry count << 8 | output within the block) tells the lane whose sum it holds.  Entries are FOUR bytes: f16 value << 16 | input.
 __global__ void ol_validate_kernel(const float4* ol, uint64_t n, uint32_t inDim, uint32_t outDim, int* bad) {
     const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
@@ -196,85 +196,65 @@ hipError_t launch_validate_outliers(const float* outliers, uint64_t n, uint32_t 
     hipLaunchKernelGGL(ol_validate_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const float4*>(outliers), n, inDim, outDim, bad);
     return hipGetLastError();
 }
-__global__ void ol_count_kernel(const float4* ol, uint64_t n, uint32_t* rowPtr) {
+__global__ void ol_count_kernel(const float4* ol, uint64_t n, uint32_t* rowPtr, uint32_t* keys, uint32_t* vals) {
     const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-    if (i < n) atomicAdd(&rowPtr[(uint32_t)ol[i].z + 1], 1u);
+    if (i >= n) return;
+    const uint32_t out = (uint32_t)ol[i].z;
+    atomicAdd(&rowPtr[out + 1], 1u);
+    keys[i] = out; vals[i] = (uint32_t)i;                  // sorted by output below (stable: table order inside an output)
 }
 __global__ __launch_bounds__(1024) void ol_scan_kernel(uint32_t* rowPtr, uint32_t outDim) {
     __shared__ uint32_t s_part[1024];
     // inclusive scan of rowPtr[1..outDim] in place (rowPtr[0] = 0): thread t owns a contiguous chunk
     const uint32_t per = (outDim + 1023) / 1024, lo = 1 + threadIdx.x * per, hi = min(outDim + 1, lo + per);
-    uint32_t sum = 0;
-    for (uint32_t i = lo; i < hi; i++) sum += rowPtr[i];
+    uint32_t sum = 0, longest = 0;
+    for (uint32_t i = lo; i < hi; i++) { sum += rowPtr[i]; longest = max(longest, rowPtr[i]); }
     s_part[threadIdx.x] = sum;
+    atomicMax(&rowPtr[outDim + 1], longest);               // one more word: the longest segment (zeroed by the launcher)
     __syncthreads();
     if (threadIdx.x == 0) { uint32_t run = 0; for (int i = 0; i < 1024; i++) { const uint32_t c = s_part[i]; s_part[i] = run; run += c; } rowPtr[0] = 0; }
     __syncthreads();
     uint32_t run = s_part[threadIdx.x];
     for (uint32_t i = lo; i < hi; i++) { run += rowPtr[i]; rowPtr[i] = run; }
 }
-__global__ void ol_place_kernel(const float4* ol, uint64_t n, const uint32_t* rowPtr, uint32_t* cursor, uint32_t* inIdx, float* value) {
-    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-    if (i >= n) return;
-    const float4 o = ol[i];
-    const uint32_t out = (uint32_t)o.z;
-    const uint32_t p = rowPtr[out] + atomicAdd(&cursor[out], 1u);
-    inIdx[p] = (uint32_t)o.y; value[p] = o.x;
-}
-// one wave per 64 outputs (lane = output), which hold 64 / bs blocks of bs outputs: round r moves the r-th entry of every
-// output that has one; inside its block an output's entry lands after those of the block's lower outputs of that round
-__global__ __launch_bounds__(64) void ol_pack_kernel(const uint32_t* rowPtr, uint32_t outDim, uint32_t bitsIn, const uint32_t* inIdx,
-                                                     const float* valIn, uint32_t* entry, uint32_t* blockPtr) {
-    const uint32_t out = blockIdx.x * 64u + threadIdx.x, lane = threadIdx.x;
-    const uint32_t bs = 1u << (16u - bitsIn);                                  // outputs per block (a power of two <= 64... 32768 for bitsIn = 1: clamped below)
-    const uint32_t bsl = min(bs, 64u);                                         // lanes of this wave per block
+// one wave per block of 64 outputs (lane = output): rank the outputs by entry count, write the meta words, then walk the steps --
+// step k places the k-th entry of every output that has one at (cursor + rank), the cursor advancing by the step's population
+__global__ __launch_bounds__(64) void ol_jds_kernel(const float4* ol, const uint32_t* sortedIdx, const uint32_t* rowPtr, uint32_t outDim,
+                                                    uint32_t* entry, uint32_t* meta, uint32_t* blockPtr) {
+    const uint32_t lane = threadIdx.x, out = blockIdx.x * 64u + lane;
     const uint32_t lo = rowPtr[min(out, outDim)], len = out < outDim ? rowPtr[out + 1] - lo : 0u;
-    const uint32_t first = lane / bsl * bsl;                                   // first lane of this lane's block (within the wave)
-    const unsigned long long blockMask = (bsl == 64u ? ~0ull : ((1ull << bsl) - 1ull)) << first;
-    uint32_t base = rowPtr[min(blockIdx.x * 64u + first, outDim)];
-    if (lane == first && blockIdx.x * 64u + first < outDim) blockPtr[(blockIdx.x * 64u + first) / bs] = base;      // (bs <= 16: inDim >= 4096)
-    for (uint32_t r = 0;; r++) {
-        const unsigned long long active = __ballot(len > r);
+    uint32_t rank = 0;
+    for (uint32_t o = 0; o < 64u; o++) {
+        const uint32_t lo2 = (uint32_t)__builtin_amdgcn_readlane((int)len, (int)o);
+        rank += (lo2 > len || (lo2 == len && o < lane)) ? 1u : 0u;
+    }
+    meta[(size_t)blockIdx.x * 64u + rank] = (len << 8) | lane;
+    uint32_t cursor = rowPtr[min(blockIdx.x * 64u, outDim)];
+    if (lane == 0) blockPtr[blockIdx.x] = cursor;
+    if (lane == 0 && blockIdx.x == gridDim.x - 1u) blockPtr[gridDim.x] = rowPtr[outDim];
+    for (uint32_t k = 0;; k++) {
+        const unsigned long long active = __ballot(len > k);
         if (!active) break;
-        const unsigned long long mine = active & blockMask;
-        if (len > r) {
-            const uint32_t p = base + (uint32_t)__popcll(mine & ((1ull << lane) - 1ull));
-            const uint32_t h = (uint32_t)__half_as_ushort(__float2half_rn(valIn[lo + r]));
-            entry[p] = (h << 16) | ((out & (bs - 1u)) << bitsIn) | inIdx[lo + r];
+        if (len > k) {
+            const float4 o = ol[sortedIdx[lo + k]];
+            entry[cursor + rank] = ((uint32_t)__half_as_ushort(__float2half_rn(o.x)) << 16) | (uint32_t)o.y;
         }
-        base += (uint32_t)__popcll(mine);
+        cursor += (uint32_t)__popcll(active);
     }
 }
-// rowPtr[outDim + 1 + b] = bits of max over the outputs of block b (64 outputs) of sum |value|: bounds the multiply's
-// fixed-point outlier sums; after the blocks, the largest number of entries of one output
-__global__ void ol_bound_kernel(const uint32_t* rowPtr, uint32_t outDim, const float* value, uint32_t* boundBits) {
-    const uint32_t out = blockIdx.x * 256u + threadIdx.x;
-    if (out >= outDim) return;
-    float sum = 0.0f;
-    for (uint32_t i = rowPtr[out]; i < rowPtr[out + 1]; i++) sum += fabsf(value[i]);
-    atomicMax(&boundBits[out / 64u], __float_as_uint(sum));       // non-negative floats order like their bit patterns
-    atomicMax(&boundBits[(outDim + 63u) / 64u], rowPtr[out + 1] - rowPtr[out]);      // one more word: the longest segment
-}
-__global__ void ol_block_end_kernel(const uint32_t* rowPtr, uint32_t outDim, uint32_t nBlocks, uint32_t* blockPtr) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) blockPtr[nBlocks] = rowPtr[outDim];
-}
-// rowPtr: [outDim + 1] by-output bounds, then [ceil(outDim/64)] bound bits, then the longest segment (kept: bound64 points
-// into it).  tmp: [outDim] cursors, then [n] inputs and [n] values of the by-output order (before packing)
+// rowPtr: [outDim + 1] by-output bounds, then one word: the longest segment.  tmp: [n] keys | [n] table indices (unsorted) | [n] keys |
+// [n] table indices (sorted by output, stably: launch_sort_pairs_u32, convert_q4.hip -- the one translation unit that carries rocPRIM)
 hipError_t launch_build_outlier_index(const float* outliers, uint64_t n, uint32_t inDim, uint32_t outDim, uint32_t* rowPtr,
-                                      uint32_t* blockPtr, uint32_t* entry, uint32_t* tmp, hipStream_t st) {
-    hipError_t e = hipMemsetAsync(rowPtr, 0, ((size_t)outDim + 2 + (outDim + 63) / 64) * 4, st); if (e != hipSuccess) return e;
-    e = hipMemsetAsync(tmp, 0, (size_t)outDim * 4, st); if (e != hipSuccess) return e;
+                                      uint32_t* blockPtr, uint32_t* entry, uint32_t* meta, uint32_t* tmp, hipStream_t st) {
+    (void)inDim;
+    hipError_t e = hipMemsetAsync(rowPtr, 0, ((size_t)outDim + 2) * 4, st); if (e != hipSuccess) return e;
     const float4* ol = reinterpret_cast<const float4*>(outliers);
-    const uint32_t nb = (uint32_t)((n + 255) / 256);
-    const uint32_t bitsIn = ol_bits_in(inDim), bs = 1u << (16u - bitsIn), nBlocks = (outDim + bs - 1) / bs;
-    uint32_t* in0 = tmp + outDim;
-    float* val0 = reinterpret_cast<float*>(in0 + n);
-    hipLaunchKernelGGL(ol_count_kernel, dim3(nb), dim3(256), 0, st, ol, n, rowPtr);
+    const uint32_t nb = (uint32_t)((n + 255) / 256), nBlocks = (outDim + 63u) / 64u;
+    uint32_t *keys = tmp, *vals = tmp + n, *keysOut = tmp + 2 * n, *valsOut = tmp + 3 * n;
+    hipLaunchKernelGGL(ol_count_kernel, dim3(nb), dim3(256), 0, st, ol, n, rowPtr, keys, vals);
     hipLaunchKernelGGL(ol_scan_kernel, dim3(1), dim3(1024), 0, st, rowPtr, outDim);
-    hipLaunchKernelGGL(ol_place_kernel, dim3(nb), dim3(256), 0, st, ol, n, rowPtr, tmp, in0, val0);
-    hipLaunchKernelGGL(ol_bound_kernel, dim3((outDim + 255) / 256), dim3(256), 0, st, rowPtr, outDim, val0, rowPtr + outDim + 1);
-    hipLaunchKernelGGL(ol_pack_kernel, dim3((outDim + 63) / 64), dim3(64), 0, st, rowPtr, outDim, bitsIn, in0, val0, entry, blockPtr);
-    hipLaunchKernelGGL(ol_block_end_kernel, dim3(1), dim3(64), 0, st, rowPtr, outDim, nBlocks, blockPtr);
+    e = launch_sort_pairs_u32(keys, keysOut, vals, valsOut, n, st); if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(ol_jds_kernel, dim3(nBlocks), dim3(64), 0, st, ol, valsOut, rowPtr, outDim, entry, meta, blockPtr);
     return hipGetLastError();
 }
 

@@ -33,16 +33,15 @@ struct MulGeom {
     uint32_t elems;        // E: u16 columns per lane of this call's tiles (= the launch's template parameter)
 };
 
-// The Q4 outliers, indexed at registration (dispatch.hip): FOUR bytes per outlier.  An entry packs the f16 value (the table
-// comes from an f16 matrix, q4_draft.py:58-67) with 16 bits naming (output within its block, input): bitsIn = bits of
-// inDim - 1, blocks of 2^(16 - bitsIn) consecutive outputs (16 outputs for 4096 inputs).  blockPtr bounds a block's entries;
-// inside a block the entries are interleaved over its outputs (first of each, second of each ...).
+// The Q4 outliers, indexed at registration (dispatch.hip): FOUR bytes per outlier (f16 value << 16 | input: inDim <= 65536), in a
+// jagged-diagonal layout per block of 64 consecutive outputs -- the outputs of a block ranked by entry count (descending), entry k of
+// rank i at blockPtr[b] + (entries of steps before k) + i -- so that ONE lane owns an output (its sum lives in a register, no
+// atomics) and a wave's step is one contiguous load.  meta[b * 64 + i] = entry count of rank i << 8 | its output within the block.
 struct OutlierIndex {
-    const uint32_t* blockPtr;  // [ceil(outDim / blockOutputs) + 1] entry bounds by block (nullptr: no outliers)
-    const uint32_t* entry;     // [n]  f16 value << 16 | output-in-block << bitsIn | input
-    const uint32_t* bound64;   // [ceil(outDim/64)] f32 bits: max over the 64 outputs of sum |value| (bounds the fixed-point sums); then the longest run of one output
+    const uint32_t* blockPtr;  // [ceil(outDim / 64) + 1] entry bounds by block of 64 outputs (nullptr: no outliers)
+    const uint32_t* entry;     // [n]  f16 value << 16 | input
+    const uint32_t* meta;      // [ceil(outDim / 64) * 64]  entry count << 8 | output in block, by rank
 };
-__host__ __device__ inline uint32_t ol_bits_in(uint32_t inDim) { uint32_t b = 1; while ((1u << b) < inDim) b++; return b; }     // inDim <= 65536
 
 // One launch = a GROUP of up to kMaxGroup independent bucketMul calls (own weights, v, out, effort, scratch):
 // the decode loop's Wq|Wk|Wv and W1|W3 (runNetwork.swift:132-134,178-182) are such groups.  A lone call's
@@ -240,6 +239,7 @@ hipError_t launch_f32_to_f16(const float* in, uint16_t* out, uint32_t n, hipStre
 hipError_t launch_cosine(const float* a, const float* b, uint32_t n, float* out3, hipStream_t st);
 hipError_t launch_validate_outliers(const float* outliers, uint64_t n, uint32_t inDim, uint32_t outDim, int* bad, hipStream_t st);
 hipError_t launch_build_outlier_index(const float* outliers, uint64_t n, uint32_t inDim, uint32_t outDim, uint32_t* rowPtr,
-                                      uint32_t* blockPtr, uint32_t* entry, uint32_t* tmp, hipStream_t st);
+                                      uint32_t* blockPtr, uint32_t* entry, uint32_t* meta, uint32_t* tmp, hipStream_t st);
+hipError_t launch_sort_pairs_u32(const uint32_t* keysIn, uint32_t* keysOut, const uint32_t* valsIn, uint32_t* valsOut, uint64_t n, hipStream_t st);   // stable (convert_q4.hip)
 
 }  // namespace effort

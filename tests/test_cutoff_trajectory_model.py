@@ -1,4 +1,4 @@
-"""CPU model of the HIP cutoff's lookup-free bisection (effort_amd/csrc/cutoff_device.h, "THE BISECTION WITHOUT ITS
+"""CPU model of the HIP cutoff's lookup-free, block-parallel bisection (effort_amd/csrc/cutoff_device.h, "THE BISECTION WITHOUT ITS
 LOOKUPS") against the oracle's findCutoff32.  The device code replaces every use of a count inside the reference's loop --
 the steering comparison and the two count-driven exit tests -- with comparisons of the threshold's bf16 CELL against five
 order statistics of the values; this restates that control flow in numpy f32 arithmetic -- including the hand-over to the
@@ -34,6 +34,50 @@ def _cell_edge_tail(nb, lo, hi, X, loops):
         nb = F((hi + lo) / F(2))
         if F(hi - lo) < F(0.00001) or loops > 100 or nb == prev:
             return nb
+
+
+K_BLK = 16
+
+
+def _bits(f):
+    return int(np.asarray(F(f)).view(np.uint32))
+
+
+def _block_rounds(nb, lo, hi, pLo, pHi, catLo, catHi, loops, T):
+    """cutoff_device.h, "THE ROUNDS, kBlk AT A TIME": a block runs the bare recurrence of the bounds for K_BLK rounds (every lane
+    the same), round r leaving its midpoint in lane r; lane r then reconstructs round r -- the bounds after it are the latest
+    midpoints at or before r that went each way -- and evaluates the reference's exits; the first lane that stops hands over.
+    Returns (fin, nb, lo, hi, pLo, pHi, loops) where the loop stops (fin: an exit of the reference; else adjacent cells)."""
+    tM2, tM1, tM, tP1, tP2 = T
+    tMs = 0xFFFFFFFF if tM >= 0x10000 else tM << 16
+    if pHi == pLo + 1:
+        return (False, nb, lo, hi, pLo, pHi, loops)
+    while True:
+        a, l, h, rec = nb, lo, hi, []
+        for r in range(K_BLK):                                   # the recurrence: runs on past the stop, harmlessly
+            rec.append(a)
+            below = _bits(a) >= tMs
+            h, l = (a, l) if below else (h, a)
+            a = F((h + l) / F(2))
+        went = [_bits(x) >= tMs for x in rec]
+        for r in range(K_BLK):                                   # "lane r"
+            hs = [j for j in range(r + 1) if went[j]]
+            ls = [j for j in range(r + 1) if not went[j]]
+            hr, lr = (rec[hs[-1]] if hs else hi), (rec[ls[-1]] if ls else lo)
+            pHr, pLr = (_bits(hr) >> 16 if hs else pHi), (_bits(lr) >> 16 if ls else pLo)
+            cHr = int(pHr < tM1) + int(pHr < tM2) if hs else catHi
+            cLr = int(pLr < tP1) + int(pLr < tP2) if ls else catLo
+            p = _bits(rec[r]) >> 16
+            nbr = F((hr + lr) / F(2))
+            finr = (tP1 <= p < tM) or bool(F(hr - lr) < F(0.00001)) or cHr > cLr or loops + r + 1 > 100 or bool(nbr == rec[r])
+            if finr or pHr == pLr + 1 or r == K_BLK - 1:
+                state = (nbr, lr, hr, pLr, pHr, cLr, cHr)
+                stopped = finr or pHr == pLr + 1
+                break
+        nb, lo, hi, pLo, pHi, catLo, catHi = state
+        loops += r + 1
+        if stopped:
+            return (bool(finr), nb, lo, hi, pLo, pHi, loops)
 
 
 def model_cutoff(v, probes_u16, q):
@@ -97,6 +141,7 @@ def model_cutoff(v, probes_u16, q):
     # count(hi) as "how many of m-1, m-2 it reaches", count(lo) as "how many of m+1, m+2": |maxCount - minCount| < 3 <=> catHi > catLo
     catHi = int(pHi < tM1) + int(pHi < tM2) if pHi != NO_HI else int(maxC >= m - 1) + int(maxC >= m - 2)
     catLo = int(pLo < tP1) + int(pLo < tP2) if pLo != NO_LO else int(minC >= m + 1) + int(minC >= m + 2)
+    blk = _block_rounds(nb, lo, hi, pLo, pHi, catLo, catHi, loops, (tM2, tM1, tM, tP1, tP2))       # the device's block form, from the same state
     fin = False
     while not fin and pHi != pLo + 1:
         p = _pat(nb)
@@ -116,6 +161,9 @@ def model_cutoff(v, probes_u16, q):
         mn = count_above(pLo) if pLo != NO_LO else minC
         assert cntEq == (cnt == m) and dLt3 == (abs(mx - mn) < 3), (cntEq, cnt, m, dLt3, mx, mn)
         fin = cntEq or bool(F(hi - lo) < F(0.00001)) or dLt3 or loops > 100 or bool(nb == prev)
+    # the block form stops in the same round with the same state, bit for bit
+    same = lambda x, y: np.asarray(F(x)).view(np.uint32) == np.asarray(F(y)).view(np.uint32)        # noqa: E731
+    assert blk[0] == fin and same(blk[1], nb) and same(blk[2], lo) and same(blk[3], hi) and blk[4:] == (pLo, pHi, loops), (blk, fin, nb, lo, hi, pLo, pHi, loops)
     if fin:
         return nb
     return _cell_edge_tail(nb, lo, hi, frompat(pHi), loops)
