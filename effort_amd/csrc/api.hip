@@ -761,8 +761,17 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
         guard.forked = true;
         for (int k = 0; k < nh; k++) if (hazard[k] != li) { HIP_TRY(c, lane_mark(c->lane[hazard[k]])); HIP_TRY(c, hipStreamWaitEvent(L.own, c->lane[hazard[k]].done, 0)); }
         if (!nh) c->nextLane = (c->nextLane + 1) % c->nLanes;
-        L.reads.insert(L.reads.end(), rd.begin(), rd.end());
-        L.writes.insert(L.writes.end(), wr.begin(), wr.end());
+        // (a range the lane holds already is not recorded twice: a loop that multiplies into the same vectors over and over --
+        //  the reference's timing loop -- would otherwise grow the lists to their cap, and every call scan thousands of ranges)
+        auto add_new = [](std::vector<Lane::Range>& have, const std::vector<Lane::Range>& more) {
+            for (const auto& x : more) {
+                bool seen = false;
+                for (const auto& y : have) if (y.lo == x.lo && y.hi == x.hi) { seen = true; break; }
+                if (!seen) have.push_back(x);
+            }
+        };
+        add_new(L.reads, rd);
+        add_new(L.writes, wr);
         return EFFORT_OK;
     };
     c->lastLane = li;

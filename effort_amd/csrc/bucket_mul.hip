@@ -749,7 +749,10 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
                     const uint32_t bBeg = __builtin_amdgcn_readfirstlane(ol.blockPtr[bFirst + bq]), bEnd = __builtin_amdgcn_readfirstlane(ol.blockPtr[bFirst + bq + 1u]);
                     // entries of the steps before k0 = sum over the outputs of min(count, k0)
                     uint32_t cur = bBeg + wave_sum_u32(min(myLen, k0));
-                    float acc = 0.0f;
+                    // (the products are f32, as the reference's; their SUM is kept in f64 -- full rate on this chip -- so that it does not
+                    //  depend on how a thin share's steps were split among the waves, nor drift over an output with thousands of
+                    //  entries: round 4's fixed-point sums were exact, the tests' bar was set with them)
+                    double acc = 0.0;
                     auto fetch = [&](uint32_t (&ent)[kOlBatch], uint32_t kk) {             // the entries of steps kk .. kk + kOlBatch - 1 asked for (clamped, branch-free)
 #pragma unroll
                         for (int u = 0; u < kOlBatch; u++) {
@@ -767,7 +770,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
 #pragma unroll
                         for (int u = 0; u < kOlBatch; u++) {
                             const float pr = x[u] * half_bits_to_float((uint16_t)(ent[u] >> 16));      // bucketMulQ4.metal:19: v[o.y] * o.x
-                            if (myLen > kk + (uint32_t)u && kk + (uint32_t)u < k1) acc += pr;           //                      out[o.z] +=
+                            if (myLen > kk + (uint32_t)u && kk + (uint32_t)u < k1) acc += (double)pr;   //                      out[o.z] +=
                         }
                     };
                     if (k0 < k1 && bEnd > bBeg) {
@@ -787,7 +790,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
                             kk += (uint32_t)kOlBatch;
                         }
                     }
-                    olsum[part * olPer + bq * 64u + myOut] = acc;                           // every (part, output of the share) is written exactly once
+                    olsum[part * olPer + bq * 64u + myOut] = (float)acc;                    // every (part, output of the share) is written exactly once
                 }
             };
             if (vLds) run_blocks(std::true_type{}); else run_blocks(std::false_type{});

@@ -80,14 +80,21 @@ __device__ __forceinline__ float block_find_cutoff(const float (&vj)[4096 / NT],
     // their 16-bit patterns
     uint32_t vp[VPT];
     uint32_t pmin = 0xFFFFu, pmax = 0u, pminnz = 0xFFFFu;
+    static_assert(VPT % 2 == 0, "block_find_cutoff: the values are converted to bfloat two at a time");
 #pragma unroll
-    for (int k = 0; k < VPT; k++) {
-        const float t = kCutoffScale * vj[k];
-        const float u = t * bf16_round(half_bits_to_float(prj[k]));
-        vp[k] = __float_as_uint(bf16_round(fabsf(u))) >> 16;
-        pmin = min(pmin, vp[k]);
-        pmax = max(pmax, vp[k]);
-        pminnz = min(pminnz, vp[k] ? vp[k] : 0xFFFFu);
+    for (int k = 0; k < VPT; k += 2) {
+        // bfloat(probe) and bfloat(|product|), two values per conversion instruction (bf16_pack2)
+        const uint32_t pr2 = bf16_pack2(half_bits_to_float(prj[k]), half_bits_to_float(prj[k + 1]));
+        const float t0 = kCutoffScale * vj[k], t1 = kCutoffScale * vj[k + 1];
+        const float u0 = t0 * __uint_as_float(pr2 << 16), u1 = t1 * __uint_as_float(pr2 & 0xFFFF0000u);
+        const uint32_t v2 = bf16_pack2(fabsf(u0), fabsf(u1));
+        vp[k] = v2 & 0xFFFFu; vp[k + 1] = v2 >> 16;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            pmin = min(pmin, vp[k + h]);
+            pmax = max(pmax, vp[k + h]);
+            pminnz = min(pminnz, vp[k + h] ? vp[k + h] : 0xFFFFu);
+        }
     }
     // wave results on DPP (no LDS round trips), one slot per wave; the count table is zeroed under the same barrier (its
     // region is free on entry): ONE barrier where there were three

@@ -121,6 +121,18 @@ __device__ __forceinline__ float bf16_round(float f) {
     return __uint_as_float(u & 0xFFFF0000u);
 }
 
+// Two of them at once, as 16-bit patterns (x in the low half): gfx950's v_cvt_pk_bf16_f32 rounds to nearest even in ONE instruction
+// where the integer form above takes six per value -- the cutoff's value pass converts 2 x 4096 numbers per workgroup, and every
+// instruction of a lone call's workgroup is four cycles of the call's dependent chain.  (Finite inputs: identical bits; NaNs are
+// quieted by the hardware's own rule.)
+typedef __bf16 effort_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float effort_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t bf16_pack2(float x, float y) {
+    effort_f32x2 v; v[0] = x; v[1] = y;
+    const effort_bf16x2 r = __builtin_convertvector(v, effort_bf16x2);
+    uint32_t u; __builtin_memcpy(&u, &r, 4); return u;
+}
+
 // ---- wave64 reductions and scans on DPP ------------------------------------------------------
 // __shfl_xor / __shfl_down compile to ds_bpermute_b32 on gfx950: an LDS round trip per step, six dependent ones per reduction
 // (~400 cycles).  row_shr:1/2/4/8 + row_bcast:15/31 fold into the VALU instruction itself (v_add_u32_dpp ...): six

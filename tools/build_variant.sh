@@ -4,5 +4,5 @@ set -e
 cd "$(dirname "$0")/../effort_amd/csrc"
 mkdir -p ../../build/variants
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden -I/opt/rocm/include $2 -c bucket_mul.hip -o ../../build/variants/$1_bm.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o ../../build/variants/$1.so api.o ../../build/variants/$1_bm.o cutoff.o dispatch.o convert.o convert_q4.o decode.o gemv.o -L/opt/rocm/lib -lrocblas -lrccl -Wl,-rpath,/opt/rocm/lib
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o ../../build/variants/$1.so api.o ../../build/variants/$1_bm.o cutoff.o dispatch.o convert.o convert_q4.o decode.o gemv.o -L/opt/rocm/lib -lrocblas -ldl -Wl,-rpath,/opt/rocm/lib
 rm -f ../../build/variants/$1_bm.o

@@ -8,5 +8,5 @@ for f in api bucket_mul cutoff dispatch convert convert_q4 decode gemv; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden -I/opt/rocm/include $2 -c $f.hip -o $D/$f.o &
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o ../../build/variants/$1.so $D/*.o -L/opt/rocm/lib -lrocblas -lrccl -Wl,-rpath,/opt/rocm/lib
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o ../../build/variants/$1.so $D/*.o -L/opt/rocm/lib -lrocblas -ldl -Wl,-rpath,/opt/rocm/lib
 rm -rf $D
