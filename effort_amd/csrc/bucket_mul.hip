@@ -138,7 +138,7 @@ __host__ __device__ inline uint32_t align_up(uint32_t x, uint32_t a) { return (x
 constexpr int kOlBatch = 16;                               // outlier entries in flight per lane
 constexpr uint32_t kOlLdsFloats = 16384;                   // v is staged whole in LDS up to this inDim (64 KB), else gathered from memory
 template <int E> __host__ __device__ inline uint32_t ol_outputs_per_item(const MulGeom& g) { return align_up((32u * E * 64u + g.slices - 1u) / g.slices, 64u); }   // whole interleave blocks
-constexpr uint32_t kOlSumFloats = 1024;                    // partial sums of a thin share split among the waves: [parts][share] <= 64 * waves floats
+constexpr uint32_t kOlSumFloats = 1024;                    // partial sums of a thin share split among the waves: [parts][blocks * 64], parts * blocks <= waves <= 16
 template <int E> __host__ __device__ inline uint32_t ol_scratch_bytes(const MulGeom& g) {
     const uint32_t per = ol_outputs_per_item<E>(g);
     return (per > kOlSumFloats ? per : kOlSumFloats) * 4u + (g.inDim <= kOlLdsFloats ? g.inDim * 4u : 0u);           // sums | v
@@ -707,10 +707,10 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     //         block's steps among `parts` waves, whose partial sums meet in LDS.  v is gathered from an LDS copy.  Round 4's
     //         form -- interleaved entries, two LDS atomics per outlier on two-level fixed-point sums -- moved 3.6 MB per call at
     //         2.4 TB/s (24 of the 80 us of a 16-call launch): DESIGN.md 4.1.
-    float* const olsum = reinterpret_cast<float*>(smem + offM);        // (means | vblk are dead by now) [parts][olPer]
+    float* const olsum = reinterpret_cast<float*>(smem + offM);        // (means | vblk are dead by now) [parts][blocks of the share * 64]
     const uint32_t olPer = ol_outputs_per_item<E>(g);
     bool olAny = false;
-    uint32_t olParts = 1u;
+    uint32_t olParts = 1u, olStride = 0u;                              // partial sums of a thin share: [parts][olStride], olStride = its blocks * 64
     if constexpr (FMT != kFp16) {
         olAny = a.ol.blockPtr != nullptr;                                                  // uniform per call
         if (olAny) {
@@ -733,7 +733,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
                 }
             // a share with fewer blocks than the workgroup has waves splits every block's steps among `parts` waves
             const uint32_t parts = (nB && nB < (uint32_t)W) ? (uint32_t)W / nB : 1u;
-            olParts = parts;
+            olParts = parts; olStride = nB * 64u;                                          // (parts * nB <= W: at most 64 * W floats)
             __syncthreads();                                                               // vfull is whole
             using lds_f = __attribute__((address_space(3))) float;
             const lds_f* const vfullL = (const lds_f*)(size_t)(uint32_t)(size_t)(__attribute__((address_space(3))) void*)vfull;
@@ -790,7 +790,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
                             kk += (uint32_t)kOlBatch;
                         }
                     }
-                    olsum[part * olPer + bq * 64u + myOut] = (float)acc;                    // every (part, output of the share) is written exactly once
+                    olsum[part * olStride + bq * 64u + myOut] = (float)acc;                    // every (part, output of the share) is written exactly once
                 }
             };
             if (vLds) run_blocks(std::true_type{}); else run_blocks(std::false_type{});
@@ -812,7 +812,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
             const uint32_t ol_o = (uint32_t)((rem & 63) * E + (rem >> 6)) * 32u + (uint32_t)slot - s * olPer;      // tile-local output, from the share's start
             if (ol_o < olPer && (uint32_t)(t * TILE_F) + s * olPer + ol_o < g.outDim) {
                 float so = olsum[ol_o];
-                for (uint32_t pp = 1; pp < olParts; pp++) so += olsum[pp * olPer + ol_o];     // (a thin share's partial sums, in wave order)
+                for (uint32_t pp = 1; pp < olParts; pp++) so += olsum[pp * olStride + ol_o];     // (a thin share's partial sums, in wave order)
                 r += so;
             }
         }
