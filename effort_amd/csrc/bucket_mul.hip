@@ -138,10 +138,14 @@ __host__ __device__ inline uint32_t align_up(uint32_t x, uint32_t a) { return (x
 constexpr int kOlBatch = 16;                               // outlier entries in flight per lane
 constexpr uint32_t kOlLdsFloats = 16384;                   // v is staged whole in LDS up to this inDim (64 KB), else gathered from memory
 template <int E> __host__ __device__ inline uint32_t ol_outputs_per_item(const MulGeom& g) { return align_up((32u * E * 64u + g.slices - 1u) / g.slices, 64u); }   // whole interleave blocks
+constexpr uint32_t kOlEarlyFloats = 4096;                  // ... up to this inDim in a region of its OWN (LdsPlan::offO), filled at the top of the item: the lean
+                                                           // kernels then work the outliers INSIDE the streaming loop (mul_item, D); above it the copy overlays the
+                                                           // staging regions once the rows are in
+constexpr int kOlMerged = 8;                               // outlier steps per half of a streaming-loop trip (merged mode)
 constexpr uint32_t kOlSumFloats = 1024;                    // partial sums of a thin share split among the waves: [parts][blocks * 64], parts * blocks <= waves <= 16
 template <int E> __host__ __device__ inline uint32_t ol_scratch_bytes(const MulGeom& g) {
     const uint32_t per = ol_outputs_per_item<E>(g);
-    return (per > kOlSumFloats ? per : kOlSumFloats) * 4u + (g.inDim <= kOlLdsFloats ? g.inDim * 4u : 0u);           // sums | v
+    return (per > kOlSumFloats ? per : kOlSumFloats) * 4u + (g.inDim <= kOlLdsFloats ? g.inDim * 4u : 0u);           // sums | v (the overlay copy: generic kernels, inDim > 4096)
 }
 
 // LDS carve (bytes), one plan for the whole launch (the largest of its geometries, so that a persistent workgroup can stage
@@ -154,14 +158,17 @@ template <int E> __host__ __device__ inline uint32_t ol_scratch_bytes(const MulG
 // pipelined and use vblk[0] only.
 template <int FMT, int E, int W>
 __host__ __device__ inline LdsPlan plan_lds(const MulGeom* geoms, int nGeoms) {
-    uint32_t slots = 0, vrows = 0, ol = 0;
+    uint32_t slots = 0, vrows = 0, ol = 0, vEarly = 0;
     for (int i = 0; i < nGeoms; i++) {
         const MulGeom& g = geoms[i];
         if (!g.slices) continue;                            // unused entry
         slots = slots > g.slots ? slots : g.slots;
         const uint32_t vr = align_up(g.sliceRows, 64);      // the loads land a whole wave (64 dwords) at a time
         vrows = vrows > vr ? vrows : vr;
-        if (FMT != kFp16) { const uint32_t x = ol_scratch_bytes<E>(g); ol = ol > x ? ol : x; }
+        if (FMT != kFp16) {
+            const uint32_t x = ol_scratch_bytes<E>(g); ol = ol > x ? ol : x;
+            if (g.inDim <= kOlEarlyFloats) vEarly = vEarly > g.inDim * 4u ? vEarly : g.inDim * 4u;
+        }
     }
     LdsPlan p;
     uint32_t o = 0;
@@ -175,6 +182,7 @@ __host__ __device__ inline LdsPlan plan_lds(const MulGeom* geoms, int nGeoms) {
     const uint32_t tbl = cutoff_table_bytes(64 * W);        // (>= the tile reduction's [G][tileFloats] partial sums)
     if (o < p.offA + tbl) o = p.offA + tbl;
     p.offC = o; o += 2048;           // [0..kCutoffLdsBytes) cutoff scratch, [1280] flags, [1344..1407] wave bounds
+    p.offO = vEarly ? o : 0u; o += vEarly;       // Q4: the whole input vector, for the outlier phase (inDim <= kOlEarlyFloats)
     static_assert(kCutoffLdsBytes <= 1280, "the cutoff scratch must end below the flags of the misc region");
     p.total = o;
     return p;
@@ -330,6 +338,41 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
 
     // ---- A. everything the selection needs lands in LDS (stage_issue): the row means of the candidate slots, the slice of v
     if (!staged) stage_issue<FMT, W, COMPACT>(ga, ref, tid, smem, lp, par);
+    // Q4 outliers (phase O below): the share of this item, and -- lean kernels, v small enough for a region of its own -- what the
+    // MERGED form needs, asked for now: the whole of v (eight loads per thread, written to LDS once the staged loads are awaited)
+    // and the wave's first block's meta word and entry bounds.
+    constexpr bool kOlMerge = FMT != kFp16 && !PERSIST && W == 8;
+    const uint32_t olPer = ol_outputs_per_item<E>(g);
+    bool olAny = false, olEarly = false;
+    uint32_t olParts = 1u, olStride = 0u;                              // partial sums of a thin share: [parts][olStride], olStride = its blocks * 64
+    uint32_t olBFirst = 0u, olNB = 0u;
+    float olVx[kOlMerge ? 8 : 1]; uint32_t olMeta0 = 0u, olBeg0 = 0u, olEnd0 = 0u;
+    auto ol_share = [&]() {                                            // the item's share of its tile's outputs, in blocks of 64
+        const uint32_t oBeg = min(t * (uint32_t)TILE_F + s * olPer, g.outDim);
+        const uint32_t oEnd = max(oBeg, min(min(t * (uint32_t)TILE_F + (s + 1u) * olPer, (t + 1u) * (uint32_t)TILE_F), g.outDim));
+        olBFirst = oBeg >> 6; olNB = ((oEnd + 63u) >> 6) - olBFirst;                        // (oBeg is a multiple of 64)
+        // a share with fewer blocks than the workgroup has waves splits every block's steps among `parts` waves
+        olParts = (olNB && olNB < (uint32_t)W) ? (uint32_t)W / olNB : 1u;
+        olStride = olNB * 64u;                                                             // (parts * blocks <= W: at most 64 * W floats)
+    };
+    if constexpr (FMT != kFp16) {
+        olAny = a.ol.blockPtr != nullptr;                                                  // uniform per call
+        if (olAny) {
+            if constexpr (kOlMerge) {
+                ol_share();
+                olEarly = g.inDim <= kOlEarlyFloats && lp.offO != 0u;
+                if (olEarly) {
+#pragma unroll
+                    for (int u = 0; u < 8; u++) olVx[u] = a.v[min((uint32_t)(u * NT + tid), g.inDim - 1u)];
+                    if ((uint32_t)wave < olNB * olParts) {
+                        const uint32_t bq = (uint32_t)wave / olParts;
+                        olMeta0 = a.ol.meta[(size_t)(olBFirst + bq) * 64u + (uint32_t)lane];
+                        olBeg0 = a.ol.blockPtr[olBFirst + bq]; olEnd0 = a.ol.blockPtr[olBFirst + bq + 1u];
+                    }
+                }
+            }
+        }
+    }
     const float rankBound = a.rankBound[e];                       // (asked for here: its round trip runs under the staged loads')
     float vj[VPT]; uint16_t prj[VPT];
     const uint16_t* pr = a.probes + (size_t)e * kProbes;
@@ -427,6 +470,13 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     // the staged loads have landed (each thread waits for its own; it reads back only what its own lane loaded until the
     // next barrier).  The slice's absolute sum bounds every partial sum of this workgroup (see the scale below).
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (kOlMerge) {
+        if (olEarly) {                                                // (published by the barrier of B, with vblk)
+            float* const vf = reinterpret_cast<float*>(smem + __builtin_amdgcn_readfirstlane(lp.offO));
+#pragma unroll
+            for (int u = 0; u < 8; u++) if ((uint32_t)(u * NT + tid) < g.inDim) vf[u * NT + tid] = olVx[u];
+        }
+    }
     float bound = 0.0f;
 #pragma unroll
     for (int u = 0; u < (FMT == kFp16 ? 1 : 2); u++) {
@@ -668,13 +718,70 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     // next item: late enough that the queue still balances the workgroups, early enough that the staged loads land under
     // the remaining rows.
     bool asked = false;
+    // ---- (Q4) the outlier stepper.  calcOutliers (bucketMulQ4.metal:13-21: out[o] += v[in] * value per outlier).  Registration laid
+    //      the table out per block of 64 outputs in jagged-diagonal order, FOUR bytes per outlier (f16 value | input; dispatch.hip):
+    //      ONE LANE OWNS AN OUTPUT and sums its products in a register -- no atomics, no fixed point -- entry after entry in the
+    //      table's order, while step k of a wave (the k-th entry of every output of the block that has one) is one contiguous
+    //      load.  The tile's outputs are shared out among its slice items in whole blocks; the waves of an item take the blocks of
+    //      its share in turn, a thin share (a lone call's: one block) splits every block's steps among `parts` waves, whose
+    //      partial sums meet in LDS.  v is gathered from an LDS copy.
+    //      MERGED (lean kernels, inDim <= 4096; round 5): the streaming loop is bound by the LDS atomics of its scatter (four per
+    //      16-bit word), the outlier steps by memory and VALU -- so a wave works its first block's steps INSIDE the streaming loop,
+    //      kOlMerged steps per half trip: the entries of the next steps asked for with the next batch of rows, the current ones
+    //      added between two batches' scatters; always executed, never branched around (a branch around a load makes hipcc drain
+    //      vmcnt(0)): past the wave's last step the loads re-read a valid entry and the adds are predicated off.  What is left
+    //      when the rows run out is drained after the loop.  (profiles/r05_q4_ablation.json: as a phase of its own the outliers
+    //      were 19 of the 74 us of a 16-call launch.)
+    using lds_f = __attribute__((address_space(3))) float;
+    uint32_t olLen = 0u, olOut = 0u, olKa = 0u, olKf = 0u, olK1 = 0u, olCur = 0u, olLast = 0u, olSlot = 0xFFFFFFFFu;
+    double olAcc = 0.0;
+    const lds_f* olV = nullptr;                                    // the LDS copy of v the stepper gathers from
+    if constexpr (kOlMerge) {
+        if (olEarly) {
+            olV = (const lds_f*)(size_t)(uint32_t)(size_t)(__attribute__((address_space(3))) void*)(smem + __builtin_amdgcn_readfirstlane(lp.offO));
+            if ((uint32_t)wave < olNB * olParts) {
+                const uint32_t bq = (uint32_t)wave / olParts, part = (uint32_t)wave % olParts;
+                olLen = olMeta0 >> 8; olOut = olMeta0 & 63u;              // lane i <-> the output of rank i: counts descend with the lane
+                const uint32_t maxLen = (uint32_t)__builtin_amdgcn_readfirstlane((int)olLen);
+                const uint32_t chunk = (maxLen + olParts - 1u) / olParts, k0 = min(maxLen, part * chunk);
+                const uint32_t bBeg = __builtin_amdgcn_readfirstlane(olBeg0), bEnd = __builtin_amdgcn_readfirstlane(olEnd0);
+                olK1 = bEnd > bBeg ? min(maxLen, k0 + chunk) : k0;
+                olKa = olKf = k0;
+                olCur = bBeg + wave_sum_u32(min(olLen, k0));              // entries of the steps before k0 = sum over the outputs of min(count, k0)
+                olLast = bEnd ? bEnd - 1u : 0u;
+                olSlot = part * olStride + bq * 64u + olOut;
+            }
+        }
+    }
+    auto ol_fetch = [&](uint32_t (&ent)[kOlMerged]) {              // the entries of the next kOlMerged steps asked for (clamped, branch-free)
+#pragma unroll
+        for (int u = 0; u < kOlMerged; u++) {
+            ent[u] = a.ol.entry[min(olCur + (uint32_t)lane, olLast)];
+            olCur += (olKf + (uint32_t)u < olK1) ? (uint32_t)__popcll(__ballot(olLen > olKf + (uint32_t)u)) : 0u;
+        }
+        olKf += (uint32_t)kOlMerged;
+    };
+    auto ol_add = [&](const uint32_t (&ent)[kOlMerged]) {
+        float x[kOlMerged];
+#pragma unroll
+        for (int u = 0; u < kOlMerged; u++) x[u] = olV[ent[u] & 0xFFFFu];                       // all the gathers of the unit go out together
+#pragma unroll
+        for (int u = 0; u < kOlMerged; u++) {
+            const float pr = x[u] * half_bits_to_float((uint16_t)(ent[u] >> 16));               // bucketMulQ4.metal:19: v[o.y] * o.x
+            if (olLen > olKa + (uint32_t)u && olKa + (uint32_t)u < olK1) olAcc += (double)pr;    //                      out[o.z] +=
+        }
+        olKa += (uint32_t)kOlMerged;
+    };
     // (measured: raising the wave priority of this loop -- s_setprio 2 -- so that a co-resident workgroup's selection does not
     //  take its issue slots is 8 % SLOWER per launch: the other workgroup's head then takes that much longer)
-    {
+    auto stream_rows = [&](auto withOl) {
+        constexpr bool OL = decltype(withOl)::value;
         Piece<E> pa[KB], pb[KB];
+        uint32_t entA[OL ? kOlMerged : 1], entB[OL ? kOlMerged : 1];
         uint32_t boffA, boffB; float dvA, dvB;
         uint32_t baseA = grab(), baseB;
         if (baseA < nU) { decode(baseA, boffA, dvA); issue(pa, boffA); }
+        if constexpr (OL) ol_fetch(entA);
         while (baseA < nU) {
             if (!asked && nU - baseA <= 4u * KB * W) asked = prefetch();
             if (wstamp && GA_TRACE(ga) && item + GA_CUTJOBS(ga) < (uint32_t)kTraceItems) {       // progress stamps (trace mode only)
@@ -684,43 +791,47 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
             baseB = grab();
             decode(baseB, boffB, dvB);
             issue(pb, boffB);
+            if constexpr (OL) ol_fetch(entB);
             accumulate(pa, dvA, __builtin_amdgcn_readfirstlane(min((uint32_t)KB, nU - baseA)));
+            if constexpr (OL) ol_add(entA);
             baseA = grab();
             decode(baseA, boffA, dvA);
             issue(pa, boffA);
+            if constexpr (OL) ol_fetch(entA);
             accumulate(pb, dvB, __builtin_amdgcn_readfirstlane(baseB < nU ? min((uint32_t)KB, nU - baseB) : 0u));
+            if constexpr (OL) ol_add(entB);
         }
-    }
+        if constexpr (OL) {                                        // the rows ran out first: the rest of the wave's block (entA: asked for, not yet added)
+            while (olKa < olK1) {
+                ol_fetch(entB); ol_add(entA);
+                if (olKa >= olK1) break;
+                ol_fetch(entA); ol_add(entB);
+            }
+        }
+    };
+    if constexpr (kOlMerge) { if (olEarly) stream_rows(std::true_type{}); else stream_rows(std::false_type{}); }
+    else stream_rows(std::false_type{});
     // (measured too: everything BUT this loop at raised priority -- no effect, 173.9 vs 173.5 us per 32-call launch)
     if (!asked) asked = prefetch();            // (a wave without rows; wave 0 always gets an answer: it is the one that pulls)
     __syncthreads();                           // every wave's atomics have landed in the tile
     if (stamp) GA_TSTAMP(ga)[20] = wall_clock64();
     if (wstamp) ph[4] = wall_clock64();
 
-    // ---- O. Q4 outliers (calcOutliers, bucketMulQ4.metal:13-21: out[o] += v[in]*value per outlier; the reference fires
-    //         one f32 atomic per outlier in table order).  Registration laid the table out per block of 64 outputs in
-    //         jagged-diagonal order, FOUR bytes per outlier (f16 value | input; dispatch.hip): ONE LANE OWNS AN OUTPUT and sums its
-    //         products in a register -- no atomics, no fixed point: out[o] += v[in] * value, entry after entry in the table's
-    //         order, as the reference's loop reads -- while step k of a wave (the k-th entry of every output of the block that
-    //         has one) is one contiguous load.  The tile's outputs are shared out among its slice items in whole blocks; the
-    //         waves of an item take the blocks of its share in turn, a thin share (a lone call's: one block) splits every
-    //         block's steps among `parts` waves, whose partial sums meet in LDS.  v is gathered from an LDS copy.  Round 4's
-    //         form -- interleaved entries, two LDS atomics per outlier on two-level fixed-point sums -- moved 3.6 MB per call at
-    //         2.4 TB/s (24 of the 80 us of a 16-call launch): DESIGN.md 4.1.
+    // ---- O. Q4 outliers, what the streaming loop did not take: everything in the generic kernels and for inDim > 4096 (v is
+    //         copied to LDS here, over the staging regions that are dead by now -- or gathered from memory beyond 16384 inputs);
+    //         in the merged form the sums of the waves' first blocks are handed over, and the blocks of a share with more blocks
+    //         than waves worked.  (Rounds 2-4: entries interleaved by blocks of 16 outputs, two LDS atomics per outlier on
+    //         two-level fixed-point sums -- 3.6 MB per call at 2.4 TB/s, 24 of the 80 us of a 16-call launch: DESIGN.md 4.1.)
     float* const olsum = reinterpret_cast<float*>(smem + offM);        // (means | vblk are dead by now) [parts][blocks of the share * 64]
-    const uint32_t olPer = ol_outputs_per_item<E>(g);
-    bool olAny = false;
-    uint32_t olParts = 1u, olStride = 0u;                              // partial sums of a thin share: [parts][olStride], olStride = its blocks * 64
     if constexpr (FMT != kFp16) {
-        olAny = a.ol.blockPtr != nullptr;                                                  // uniform per call
         if (olAny) {
             const OutlierIndex& ol = a.ol;
-            float* const vfull = olsum + (olPer > kOlSumFloats ? olPer : kOlSumFloats);
+            // (merged form: the copy of v sits in a region of its own, filled already; otherwise it is made here, over the staging regions)
+            float* const vfull = olEarly ? reinterpret_cast<float*>(smem + __builtin_amdgcn_readfirstlane(lp.offO)) : olsum + (olPer > kOlSumFloats ? olPer : kOlSumFloats);
             const bool vLds = g.inDim <= kOlLdsFloats;
-            const uint32_t oBeg = min(t * (uint32_t)TILE_F + s * olPer, g.outDim);
-            const uint32_t oEnd = max(oBeg, min(min(t * (uint32_t)TILE_F + (s + 1u) * olPer, (t + 1u) * (uint32_t)TILE_F), g.outDim));
-            const uint32_t bFirst = oBeg >> 6, nB = ((oEnd + 63u) >> 6) - bFirst;               // (oBeg is a multiple of 64)
-            if (vLds)
+            if constexpr (!kOlMerge) ol_share();                                           // (the generic kernels: not held across the streaming loop)
+            const uint32_t bFirst = olBFirst, nB = olNB, parts = olParts;
+            if (vLds && !olEarly) {
                 for (uint32_t i0 = 0; i0 < g.inDim; i0 += NT * 8u) {                           // eight loads in flight (clamped, branch-free)
                     float x[8];
 #pragma unroll
@@ -731,16 +842,14 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
                         if (i < g.inDim) vfull[i] = x[u];
                     }
                 }
-            // a share with fewer blocks than the workgroup has waves splits every block's steps among `parts` waves
-            const uint32_t parts = (nB && nB < (uint32_t)W) ? (uint32_t)W / nB : 1u;
-            olParts = parts; olStride = nB * 64u;                                          // (parts * nB <= W: at most 64 * W floats)
-            __syncthreads();                                                               // vfull is whole
-            using lds_f = __attribute__((address_space(3))) float;
+                __syncthreads();                                                           // vfull is whole
+            }
+            if (olSlot != 0xFFFFFFFFu) olsum[olSlot] = (float)olAcc;                       // merged form: the wave's first block, summed under the rows
             const lds_f* const vfullL = (const lds_f*)(size_t)(uint32_t)(size_t)(__attribute__((address_space(3))) void*)vfull;
             // (v from its LDS copy or from memory: two instantiations of the loop, NOT one loop reading through `vLds ? vfull : a.v`
             //  -- hipcc turns that select into a generic pointer and every gather into a FLAT load behind s_waitcnt vmcnt(0) lgkmcnt(0))
             auto run_blocks = [&](auto fromLds) {
-                for (uint32_t q = (uint32_t)wave; q < nB * parts; q += (uint32_t)W) {     // uniform per wave
+                for (uint32_t q = (uint32_t)wave + (olEarly ? (uint32_t)W : 0u); q < nB * parts; q += (uint32_t)W) {     // uniform per wave
                     const uint32_t bq = q / parts, part = q % parts;
                     const uint32_t meta = ol.meta[(size_t)(bFirst + bq) * 64u + (uint32_t)lane];
                     const uint32_t myLen = meta >> 8, myOut = meta & 63u;                  // lane i <-> the output of rank i: counts descend with the lane

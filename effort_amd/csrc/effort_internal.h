@@ -80,7 +80,7 @@ struct CallDesc {                    // 112 bytes
     const float* resid;        // nullable epilogue: out = resid + product (h.add(by:), runNetwork.swift:172,183); may alias out
 };
 // Where the regions of a workgroup's dynamic LDS start (plan_lds in bucket_mul.hip; computed by the launcher, not by every workgroup).
-struct LdsPlan { uint32_t offM, offV[2], offA, offL, offC, total; };
+struct LdsPlan { uint32_t offM, offV[2], offA, offL, offC, offO, total; };     // offO: Q4, the whole input vector for the outlier phase (0: none)
 // Layout: what EVERY workgroup reads first comes first and together -- the scalars and the LDS plan share the first 64-byte line
 // of the kernel-argument block, the scratch pointers the second -- so that a workgroup's first scalar loads are two lines, not a
 // chain of dependent ones (a plain grid's workgroup runs its prologue once, on the dependent chain of the call).
