@@ -398,7 +398,8 @@ extern "C" effort_w* effort_weights_q4(effort_ctx* c, const void* buckets, const
         const uint32_t olBlocks = ((uint32_t)outDim + 63u) / 64u;
         bool ok = hipMalloc(&rowPtr, ((size_t)outDim + 2) * 4) == hipSuccess && hipMalloc(&w->olBlockPtr, ((size_t)olBlocks + 1) * 4) == hipSuccess &&
                   hipMalloc(&w->olMeta, (size_t)olBlocks * 64 * 4) == hipSuccess &&
-                  hipMalloc(&w->olEntry, (size_t)nOutliers * 4) == hipSuccess && hipMalloc(&tmp, 4 * (size_t)nOutliers * 4) == hipSuccess;
+                  hipMalloc(&w->olEntry, ((size_t)nOutliers + 64) * 4) == hipSuccess && hipMalloc(&tmp, 4 * (size_t)nOutliers * 4) == hipSuccess;
+        if (ok) ok = hipMemsetAsync(w->olEntry + (size_t)nOutliers, 0, 64 * 4, c->stream) == hipSuccess;     // padding: a step's load reads 64 entries from its cursor
         if (ok) ok = launch_build_outlier_index(static_cast<const float*>(outliers), w->nOutliers, (uint32_t)inDim, (uint32_t)outDim, rowPtr, w->olBlockPtr,
                                                 w->olEntry, w->olMeta, tmp, c->stream) == hipSuccess;
         if (ok) ok = hipStreamSynchronize(c->stream) == hipSuccess;

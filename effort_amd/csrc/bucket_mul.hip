@@ -733,8 +733,8 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     //      when the rows run out is drained after the loop.  (profiles/r05_q4_ablation.json: as a phase of its own the outliers
     //      were 19 of the 74 us of a 16-call launch.)
     using lds_f = __attribute__((address_space(3))) float;
-    uint32_t olLen = 0u, olOut = 0u, olKa = 0u, olKf = 0u, olK1 = 0u, olCur = 0u, olLast = 0u, olSlot = 0xFFFFFFFFu;
-    double olAcc = 0.0;
+    uint32_t olLen = 0u, olOut = 0u, olKa = 0u, olKf = 0u, olK1 = 0u, olCur = 0u, olSlot = 0xFFFFFFFFu;
+    float olAcc = 0.0f;
     const lds_f* olV = nullptr;                                    // the LDS copy of v the stepper gathers from
     if constexpr (kOlMerge) {
         if (olEarly) {
@@ -742,22 +742,29 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
             if ((uint32_t)wave < olNB * olParts) {
                 const uint32_t bq = (uint32_t)wave / olParts, part = (uint32_t)wave % olParts;
                 olLen = olMeta0 >> 8; olOut = olMeta0 & 63u;              // lane i <-> the output of rank i: counts descend with the lane
+                const uint32_t olLenAll = olLen;
                 const uint32_t maxLen = (uint32_t)__builtin_amdgcn_readfirstlane((int)olLen);
                 const uint32_t chunk = (maxLen + olParts - 1u) / olParts, k0 = min(maxLen, part * chunk);
                 const uint32_t bBeg = __builtin_amdgcn_readfirstlane(olBeg0), bEnd = __builtin_amdgcn_readfirstlane(olEnd0);
                 olK1 = bEnd > bBeg ? min(maxLen, k0 + chunk) : k0;
                 olKa = olKf = k0;
-                olCur = bBeg + wave_sum_u32(min(olLen, k0));              // entries of the steps before k0 = sum over the outputs of min(count, k0)
-                olLast = bEnd ? bEnd - 1u : 0u;
+                olCur = bBeg + wave_sum_u32(min(olLenAll, k0));           // entries of the steps before k0 = sum over the outputs of min(count, k0)
+                olLen = min(olLenAll, olK1);                              // (this wave's steps end at olK1: one test per step, `count > step`)
                 olSlot = part * olStride + bq * 64u + olOut;
             }
         }
     }
-    auto ol_fetch = [&](uint32_t (&ent)[kOlMerged]) {              // the entries of the next kOlMerged steps asked for (clamped, branch-free)
+    // acc + x * (the f16 in the high half of the entry): one v_fma_mix_f32 reads the half in place (the FP16 multiply's own idiom)
+    auto ol_fma = [](float x, uint32_t ent, float acc) -> float {
+        float r;
+        asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "=v"(r) : "v"(x), "v"(ent), "v"(acc));
+        return r;
+    };
+    auto ol_fetch = [&](uint32_t (&ent)[kOlMerged]) {              // the entries of the next kOlMerged steps asked for (branch-free: lanes past a step's population read on into the next entries)
 #pragma unroll
         for (int u = 0; u < kOlMerged; u++) {
-            ent[u] = a.ol.entry[min(olCur + (uint32_t)lane, olLast)];
-            olCur += (olKf + (uint32_t)u < olK1) ? (uint32_t)__popcll(__ballot(olLen > olKf + (uint32_t)u)) : 0u;
+            ent[u] = (a.ol.entry + olCur)[lane];                   // (a uniform base + 4 * lane: no address arithmetic per step; the array ends in 64 entries of padding)
+            olCur += (uint32_t)__popcll(__ballot(olLen > olKf + (uint32_t)u));
         }
         olKf += (uint32_t)kOlMerged;
     };
@@ -766,10 +773,8 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
 #pragma unroll
         for (int u = 0; u < kOlMerged; u++) x[u] = olV[ent[u] & 0xFFFFu];                       // all the gathers of the unit go out together
 #pragma unroll
-        for (int u = 0; u < kOlMerged; u++) {
-            const float pr = x[u] * half_bits_to_float((uint16_t)(ent[u] >> 16));               // bucketMulQ4.metal:19: v[o.y] * o.x
-            if (olLen > olKa + (uint32_t)u && olKa + (uint32_t)u < olK1) olAcc += (double)pr;    //                      out[o.z] +=
-        }
+        for (int u = 0; u < kOlMerged; u++)                                                      // bucketMulQ4.metal:19: out[o.z] += v[o.y] * o.x
+            { const float r = ol_fma(x[u], ent[u], olAcc); olAcc = olLen > olKa + (uint32_t)u ? r : olAcc; }      // (a select, not a branch)
         olKa += (uint32_t)kOlMerged;
     };
     // (measured: raising the wave priority of this loop -- s_setprio 2 -- so that a co-resident workgroup's selection does not
@@ -844,7 +849,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
                 }
                 __syncthreads();                                                           // vfull is whole
             }
-            if (olSlot != 0xFFFFFFFFu) olsum[olSlot] = (float)olAcc;                       // merged form: the wave's first block, summed under the rows
+            if (olSlot != 0xFFFFFFFFu) olsum[olSlot] = olAcc;                       // merged form: the wave's first block, summed under the rows
             const lds_f* const vfullL = (const lds_f*)(size_t)(uint32_t)(size_t)(__attribute__((address_space(3))) void*)vfull;
             // (v from its LDS copy or from memory: two instantiations of the loop, NOT one loop reading through `vLds ? vfull : a.v`
             //  -- hipcc turns that select into a generic pointer and every gather into a FLAT load behind s_waitcnt vmcnt(0) lgkmcnt(0))
@@ -852,21 +857,22 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
                 for (uint32_t q = (uint32_t)wave + (olEarly ? (uint32_t)W : 0u); q < nB * parts; q += (uint32_t)W) {     // uniform per wave
                     const uint32_t bq = q / parts, part = q % parts;
                     const uint32_t meta = ol.meta[(size_t)(bFirst + bq) * 64u + (uint32_t)lane];
-                    const uint32_t myLen = meta >> 8, myOut = meta & 63u;                  // lane i <-> the output of rank i: counts descend with the lane
-                    const uint32_t maxLen = (uint32_t)__builtin_amdgcn_readfirstlane((int)myLen);
+                    const uint32_t lenAll = meta >> 8, myOut = meta & 63u;                 // lane i <-> the output of rank i: counts descend with the lane
+                    const uint32_t maxLen = (uint32_t)__builtin_amdgcn_readfirstlane((int)lenAll);
                     const uint32_t chunk = (maxLen + parts - 1u) / parts, k0 = min(maxLen, part * chunk), k1 = min(maxLen, k0 + chunk);
+                    const uint32_t myLen = min(lenAll, k1);                                // (this wave's steps end at k1: one test per step, `count > step`)
                     const uint32_t bBeg = __builtin_amdgcn_readfirstlane(ol.blockPtr[bFirst + bq]), bEnd = __builtin_amdgcn_readfirstlane(ol.blockPtr[bFirst + bq + 1u]);
                     // entries of the steps before k0 = sum over the outputs of min(count, k0)
-                    uint32_t cur = bBeg + wave_sum_u32(min(myLen, k0));
-                    // (the products are f32, as the reference's; their SUM is kept in f64 -- full rate on this chip -- so that it does not
-                    //  depend on how a thin share's steps were split among the waves, nor drift over an output with thousands of
-                    //  entries: round 4's fixed-point sums were exact, the tests' bar was set with them)
-                    double acc = 0.0;
+                    uint32_t cur = bBeg + wave_sum_u32(min(lenAll, k0));
+                    // (f32 sums, like the reference's float atomics; one fused multiply-add per outlier.  An f64 sum was tried for
+                    //  independence of how a thin share's steps are split among the waves: v_cvt_f64_f32 + v_add_f64 per step cost the
+                    //  phase a quarter of its time)
+                    float acc = 0.0f;
                     auto fetch = [&](uint32_t (&ent)[kOlBatch], uint32_t kk) {             // the entries of steps kk .. kk + kOlBatch - 1 asked for (clamped, branch-free)
 #pragma unroll
                         for (int u = 0; u < kOlBatch; u++) {
-                            ent[u] = ol.entry[min(cur + (uint32_t)lane, bEnd - 1u)];
-                            cur += (kk + (uint32_t)u < k1) ? (uint32_t)__popcll(__ballot(myLen > kk + (uint32_t)u)) : 0u;
+                            ent[u] = (ol.entry + cur)[lane];
+                            cur += (uint32_t)__popcll(__ballot(myLen > kk + (uint32_t)u));
                         }
                     };
                     auto add = [&](const uint32_t (&ent)[kOlBatch], uint32_t kk) {
@@ -877,10 +883,8 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
                             if constexpr (decltype(fromLds)::value) x[u] = vfullL[in]; else x[u] = a.v[in];
                         }
 #pragma unroll
-                        for (int u = 0; u < kOlBatch; u++) {
-                            const float pr = x[u] * half_bits_to_float((uint16_t)(ent[u] >> 16));      // bucketMulQ4.metal:19: v[o.y] * o.x
-                            if (myLen > kk + (uint32_t)u && kk + (uint32_t)u < k1) acc += (double)pr;   //                      out[o.z] +=
-                        }
+                        for (int u = 0; u < kOlBatch; u++)                                                  // bucketMulQ4.metal:19: out[o.z] += v[o.y] * o.x
+                            { const float r = ol_fma(x[u], ent[u], acc); acc = myLen > kk + (uint32_t)u ? r : acc; }      // (a select, not a branch)
                     };
                     if (k0 < k1 && bEnd > bBeg) {
                         uint32_t entA[kOlBatch], entB[kOlBatch];
@@ -899,7 +903,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
                             kk += (uint32_t)kOlBatch;
                         }
                     }
-                    olsum[part * olStride + bq * 64u + myOut] = (float)acc;                    // every (part, output of the share) is written exactly once
+                    olsum[part * olStride + bq * 64u + myOut] = acc;                            // every (part, output of the share) is written exactly once
                 }
             };
             if (vLds) run_blocks(std::true_type{}); else run_blocks(std::false_type{});
