@@ -60,7 +60,7 @@ IN_DIM, OUT_DIM = 4096, 11008
 N_MATS = 32
 SWEEP = [0.10, 0.15, 0.20, 0.25, 0.30, 0.40, 0.50, 0.60, 0.70, 0.80, 0.90, 1.00]
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PMC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")]   # rocprofv3 --pmc passes folded by tools/pmc_traffic.py
+PMC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")]   # rocprofv3 --pmc passes folded by tools/pmc_traffic.py
 
 
 def log(*a):

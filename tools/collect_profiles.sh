@@ -2,7 +2,7 @@
 # Regenerates everything under profiles/ on a GPU box (run from the repo root through gpurun; outputs land in gpurun_out/).
 #   gpurun --timeout 2400 -- 'ROUND=r03 bash tools/collect_profiles.sh'   then copy gpurun_out/${ROUND}_* into profiles/
 set -u
-R=${ROUND:-r04}
+R=${ROUND:-r05}
 O=gpurun_out
 mkdir -p $O
 export TMPDIR=/tmp

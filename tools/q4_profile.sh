@@ -3,7 +3,7 @@
 #   tools/build_variant_all.sh lab "-DEFFORT_LAB=1"; tools/build_variant_all.sh noscatter "-DEFFORT_LAB=1 -DEFFORT_ABLATE_NOSCATTER=1"
 #   gpurun --timeout 900 -- 'ROUND=r04 bash tools/q4_profile.sh'      then copy gpurun_out/${ROUND}_q4_* into profiles/
 set -u
-R=${ROUND:-r04}
+R=${ROUND:-r05}
 O=gpurun_out
 mkdir -p $O
 export TMPDIR=/tmp
