@@ -684,10 +684,12 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     // The waves of a workgroup do NOT run at one speed (the older wave wins the arbitration for issue slots and the memory
     // pipeline: measured, wave 0 gets through a static share of the rows 2-3x sooner than the last wave and then idles at
     // the barrier), so the list is handed out dynamically: a wave takes the next KB entries with one LDS atomic.
-    uint32_t* cursor = flags + 5;                  // (a second, short list -- the speculative selection's open rows -- has its own: flags[8])
+    uint32_t curIdx = 5u;                           // the list's cursor: flags[5] (a second, short list -- the speculative selection's open rows -- has flags[8]).
+                                                    // An INDEX, not a pointer: a pointer chosen at run time loses its address space, and the atomic below
+                                                    // becomes a FLAT one, which drains the wave's row loads at every batch (measured: lone call 19.4 -> 24.1 us)
     auto grab = [&]() -> uint32_t {
         uint32_t bq = 0;
-        if (lane == 0) bq = atomicAdd(cursor, (uint32_t)KB);
+        if (lane == 0) bq = atomicAdd(&flags[curIdx], (uint32_t)KB);
         return __builtin_amdgcn_readfirstlane(bq);
     };
 
@@ -883,7 +885,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
         if (trip == 0 || redo) {
             select(spec && !redo, (spec && !redo) ? specLo : cutoff, (spec && !redo) ? specHi : cutoff);
             n = flags[4];
-            nU = (GA_ABLATE(ga) & 4u) ? 0u : __builtin_amdgcn_readfirstlane(n); cursor = flags + 5;
+            nU = (GA_ABLATE(ga) & 4u) ? 0u : __builtin_amdgcn_readfirstlane(n); curIdx = 5u;
             if (stamp) GA_TSTAMP(ga)[19] = wall_clock64();
             if (wstamp) ph[3] = wall_clock64();
         } else {
@@ -916,7 +918,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
             __syncthreads();
             const uint32_t n2 = flags[7];
             n += n2;
-            nU = __builtin_amdgcn_readfirstlane(n2); cursor = flags + 8;
+            nU = __builtin_amdgcn_readfirstlane(n2); curIdx = 8u;
         }
         if constexpr (kSpec) {
             // wave 0: the bisection, now -- under the other waves' streaming; then it streams with them

@@ -1102,3 +1102,47 @@ def test_hip_q4_converter(ea, q4_case, q4_11008):
             assert out["bucket.stats"].cpu().numpy().tobytes() == L["bucket.stats"].tobytes(), (inDim, outDim)
             assert out["outliers"].cpu().numpy().tobytes() == L["outliers"].tobytes(), (inDim, outDim)
             assert out["probes"].cpu().numpy().view(np.uint16).tobytes() == L["probes"].view(np.uint16).tobytes()
+
+
+@pytest.mark.parametrize("kind", ["gauss", "heavy", "zeros", "few", "tiny", "ties"])
+def test_speculative_selection_exits_and_open_rows(ea, oracle_cpu, kind):
+    """Plain-grid launches select their rows BEFORE the cutoff is known -- with the bracket the cutoff's order statistics give --
+    stream the certain rows while one wave bisects, then decide the rows left open with the exact cutoff (bucket_mul.hip,
+    "SPECULATIVE SELECTION").  Inputs that leave the reference's loop through every exit: the count exits (gauss, heavy: inside the
+    bracket), bounds closer than 1e-5 / the fixed point (tiny values: the loop ends OUTSIDE the bracket and the item is redone),
+    zeros (a table that starts at the smallest nonzero value), few distinct values and exact ties at the threshold (many rows with
+    the cutoff's own score: open rows by the hundred).  Row selection must be EXACT (dispatch.size, cutoff bits) and the product
+    within the bar, for a lone call and as a group of three on one input; Q4 too."""
+    inDim, outDim = 4096, 4096
+    rng = np.random.default_rng(abs(hash(kind)) % 1000)
+    W = make_w(outDim, inDim, seed=55)
+    v = rng.standard_normal(inDim).astype(np.float32)
+    if kind == "heavy":
+        v = (v * np.exp(2.0 * rng.standard_normal(inDim))).astype(np.float32)
+    elif kind == "zeros":
+        v[rng.integers(0, inDim, 1500)] = 0
+    elif kind == "few":
+        v = rng.choice(np.array([0.5, 1.0, 2.0, 3.0], np.float32), inDim)
+        W[np.arange(inDim), np.arange(inDim)] = rng.choice(np.array([0.01, 0.02], np.float16), inDim)       # the probes: the diagonal (convert.metal:14-31)
+    elif kind == "tiny":
+        v = (v * 1e-9).astype(np.float32)
+    elif kind == "ties":
+        v = np.sign(v).astype(np.float32)                       # |v| = 1 everywhere: a row's score is its mean alone -- whole rank planes tie
+        W = (np.sign(W.astype(np.float32)) * np.float32(0.015625)).astype(np.float16)
+    b, s, p, oob = oracle_cpu.convert_fp16(W)
+    assert oob == 0
+    ew = gpu_weights(ea, W, b, s, p)
+    vd = devf(v)
+    g = ea.gpu()
+    outs = [torch.full((outDim,), float("nan"), device=DEV) for _ in range(3)]
+    for effort in (0.02, 0.1, 0.25, 0.5, 0.9, 1.0):
+        want, n, cutoff = oracle_cpu.bucket_mul(v, b, s, p, inDim, outDim, effort)
+        ea.bucketMul(vd, ew, None, outs[0], effort)                             # a lone call: the lean kernel
+        g.eval()
+        assert g.last_dispatch_count() == n and np.float32(g.last_cutoff()).tobytes() == np.float32(cutoff).tobytes(), (kind, effort, g.last_dispatch_count(), n)
+        assert close(outs[0].cpu().numpy(), want), (kind, effort)
+        ea.bucketMulGroup([(vd, ew, None, o, effort) for o in outs])           # three calls of one launch (another slicing)
+        g.eval()
+        for i, o in enumerate(outs):
+            assert g.last_dispatch_count(i) == n and g.last_cutoff(i) == cutoff, (kind, effort, i)
+            assert close(o.cpu().numpy(), want), (kind, effort, i)
