@@ -326,7 +326,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     const uint32_t offA = __builtin_amdgcn_readfirstlane(lp.offA);
     int* acc = reinterpret_cast<int*>(smem + offA);                          // ONE fixed-point tile shared by the W waves
     float* vblk = reinterpret_cast<float*>(smem + __builtin_amdgcn_readfirstlane((par & 1u) ? lp.offV[1] : lp.offV[0]));     // (a select, not lp.offV[par & 1]: a dynamically indexed plan lives in scratch)
-    uint32_t* flags = reinterpret_cast<uint32_t*>(smem + offC + 1280);       // [0] last arriver, [2..3] cutoff job verdict, [4] list length, [5] its cursor, [6] rows the speculative selection left open, [7] [8] length / cursor of the second list
+    uint32_t* flags = reinterpret_cast<uint32_t*>(smem + offC + 1280);       // [0] last arriver, [2..3] cutoff job verdict, [4] list length
     float* wbound = reinterpret_cast<float*>(smem + offC + 1344);            // [16] per-wave sums of |v_j| over the slice
     uint16_t* list = reinterpret_cast<uint16_t*>(smem + offL);
     const uint32_t* m32 = reinterpret_cast<const uint32_t*>(smem + offM);   // one dword per candidate slot (see stage_issue)
@@ -489,7 +489,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     }
     bound = wave_sum_f32(bound);                                  // (only the exponent of the slice's bound matters: any order)
     if (lane == 0) wbound[wave] = bound;
-    if (tid == 0) { flags[4] = 0u; flags[5] = 0u; flags[6] = 0u; flags[7] = 0u; flags[8] = 0u; }   // the lists are empty, none of them handed out
+    if (tid == 0) { flags[4] = 0u; flags[5] = 0u; }               // the list is empty, none of it handed out
     if (stamp) GA_TSTAMP(ga)[17] = wall_clock64();
     if (wstamp) ph[1] = wall_clock64();
 
@@ -514,43 +514,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
         if (fromJob) { cutoff = __uint_as_float(flags[3]); cachedCall = ci; cachedCutoff = cutoff; }
         else load_cut_inputs();
     }
-    // SPECULATIVE SELECTION (lean kernels; round 5).  The serial part of the cutoff -- one wave's bisection, ~0.8 us with seven waves
-    // idle -- comes off a plain grid's dependent chain: once the count table stands, EVERY wave reads the five order statistics
-    // T(m-2) .. T(m+2) from it, and the reference's loop, whichever count-driven exit it takes, ends with its threshold between the
-    // first float of cell min(T(m+2), T(m) - 1) and the last float of cell max(T(m-2) - 1, T(m)) (exit `count == m`: a cell in
-    // [T(m+1), T(m)); exit `|maxCount - minCount| < 3`: bounds whose counts are within two of m; adjacent cells: T(m) - 1 and T(m)).
-    // So the selection runs AT ONCE with that bracket [lo, hi]: rows whose score exceeds hi are kept for certain and listed, rows at
-    // or below lo are dropped for certain, the few in between (a fraction of a percent: the bracket is a handful of bfloat cells wide)
-    // are set aside; then wave 0 runs the bisection WHILE the others stream the certain rows (it joins them when it is done: the
-    // rows are handed out dynamically), and after the stream the open rows are decided with the exact cutoff and streamed in a
-    // second, short pass.  The other exits (bounds closer than 1e-5, the fixed point, 100 rounds: tiny or degenerate values) can end
-    // anywhere between the bounds: the result is CHECKED against the bracket, and outside it -- or with more open rows than a second
-    // list holds -- the tile is cleared and the item redone with the exact cutoff, as the sequential path does it.  Same rows, same
-    // integer sums: bit-identical either way.
-    constexpr bool kSpec = !PERSIST;
-    bool spec = false;                                               // uniform
-    float specLo = 0.0f, specHi = 0.0f;
-    CutoffState cst; CutoffCells ccells;
-    float* const s_res = reinterpret_cast<float*>(smem + offC) + 24;  // (block_find_cutoff's result word)
     if (fromJob) {
-    } else if (needCut && kSpec) {
-        cutoff_head<NT>(vj, prj, a.q, smem + offC, tbl, cst, nullptr);
-        if (cst.table) {                                             // uniform
-            ccells = cutoff_cells<NT>(cst, smem + offC, tbl);
-            const uint32_t tM = ccells.tM, tP2 = ccells.tP2, tM2 = ccells.tM2;
-            const bool cellsOK = tM - 1u < 0x7F7Fu && tP2 - 1u < 0x7F7Fu && tM2 - 1u < 0x7F7Fu;      // three real cells of finite bfloats (not 0, not "+inf")
-            const uint32_t cL = min(tP2, tM - 1u), cH = max(tM2 - 1u, tM);
-            specLo = __uint_as_float(cL << 16); specHi = __uint_as_float((cH << 16) | 0xFFFFu);
-            spec = cellsOK && cH < 0x7F7Fu;
-        }
-        if (spec) __syncthreads();                                   // every wave has read what it needs of the table: its region becomes tile and list
-        else if (cst.table) {                                        // the sequential finish: wave 0 bisects, the others wait
-            if (wave == 0) { const float c = cutoff_bisect(cst, ccells); if (lane == 0) s_res[0] = c; }
-            __syncthreads();
-            cutoff = s_res[0];
-        } else if (!cst.done) { int lps = cst.loops; cutoff = bisect_to_cell_edge(cst.newBound, cst.minBound, cst.maxBound, __uint_as_float(cst.patHi << 16), lps); }
-        else cutoff = cst.newBound;
-        cachedCall = ci; cachedCutoff = cutoff;
     } else if (needCut) {
         cutoff = block_find_cutoff<NT>(vj, prj, a.q, smem + offC, tbl, []() {}, stamp ? GA_TSTAMP(ga) + 8 : nullptr);
         cachedCall = ci; cachedCutoff = cutoff;
@@ -600,77 +564,53 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     //  uniform branch: a lone call's slices have 2048 slots -- one block of four rounds with 512 threads -- a 32-call launch's
     //  8192)
     const bool sel = !(GA_ABLATE(ga) & 8u);
+    uint32_t keepMask = 0;                                  // bit r: this thread's slot of round r is kept
+    uint32_t before[kRounds];                               // (wave-uniform) survivors of the wave's earlier rounds
+    uint32_t wtot = 0;
     const uint16_t* m16 = reinterpret_cast<const uint16_t*>(m32);
-    // select(spec, lo, hi): rows with hi < score go to the list; with `spec`, rows with lo < score <= hi are set aside at the list's
-    // far end (flags[6] counts them).  Without: lo == hi == the cutoff, the reference's test.  Ends with a barrier.
-    auto select = [&](const bool SPin, const float xlo, const float xhi) {
-        const bool SP = kSpec && SPin;                          // (uniform; constant false in the generic kernels)
-        uint32_t keepMask = 0, openMask = 0;                    // bit r: this thread's slot of round r is kept / left open
-        uint32_t before[kRounds];                               // (wave-uniform) survivors of the wave's earlier rounds
-        uint32_t wtot = 0, otot = 0;
 #pragma unroll
-        for (int blk = 0; blk < kRounds / 4; blk++) {
-            if ((uint32_t)(blk * 4 * NT) >= nSlots) {           // uniform
+    for (int blk = 0; blk < kRounds / 4; blk++) {
+        if ((uint32_t)(blk * 4 * NT) >= nSlots) {           // uniform
 #pragma unroll
-                for (int u = 0; u < 4; u++) before[blk * 4 + u] = wtot;
-                continue;
-            }
-            uint32_t mraw[4]; float vq[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const uint32_t c = min((uint32_t)((blk * 4 + u) * NT + tid), slotCap);
-                if constexpr (COMPACT && FMT == kFp16) { mraw[u] = (uint32_t)m16[c] << 16; vq[u] = 0.0f; }      // compact means: u16 per slot, kept in the high half
-                else { mraw[u] = m32[c]; vq[u] = FMT != kFp16 ? vblk[min(c >> 3, nb - 1u)] : 0.0f; }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int rr = blk * 4 + u;
-                before[rr] = wtot;
-                const uint32_t c = rr * NT + tid;
-                float score; bool valid;
-                if (FMT == kFp16) { score = (kCutoffScale * half_bits_to_float((uint16_t)(mraw[u] >> 16))) * ax; valid = ((c >> lg) < g.rowsPerIn) & sel; }
-                else { score = (kCutoffScale * __uint_as_float(mraw[u])) * fabsf(vq[u]); valid = (c < nSlots) & sel; }
-                const bool k = (xhi < score) & valid;
-                keepMask |= k ? (1u << rr) : 0u;
-                wtot += (uint32_t)__popcll(__ballot(k));
-                if (SP) {
-                    const bool o = (xlo < score) & !(xhi < score) & valid;
-                    openMask |= o ? (1u << rr) : 0u;
-                    otot += (uint32_t)__popcll(__ballot(o));
-                }
-            }
+            for (int u = 0; u < 4; u++) before[blk * 4 + u] = wtot;
+            continue;
         }
-        uint32_t wbase = 0, obase = 0;
-        if (lane == 0) wbase = atomicAdd(&flags[4], wtot);
-        wbase = __builtin_amdgcn_readfirstlane(wbase);
-        if (SP) {
-            otot = __builtin_amdgcn_readfirstlane(otot);
-            if (otot) {                                             // uniform per wave; rare
-                if (lane == 0) obase = atomicAdd(&flags[6], otot);
-                obase = __builtin_amdgcn_readfirstlane(obase);
-            }
+        uint32_t mraw[4]; float vq[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t c = min((uint32_t)((blk * 4 + u) * NT + tid), slotCap);
+            if constexpr (COMPACT && FMT == kFp16) { mraw[u] = (uint32_t)m16[c] << 16; vq[u] = 0.0f; }      // compact means: u16 per slot, kept in the high half
+            else { mraw[u] = m32[c]; vq[u] = FMT != kFp16 ? vblk[min(c >> 3, nb - 1u)] : 0.0f; }
         }
 #pragma unroll
-        for (int rr = 0; rr < kRounds; rr++) {
-            if ((uint32_t)(rr * NT) >= nSlots) break;           // uniform
+        for (int u = 0; u < 4; u++) {
+            const int rr = blk * 4 + u;
+            before[rr] = wtot;
             const uint32_t c = rr * NT + tid;
-            const uint16_t code = (uint16_t)(FMT == kFp16 ? (((c >> lg) << 12) | (c & ((1u << lg) - 1u))) : c);
-            const bool k = (keepMask >> rr) & 1u;
-            const unsigned long long m = __ballot(k);
-            const uint32_t pos = wbase + before[rr] + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            if (k) list[pos] = code;
-            if (SP) {
-                if (otot) {                                         // uniform per wave
-                    const bool o = (openMask >> rr) & 1u;
-                    const unsigned long long mo = __ballot(o);
-                    if (o) list[nSlots - 1u - (obase + __builtin_amdgcn_mbcnt_hi((uint32_t)(mo >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mo, 0u)))] = code;
-                    obase += (uint32_t)__popcll(mo);
-                }
-            }
+            bool k;
+            if (FMT == kFp16) k = (cutoff < (kCutoffScale * half_bits_to_float((uint16_t)(mraw[u] >> 16))) * ax) & ((c >> lg) < g.rowsPerIn) & sel;
+            else k = (cutoff < (kCutoffScale * __uint_as_float(mraw[u])) * fabsf(vq[u])) & (c < nSlots) & sel;
+            keepMask |= k ? (1u << rr) : 0u;
+            wtot += (uint32_t)__popcll(__ballot(k));
         }
-        __syncthreads();
-    };
-    uint32_t n = 0;                                              // rows kept (dispatch.size of the slice)
+    }
+    uint32_t wbase = 0;
+    if (lane == 0) wbase = atomicAdd(&flags[4], wtot);
+    wbase = __builtin_amdgcn_readfirstlane(wbase);
+#pragma unroll
+    for (int rr = 0; rr < kRounds; rr++) {
+        if ((uint32_t)(rr * NT) >= nSlots) break;           // uniform
+        const uint32_t c = rr * NT + tid;
+        const bool k = (keepMask >> rr) & 1u;
+        const unsigned long long m = __ballot(k);
+        const uint32_t pos = wbase + before[rr] + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if (k) list[pos] = (uint16_t)(FMT == kFp16 ? (((c >> lg) << 12) | (c & ((1u << lg) - 1u))) : c);
+    }
+    __syncthreads();
+    const uint32_t n = flags[4];
+    if (t == 0 && tid == 0) a_sliceCounts[s] = n;                  // dispatch.size = sum over slices (test hook)
+    if (stamp) GA_TSTAMP(ga)[19] = wall_clock64();
+    if (wstamp) ph[3] = wall_clock64();
 
     // ---- D. stream the kept rows, scatter-accumulate into the LDS tile ----------------
     const uint32_t col = t * (64u * E) + (uint32_t)lane * E;
@@ -680,16 +620,14 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     // lanes past the last column re-read the row's LAST piece -- the line their neighbours are fetching anyway.  (They used to
     // re-read column 0: one more 128-byte line per kept row for the ragged last tile, 68 MB of a 32-call launch's 824.)
     const uint32_t voff = (colOK ? col : (g.cols - 1u) / (uint32_t)E * (uint32_t)E) * 2u;
-    uint32_t nU = (GA_ABLATE(ga) & 4u) ? 0u : __builtin_amdgcn_readfirstlane(n);   // rows of the list being streamed: workgroup-uniform, kept in an SGPR
+    const uint32_t nU = (GA_ABLATE(ga) & 4u) ? 0u : __builtin_amdgcn_readfirstlane(n);   // n is workgroup-uniform; keep it in an SGPR
     // The waves of a workgroup do NOT run at one speed (the older wave wins the arbitration for issue slots and the memory
     // pipeline: measured, wave 0 gets through a static share of the rows 2-3x sooner than the last wave and then idles at
     // the barrier), so the list is handed out dynamically: a wave takes the next KB entries with one LDS atomic.
-    uint32_t curIdx = 5u;                           // the list's cursor: flags[5] (a second, short list -- the speculative selection's open rows -- has flags[8]).
-                                                    // An INDEX, not a pointer: a pointer chosen at run time loses its address space, and the atomic below
-                                                    // becomes a FLAT one, which drains the wave's row loads at every batch (measured: lone call 19.4 -> 24.1 us)
+    uint32_t* const cursor = flags + 5;
     auto grab = [&]() -> uint32_t {
         uint32_t bq = 0;
-        if (lane == 0) bq = atomicAdd(&flags[curIdx], (uint32_t)KB);
+        if (lane == 0) bq = atomicAdd(cursor, (uint32_t)KB);
         return __builtin_amdgcn_readfirstlane(bq);
     };
 
@@ -876,76 +814,11 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
             }
         }
     };
-    // C and D as ONE loop (select -> stream -> barrier), so that each has ONE call site -- inlined several times, hipcc stops
-    // inlining the pieces and their register arrays go to scratch.  Sequential selection: one trip.  Speculative: trip 0 selects with
-    // the bracket and streams the certain rows while wave 0 bisects; trip 1 either streams the open rows the exact cutoff keeps, or
-    // -- the loop ended outside the bracket -- redoes the item with the exact cutoff.
-    bool redo = false;
-    for (uint32_t trip = 0;; trip++) {
-        if (trip == 0 || redo) {
-            select(spec && !redo, (spec && !redo) ? specLo : cutoff, (spec && !redo) ? specHi : cutoff);
-            n = flags[4];
-            nU = (GA_ABLATE(ga) & 4u) ? 0u : __builtin_amdgcn_readfirstlane(n); curIdx = 5u;
-            if (stamp) GA_TSTAMP(ga)[19] = wall_clock64();
-            if (wstamp) ph[3] = wall_clock64();
-        } else {
-            // the open rows, decided with the exact cutoff: the reference's test on the same operands; the kept ones make a second list
-            const uint32_t nOpen = flags[6];
-            for (uint32_t i0 = 0; i0 < nOpen; i0 += (uint32_t)NT) {
-                const uint32_t i = i0 + (uint32_t)tid;
-                bool k = false; uint16_t code = 0;
-                if (i < nOpen) {
-                    code = list[nSlots - 1u - i];
-                    float score;
-                    if (FMT == kFp16) {
-                        const uint32_t rank = (uint32_t)code >> 12, jl = (uint32_t)code & 4095u, c = (rank << lg) | jl;
-                        uint32_t mr;
-                        if constexpr (COMPACT && FMT == kFp16) mr = (uint32_t)m16[c] << 16; else mr = m32[c];
-                        score = (kCutoffScale * half_bits_to_float((uint16_t)(mr >> 16))) * fabsf(vblk[jl]);
-                    } else {
-                        score = (kCutoffScale * __uint_as_float(m32[code])) * fabsf(vblk[(uint32_t)code >> 3]);
-                    }
-                    k = cutoff < score;
-                }
-                const unsigned long long m = __ballot(k);
-                uint32_t base2 = 0;
-                if (m) {                                           // uniform per wave
-                    if (lane == 0) base2 = atomicAdd(&flags[7], (uint32_t)__popcll(m));
-                    base2 = __builtin_amdgcn_readfirstlane(base2);
-                    if (k) list[base2 + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = code;
-                }
-            }
-            __syncthreads();
-            const uint32_t n2 = flags[7];
-            n += n2;
-            nU = __builtin_amdgcn_readfirstlane(n2); curIdx = 8u;
-        }
-        if constexpr (kSpec) {
-            // wave 0: the bisection, now -- under the other waves' streaming; then it streams with them
-            if (spec && trip == 0 && wave == 0) { const float c = cutoff_bisect(cst, ccells); if (lane == 0) s_res[0] = c; }
-        }
-        if constexpr (kOlMerge) { if (olEarly) stream_rows(std::true_type{}); else stream_rows(std::false_type{}); }
-        else stream_rows(std::false_type{});
-        // (measured too: everything BUT this loop at raised priority -- no effect, 173.9 vs 173.5 us per 32-call launch)
-        if (!asked) asked = prefetch();        // (a wave without rows; wave 0 always gets an answer: it is the one that pulls)
-        __syncthreads();                       // every wave's atomics have landed in the tile (and, speculating, the cutoff is published)
-        if constexpr (!kSpec) break;
-        else {
-            if (!spec || trip == 1u) break;    // (uniform)
-            cutoff = s_res[0];
-            cachedCutoff = cutoff;
-            const uint32_t nOpen = flags[6];
-            if (!(specLo <= cutoff && cutoff <= specHi) || 2u * nOpen > nSlots - n) {
-                // the loop ended outside the bracket -- bounds closer than 1e-5, the fixed point, 100 rounds -- or the open rows would
-                // not fit beside a second list: clear the tile and redo the item with the exact cutoff
-                for (int i = tid; i < TILE_L; i += NT) acc[i] = 0;
-                if (tid == 0) { flags[4] = 0u; flags[5] = 0u; }
-                __syncthreads();
-                redo = true;
-            } else if (nOpen == 0u) break;
-        }
-    }
-    if (t == 0 && tid == 0) a_sliceCounts[s] = n;                  // dispatch.size = sum over slices (test hook)
+    if constexpr (kOlMerge) { if (olEarly) stream_rows(std::true_type{}); else stream_rows(std::false_type{}); }
+    else stream_rows(std::false_type{});
+    // (measured too: everything BUT this loop at raised priority -- no effect, 173.9 vs 173.5 us per 32-call launch)
+    if (!asked) asked = prefetch();            // (a wave without rows; wave 0 always gets an answer: it is the one that pulls)
+    __syncthreads();                           // every wave's atomics have landed in the tile
     if (stamp) GA_TSTAMP(ga)[20] = wall_clock64();
     if (wstamp) ph[4] = wall_clock64();
 

@@ -56,24 +56,10 @@ __device__ __forceinline__ float bisect_to_cell_edge(float newBound, float minBo
     return newBound;
 }
 
-// What the head of the evaluation leaves behind, uniform in the workgroup: the bracket and counters of the reference's loop after
-// the (rare) ballot rounds, and whether the suffix table over the cells [base, ...] stands in `tbl` (with the count of values at
-// or above its first cell in the scratch).  done: the loop has exited already (newBound is the result).
-struct CutoffState {
-    float minBound, maxBound, newBound;
-    int loops, minCount, maxCount;
-    uint32_t patLo, patHi, base, effort;
-    bool done, table;
-};
-constexpr uint32_t kCutNoLo = 0xFFFF0000u, kCutNoHi = 0xFFF00000u;      // "bound never set": its count is the reference's initial value
-// The five order statistics the lookup-free rounds compare cells with: T(k) = the first cell whose count is below k, k = m-2 .. m+2.
-struct CutoffCells { uint32_t tM2, tM1, tM, tP1, tP2; };
-
-// ---- the head: values, min / max, ballot rounds while the value range exceeds the table, the suffix table.  Contains barriers:
-//      call from uniform control flow.  On return the table (st.table) is complete and visible to every wave.
-template <int NT>
-__device__ __forceinline__ void cutoff_head(const float (&vj)[4096 / NT], const uint16_t (&prj)[4096 / NT], uint32_t q, char* lds, uint32_t* tbl,
-                                            CutoffState& st, unsigned long long* dbg = nullptr) {
+template <int NT, typename Idle>
+__device__ __forceinline__ float block_find_cutoff(const float (&vj)[4096 / NT], const uint16_t (&prj)[4096 / NT],
+                                                   uint32_t q, char* lds, uint32_t* tbl, Idle idle,
+                                                   unsigned long long* dbg = nullptr) {
     static_assert(4096 % NT == 0 && NT % 64 == 0 && NT <= 1024, "block_find_cutoff: bad workgroup size");
     constexpr int VPT = 4096 / NT;                      // probe products per thread
     constexpr int NW = NT / 64;
@@ -136,7 +122,7 @@ __device__ __forceinline__ void cutoff_head(const float (&vj)[4096 / NT], const 
     float newBound = (minBound + maxBound) / 2;          // :195
     const uint32_t effort = 4096u - q;                   // :154
     int loops = 0, minCount = 4096, maxCount = 0;        // :175-176,198
-    constexpr uint32_t kNoLo = kCutNoLo, kNoHi = kCutNoHi;
+    constexpr uint32_t kNoLo = 0xFFFF0000u, kNoHi = 0xFFF00000u;
     uint32_t patLo = kNoLo, patHi = kNoHi;               // bf16 cells of the bounds whose counts are known
     int nPasses = 0;
     bool done = false;
@@ -171,7 +157,7 @@ __device__ __forceinline__ void cutoff_head(const float (&vj)[4096 / NT], const 
         done = round(s_cnt[slot]);
     }
     if (dbg && tid == 0) dbg[1] = wall_clock64();
-    st.table = false; st.base = 0u;
+
     if (!done && patHi != patLo + 1u) {                  // uniform
         // ---- table over the cells [base, top]: suffix[i] = #{values with pattern > base + i} ---------------
         const uint32_t base = lowCell(), top = topCell();
@@ -200,176 +186,130 @@ __device__ __forceinline__ void cutoff_head(const float (&vj)[4096 / NT], const 
         __syncthreads();
         if (dbg && tid == 0) dbg[2] = wall_clock64();
 
-        st.table = true; st.base = base;
-    }
-    st.minBound = minBound; st.maxBound = maxBound; st.newBound = newBound; st.loops = loops; st.minCount = minCount; st.maxCount = maxCount;
-    st.patLo = patLo; st.patHi = patHi; st.effort = effort; st.done = done;
-    (void)s_res; (void)wave;
-}
-
-// ---- T(m-2) .. T(m+2) from the table (st.table): a FULL wave, two LDS latencies, no barrier.  Any wave may run it.
-template <int NT>
-__device__ __forceinline__ CutoffCells cutoff_cells(const CutoffState& st, const char* lds, const uint32_t* tbl) {
-    constexpr uint32_t BPT = kCutoffBinsPerThread, CAP = (uint32_t)NT * BPT;
-    const uint32_t* s_all = reinterpret_cast<const uint32_t*>(lds) + 25;
-    const int lane = (int)(threadIdx.x & 63u);
-    const uint32_t base = st.base, effort = st.effort;
-    const uint32_t allGE = s_all[0];
-    // THE BISECTION WITHOUT ITS LOOKUPS.  A count enters a round of the reference's loop in three places: the comparison
-    // `countAbove < effort` that steers the bounds, and the exit tests `countAbove == effort` and |maxCount - minCount| < 3.
-    // Counts are monotone in the threshold's bf16 cell, so each of them is a comparison of CELLS with a few order
-    // statistics of the values: with T(k) = the first cell whose count is below k (count(p) >= k  <=>  p < T(k)) and
-    // m = effort,
-    //     countAbove <  m                 <=>  p >= T(m)
-    //     countAbove == m                 <=>  T(m+1) <= p < T(m)
-    //     |maxCount - minCount| < 3       <=>  (count(hi) >= m-1 and count(lo) <= m+1) or (count(hi) >= m-2 and count(lo) <= m)
-    // (count(hi) < m <= count(lo) always; bounds never set yet count 0 / 4096, the reference's initial values).  The five
-    // cells T(m-2) .. T(m+2) are found ONCE, with two 64-lane probes of the table each (issued together); the rounds
-    // then run with no LDS round trip inside -- it was ~330 cycles a round with the lookup on the dependent chain, 1.4 us
-    // for 9 rounds and 2.7 for 29 -- as a chain of ~25 VALU instructions.  Same float operations in the same order, the
-    // same exits in the same round: bit-identical (tests/test_cutoff_trajectory_model.py restates this on the CPU).
-    // T(k) for the five k at once: ONE probe of the segment ends serves all five first levels, the five second-level
-    // probes are issued together, and the special cases are selects on the results -- no branch, two LDS latencies in all.
-    constexpr uint32_t kSeg = CAP / 64u, kSub = (kSeg + 63u) / 64u;     // cells per lane of the first probe; second-level probes per lane
-    const uint32_t c1 = tbl[(uint32_t)lane * kSeg + kSeg - 1u];         // the last cell of each segment (cells past `top` hold `above`)
-    const int m = (int)effort;
-    uint32_t seg[5], c2[5][kSub], tk[5];
-#pragma unroll
-    for (int j = 0; j < 5; j++) {
-        const int k = m - 2 + j;
-        seg[j] = (uint32_t)__popcll(__ballot((int)c1 >= k));            // (counts <= 4096: the signed compare also serves k <= 0)
-#pragma unroll
-        for (uint32_t u = 0; u < kSub; u++) c2[j][u] = tbl[min(seg[j], 63u) * kSeg + min(u * 64u + (uint32_t)lane, kSeg - 1u)];
-    }
-#pragma unroll
-    for (int j = 0; j < 5; j++) {
-        const int k = m - 2 + j;
-        uint32_t n = seg[j] * kSeg;
-#pragma unroll
-        for (uint32_t u = 0; u < kSub; u++) n += (uint32_t)__popcll(__ballot(u * 64u + (uint32_t)lane < kSeg && (int)c2[j][u] >= k));
-        // every count is >= k (k <= 0, or the whole table and -- its last cell holds `above` -- everything beyond it): +inf;
-        // none is (k > 4096, or more than the values at or above the table's first cell): 0
-        tk[j] = (k <= 0 || seg[j] >= 64u) ? 0xFFFFFFFFu : ((k > 4096 || (int)allGE < k) ? 0u : base + n);
-    }
-    CutoffCells c; c.tM2 = tk[0]; c.tM1 = tk[1]; c.tM = tk[2]; c.tP1 = tk[3]; c.tP2 = tk[4];
-    return c;
-}
-
-// ---- the rounds and the tail, from the head's state and the five cells: ONE full wave, no barrier, no memory; every lane returns
-//      the value findCutoff32 writes.
-__device__ __forceinline__ float cutoff_bisect(const CutoffState& st, const CutoffCells& cells, int* loopsOut = nullptr) {
-    constexpr uint32_t kNoLo = kCutNoLo, kNoHi = kCutNoHi;
-    const int lane = (int)(threadIdx.x & 63u);
-    float newBound = st.newBound, minBound = st.minBound, maxBound = st.maxBound;
-    int loops = st.loops;
-    const int minCount = st.minCount, maxCount = st.maxCount, m = (int)st.effort;
-    uint32_t patLo = st.patLo, patHi = st.patHi;
-    bool done = st.done;
-    uint32_t tM2 = cells.tM2, tM1 = cells.tM1, tM = cells.tM, tP1 = cells.tP1, tP2 = cells.tP2;
-    float nb = newBound, lo = minBound, hi = maxBound;
-    uint32_t pLo = patLo, pHi = patHi, nLoops = (uint32_t)loops;
-    // the third test needs count(hi) only as "how many of m-1, m-2 it reaches" and count(lo) as "how many of m+1, m+2":
-    //   |maxCount - minCount| < 3  <=>  catHi > catLo.   Bounds never set yet count 0 / 4096 (the reference's initial values).
-    uint32_t catHi = patHi != kNoHi ? (uint32_t)(patHi < tM1) + (uint32_t)(patHi < tM2) : (uint32_t)(maxCount >= m - 1) + (uint32_t)(maxCount >= m - 2);
-    uint32_t catLo = patLo != kNoLo ? (uint32_t)(patLo < tP1) + (uint32_t)(patLo < tP2) : (uint32_t)(minCount >= m + 1) + (uint32_t)(minCount >= m + 2);
-    // THE ROUNDS, kBlk AT A TIME, THEIR EXIT TESTS IN PARALLEL (round 5).  What makes a round depend on the one before it is
-    // the bounds alone: newBound = (hi + lo) / 2, and which bound it replaces -- `countAbove < effort`, i.e. the midpoint's
-    // bits against the first float of cell T(m) (non-negative floats order like their bit patterns).  That recurrence is six
-    // VALU instructions.  Everything else a round does -- the three count-driven exit tests, the 1e-5 test, the 100-round
-    // cap, the fixed point, the hand-over to the closed-form tail at adjacent cells -- only decides WHERE the loop stops, and
-    // rounds run past that point have no side effect.  So a block of kBlk rounds runs the bare recurrence, identical in every
-    // lane, round r leaving the midpoint it tested in lane r; then lane r reconstructs round r on its own -- the bounds
-    // after the round are the latest midpoints at or before r that went each way (two bpermutes), their cells and count
-    // categories follow -- and evaluates the reference's exits for it; the first lane that stops (a ballot) hands its state
-    // to the wave.  Same float operations on the same operands, the same exit taken in the same round: bit-identical
-    // (tests/test_cutoff_trajectory_model.py restates the block form on the CPU against the count-by-count loop).  It was a
-    // chain of ~38 instructions and a branch per round (~260 cycles: 1.0 us for 9 rounds, 3.2 for 29); a block of 16 rounds
-    // is ~100 + ~70 instructions.
-    constexpr int kBlk = 16;
-    const uint32_t tMs0 = tM >= 0x10000u ? 0xFFFFFFFFu : (tM << 16);        // (T(m) is a cell, 0, or +inf)
-    bool fin = done;
-    if (!fin && pHi != pLo + 1u) {
-        for (;;) {
-            float a = nb, l = lo, h = hi, rec = 0.0f;
-            uint32_t tMs = tMs0;
-            asm volatile("" : "+v"(a), "+v"(l), "+v"(h), "+v"(tMs));          // VGPRs: left uniform, hipcc splits every round between SALU and VALU
-#pragma unroll
-            for (int r = 0; r < kBlk; r++) {
-                rec = lane == r ? a : rec;                                    // the midpoint round r tests
-                const bool below = __float_as_uint(a) >= tMs;                 // countAbove < effort
-                h = below ? a : h;                                            // :214-220
-                l = below ? l : a;
-                a = (h + l) / 2;                                              // :222
-            }
-            // lane r < kBlk: round r of the block
-            const uint32_t lr = (uint32_t)lane & (uint32_t)(kBlk - 1);
-            const uint32_t p = __float_as_uint(rec) >> 16;
-            const bool wentHi = __float_as_uint(rec) >= tMs;                  // this round's midpoint became the upper bound
-            const uint32_t kmask = (1u << kBlk) - 1u;
-            const uint32_t hb = (uint32_t)__ballot(wentHi) & kmask, lb = ~hb & kmask;      // (uniform) which rounds went which way
-            const uint32_t upto = (2u << lr) - 1u;
-            const uint32_t hSeen = hb & upto, lSeen = lb & upto;
-            const float hFrom = __shfl(rec, hSeen ? 31 - __clz(hSeen) : 0), lFrom = __shfl(rec, lSeen ? 31 - __clz(lSeen) : 0);
-            const float hr = hSeen ? hFrom : hi, lor = lSeen ? lFrom : lo;   // the bounds AFTER round r
-            const uint32_t pHr = hSeen ? __float_as_uint(hr) >> 16 : pHi, pLr = lSeen ? __float_as_uint(lor) >> 16 : pLo;
-            const uint32_t cHr = hSeen ? (uint32_t)(pHr < tM1) + (uint32_t)(pHr < tM2) : catHi;
-            const uint32_t cLr = lSeen ? (uint32_t)(pLr < tP1) + (uint32_t)(pLr < tP2) : catLo;
-            const float nbr = (hr + lor) / 2;                                 // :222
-            // :227-229 (countAbove == effort | the bounds | the counts), :236, and the fixed point
-            const bool finr = ((p >= tP1) & (p < tM)) | (hr - lor < 0.00001f) | (cHr > cLr) | (nLoops + lr + 1u > 100u) | (nbr == rec);
-            const bool stopr = finr | (pHr == pLr + 1u);                      // ... or the bounds sit in adjacent cells: the closed-form tail
-            const uint32_t sm = (uint32_t)__ballot(stopr) & kmask;
-            const int e = sm ? __builtin_ctz(sm) : kBlk - 1;                  // (uniform) the round the loop stops in, or the block's last
-            nb = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(nbr), e));
-            lo = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(lor), e));
-            hi = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(hr), e));
-            pLo = __builtin_amdgcn_readlane(pLr, e); pHi = __builtin_amdgcn_readlane(pHr, e);
-            catLo = __builtin_amdgcn_readlane(cLr, e); catHi = __builtin_amdgcn_readlane(cHr, e);
-            nLoops += (uint32_t)e + 1u;
-            if (sm) { fin = (__builtin_amdgcn_readlane((uint32_t)finr, e) & 1u) != 0u; break; }
-        }
-    }
-    done = fin;
-    newBound = nb; minBound = lo; maxBound = hi; patLo = pLo; patHi = pHi; loops = (int)nLoops;
-    if (!done) {
-        // tail: bounds in adjacent cells with known counts (below the target at and above X, not below it
-        // under X); those counts differ by >= 3 and neither equals the target, or the loop had exited.
-        newBound = bisect_to_cell_edge(newBound, minBound, maxBound, __uint_as_float(patHi << 16), loops);
-    }
-    if (loopsOut) *loopsOut = loops;
-    return newBound;
-}
-
-// ---- the whole evaluation: head, then wave 0 runs cells + rounds while the others wait (`idle`), result through LDS.
-template <int NT, typename Idle>
-__device__ __forceinline__ float block_find_cutoff(const float (&vj)[4096 / NT], const uint16_t (&prj)[4096 / NT],
-                                                   uint32_t q, char* lds, uint32_t* tbl, Idle idle,
-                                                   unsigned long long* dbg = nullptr) {
-    float* s_res = reinterpret_cast<float*>(lds) + 24;             // [0] result
-    CutoffState st;
-    cutoff_head<NT>(vj, prj, q, lds, tbl, st, dbg);
-    const int tid = (int)threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float newBound = st.newBound;
-    int loops = st.loops;
-    if (st.table) {                                      // uniform
         if (wave == 0) {
-            const CutoffCells cells = cutoff_cells<NT>(st, lds, tbl);
-            newBound = cutoff_bisect(st, cells, &loops);
-            if ((tid & 63) == 0) s_res[0] = newBound;
+            // ---- the bisection proper, one wave, one LDS lookup per round ------------------------------------
+            const uint32_t allGE = s_all[0];
+            // THE BISECTION WITHOUT ITS LOOKUPS.  A count enters a round of the reference's loop in three places: the comparison
+            // `countAbove < effort` that steers the bounds, and the exit tests `countAbove == effort` and |maxCount - minCount| < 3.
+            // Counts are monotone in the threshold's bf16 cell, so each of them is a comparison of CELLS with a few order
+            // statistics of the values: with T(k) = the first cell whose count is below k (count(p) >= k  <=>  p < T(k)) and
+            // m = effort,
+            //     countAbove <  m                 <=>  p >= T(m)
+            //     countAbove == m                 <=>  T(m+1) <= p < T(m)
+            //     |maxCount - minCount| < 3       <=>  (count(hi) >= m-1 and count(lo) <= m+1) or (count(hi) >= m-2 and count(lo) <= m)
+            // (count(hi) < m <= count(lo) always; bounds never set yet count 0 / 4096, the reference's initial values).  The five
+            // cells T(m-2) .. T(m+2) are found ONCE, with two 64-lane probes of the table each (issued together); the rounds
+            // then run with no LDS round trip inside -- it was ~330 cycles a round with the lookup on the dependent chain, 1.4 us
+            // for 9 rounds and 2.7 for 29 -- as a chain of ~25 VALU instructions.  Same float operations in the same order, the
+            // same exits in the same round: bit-identical (tests/test_cutoff_trajectory_model.py restates this on the CPU).
+            // T(k) for the five k at once: ONE probe of the segment ends serves all five first levels, the five second-level
+            // probes are issued together, and the special cases are selects on the results -- no branch, two LDS latencies in all.
+            constexpr uint32_t kSeg = CAP / 64u, kSub = (kSeg + 63u) / 64u;     // cells per lane of the first probe; second-level probes per lane
+            const uint32_t c1 = tbl[(uint32_t)lane * kSeg + kSeg - 1u];         // the last cell of each segment (cells past `top` hold `above`)
+            const int m = (int)effort;
+            uint32_t seg[5], c2[5][kSub], tk[5];
+#pragma unroll
+            for (int j = 0; j < 5; j++) {
+                const int k = m - 2 + j;
+                seg[j] = (uint32_t)__popcll(__ballot((int)c1 >= k));            // (counts <= 4096: the signed compare also serves k <= 0)
+#pragma unroll
+                for (uint32_t u = 0; u < kSub; u++) c2[j][u] = tbl[min(seg[j], 63u) * kSeg + min(u * 64u + (uint32_t)lane, kSeg - 1u)];
+            }
+#pragma unroll
+            for (int j = 0; j < 5; j++) {
+                const int k = m - 2 + j;
+                uint32_t n = seg[j] * kSeg;
+#pragma unroll
+                for (uint32_t u = 0; u < kSub; u++) n += (uint32_t)__popcll(__ballot(u * 64u + (uint32_t)lane < kSeg && (int)c2[j][u] >= k));
+                // every count is >= k (k <= 0, or the whole table and -- its last cell holds `above` -- everything beyond it): +inf;
+                // none is (k > 4096, or more than the values at or above the table's first cell): 0
+                tk[j] = (k <= 0 || seg[j] >= 64u) ? 0xFFFFFFFFu : ((k > 4096 || (int)allGE < k) ? 0u : base + n);
+            }
+            uint32_t tM2 = tk[0], tM1 = tk[1], tM = tk[2], tP1 = tk[3], tP2 = tk[4];
+            float nb = newBound, lo = minBound, hi = maxBound;
+            uint32_t pLo = patLo, pHi = patHi, nLoops = (uint32_t)loops;
+            // the third test needs count(hi) only as "how many of m-1, m-2 it reaches" and count(lo) as "how many of m+1, m+2":
+            //   |maxCount - minCount| < 3  <=>  catHi > catLo.   Bounds never set yet count 0 / 4096 (the reference's initial values).
+            uint32_t catHi = patHi != kNoHi ? (uint32_t)(patHi < tM1) + (uint32_t)(patHi < tM2) : (uint32_t)(maxCount >= m - 1) + (uint32_t)(maxCount >= m - 2);
+            uint32_t catLo = patLo != kNoLo ? (uint32_t)(patLo < tP1) + (uint32_t)(patLo < tP2) : (uint32_t)(minCount >= m + 1) + (uint32_t)(minCount >= m + 2);
+            // THE ROUNDS, kBlk AT A TIME, THEIR EXIT TESTS IN PARALLEL (round 5).  What makes a round depend on the one before it is
+            // the bounds alone: newBound = (hi + lo) / 2, and which bound it replaces -- `countAbove < effort`, i.e. the midpoint's
+            // bits against the first float of cell T(m) (non-negative floats order like their bit patterns).  That recurrence is six
+            // VALU instructions.  Everything else a round does -- the three count-driven exit tests, the 1e-5 test, the 100-round
+            // cap, the fixed point, the hand-over to the closed-form tail at adjacent cells -- only decides WHERE the loop stops, and
+            // rounds run past that point have no side effect.  So a block of kBlk rounds runs the bare recurrence, identical in every
+            // lane, round r leaving the midpoint it tested in lane r; then lane r reconstructs round r on its own -- the bounds
+            // after the round are the latest midpoints at or before r that went each way (two bpermutes), their cells and count
+            // categories follow -- and evaluates the reference's exits for it; the first lane that stops (a ballot) hands its state
+            // to the wave.  Same float operations on the same operands, the same exit taken in the same round: bit-identical
+            // (tests/test_cutoff_trajectory_model.py restates the block form on the CPU against the count-by-count loop).  It was a
+            // chain of ~38 instructions and a branch per round (~260 cycles: 1.0 us for 9 rounds, 3.2 for 29); a block of 16 rounds
+            // is ~100 + ~70 instructions.
+            constexpr int kBlk = 16;
+            const uint32_t tMs0 = tM >= 0x10000u ? 0xFFFFFFFFu : (tM << 16);        // (T(m) is a cell, 0, or +inf)
+            bool fin = done;
+            if (!fin && pHi != pLo + 1u) {
+                for (;;) {
+                    float a = nb, l = lo, h = hi, rec = 0.0f;
+                    uint32_t tMs = tMs0;
+                    asm volatile("" : "+v"(a), "+v"(l), "+v"(h), "+v"(tMs));          // VGPRs: left uniform, hipcc splits every round between SALU and VALU
+#pragma unroll
+                    for (int r = 0; r < kBlk; r++) {
+                        rec = lane == r ? a : rec;                                    // the midpoint round r tests
+                        const bool below = __float_as_uint(a) >= tMs;                 // countAbove < effort
+                        h = below ? a : h;                                            // :214-220
+                        l = below ? l : a;
+                        a = (h + l) / 2;                                              // :222
+                    }
+                    // lane r < kBlk: round r of the block
+                    const uint32_t lr = (uint32_t)lane & (uint32_t)(kBlk - 1);
+                    const uint32_t p = __float_as_uint(rec) >> 16;
+                    const bool wentHi = __float_as_uint(rec) >= tMs;                  // this round's midpoint became the upper bound
+                    const uint32_t kmask = (1u << kBlk) - 1u;
+                    const uint32_t hb = (uint32_t)__ballot(wentHi) & kmask, lb = ~hb & kmask;      // (uniform) which rounds went which way
+                    const uint32_t upto = (2u << lr) - 1u;
+                    const uint32_t hSeen = hb & upto, lSeen = lb & upto;
+                    const float hFrom = __shfl(rec, hSeen ? 31 - __clz(hSeen) : 0), lFrom = __shfl(rec, lSeen ? 31 - __clz(lSeen) : 0);
+                    const float hr = hSeen ? hFrom : hi, lor = lSeen ? lFrom : lo;   // the bounds AFTER round r
+                    const uint32_t pHr = hSeen ? __float_as_uint(hr) >> 16 : pHi, pLr = lSeen ? __float_as_uint(lor) >> 16 : pLo;
+                    const uint32_t cHr = hSeen ? (uint32_t)(pHr < tM1) + (uint32_t)(pHr < tM2) : catHi;
+                    const uint32_t cLr = lSeen ? (uint32_t)(pLr < tP1) + (uint32_t)(pLr < tP2) : catLo;
+                    const float nbr = (hr + lor) / 2;                                 // :222
+                    // :227-229 (countAbove == effort | the bounds | the counts), :236, and the fixed point
+                    const bool finr = ((p >= tP1) & (p < tM)) | (hr - lor < 0.00001f) | (cHr > cLr) | (nLoops + lr + 1u > 100u) | (nbr == rec);
+                    const bool stopr = finr | (pHr == pLr + 1u);                      // ... or the bounds sit in adjacent cells: the closed-form tail
+                    const uint32_t sm = (uint32_t)__ballot(stopr) & kmask;
+                    const int e = sm ? __builtin_ctz(sm) : kBlk - 1;                  // (uniform) the round the loop stops in, or the block's last
+                    nb = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(nbr), e));
+                    lo = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(lor), e));
+                    hi = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(hr), e));
+                    pLo = __builtin_amdgcn_readlane(pLr, e); pHi = __builtin_amdgcn_readlane(pHr, e);
+                    catLo = __builtin_amdgcn_readlane(cLr, e); catHi = __builtin_amdgcn_readlane(cHr, e);
+                    nLoops += (uint32_t)e + 1u;
+                    if (sm) { fin = (__builtin_amdgcn_readlane((uint32_t)finr, e) & 1u) != 0u; break; }
+                }
+            }
+            done = fin;
+            newBound = nb; minBound = lo; maxBound = hi; patLo = pLo; patHi = pHi; loops = (int)nLoops;
+            if (!done) {
+                // tail: bounds in adjacent cells with known counts (below the target at and above X, not below it
+                // under X); those counts differ by >= 3 and neither equals the target, or the loop had exited.
+                newBound = bisect_to_cell_edge(newBound, minBound, maxBound, __uint_as_float(patHi << 16), loops);
+            }
+            if (lane == 0) s_res[0] = newBound;
         } else {
             idle();
         }
         __syncthreads();
         newBound = s_res[0];
-    } else if (!st.done) {
+    } else if (!done) {
         // adjacent cells already (possible only after ballot passes): tail needs no table
-        newBound = bisect_to_cell_edge(st.newBound, st.minBound, st.maxBound, __uint_as_float(st.patHi << 16), loops);
+        newBound = bisect_to_cell_edge(newBound, minBound, maxBound, __uint_as_float(patHi << 16), loops);
         idle();
     } else {
         idle();
     }
-    if (dbg && tid == 0) { dbg[3] = wall_clock64(); dbg[4] = dbg[3]; dbg[5] = (unsigned long long)loops * 1000ull; dbg[7] = clock64(); }
+    if (dbg && tid == 0) { dbg[3] = wall_clock64(); dbg[4] = dbg[3]; dbg[5] = (unsigned long long)loops * 1000ull + nPasses; dbg[7] = clock64(); }
     return newBound;
 }
 
