@@ -89,7 +89,7 @@ def _lds_atomic_peak():
     try:
         for line in open(os.path.join(ROOT, "profiles", "r04_q4_microbench_scatter.txt")):
             if "ds_add_u32" in line:
-                return float(line.split("elem/ns/CU")[0].split()[-1]) * 256, "profiles/r04_q4_microbench_scatter.txt (tools/microbench.hip on an MI355X)"
+                return float(line.split("elem/ns/CU")[0].split()[-1]) * 256, "profiles/r04_q4_microbench_scatter.txt (tools/lab/microbench.hip on an MI355X)"
     except Exception:                                        # noqa: BLE001
         pass
     return 13 * 2.4 * 256, "13 ds_add_u32 per clock and CU (DESIGN 4.1) x 2.4 GHz x 256 CUs"
@@ -1094,7 +1094,7 @@ def main():
                     r["achieved_GBps_4B_outliers"] = round((ab - 12 * nol) / tx / 1e9, 1)
                     r["frac_of_hbm_peak_4B_outliers"] = round((ab - 12 * nol) / tx / 1e9 / HBM_PEAK_GBPS, 4)
                     # what bounds the Q4 multiply is its LDS scatter, not memory: four integer LDS atomics per 16-bit word of a kept row
-                    # (one per nibble), against the measured ds_add_u32 rate of the chip (tools/microbench.hip:
+                    # (one per nibble), against the measured ds_add_u32 rate of the chip (tools/lab/microbench.hip:
                     # elements per ns and CU, profiles/r04_q4_microbench_scatter.txt; 13 per clock and CU at 2.4 GHz when that file is absent)
                     atomics = Dx * (outDim_x // 32) * 4          # (the outlier phase has none since round 5: a lane sums its output in a register)
                     r["roofline_lds_atomic"] = {"bound": "lds_atomic", "atomics_per_call": atomics, "achieved_Gatomics_per_s": round(atomics / tx / 1e9, 1),

@@ -166,7 +166,7 @@ static bool lane_alloc(effort_ctx* c, Lane& L) {
 }
 // The lanes' streams and events are POOLED per process and never destroyed: a stream or event that took part in a hipGraph
 // capture and is destroyed while other captured graphs are alive crashes a later hipGraphLaunch inside the runtime (ROCm 7.2:
-// segfault in hipGraphLaunch after a multi-lane context was destroyed; tools/lane_crash.py reproduces it).  A context returns
+// segfault in hipGraphLaunch after a multi-lane context was destroyed; tools/lab/lane_crash.py reproduces it).  A context returns
 // them to the pool; the next one takes them from there.
 // The pools are keyed by DEVICE: a stream or event belongs to the device that was current when it was created, and a context
 // of another device must never be handed one (its launches would go to the wrong GPU).  The caller has made `device` current.
@@ -564,7 +564,7 @@ static bool supported(int W, int E) {
 }
 
 // Row slices per call when the launch carries `groupSize` calls and a lane owns E columns.  Measured on MI355X
-// (tools/tune.py, 4096x4096 .. 14336x4096, 10-100 % effort): a workgroup's life is mostly fixed-latency steps (staging,
+// (tools/lab/tune.py, 4096x4096 .. 14336x4096, 10-100 % effort): a workgroup's life is mostly fixed-latency steps (staging,
 // cutoff, selection, hand-off), so FEWER, fatter items win even when they leave CUs idle -- about 3/4 of an item per CU
 // for small groups, with slices between 128 and 512 input rows; from 8 calls on, the fattest slices (512 rows).
 static uint32_t pick_slices(const effort_ctx* c, const effort_w* w, int groupSize, int E, uint32_t groupTiles = 0) {

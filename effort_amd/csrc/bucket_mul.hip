@@ -28,7 +28,7 @@
 //      address VALU).  Each product is added into ONE LDS accumulator tile acc[slot][j][lane] shared by the
 //      workgroup (slot = the 4 position bits of the f16 weight; Q4: sub-bucket*8 + the 3 position bits of the
 //      nibble) with an INTEGER LDS atomic: products are converted to fixed point on a per-workgroup power-of-two
-//      grid.  Measured on MI355X (tools/microbench.hip, elements/clk/CU): ds_add_f32 0.5, read-add-write on
+//      grid.  Measured on MI355X (tools/lab/microbench.hip, elements/clk/CU): ds_add_f32 0.5, read-add-write on
 //      private per-wave tiles 6.8, 16-way register select 2.1, ds_add_u32 13.  Integer addition is associative:
 //      the result does not depend on the order waves run in.  The layout puts lane l on LDS bank l%32 whatever
 //      the slot, so a wave's scatter is bank-conflict free.
@@ -656,7 +656,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     };
     // One row piece -> E (Q4: 4E) integer LDS atomics on the workgroup's tile.  Why fixed point: a float
     // read-add-write needs a PRIVATE tile per wave (W x the LDS, so two workgroups per CU at best) and two LDS
-    // instructions per element; ds_add_f32 runs at 0.5 elements/clk/CU; ds_add_u32 runs at 13 (tools/microbench.hip),
+    // instructions per element; ds_add_f32 runs at 0.5 elements/clk/CU; ds_add_u32 runs at 13 (tools/lab/microbench.hip),
     // lets all waves share one tile, and -- integer addition being associative -- makes the sum independent of the
     // order in which waves and workgroups happen to run.  Each product is rounded once to the grid 2^-k (k above: at
     // least 30 bits below the bound L), finer than the f32 rounding of a running sum; the reference's own summation
@@ -1113,7 +1113,7 @@ __device__ __forceinline__ void cutoff_job(const GroupKArgs& ga, uint32_t ci, ch
 // The kernel: every workgroup pulls items until the queue of its XCD is dry.  Launched with one item per workgroup it
 // is a plain grid; launched with fewer workgroups than items (ga.persistent) the workgroups are PERSISTENT: the
 // dispatcher only places ~40 workgroups/us chip-wide and spreads a large grid unevenly over the CUs (measured with
-// tools/microbench.hip: residency probe), so a group launch sizes its grid to the chip -- R workgroups per CU,
+// tools/lab/microbench.hip: residency probe), so a group launch sizes its grid to the chip -- R workgroups per CU,
 // R fixed by the LDS each one asks for -- and balances the work itself.
 // (Round 4's CHAIN instantiation -- a layer's dependent multiplies as stages of ONE launch, measured 22 % slower than the launches of
 //  their own -- lives on branch `chain-launch`: DESIGN.md 4.5.)

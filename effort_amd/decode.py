@@ -165,7 +165,7 @@ class Decoder:
         # instead of 8.  Dense-FFN models only; the dense baseline keeps the separate glue kernels.  On by default since round 3:
         # with every operand of a prologue asked for at the top of the item (they were two more dependent round trips) and the
         # residual asked for before the slabs, all three folded are 306 against 300 tokens/s at 25 % effort (253 against 247 at
-        # 50 %); the gate alone or the residuals alone still lose 1 % (tools/decode_ab.py --fused-glue ...).  Bit-identical logits.
+        # 50 %); the gate alone or the residuals alone still lose 1 % (tools/lab/decode_ab.py --fused-glue ...).  Bit-identical logits.
         # fused_glue may also name WHICH steps fold into the multiplies: any of "norm" (rmsNorm into wq|wk|wv and w1|w3), "gate"
         # (silu into w2), "resid" (the residual adds after wo and w2); True = all three
         parts = ("norm", "gate", "resid") if fused_glue is True else tuple(fused_glue or ())

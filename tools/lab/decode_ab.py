@@ -2,7 +2,7 @@
 """A/B of decode-loop speed under library knobs, one model build: tokens/s dense (own GEMV) and effort runs with the
 row prefetch of lone calls on / off.
 
-    python tools/decode_ab.py [--layers 32] [--tokens 48] [--efforts 0.25,1.0]
+    python tools/lab/decode_ab.py [--layers 32] [--tokens 48] [--efforts 0.25,1.0]
 """
 import argparse
 import json
@@ -11,7 +11,7 @@ import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from effort_amd.decode import Decoder, MistralConfig, Model  # noqa: E402
 
 

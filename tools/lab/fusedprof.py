@@ -2,7 +2,7 @@
 """Phase stamps of item 0 of a lone call, plain against fused prologues / epilogue (tools only)."""
 import os, sys
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import effort_amd as ea
 from bench import make_weights
 dev = torch.device("cuda", 0)

@@ -5,7 +5,7 @@
 //   serial : one stream, every kernel after the previous one (what a captured decode graph does today)
 //   gated  : C_{k+1} is enqueued after P_{k-1} (two side streams), so it starts -- dispatch ramp, kernel arguments, the weight-only
 //            head -- while C_k still runs, then SPINS on a flag that P_k raises when v is complete.  At most two C's are resident.
-// Prints us per (C, P) pair for both.     hipcc --offload-arch=gfx950 -O3 -o build/gatebench tools/gatebench.hip
+// Prints us per (C, P) pair for both.     hipcc --offload-arch=gfx950 -O3 -o build/gatebench tools/lab/gatebench.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Launch-geometry sweep of the decode loop's multiply launches (lone calls and small groups, possibly of mixed shapes).
 
-    python tools/geosweep.py --launch 4096x4096,4096x1024,4096x1024 [--effort 0.25] [--configs "8,2,0;8,2,48;16,1,32"]
+    python tools/lab/geosweep.py --launch 4096x4096,4096x1024,4096x1024 [--effort 0.25] [--configs "8,2,0;8,2,48;16,1,32"]
 
 A launch = one effort_bucketmul_group of the listed shapes (in x out) on ONE input vector.  Per configuration
 (waves,elems,slices; 0 = heuristic): microseconds per launch from a hipGraph of 16 back-to-back launches over rotating
@@ -14,7 +14,7 @@ import time
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 
 
 def main():

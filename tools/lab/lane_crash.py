@@ -8,7 +8,7 @@ import torch
 
 if not os.environ.get('LD_PRELOAD'):
     faulthandler.enable()
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import effort_amd as ea  # noqa: E402
 from bench import LaneJob, make_weights  # noqa: E402
 

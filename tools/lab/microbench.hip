@@ -2,7 +2,7 @@
 //   * device facts (CUs, clocks, wall-clock rate)
 //   * HBM streaming read rate with 16-B and 2-B per-lane loads
 //   * scatter-accumulate primitives: ds_add_f32, ds_add_u32, LDS read-add-write, register select chain
-// Build: hipcc --offload-arch=gfx950 -O3 tools/microbench.hip -o tools/microbench ; run on the GPU box.
+// Build: hipcc --offload-arch=gfx950 -O3 tools/lab/microbench.hip -o tools/microbench ; run on the GPU box.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

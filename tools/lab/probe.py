@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Ablation probe for the multiply kernel (profiling aid): run with EFFORT_DEBUG=<mask> in the environment.
 
-    EFFORT_DEBUG=0 python tools/probe.py ; EFFORT_DEBUG=1 python tools/probe.py ; ...
+    EFFORT_DEBUG=0 python tools/lab/probe.py ; EFFORT_DEBUG=1 python tools/lab/probe.py ; ...
 
 Prints the kernel's device-clock duration per launch geometry, plus (mask 0 only) a calibration read of
 the same bytes with a plain torch reduction so the box's achievable HBM rate is on the same page.
@@ -13,7 +13,7 @@ import time
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 
 
 def main():

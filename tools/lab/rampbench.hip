@@ -1,6 +1,6 @@
 // rampbench -- how long the dispatcher takes to START a grid (tools only): every workgroup stamps the device wall clock first thing;
 // the spread first -> last start, by workgroup size, dynamic LDS and register footprint.
-//   hipcc --offload-arch=gfx950 -O3 -o build/rampbench tools/rampbench.hip
+//   hipcc --offload-arch=gfx950 -O3 -o build/rampbench tools/lab/rampbench.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

@@ -9,7 +9,7 @@
 //   mode 3  every row of the slice, whole (dense streaming of the same buffers: the ceiling)
 //   mode 4  like 0, rows stored INPUT-major (r = j * 16 + rank): an input's kept ranks 0 .. k-1 are neighbours in memory
 //   mode 5  like 1, input-major
-// Prints TB/s of bytes actually requested.    hipcc --offload-arch=gfx950 -O3 -o build/rowbench tools/rowbench.hip
+// Prints TB/s of bytes actually requested.    hipcc --offload-arch=gfx950 -O3 -o build/rowbench tools/lab/rowbench.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

@@ -4,7 +4,7 @@
 //   mode 0  16-byte loads past L1 (sc1), 16 in flight per thread                  [today's last arriver]
 //   mode 1  64-bit atomic swaps with return (device scope), 32 in flight per thread
 //   mode 2  32-bit atomic swaps with return, 64 in flight
-// Prints the reducer kernel's duration.      hipcc --offload-arch=gfx950 -O3 -o build/swapbench tools/swapbench.hip
+// Prints the reducer kernel's duration.      hipcc --offload-arch=gfx950 -O3 -o build/swapbench tools/lab/swapbench.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Sweep the multiply kernel's launch geometry (waves/workgroup, elements/lane, row slices) on one GPU.
 
-    python tools/tune.py [--shape 4096x11008] [--efforts 0.25,1.0] [--mats 16]
+    python tools/lab/tune.py [--shape 4096x11008] [--efforts 0.25,1.0] [--mats 16]
 
 Prints one line per configuration: per-call time from hipGraph replays over rotating matrices, and the
 multiply kernel's own duration from the device wall clock.  Used to pick the heuristics in api.hip.
@@ -14,7 +14,7 @@ import time
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 
 
 def main():

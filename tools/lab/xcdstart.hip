@@ -1,10 +1,10 @@
-// xcdstart -- WHICH workgroups of a grid start late (tools only).  tools/rampbench.hip found that any grid of 192-512 workgroups takes
+// xcdstart -- WHICH workgroups of a grid start late (tools only).  tools/lab/rampbench.hip found that any grid of 192-512 workgroups takes
 // ~1.3 us from its first to its last workgroup's first instruction; the per-item trace of a lone multiply (tools/timeline.py) shows
 // that this is not a gradual ramp: seven XCDs start within 0.2 us and ONE starts ~0.9 us later, and its items are the launch's last.
 // This probe stamps every workgroup's start with its XCC_ID, for isolated launches and for back-to-back launches of one hipGraph
 // (each preceded by a kernel shaped like the previous multiply), and prints per XCD: the mean offset of its first and of its last
 // workgroup start from the launch's first start, and how often it was the last XCD to start.
-//   hipcc --offload-arch=gfx950 -O3 -o build/xcdstart tools/xcdstart.hip
+//   hipcc --offload-arch=gfx950 -O3 -o build/xcdstart tools/lab/xcdstart.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
