@@ -48,6 +48,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 import torch
@@ -100,6 +101,7 @@ ALIGN_ROWS = True    # (--no-align) the converter writes the bucket rows on whol
 
 
 COMPACT_LIMIT = 4096        # bytes: the driver keeps ~8 KB of stdout tail; the last line must fit with room to spare
+AUX_DEADLINE_S = int(os.environ.get("BENCH_AUX_DEADLINE_S", "420"))      # N > 1: the auxiliary legs' budget after the headline (see aux_overdue)
 
 
 def _pick(d, keys):
@@ -171,7 +173,7 @@ def compact_line(result: dict) -> str:
         pass
     mg = result.get("multi_gpu")
     if isinstance(mg, dict):
-        m = _pick(mg, ("ms_per_step_kernel_only", "ms_per_step_with_all_gather", "steps_per_round"))
+        m = _pick(mg, ("ms_per_step_kernel_only", "ms_per_step_with_all_gather", "steps_per_round", "aborted"))
         if isinstance(mg.get("columns"), dict):
             m["columns"] = _pick(mg["columns"], ("ms_per_step_kernel_only", "ms_per_step_with_all_gather", "effective_GBps_whole_job", "error"))
         if isinstance(mg.get("layer_latency"), dict):
@@ -789,6 +791,23 @@ def main():
         "timed_region_ms": round(dt * args.steps * reps * 1e3, 3), "timed_replays": 1, "timed_steps": args.steps * reps,
         "timed_region_note": f"the {args.steps}-step job {reps} times back to back: rounds of {16 * S} steps (one hipGraph each), a round's all-gather under the next round's compute" if dist else f"the {args.steps}-step job {reps} times back to back in ONE hipGraph, one launch; the {args.steps}-step graph replayed {reps} times instead (its lanes drain at every replay's end): {dt_replayed * 1e3:.5f} ms per step",
     }
+    aux_done = threading.Event()
+    if dist:
+        # the headline above is complete; what follows on N > 1 are auxiliary legs full of collectives.  One rank failing inside
+        # one (and skipping its collective) would park the others in RCCL for ever and the driver would get NO line: a timer
+        # on every rank prints the headline as measured (rank 0) and ends the process instead
+        def aux_overdue():
+            if aux_done.is_set():
+                return
+            aux_done.set()
+            if rank == 0:
+                result.setdefault("multi_gpu", {})["aborted"] = f"auxiliary legs still running {AUX_DEADLINE_S} s after the headline; line printed by the watchdog"
+                sys.stderr.flush()
+                print(compact_line(result), flush=True)
+            os._exit(0)
+        watchdog = threading.Timer(AUX_DEADLINE_S, aux_overdue)
+        watchdog.daemon = True
+        watchdog.start()
     if dist:
         result["rccl_ranks"] = dist.get_world_size()
         result["multi_gpu"] = {"partition": "matrices (weak scaling: every rank its own 32 matrices)", "ms_per_step_kernel_only": round(dt_kernel * 1e3, 5),
@@ -1307,7 +1326,10 @@ def main():
             log(f"bench_full.json not written: {ex!r}")
         log("FULL_RECORD " + full)
         sys.stderr.flush()
-        print(compact_line(result), flush=True)
+        if not aux_done.is_set():
+            aux_done.set()
+            print(compact_line(result), flush=True)
+    aux_done.set()
     if dist:
         dist.destroy_process_group()
 
