@@ -338,6 +338,11 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
 
     // ---- A. everything the selection needs lands in LDS (stage_issue): the row means of the candidate slots, the slice of v
     if (!staged) stage_issue<FMT, W, COMPACT>(ga, ref, tid, smem, lp, par);
+    // plain grids (one item per workgroup: the accumulator region is untouched so far): the cutoff's count table, which borrows
+    // that region, is cleared HERE, and the barrier its adds need behind the clearing passes under the staged loads' round trip
+    // (block_find_cutoff, PREZERO) instead of on the cutoff's own chain
+    constexpr bool kPreZero = !PERSIST;
+    if constexpr (kPreZero) cutoff_table_zero<NT>(reinterpret_cast<uint32_t*>(smem + offA), tid);
     // Q4 outliers (phase O below): the share of this item, and -- lean kernels, v small enough for a region of its own -- what the
     // MERGED form needs, asked for now: the whole of v (eight loads per thread, written to LDS once the staged loads are awaited)
     // and the wave's first block's meta word and entry bounds.
@@ -461,6 +466,10 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
             for (int i = 0; i < VPT; i++) { vj[i] = *(a.v + tid + NT * i); prj[i] = pr[tid + NT * i]; }
         }
     };
+    if constexpr (kPreZero) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // (the clearing stores; NOT __syncthreads: it would await the loads in flight)
+        __builtin_amdgcn_s_barrier();
+    }
     if (needCut && !viaJob) load_cut_inputs();
     // the call's cutoff job publishes ONE word: the cutoff's bits (a non-negative float) with the sign bit raised.  Thread 0
     // asks for it here, before the staged loads are awaited
@@ -489,7 +498,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     }
     bound = wave_sum_f32(bound);                                  // (only the exponent of the slice's bound matters: any order)
     if (lane == 0) wbound[wave] = bound;
-    if (tid == 0) { flags[4] = 0u; flags[5] = 0u; }               // the list is empty, none of it handed out
+    if (tid == 0) { flags[4] = 0u; flags[5] = (uint32_t)(W * KB); }      // the list is empty; its first W batches go to the waves by index (D), the cursor starts behind them
     if (stamp) GA_TSTAMP(ga)[17] = wall_clock64();
     if (wstamp) ph[1] = wall_clock64();
 
@@ -516,7 +525,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     }
     if (fromJob) {
     } else if (needCut) {
-        cutoff = block_find_cutoff<NT>(vj, prj, a.q, smem + offC, tbl, []() {}, stamp ? GA_TSTAMP(ga) + 8 : nullptr);
+        cutoff = block_find_cutoff<NT, kPreZero>(vj, prj, a.q, smem + offC, tbl, []() {}, stamp ? GA_TSTAMP(ga) + 8 : nullptr);
         cachedCall = ci; cachedCutoff = cutoff;
         // (BucketMul.cutoff, bucketMul.swift:22, is stored with the slab, in E: a store here sits in front of the `s_waitcnt vmcnt(0)` that
         //  rankBound's consumer needs, and the call's first workgroup waited a microsecond for its acknowledgement)
@@ -529,6 +538,28 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
         cutoff = a_cutoff[0];
         __syncthreads();                                             // publishes vblk / wbound / the list length
     }
+    // What the selection's first block needs from LDS -- the means of its four rounds, |v| of this thread's input row, the waves'
+    // bounds -- asked for HERE, together, beside the cutoff's own read-back: one LDS round trip (~250 cycles on a lone call's
+    // chain) where the scheduler, left alone, made four dependent ones (a wait inside the branch around |v|, one after the first mean)
+    const uint32_t slotCap = __builtin_amdgcn_readfirstlane((lp.offV[0] - lp.offM) / 4u) - 1u;      // last dword of the means region
+    const uint16_t* m16 = reinterpret_cast<const uint16_t*>(m32);
+    auto load_block = [&](int blk, uint32_t (&mraw)[4], float (&vq)[4]) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t c = min((uint32_t)((blk * 4 + u) * NT + tid), slotCap);
+            if constexpr (COMPACT && FMT == kFp16) { mraw[u] = (uint32_t)m16[c] << 16; vq[u] = 0.0f; }      // compact means: u16 per slot, kept in the high half
+            else { mraw[u] = m32[c]; vq[u] = FMT != kFp16 ? vblk[min(c >> 3, nb - 1u)] : 0.0f; }
+        }
+    };
+    uint32_t mraw0[4]; float vq0[4];
+    load_block(0, mraw0, vq0);
+    const uint32_t jlSel = (uint32_t)tid & ((1u << lg) - 1u);
+    float axRaw = 0.0f;
+    if (FMT == kFp16) axRaw = vblk[min(jlSel, nb - 1u)];
+    float wb[W];
+#pragma unroll
+    for (int w2 = 0; w2 < W; w2++) wb[w2] = wbound[w2];
+    __builtin_amdgcn_sched_barrier(0);
     for (int i = tid; i < TILE_L; i += NT) acc[i] = 0;               // the table is dead: zero the tile (barrier in C)
     // Fixed-point scale of this workgroup's tile.  Every product is |v_j| * |w| with |w| <= (max |w| of its rank), so
     // every partial sum is bounded by L = (sum over the slice of |v_j|) * (sum over ranks of that rank's max |w|)
@@ -537,7 +568,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     // power of two, scaling and un-scaling are exact.
     float L = 0.0f;
 #pragma unroll
-    for (int w2 = 0; w2 < W; w2++) L += wbound[w2];
+    for (int w2 = 0; w2 < W; w2++) L += wb[w2];
     L *= rankBound;
     int kexp = 30 - (int)((__float_as_uint(L) >> 23) & 0xFFu) + 126;     // L < 2^(e-126)  =>  2^kexp * L < 2^30
     kexp = L > 0.0f ? max(-100, min(100, kexp)) : 0;
@@ -557,9 +588,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     // lanes of the ballot).  The list order therefore depends on the order in which the waves arrive -- it does not
     // matter: every listed row is added with integer arithmetic (see D), and the reference's own list is appended with an
     // atomic counter in no particular order (bucketMul.metal:71).
-    float ax = 0.0f;
-    if (FMT == kFp16) { const uint32_t jl = (uint32_t)tid & ((1u << lg) - 1u); ax = jl < nb ? fabsf(vblk[jl]) : 0.0f; }
-    const uint32_t slotCap = __builtin_amdgcn_readfirstlane((lp.offV[0] - lp.offM) / 4u) - 1u;      // last dword of the means region
+    const float ax = (FMT == kFp16 && jlSel < nb) ? fabsf(axRaw) : 0.0f;
     // (the rounds go in blocks of four, a block's reads issued together; blocks wholly past the slice's slots are skipped with a
     //  uniform branch: a lone call's slices have 2048 slots -- one block of four rounds with 512 threads -- a 32-call launch's
     //  8192)
@@ -567,20 +596,19 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     uint32_t keepMask = 0;                                  // bit r: this thread's slot of round r is kept
     uint32_t before[kRounds];                               // (wave-uniform) survivors of the wave's earlier rounds
     uint32_t wtot = 0;
-    const uint16_t* m16 = reinterpret_cast<const uint16_t*>(m32);
 #pragma unroll
     for (int blk = 0; blk < kRounds / 4; blk++) {
-        if ((uint32_t)(blk * 4 * NT) >= nSlots) {           // uniform
+        if (blk > 0 && (uint32_t)(blk * 4 * NT) >= nSlots) {           // uniform
 #pragma unroll
             for (int u = 0; u < 4; u++) before[blk * 4 + u] = wtot;
             continue;
         }
         uint32_t mraw[4]; float vq[4];
+        if (blk == 0) {
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const uint32_t c = min((uint32_t)((blk * 4 + u) * NT + tid), slotCap);
-            if constexpr (COMPACT && FMT == kFp16) { mraw[u] = (uint32_t)m16[c] << 16; vq[u] = 0.0f; }      // compact means: u16 per slot, kept in the high half
-            else { mraw[u] = m32[c]; vq[u] = FMT != kFp16 ? vblk[min(c >> 3, nb - 1u)] : 0.0f; }
+            for (int u = 0; u < 4; u++) { mraw[u] = mraw0[u]; vq[u] = vq0[u]; }
+        } else {
+            load_block(blk, mraw, vq);
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -607,7 +635,10 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
         if (k) list[pos] = (uint16_t)(FMT == kFp16 ? (((c >> lg) << 12) | (c & ((1u << lg) - 1u))) : c);
     }
     __syncthreads();
+    // (the list's length and this wave's FIRST batch of entries -- a static share, batch `wave` -- in one LDS round trip; entries past
+    //  the length are garbage and replaced below)
     const uint32_t n = flags[4];
+    const uint32_t code0 = list[(uint32_t)(wave * KB) + ((uint32_t)lane & (uint32_t)(KB - 1))];
     if (t == 0 && tid == 0) a_sliceCounts[s] = n;                  // dispatch.size = sum over slices (test hook)
     if (stamp) GA_TSTAMP(ga)[19] = wall_clock64();
     if (wstamp) ph[3] = wall_clock64();
@@ -635,12 +666,8 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     // up to 2*KB row pieces in flight.  Loads are never predicated: a batch that runs past the wave's
     // last row re-reads that last row (an L1/L2 hit) -- a branch around a load makes hipcc drain
     // vmcnt(0) -- and the accumulate step skips the surplus with a wave-uniform test.
-    auto decode = [&](uint32_t i0, uint32_t& boff, float& dv) {
-        // lane u decodes list entry i0+u (clamped); the row loops read it back with v_readlane into SGPRs
-        boff = 0; dv = 0.0f;
-        if (lane < KB && nU) {
-            const uint32_t kk = min(i0 + (uint32_t)lane, nU - 1u);
-            const uint32_t code = list[kk];
+    auto decode_code = [&](uint32_t code, uint32_t& boff, float& dv) {
+        {
             uint32_t rowIdx;
             if (FMT == kFp16) { const uint32_t rank = code >> 12, jl = code & 4095u; rowIdx = rank * g.inDim + j0 + jl; dv = vblk[jl] * scale; }
             else {   // entry value = v*mean (bucketMulQ4.metal:52), the one magnitude of the row; carried in fixed point
@@ -649,6 +676,15 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
             }
             boff = (e * g.expertRows + rowIdx) * g.rowPitch;        // byte offset of the bucket row (< 4 GiB, checked at registration)
         }
+    };
+    auto decode = [&](uint32_t i0, uint32_t& boff, float& dv) {
+        // lane u decodes list entry i0+u (clamped); the row loops read it back with v_readlane into SGPRs
+        boff = 0; dv = 0.0f;
+        if (lane < KB && nU) decode_code(list[min(i0 + (uint32_t)lane, nU - 1u)], boff, dv);
+    };
+    auto decode_first = [&](uint32_t i0, uint32_t& boff, float& dv) {      // the entries were asked for with the list's length; a lane past it repeats the batch's first row
+        boff = 0; dv = 0.0f;
+        if (lane < KB && nU) decode_code(i0 + (uint32_t)lane < nU ? code0 : (uint32_t)__builtin_amdgcn_readfirstlane((int)code0), boff, dv);
     };
     auto issue = [&](Piece<E> (&piece)[KB], uint32_t boff) {
 #pragma unroll
@@ -784,8 +820,8 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
         Piece<E> pa[KB], pb[KB];
         uint32_t entA[OL ? kOlMerged : 1], entB[OL ? kOlMerged : 1];
         uint32_t boffA, boffB; float dvA, dvB;
-        uint32_t baseA = grab(), baseB;
-        if (baseA < nU) { decode(baseA, boffA, dvA); issue(pa, boffA); }
+        uint32_t baseA = (uint32_t)(wave * KB), baseB;             // (no LDS atomic for the first batch: the cursor starts at W * KB)
+        if (baseA < nU) { decode_first(baseA, boffA, dvA); issue(pa, boffA); }
         if constexpr (OL) ol_fetch(entA);
         while (baseA < nU) {
             if (!asked && nU - baseA <= 4u * KB * W) asked = prefetch();

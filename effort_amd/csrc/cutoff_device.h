@@ -27,7 +27,22 @@ namespace effort {
 
 constexpr uint32_t kCutoffBinsPerThread = 8;
 constexpr uint32_t kCutoffLdsBytes = 512;     // small scratch: count slots, per-wave min/max, scan totals, result
-__host__ __device__ constexpr uint32_t cutoff_table_bytes(int NT) { return (uint32_t)NT * kCutoffBinsPerThread * 4u; }
+// The table's cells are read back by ONE wave, lane L taking the kSeg = cells / 64 consecutive cells [L * kSeg, (L + 1) * kSeg) with
+// 16-byte loads: four pad dwords after every kSeg cells make the lanes' stride 4 (mod 64) dwords -- no bank conflicts.
+__host__ __device__ constexpr uint32_t cutoff_table_bytes(int NT) { return ((uint32_t)NT * kCutoffBinsPerThread + 64u * 4u) * 4u; }
+template <int NT> __device__ __forceinline__ uint32_t cutoff_cell_index(uint32_t c) {
+    constexpr uint32_t kSeg = (uint32_t)NT * kCutoffBinsPerThread / 64u;
+    static_assert((kSeg & (kSeg - 1u)) == 0u && kSeg >= kCutoffBinsPerThread, "cutoff table: cells per lane must be a power of two holding whole threads");
+    return c + ((c / kSeg) << 2);
+}
+// every thread clears its kCutoffBinsPerThread cells (a caller that passes PREZERO = true does this, and a barrier, before the call)
+template <int NT> __device__ __forceinline__ void cutoff_table_zero(uint32_t* tbl, int tid) {
+    uint4* z4 = reinterpret_cast<uint4*>(tbl + cutoff_cell_index<NT>((uint32_t)tid * kCutoffBinsPerThread));
+    z4[0] = make_uint4(0, 0, 0, 0); z4[1] = make_uint4(0, 0, 0, 0);
+}
+// PREZERO callers count into a FIXED window of cells before the value range is known (one barrier and one LDS round trip less on
+// the chain): [2^-10, 2^-10 * 2^(cells / 128)) -- 2^22 for 4096 cells.  Nonzero values outside it: the table is rebuilt the usual way.
+constexpr uint32_t kCutoffWindowBase = (127u - 10u) << 7;
 
 // NT threads (multiple of 64, <= 1024, dividing 4096); lds = kCutoffLdsBytes of scratch; tbl =
 // cutoff_table_bytes(NT) of scratch, 16-byte aligned (may alias memory the caller initialises afterwards).
@@ -56,7 +71,7 @@ __device__ __forceinline__ float bisect_to_cell_edge(float newBound, float minBo
     return newBound;
 }
 
-template <int NT, typename Idle>
+template <int NT, bool PREZERO = false, typename Idle>
 __device__ __forceinline__ float block_find_cutoff(const float (&vj)[4096 / NT], const uint16_t (&prj)[4096 / NT],
                                                    uint32_t q, char* lds, uint32_t* tbl, Idle idle,
                                                    unsigned long long* dbg = nullptr) {
@@ -65,10 +80,8 @@ __device__ __forceinline__ float block_find_cutoff(const float (&vj)[4096 / NT],
     constexpr int NW = NT / 64;
     constexpr uint32_t BPT = kCutoffBinsPerThread, CAP = (uint32_t)NT * BPT;
     uint32_t* s_cnt = reinterpret_cast<uint32_t*>(lds);            // [4] rotating count slots (ballot passes)
-    uint32_t* s_wm = reinterpret_cast<uint32_t*>(lds) + 32;        // [NW][3] per wave: min pattern, max pattern, min NONZERO pattern
-    uint32_t* s_tot = reinterpret_cast<uint32_t*>(lds) + 8;        // [16] wave totals of the scan
+    uint32_t* s_wm = reinterpret_cast<uint32_t*>(lds) + 32;        // [3][NW] per wave: min pattern, max pattern, min NONZERO pattern (16-byte aligned)
     float* s_res = reinterpret_cast<float*>(lds) + 24;             // [0] result
-    uint32_t* s_all = reinterpret_cast<uint32_t*>(lds) + 25;       // [0] values at or above the table's first cell
     int tid0 = threadIdx.x;
     asm volatile("" : "+v"(tid0));      // opaque: a caller looping over work items must not hoist tid-derived state
     const int tid = tid0, lane = tid & 63;
@@ -96,18 +109,41 @@ __device__ __forceinline__ float block_find_cutoff(const float (&vj)[4096 / NT],
             pminnz = min(pminnz, vp[k + h] ? vp[k + h] : 0xFFFFu);
         }
     }
+    // PREZERO (the table was cleared, and a barrier passed, before the call): count into the fixed window NOW -- the adds run
+    // under the reductions below and are complete at the barrier that publishes the value range
+    if constexpr (PREZERO) {
+        // (no branch around the add: a value outside the window -- a zero, mostly -- counts into this lane's pad dwords, which nobody reads)
+        const uint32_t pad = (uint32_t)lane * (CAP / 64u + 4u) + CAP / 64u;
+#pragma unroll
+        for (int k = 0; k < VPT; k++) {
+            const uint32_t c = vp[k] - kCutoffWindowBase;
+            atomicAdd(&tbl[c < CAP ? cutoff_cell_index<NT>(c) : pad], 1u);
+        }
+    }
     // wave results on DPP (no LDS round trips), one slot per wave; the count table is zeroed under the same barrier (its
     // region is free on entry): ONE barrier where there were three
     pmin = wave_min_u32(pmin); pmax = wave_max_u32(pmax); pminnz = wave_min_u32(pminnz);
-    if (lane == 0) { s_wm[wave * 3 + 0] = pmin; s_wm[wave * 3 + 1] = pmax; s_wm[wave * 3 + 2] = pminnz; }
-    {
-        uint4* z4 = reinterpret_cast<uint4*>(tbl + tid * BPT);
-        z4[0] = make_uint4(0, 0, 0, 0); z4[1] = make_uint4(0, 0, 0, 0);
-    }
+    if (lane == 0) { s_wm[wave] = pmin; s_wm[NW + wave] = pmax; s_wm[2 * NW + wave] = pminnz; }
+    if constexpr (!PREZERO) cutoff_table_zero<NT>(tbl, tid);
     __syncthreads();
+    // (the waves' results in ONE batch of 16-byte loads: left to the scheduler they came in two, a second LDS latency on the chain)
     uint32_t mmin = 0xFFFFFFFFu, mmax = 0u, mnz = 0xFFFFFFFFu;
+    if constexpr (NW % 4 == 0) {
+        uint4 wm[3 * NW / 4];
 #pragma unroll
-    for (int w2 = 0; w2 < NW; w2++) { mmin = min(mmin, s_wm[w2 * 3 + 0]); mmax = max(mmax, s_wm[w2 * 3 + 1]); mnz = min(mnz, s_wm[w2 * 3 + 2]); }
+        for (int i = 0; i < 3 * NW / 4; i++) wm[i] = reinterpret_cast<const uint4*>(s_wm)[i];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NW / 4; i++) {
+            const uint4 a = wm[i], b = wm[NW / 4 + i], c = wm[2 * NW / 4 + i];
+            mmin = min(min(mmin, a.x), min(min(a.y, a.z), a.w));
+            mmax = max(max(mmax, b.x), max(max(b.y, b.z), b.w));
+            mnz = min(min(mnz, c.x), min(min(c.y, c.z), c.w));
+        }
+    } else {
+#pragma unroll
+        for (int w2 = 0; w2 < NW; w2++) { mmin = min(mmin, s_wm[w2]); mmax = max(mmax, s_wm[NW + w2]); mnz = min(mnz, s_wm[2 * NW + w2]); }
+    }
     const uint32_t pminAll = mmin, pmaxAll = mmax;
     // Exact zeros (a zero input, or a probe zeroed as a Q4 outlier) exceed no threshold, so the count table only has
     // to start at the smallest NONZERO value: below it every count is the same.  (Without this, zeros make the value
@@ -159,36 +195,48 @@ __device__ __forceinline__ float block_find_cutoff(const float (&vj)[4096 / NT],
     if (dbg && tid == 0) dbg[1] = wall_clock64();
 
     if (!done && patHi != patLo + 1u) {                  // uniform
-        // ---- table over the cells [base, top]: suffix[i] = #{values with pattern > base + i} ---------------
-        const uint32_t base = lowCell(), top = topCell();
+        // ---- histogram over the cells [base, top]; ONE wave turns it into the five order statistics the rounds need ----
+        uint32_t base = lowCell();
+        const uint32_t top = topCell();
         const uint32_t above = (patHi != kNoHi) ? (uint32_t)maxCount : 0u;     // values beyond the top cell
-        uint4* t4 = reinterpret_cast<uint4*>(tbl + tid * BPT);      // (zeroed on entry)
+        bool counted = false;                                                  // (uniform)
+        if constexpr (PREZERO) {
+            // every nonzero value inside the window: the counts are in place, cells below the smallest value simply hold 0
+            counted = nPasses == 0 && pminNZ >= kCutoffWindowBase && pmaxAll - kCutoffWindowBase < CAP;
+            if (counted) base = kCutoffWindowBase;
+            else { cutoff_table_zero<NT>(tbl, tid); __syncthreads(); }
+        }
+        if (!counted) {
 #pragma unroll
-        for (int k = 0; k < VPT; k++) if (vp[k] >= base && vp[k] <= top) atomicAdd(&tbl[vp[k] - base], 1u);
-        __syncthreads();
-        uint4 a4 = t4[0], b4 = t4[1];
-        uint32_t h[BPT] = {a4.x, a4.y, a4.z, a4.w, b4.x, b4.y, b4.z, b4.w};
-        uint32_t mine = 0;
-#pragma unroll
-        for (uint32_t i = 0; i < BPT; i++) mine += h[i];
-        // inclusive suffix sum over the lanes of this wave = wave total - inclusive prefix + own (integers: exact)
-        const uint32_t pre = wave_prefix_sum_u32(mine), wtotal = (uint32_t)__builtin_amdgcn_readlane((int)pre, 63);
-        const uint32_t suf = wtotal - pre + mine;
-        if (lane == 0) s_tot[wave] = wtotal;             // wave total
-        __syncthreads();
-        uint32_t running = above + suf - mine;           // values in cells owned by later lanes / waves, or beyond top
-#pragma unroll
-        for (int w2 = 0; w2 < NW; w2++) running += (w2 > wave) ? s_tot[w2] : 0u;
-#pragma unroll
-        for (int i = (int)BPT - 1; i >= 0; i--) { const uint32_t c = running; running += h[i]; h[i] = c; }
-        if (tid == 0) s_all[0] = running;                // values with pattern >= base
-        t4[0] = make_uint4(h[0], h[1], h[2], h[3]); t4[1] = make_uint4(h[4], h[5], h[6], h[7]);
-        __syncthreads();
-        if (dbg && tid == 0) dbg[2] = wall_clock64();
+            for (int k = 0; k < VPT; k++) if (vp[k] >= base && vp[k] <= top) atomicAdd(&tbl[cutoff_cell_index<NT>(vp[k] - base)], 1u);
+            __syncthreads();
+        }
 
         if (wave == 0) {
-            // ---- the bisection proper, one wave, one LDS lookup per round ------------------------------------
-            const uint32_t allGE = s_all[0];
+            // count(c) = #{values with pattern > base + c} (+ above).  Lane L adds up its kSeg cells; a DPP scan over the lanes
+            // gives count(last cell of lane L) -- the first level of every search below; the second level reads the 64 (128)
+            // cells of the one lane the answer lies in, one (two) per lane, and scans them the same way.  (Until round 5 the whole
+            // workgroup turned the histogram into a table of suffix counts -- a scan across the waves, two more barriers, four
+            // LDS round trips -- which wave 0 then probed.)
+            constexpr uint32_t kSeg = CAP / 64u, kSub = (kSeg + 63u) / 64u, kSegP = kSeg + 4u;
+            const uint4* row = reinterpret_cast<const uint4*>(tbl + (uint32_t)lane * kSegP);
+            // (the loads of a batch are ALL issued before the first sum -- one LDS latency per batch of 16, ~250 cycles here, not one
+            //  per four loads as the scheduler would have it)
+            uint32_t mine = 0;
+            constexpr uint32_t kBatch = kSeg / 4u < 16u ? kSeg / 4u : 16u;
+#pragma unroll
+            for (uint32_t i0 = 0; i0 < kSeg / 4u; i0 += kBatch) {
+                uint4 xs[kBatch];
+#pragma unroll
+                for (uint32_t i = 0; i < kBatch; i++) xs[i] = row[i0 + i];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (uint32_t i = 0; i < kBatch; i++) mine += (xs[i].x + xs[i].y) + (xs[i].z + xs[i].w);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const uint32_t pre = wave_prefix_sum_u32(mine), wtotal = (uint32_t)__builtin_amdgcn_readlane((int)pre, 63);
+            const uint32_t c1 = above + wtotal - pre;                          // count(last cell of this lane's segment)
+            const uint32_t allGE = above + wtotal;                             // values with pattern >= base
             // THE BISECTION WITHOUT ITS LOOKUPS.  A count enters a round of the reference's loop in three places: the comparison
             // `countAbove < effort` that steers the bounds, and the exit tests `countAbove == effort` and |maxCount - minCount| < 3.
             // Counts are monotone in the threshold's bf16 cell, so each of them is a comparison of CELLS with a few order
@@ -198,33 +246,42 @@ __device__ __forceinline__ float block_find_cutoff(const float (&vj)[4096 / NT],
             //     countAbove == m                 <=>  T(m+1) <= p < T(m)
             //     |maxCount - minCount| < 3       <=>  (count(hi) >= m-1 and count(lo) <= m+1) or (count(hi) >= m-2 and count(lo) <= m)
             // (count(hi) < m <= count(lo) always; bounds never set yet count 0 / 4096, the reference's initial values).  The five
-            // cells T(m-2) .. T(m+2) are found ONCE, with two 64-lane probes of the table each (issued together); the rounds
-            // then run with no LDS round trip inside -- it was ~330 cycles a round with the lookup on the dependent chain, 1.4 us
-            // for 9 rounds and 2.7 for 29 -- as a chain of ~25 VALU instructions.  Same float operations in the same order, the
-            // same exits in the same round: bit-identical (tests/test_cutoff_trajectory_model.py restates this on the CPU).
-            // T(k) for the five k at once: ONE probe of the segment ends serves all five first levels, the five second-level
-            // probes are issued together, and the special cases are selects on the results -- no branch, two LDS latencies in all.
-            constexpr uint32_t kSeg = CAP / 64u, kSub = (kSeg + 63u) / 64u;     // cells per lane of the first probe; second-level probes per lane
-            const uint32_t c1 = tbl[(uint32_t)lane * kSeg + kSeg - 1u];         // the last cell of each segment (cells past `top` hold `above`)
+            // cells T(m-2) .. T(m+2) are found ONCE; the rounds then run with no LDS round trip inside -- it was ~330 cycles a
+            // round with the lookup on the dependent chain, 1.4 us for 9 rounds and 2.7 for 29 -- as a chain of VALU instructions.
+            // Same float operations in the same order, the same exits in the same round: bit-identical
+            // (tests/test_cutoff_trajectory_model.py restates this on the CPU).
+            // T(k) = base + #{cells with count >= k} (counts fall with the cell): whole segments from the ballot over c1, the
+            // rest from the segment the boundary lies in.  The five k are neighbours, so their segments nearly always coincide:
+            // a segment is read and scanned once per run of equal segments (uniform branch).
             const int m = (int)effort;
-            uint32_t seg[5], c2[5][kSub], tk[5];
+            uint32_t tk[5], cnt[kSub], sgHeld = 0xFFFFFFFFu;
+#pragma unroll
+            for (uint32_t u = 0; u < kSub; u++) cnt[u] = 0u;
 #pragma unroll
             for (int j = 0; j < 5; j++) {
                 const int k = m - 2 + j;
-                seg[j] = (uint32_t)__popcll(__ballot((int)c1 >= k));            // (counts <= 4096: the signed compare also serves k <= 0)
+                const uint32_t sgAll = (uint32_t)__popcll(__ballot((int)c1 >= k));   // (counts <= 4096: the signed compare also serves k <= 0)
+                const uint32_t sg = min(sgAll, 63u);
+                if (sg != sgHeld) {                                                 // uniform
+                    sgHeld = sg;
+                    uint32_t x[kSub], later = (uint32_t)__builtin_amdgcn_readlane((int)c1, (int)sg);
 #pragma unroll
-                for (uint32_t u = 0; u < kSub; u++) c2[j][u] = tbl[min(seg[j], 63u) * kSeg + min(u * 64u + (uint32_t)lane, kSeg - 1u)];
-            }
+                    for (uint32_t u = 0; u < kSub; u++) x[u] = (u * 64u + (uint32_t)lane < kSeg) ? tbl[sg * kSegP + min(u * 64u + (uint32_t)lane, kSeg - 1u)] : 0u;
 #pragma unroll
-            for (int j = 0; j < 5; j++) {
-                const int k = m - 2 + j;
-                uint32_t n = seg[j] * kSeg;
+                    for (int u = (int)kSub - 1; u >= 0; u--) {                       // count(cell) = everything in later cells
+                        const uint32_t p2 = wave_prefix_sum_u32(x[u]), t2 = (uint32_t)__builtin_amdgcn_readlane((int)p2, 63);
+                        cnt[u] = later + t2 - p2;
+                        later += t2;
+                    }
+                }
+                uint32_t n = sg * kSeg;
 #pragma unroll
-                for (uint32_t u = 0; u < kSub; u++) n += (uint32_t)__popcll(__ballot(u * 64u + (uint32_t)lane < kSeg && (int)c2[j][u] >= k));
+                for (uint32_t u = 0; u < kSub; u++) n += (uint32_t)__popcll(__ballot(u * 64u + (uint32_t)lane < kSeg && (int)cnt[u] >= k));
                 // every count is >= k (k <= 0, or the whole table and -- its last cell holds `above` -- everything beyond it): +inf;
                 // none is (k > 4096, or more than the values at or above the table's first cell): 0
-                tk[j] = (k <= 0 || seg[j] >= 64u) ? 0xFFFFFFFFu : ((k > 4096 || (int)allGE < k) ? 0u : base + n);
+                tk[j] = (k <= 0 || sgAll >= 64u) ? 0xFFFFFFFFu : ((k > 4096 || (int)allGE < k) ? 0u : base + n);
             }
+            if (dbg && tid == 0) dbg[2] = wall_clock64();
             uint32_t tM2 = tk[0], tM1 = tk[1], tM = tk[2], tP1 = tk[3], tP2 = tk[4];
             float nb = newBound, lo = minBound, hi = maxBound;
             uint32_t pLo = patLo, pHi = patHi, nLoops = (uint32_t)loops;
@@ -238,9 +295,9 @@ __device__ __forceinline__ float block_find_cutoff(const float (&vj)[4096 / NT],
             // VALU instructions.  Everything else a round does -- the three count-driven exit tests, the 1e-5 test, the 100-round
             // cap, the fixed point, the hand-over to the closed-form tail at adjacent cells -- only decides WHERE the loop stops, and
             // rounds run past that point have no side effect.  So a block of kBlk rounds runs the bare recurrence, identical in every
-            // lane, round r leaving the midpoint it tested in lane r; then lane r reconstructs round r on its own -- the bounds
-            // after the round are the latest midpoints at or before r that went each way (two bpermutes), their cells and count
-            // categories follow -- and evaluates the reference's exits for it; the first lane that stops (a ballot) hands its state
+            // lane, round r leaving the midpoint it tested and the bounds after it in lane r; then lane r reconstructs round r on
+            // its own -- whether a round of this block set each bound (a ballot), their cells and count categories
+            // follow -- and evaluates the reference's exits for it; the first lane that stops (a ballot) hands its state
             // to the wave.  Same float operations on the same operands, the same exit taken in the same round: bit-identical
             // (tests/test_cutoff_trajectory_model.py restates the block form on the CPU against the count-by-count loop).  It was a
             // chain of ~38 instructions and a branch per round (~260 cycles: 1.0 us for 9 rounds, 3.2 for 29); a block of 16 rounds
@@ -250,7 +307,7 @@ __device__ __forceinline__ float block_find_cutoff(const float (&vj)[4096 / NT],
             bool fin = done;
             if (!fin && pHi != pLo + 1u) {
                 for (;;) {
-                    float a = nb, l = lo, h = hi, rec = 0.0f;
+                    float a = nb, l = lo, h = hi, rec = 0.0f, hAt = hi, lAt = lo;
                     uint32_t tMs = tMs0;
                     asm volatile("" : "+v"(a), "+v"(l), "+v"(h), "+v"(tMs));          // VGPRs: left uniform, hipcc splits every round between SALU and VALU
 #pragma unroll
@@ -259,6 +316,8 @@ __device__ __forceinline__ float block_find_cutoff(const float (&vj)[4096 / NT],
                         const bool below = __float_as_uint(a) >= tMs;                 // countAbove < effort
                         h = below ? a : h;                                            // :214-220
                         l = below ? l : a;
+                        hAt = lane == r ? h : hAt;                                    // the bounds AFTER round r, kept by lane r (two selects off
+                        lAt = lane == r ? l : lAt;                                    //  the chain; they were two ds_bpermutes after the block)
                         a = (h + l) / 2;                                              // :222
                     }
                     // lane r < kBlk: round r of the block
@@ -269,8 +328,7 @@ __device__ __forceinline__ float block_find_cutoff(const float (&vj)[4096 / NT],
                     const uint32_t hb = (uint32_t)__ballot(wentHi) & kmask, lb = ~hb & kmask;      // (uniform) which rounds went which way
                     const uint32_t upto = (2u << lr) - 1u;
                     const uint32_t hSeen = hb & upto, lSeen = lb & upto;
-                    const float hFrom = __shfl(rec, hSeen ? 31 - __clz(hSeen) : 0), lFrom = __shfl(rec, lSeen ? 31 - __clz(lSeen) : 0);
-                    const float hr = hSeen ? hFrom : hi, lor = lSeen ? lFrom : lo;   // the bounds AFTER round r
+                    const float hr = hAt, lor = lAt;                                  // the bounds AFTER round r (hSeen / lSeen: whether a round of THIS block set them)
                     const uint32_t pHr = hSeen ? __float_as_uint(hr) >> 16 : pHi, pLr = lSeen ? __float_as_uint(lor) >> 16 : pLo;
                     const uint32_t cHr = hSeen ? (uint32_t)(pHr < tM1) + (uint32_t)(pHr < tM2) : catHi;
                     const uint32_t cLr = lSeen ? (uint32_t)(pLr < tP1) + (uint32_t)(pLr < tP2) : catLo;
