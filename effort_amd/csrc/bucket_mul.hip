@@ -333,6 +333,12 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     const float* means = reinterpret_cast<const float*>(smem + offM);        // Q4: the row means as f32
 
     const uint32_t j0 = s * B;
+    // Geometry the hand-off (E) needs, worked out NOW and parked in vector registers: the kernel runs at its scalar-register limit, and
+    // hipcc, rather than hold these, re-reads the geometry from the kernel-argument segment where they are used -- behind a barrier,
+    // a scalar-memory latency on the call's chain each time
+    uint32_t vSlabOff = (s * g.tiles + t) * (uint32_t)(TILE_F * 4), vSlabBytes = (uint32_t)min((size_t)0xFFFFFFFFu, (size_t)g.slices * g.tiles * TILE_F * 4);
+    uint32_t vSlices = g.slices, vSliceStride = g.tiles * (uint32_t)(TILE_F * 4);
+    if constexpr (!PERSIST) asm volatile("" : "+v"(vSlabOff), "+v"(vSlabBytes), "+v"(vSlices), "+v"(vSliceStride));      // (the persistent instantiations have no register to spare)
     const uint32_t nb = min(B, g.inDim - j0);
     const uint32_t e = a.expNo ? a.expNo[0] : 0u;
 
@@ -479,6 +485,24 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     // the staged loads have landed (each thread waits for its own; it reads back only what its own lane loaded until the
     // next barrier).  The slice's absolute sum bounds every partial sum of this workgroup (see the scale below).
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // (plain grids) what the streaming phase (D) starts with -- the bucket buffer's descriptor, this lane's column offset, the row
+    // arithmetic -- parked in vector registers like the hand-off's geometry above: re-read from the kernel-argument segment where D
+    // begins, they were a scalar-memory round trip between the selection and the first row load
+    uint32_t vColOK = 0, voff = 0, vRecords = 0, vBuckLo = 0, vBuckHi = 0, vRowPitch = 0, vInDim = 0, vRow0 = 0;
+    auto stream_geom = [&]() {
+        const uint32_t col = t * (64u * E) + (uint32_t)lane * E;
+        vColOK = col < g.cols ? 1u : 0u;                           // a piece past the last column is skipped whole
+        // lanes past the last column re-read the row's LAST piece -- the line their neighbours are fetching anyway.  (They used to
+        // re-read column 0: one more 128-byte line per kept row for the ragged last tile, 68 MB of a 32-call launch's 824.)
+        voff = (vColOK ? col : (g.cols - 1u) / (uint32_t)E * (uint32_t)E) * 2u;
+        vRecords = (uint32_t)min((size_t)0xFFFFFFFFu, (size_t)g.numExperts * g.expertRows * g.rowPitch - (size_t)a.bucketsTrim);
+        vBuckLo = (uint32_t)(size_t)a.buckets; vBuckHi = (uint32_t)((size_t)a.buckets >> 32);
+        vRowPitch = g.rowPitch; vInDim = g.inDim; vRow0 = e * g.expertRows + (FMT == kFp16 ? j0 : j0 * 8u);
+    };
+    if constexpr (!PERSIST) {
+        stream_geom();
+        asm volatile("" : "+v"(vColOK), "+v"(voff), "+v"(vRecords), "+v"(vBuckLo), "+v"(vBuckHi), "+v"(vRowPitch), "+v"(vInDim), "+v"(vRow0));
+    }
     if constexpr (kOlMerge) {
         if (olEarly) {                                                // (published by the barrier of B, with vblk)
             float* const vf = reinterpret_cast<float*>(smem + __builtin_amdgcn_readfirstlane(lp.offO));
@@ -644,13 +668,11 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     if (wstamp) ph[3] = wall_clock64();
 
     // ---- D. stream the kept rows, scatter-accumulate into the LDS tile ----------------
-    const uint32_t col = t * (64u * E) + (uint32_t)lane * E;
-    const bool colOK = col < g.cols;                               // a piece past the last column is skipped whole
+    if constexpr (PERSIST) stream_geom();                          // (the persistent instantiations have no register to park anything in)
+    const bool colOK = vColOK != 0u;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint16_t*>(a.buckets), 0, (int)min((size_t)0xFFFFFFFFu, (size_t)g.numExperts * g.expertRows * g.rowPitch - (size_t)a.bucketsTrim), 0x00020000);
-    // lanes past the last column re-read the row's LAST piece -- the line their neighbours are fetching anyway.  (They used to
-    // re-read column 0: one more 128-byte line per kept row for the ragged last tile, 68 MB of a 32-call launch's 824.)
-    const uint32_t voff = (colOK ? col : (g.cols - 1u) / (uint32_t)E * (uint32_t)E) * 2u;
+        reinterpret_cast<uint16_t*>((size_t)(uint32_t)__builtin_amdgcn_readfirstlane(vBuckLo) | ((size_t)(uint32_t)__builtin_amdgcn_readfirstlane(vBuckHi) << 32)), 0,     // (uint32_t: readfirstlane returns int, and a sign-extended low half is another pointer)
+        (int)__builtin_amdgcn_readfirstlane(vRecords), 0x00020000);
     const uint32_t nU = (GA_ABLATE(ga) & 4u) ? 0u : __builtin_amdgcn_readfirstlane(n);   // n is workgroup-uniform; keep it in an SGPR
     // The waves of a workgroup do NOT run at one speed (the older wave wins the arbitration for issue slots and the memory
     // pipeline: measured, wave 0 gets through a static share of the rows 2-3x sooner than the last wave and then idles at
@@ -669,12 +691,12 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     auto decode_code = [&](uint32_t code, uint32_t& boff, float& dv) {
         {
             uint32_t rowIdx;
-            if (FMT == kFp16) { const uint32_t rank = code >> 12, jl = code & 4095u; rowIdx = rank * g.inDim + j0 + jl; dv = vblk[jl] * scale; }
+            if (FMT == kFp16) { const uint32_t rank = code >> 12, jl = code & 4095u; rowIdx = rank * vInDim + jl; dv = vblk[jl] * scale; }
             else {   // entry value = v*mean (bucketMulQ4.metal:52), the one magnitude of the row; carried in fixed point
-                rowIdx = j0 * 8u + code;
+                rowIdx = code;
                 dv = __int_as_float(__float2int_rn((vblk[code >> 3] * means[code]) * scale));
             }
-            boff = (e * g.expertRows + rowIdx) * g.rowPitch;        // byte offset of the bucket row (< 4 GiB, checked at registration)
+            boff = (vRow0 + rowIdx) * vRowPitch;                    // byte offset of the bucket row (< 4 GiB, checked at registration); vRow0 = e * expertRows + the slice's first row
         }
     };
     auto decode = [&](uint32_t i0, uint32_t& boff, float& dv) {
@@ -949,9 +971,9 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
 
     // ---- E. the tile, back in f32 -> one slab (native [slot][j][lane] order), write-through; ticket; last arriver
     //         of the tile reduces the S slabs in slice order and writes out[] -------------------------------
-    const size_t slabBytes = (size_t)g.slices * g.tiles * TILE_F * 4;
-    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(a_slabs, 0, (int)slabBytes, 0x00020000);
-    const uint32_t slabOff = (s * g.tiles + t) * (uint32_t)(TILE_F * 4);
+    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(a_slabs, 0, (int)__builtin_amdgcn_readfirstlane(vSlabBytes), 0x00020000);
+    const uint32_t slabOff = __builtin_amdgcn_readfirstlane(vSlabOff);
+    const uint32_t nSlices = __builtin_amdgcn_readfirstlane(vSlices);
     auto tile_out = [&](int o) -> float {                           // output o of the tile, native [slot][j][lane] order
         if (FMT == kFp16) return (float)acc[o] * unscale;
         const int slot = o / (E * 64), rem = o % (E * 64);          // slot = sub-bucket*8 + position
@@ -970,11 +992,22 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     if (fused && b == 0 && tid == 0 && !GA_CUTJOBS(ga)) a_cutoff[0] = cutoff;       // BucketMul.cutoff (bucketMul.swift:22) of a call without a cutoff job
     // (Round 4 built this hand-off WITHOUT ticket and drain -- a reducer named up front polling sentinel slabs -- and measured it
     //  slower on plain grids: branch `chain-launch`)
-    for (int o = tid * 2; o < TILE_F; o += NT * 2) {
-        const float s0 = tile_out(o), s1 = tile_out(o + 1);
-        typedef uint32_t u2 __attribute__((ext_vector_type(2)));
-        u2 pk; pk[0] = __float_as_uint(s0); pk[1] = __float_as_uint(s1);
-        __builtin_amdgcn_raw_buffer_store_b64(pk, srs, (uint32_t)o * 4u, slabOff, kSc1);
+    {   // (a fixed trip count, the tile read back in ONE LDS round trip: `for (o = tid * 2; o < TILE_F; ...)` compiled to a loop of dependent ones)
+        constexpr int kIt = (TILE_F + NT * 2 - 1) / (NT * 2);
+        float s0[kIt], s1[kIt];
+#pragma unroll
+        for (int it = 0; it < kIt; it++) {
+            const int o = min(tid * 2 + it * NT * 2, TILE_F - 2);
+            s0[it] = tile_out(o); s1[it] = tile_out(o + 1);
+        }
+#pragma unroll
+        for (int it = 0; it < kIt; it++) {
+            const int o = tid * 2 + it * NT * 2;
+            if (TILE_F % (NT * 2) != 0 && o >= TILE_F) continue;
+            typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+            u2 pk; pk[0] = __float_as_uint(s0[it]); pk[1] = __float_as_uint(s1[it]);
+            __builtin_amdgcn_raw_buffer_store_b64(pk, srs, (uint32_t)o * 4u, slabOff, kSc1);
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          // this wave's slab stores have left the CU
     if (stamp) { GA_TSTAMP(ga)[21] = wall_clock64(); GA_TSTAMP(ga)[22] = n; }
@@ -1004,7 +1037,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
         __syncthreads();
         if (tid == 0) {
             const uint32_t ticket = __hip_atomic_fetch_add(&a_counters[t], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            flags[0] = (ticket == g.slices - 1u) ? 1u : 0u;
+            flags[0] = (ticket == nSlices - 1u) ? 1u : 0u;
         }
         __syncthreads();
         if (flags[0] == 0u) { flush_stamps(); return; }
@@ -1018,7 +1051,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     const bool rstamp = GA_TSTAMP(ga) && ci == 0 && t == 0 && tid == 0;
     if (rstamp) GA_TSTAMP(ga)[23] = wall_clock64();
     typedef uint32_t u4v __attribute__((ext_vector_type(4)));
-    const uint32_t sliceStride = g.tiles * (uint32_t)(TILE_F * 4);
+    const uint32_t sliceStride = __builtin_amdgcn_readfirstlane(vSliceStride);
     // G thread groups share the slices when the workgroup has more threads than the tile has float4 columns (E = 1): each
     // group then has at most 16 slices = ONE round trip; the groups' partial sums meet in LDS and are added in group order.
     constexpr int kCols4 = TILE_F / 4;
@@ -1031,8 +1064,8 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     auto reduce_tile = [&](auto kc) {
         constexpr int kRed = decltype(kc)::value;          // 16-byte slab loads in flight per thread
         const int grp = G > 1 ? tid / kCols4 : 0;
-        const uint32_t per = G > 1 ? ((g.slices + G - 1) / G + 3u) / 4u * 4u : g.slices;   // slices per group, a multiple of 4
-        const uint32_t sl0 = (uint32_t)grp * per, sl1 = min(g.slices, sl0 + per);
+        const uint32_t per = G > 1 ? ((nSlices + G - 1) / G + 3u) / 4u * 4u : nSlices;   // slices per group, a multiple of 4
+        const uint32_t sl0 = (uint32_t)grp * per, sl1 = min(nSlices, sl0 + per);
         for (int o = (G > 1 ? tid % kCols4 : tid) * 4; o < TILE_F; o += (G > 1 ? kCols4 : NT) * 4) {
             const uint32_t vo = t * (uint32_t)(TILE_F * 4) + (uint32_t)o * 4u;
             // the residual of this thread's four outputs is asked for BEFORE the slabs (it was a dependent round trip after them:
@@ -1053,7 +1086,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
                 u4v r[kRed];
 #pragma unroll
                 for (int i = 0; i < kRed; i++)
-                    r[i] = __builtin_amdgcn_raw_buffer_load_b128(srs, vo, min(sl + i, g.slices - 1u) * sliceStride, kSc1);
+                    r[i] = __builtin_amdgcn_raw_buffer_load_b128(srs, vo, min(sl + i, nSlices - 1u) * sliceStride, kSc1);
 #pragma unroll
                 for (int i = 0; i < kRed; i++) {
                     if (sl + i < sl1) {
@@ -1091,7 +1124,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     };
     // (the four running sums take slices i%4; chunk sizes are multiples of 4, so the order does not depend on the chunk.
     //  Up to 16 slices per thread group the whole reduction is ONE memory round trip per thread.)
-    if (g.slices <= 8u * G) reduce_tile(std::integral_constant<int, 8>{});
+    if (nSlices <= 8u * G) reduce_tile(std::integral_constant<int, 8>{});
     else reduce_tile(std::integral_constant<int, 16>{});
     // (G > 1: thread group 0 reads the partial sums in the accumulator region after reduce_tile's only barrier; a persistent
     //  workgroup's next item -- or cutoff job -- zeroes its count table there, so the region must be quiescent first)

@@ -7,7 +7,11 @@ for v in main new; do
   echo "== $v rep $rep" >> $O/ab.txt
   timeout 200 python tools/qbench.py --group 1 --reps 3 --tag lone-$v >> $O/ab.txt 2>&1
   timeout 200 python tools/qbench.py --group 3 --reps 3 --tag three-$v >> $O/ab.txt 2>&1
-  timeout 200 python tools/cutprof.py >> $O/ab.txt 2>&1
+  timeout 200 python tools/cutprof.py 2>&1 | grep "11008) effort 0.25" >> $O/ab.txt
+  timeout 200 python tools/qbench.py --group 32 --reps 2 --overlap 4 --steps-per-graph 8 --tag big-$v >> $O/ab.txt 2>&1
+  timeout 200 python tools/qbench.py --shape 4096x4096 --group 32 --reps 2 --tag sq32-$v >> $O/ab.txt 2>&1
+  timeout 200 python tools/qbench.py --q4 1 --group 16 --reps 2 --tag q4x16-$v >> $O/ab.txt 2>&1
+  timeout 200 python tools/qbench.py --q4 1 --group 1 --reps 2 --tag q4lone-$v >> $O/ab.txt 2>&1
 done
 done
 for v in main new main new; do
