@@ -318,7 +318,12 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
 #endif                        // every workgroup: phase durations summed into tstamp[32..]
     unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};
     if (wstamp) ph[0] = wall_clock64();
+#ifdef EFFORT_CUT_FINE                                                    // (lab: the cutoff's fine stamps take the item stamps' words)
+    const bool stampCut = GA_TSTAMP(ga) && item == 0 && tid == 0, stamp = false;
+#else
     const bool stamp = GA_TSTAMP(ga) && item == 0 && tid == 0;            // phase stamps of item 0 (profiling aid)
+    const bool stampCut = stamp;
+#endif
     if (stamp) GA_TSTAMP(ga)[16] = wall_clock64();
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t B = g.sliceRows;
@@ -549,7 +554,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     }
     if (fromJob) {
     } else if (needCut) {
-        cutoff = block_find_cutoff<NT, kPreZero>(vj, prj, a.q, smem + offC, tbl, []() {}, stamp ? GA_TSTAMP(ga) + 8 : nullptr);
+        cutoff = block_find_cutoff<NT, kPreZero>(vj, prj, a.q, smem + offC, tbl, []() {}, stampCut ? GA_TSTAMP(ga) + 8 : nullptr);
         cachedCall = ci; cachedCutoff = cutoff;
         // (BucketMul.cutoff, bucketMul.swift:22, is stored with the slab, in E: a store here sits in front of the `s_waitcnt vmcnt(0)` that
         //  rankBound's consumer needs, and the call's first workgroup waited a microsecond for its acknowledgement)
@@ -1192,6 +1197,20 @@ __global__ __launch_bounds__(64 * W, (W <= 8 ? EFFORT_MIN_WAVES_PER_EU : 4)) voi
     __shared__ uint32_t s_item;
     __shared__ unsigned long long s_next;                  // the item after the current one | the generation (item count) it was pulled in << 32: ONE word,
                                                            // so that a wave polling mid-loop can never pair a new generation with a stale item
+#ifndef EFFORT_NO_TOUCH
+    // Plain grids: a workgroup's first ~10 scalar loads -- item range, call descriptor, geometry, pointers -- depend on one another,
+    // and each first touch of a 64-byte line of the kernel-argument segment misses the scalar cache: the misses queue up behind one
+    // another on the call's chain.  One dword of every line a small group's prologue reads (header, ranges, geometries, the first
+    // three descriptors) is asked for HERE, all at once; the values go nowhere -- the lines are warm when the chain asks for them.
+    if constexpr (!PERSIST) {
+        const uint32_t* const kw = reinterpret_cast<const uint32_t*>(&ga);
+        uint32_t touch[12];
+#pragma unroll
+        for (int i = 0; i < 12; i++) touch[i] = kw[i * 16];
+#pragma unroll
+        for (int i = 0; i < 12; i++) asm volatile("" :: "s"(touch[i]));
+    }
+#endif
     const uint32_t total = ga.totalItems + GA_CUTJOBS(ga);
     uint32_t cachedCall = 0xFFFFFFFFu; float cachedCutoff = 0.0f;
     const uint32_t x = blockIdx.x & 7u;                    // block b sits on XCD b%8; item i wants XCD i%8

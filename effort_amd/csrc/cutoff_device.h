@@ -71,6 +71,11 @@ __device__ __forceinline__ float bisect_to_cell_edge(float newBound, float minBo
     return newBound;
 }
 
+#ifdef EFFORT_CUT_FINE            // lab builds: shader-clock stamps inside the cutoff (tools/lab/cutfine.py), ten of them at dbg[8..17]
+#define EFFORT_FSTAMP(i) if (dbg && tid == 0) fine[i] = clock64();
+#else
+#define EFFORT_FSTAMP(i)
+#endif
 template <int NT, bool PREZERO = false, typename Idle>
 __device__ __forceinline__ float block_find_cutoff(const float (&vj)[4096 / NT], const uint16_t (&prj)[4096 / NT],
                                                    uint32_t q, char* lds, uint32_t* tbl, Idle idle,
@@ -87,6 +92,10 @@ __device__ __forceinline__ float block_find_cutoff(const float (&vj)[4096 / NT],
     const int tid = tid0, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (dbg && tid == 0) { dbg[0] = wall_clock64(); dbg[6] = clock64(); }
+#ifdef EFFORT_CUT_FINE
+    unsigned long long fine[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    EFFORT_FSTAMP(0)
 
     if (tid < 4) s_cnt[tid] = 0;
     // the 4096 values bf16(|(1e5*v[j]) * bf16(probe[j])|), products evaluated left to right (:160), kept as
@@ -120,12 +129,14 @@ __device__ __forceinline__ float block_find_cutoff(const float (&vj)[4096 / NT],
             atomicAdd(&tbl[c < CAP ? cutoff_cell_index<NT>(c) : pad], 1u);
         }
     }
+    EFFORT_FSTAMP(1)
     // wave results on DPP (no LDS round trips), one slot per wave; the count table is zeroed under the same barrier (its
     // region is free on entry): ONE barrier where there were three
     pmin = wave_min_u32(pmin); pmax = wave_max_u32(pmax); pminnz = wave_min_u32(pminnz);
     if (lane == 0) { s_wm[wave] = pmin; s_wm[NW + wave] = pmax; s_wm[2 * NW + wave] = pminnz; }
     if constexpr (!PREZERO) cutoff_table_zero<NT>(tbl, tid);
     __syncthreads();
+    EFFORT_FSTAMP(2)
     // (the waves' results in ONE batch of 16-byte loads: left to the scheduler they came in two, a second LDS latency on the chain)
     uint32_t mmin = 0xFFFFFFFFu, mmax = 0u, mnz = 0xFFFFFFFFu;
     if constexpr (NW % 4 == 0) {
@@ -193,6 +204,7 @@ __device__ __forceinline__ float block_find_cutoff(const float (&vj)[4096 / NT],
         done = round(s_cnt[slot]);
     }
     if (dbg && tid == 0) dbg[1] = wall_clock64();
+    EFFORT_FSTAMP(3)
 
     if (!done && patHi != patLo + 1u) {                  // uniform
         // ---- histogram over the cells [base, top]; ONE wave turns it into the five order statistics the rounds need ----
@@ -234,6 +246,7 @@ __device__ __forceinline__ float block_find_cutoff(const float (&vj)[4096 / NT],
                 for (uint32_t i = 0; i < kBatch; i++) mine += (xs[i].x + xs[i].y) + (xs[i].z + xs[i].w);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            EFFORT_FSTAMP(4)
             const uint32_t pre = wave_prefix_sum_u32(mine), wtotal = (uint32_t)__builtin_amdgcn_readlane((int)pre, 63);
             const uint32_t c1 = above + wtotal - pre;                          // count(last cell of this lane's segment)
             const uint32_t allGE = above + wtotal;                             // values with pattern >= base
@@ -282,6 +295,7 @@ __device__ __forceinline__ float block_find_cutoff(const float (&vj)[4096 / NT],
                 tk[j] = (k <= 0 || sgAll >= 64u) ? 0xFFFFFFFFu : ((k > 4096 || (int)allGE < k) ? 0u : base + n);
             }
             if (dbg && tid == 0) dbg[2] = wall_clock64();
+            EFFORT_FSTAMP(5)
             uint32_t tM2 = tk[0], tM1 = tk[1], tM = tk[2], tP1 = tk[3], tP2 = tk[4];
             float nb = newBound, lo = minBound, hi = maxBound;
             uint32_t pLo = patLo, pHi = patHi, nLoops = (uint32_t)loops;
@@ -347,6 +361,7 @@ __device__ __forceinline__ float block_find_cutoff(const float (&vj)[4096 / NT],
                     if (sm) { fin = (__builtin_amdgcn_readlane((uint32_t)finr, e) & 1u) != 0u; break; }
                 }
             }
+            EFFORT_FSTAMP(6)
             done = fin;
             newBound = nb; minBound = lo; maxBound = hi; patLo = pLo; patHi = pHi; loops = (int)nLoops;
             if (!done) {
@@ -354,6 +369,7 @@ __device__ __forceinline__ float block_find_cutoff(const float (&vj)[4096 / NT],
                 // under X); those counts differ by >= 3 and neither equals the target, or the loop had exited.
                 newBound = bisect_to_cell_edge(newBound, minBound, maxBound, __uint_as_float(patHi << 16), loops);
             }
+            EFFORT_FSTAMP(7)
             if (lane == 0) s_res[0] = newBound;
         } else {
             idle();
@@ -367,6 +383,10 @@ __device__ __forceinline__ float block_find_cutoff(const float (&vj)[4096 / NT],
     } else {
         idle();
     }
+    EFFORT_FSTAMP(8)
+#ifdef EFFORT_CUT_FINE
+    if (dbg && tid == 0) { for (int i = 0; i < 10; i++) dbg[8 + i] = fine[i]; }
+#endif
     if (dbg && tid == 0) { dbg[3] = wall_clock64(); dbg[4] = dbg[3]; dbg[5] = (unsigned long long)loops * 1000ull + nPasses; dbg[7] = clock64(); }
     return newBound;
 }
