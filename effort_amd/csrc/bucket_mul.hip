@@ -311,7 +311,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     int tid0 = threadIdx.x;
     asm volatile("" : "+v"(tid0));      // opaque per item: keeps the compiler from hoisting every tid-derived value out of the item loop (+50 VGPRs)
     const int tid = tid0, lane = tid & 63;
-#ifdef EFFORT_NO_STAMPS
+#if defined(EFFORT_NO_STAMPS) || defined(EFFORT_CUT_FINE)
     const bool wstamp = false;
 #else
     const bool wstamp = GA_TSTAMP(ga) && tid == 0;
@@ -320,7 +320,9 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     if (wstamp) ph[0] = wall_clock64();
 #ifdef EFFORT_CUT_FINE                                                    // (lab: the cutoff's fine stamps take the item stamps' words)
     const bool stampCut = GA_TSTAMP(ga) && item == 0 && tid == 0, stamp = false;
+#define EFFORT_PSTAMP(i) if (stampCut) GA_TSTAMP(ga)[26 + (i)] = clock64();
 #else
+#define EFFORT_PSTAMP(i)
     const bool stamp = GA_TSTAMP(ga) && item == 0 && tid == 0;            // phase stamps of item 0 (profiling aid)
     const bool stampCut = stamp;
 #endif
@@ -348,7 +350,9 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     const uint32_t e = a.expNo ? a.expNo[0] : 0u;
 
     // ---- A. everything the selection needs lands in LDS (stage_issue): the row means of the candidate slots, the slice of v
+    EFFORT_PSTAMP(1)
     if (!staged) stage_issue<FMT, W, COMPACT>(ga, ref, tid, smem, lp, par);
+    EFFORT_PSTAMP(2)
     // plain grids (one item per workgroup: the accumulator region is untouched so far): the cutoff's count table, which borrows
     // that region, is cleared HERE, and the barrier its adds need behind the clearing passes under the staged loads' round trip
     // (block_find_cutoff, PREZERO) instead of on the cutoff's own chain
@@ -482,6 +486,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
         __builtin_amdgcn_s_barrier();
     }
     if (needCut && !viaJob) load_cut_inputs();
+    EFFORT_PSTAMP(3)
     // the call's cutoff job publishes ONE word: the cutoff's bits (a non-negative float) with the sign bit raised.  Thread 0
     // asks for it here, before the staged loads are awaited
     uint32_t* const cutWords = ga.queue + 9 * 16;
@@ -490,6 +495,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     // the staged loads have landed (each thread waits for its own; it reads back only what its own lane loaded until the
     // next barrier).  The slice's absolute sum bounds every partial sum of this workgroup (see the scale below).
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    EFFORT_PSTAMP(4)
     // (plain grids) what the streaming phase (D) starts with -- the bucket buffer's descriptor, this lane's column offset, the row
     // arithmetic -- parked in vector registers like the hand-off's geometry above: re-read from the kernel-argument segment where D
     // begins, they were a scalar-memory round trip between the selection and the first row load
@@ -1137,6 +1143,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     if (rstamp) GA_TSTAMP(ga)[24] = wall_clock64();
     if (tid == 0) {
         __hip_atomic_store(&a_counters[t], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next call
+#ifndef EFFORT_CUT_FINE
         if (GA_TSTAMP(ga)) {
             flush_stamps();
             const uint32_t done = __hip_atomic_fetch_add(ga.groupDone, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1151,6 +1158,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
                 __hip_atomic_store(ga.groupDone, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
+#endif
     }
 }
 
@@ -1197,6 +1205,9 @@ __global__ __launch_bounds__(64 * W, (W <= 8 ? EFFORT_MIN_WAVES_PER_EU : 4)) voi
     __shared__ uint32_t s_item;
     __shared__ unsigned long long s_next;                  // the item after the current one | the generation (item count) it was pulled in << 32: ONE word,
                                                            // so that a wave polling mid-loop can never pair a new generation with a stale item
+#ifdef EFFORT_CUT_FINE
+    if (GA_TSTAMP(ga) && blockIdx.x == 0 && threadIdx.x == 0) GA_TSTAMP(ga)[26] = clock64();
+#endif
 #ifndef EFFORT_NO_TOUCH
     // Plain grids: a workgroup's first ~10 scalar loads -- item range, call descriptor, geometry, pointers -- depend on one another,
     // and each first touch of a 64-byte line of the kernel-argument segment misses the scalar cache: the misses queue up behind one
@@ -1211,6 +1222,12 @@ __global__ __launch_bounds__(64 * W, (W <= 8 ? EFFORT_MIN_WAVES_PER_EU : 4)) voi
         for (int i = 0; i < 12; i++) asm volatile("" :: "s"(touch[i]));
     }
 #endif
+#ifdef EFFORT_CUT_FINE
+#define EFFORT_ESTAMP(i) if (GA_TSTAMP(ga) && blockIdx.x == 0 && threadIdx.x == 0) GA_TSTAMP(ga)[16 + (i)] = clock64();
+#else
+#define EFFORT_ESTAMP(i)
+#endif
+    EFFORT_ESTAMP(0)
     const uint32_t total = ga.totalItems + GA_CUTJOBS(ga);
     uint32_t cachedCall = 0xFFFFFFFFu; float cachedCutoff = 0.0f;
     const uint32_t x = blockIdx.x & 7u;                    // block b sits on XCD b%8; item i wants XCD i%8
@@ -1256,10 +1273,12 @@ __global__ __launch_bounds__(64 * W, (W <= 8 ? EFFORT_MIN_WAVES_PER_EU : 4)) voi
             continue;
         }
         ItemRef ref;
+        EFFORT_ESTAMP(1)
         if (!locate_item(ga, item - GA_CUTJOBS(ga), ref)) {    // padding of the item grid (slices are dealt in rounds of 8)
             item = GA_PERSISTENT(ga) ? pull_sync() : total;
             continue;
         }
+        EFFORT_ESTAMP(2)
         gen++;
         bool stagedNext = false;
         auto prefetch = [&]() -> bool {

@@ -234,6 +234,8 @@ __device__ __forceinline__ float block_find_cutoff(const float (&vj)[4096 / NT],
             const uint4* row = reinterpret_cast<const uint4*>(tbl + (uint32_t)lane * kSegP);
             // (the loads of a batch are ALL issued before the first sum -- one LDS latency per batch of 16, ~250 cycles here, not one
             //  per four loads as the scheduler would have it)
+            // (measured with shader-clock stamps, tools/lab/cutfine.py: a wave's sixteen 16-byte reads cost ~64 cycles each whatever the
+            //  number of active lanes -- masking the lanes whose cells cannot hold a value was 140 cycles SLOWER; read + sum ~1050 cycles)
             uint32_t mine = 0;
             constexpr uint32_t kBatch = kSeg / 4u < 16u ? kSeg / 4u : 16u;
 #pragma unroll
@@ -385,7 +387,7 @@ __device__ __forceinline__ float block_find_cutoff(const float (&vj)[4096 / NT],
     }
     EFFORT_FSTAMP(8)
 #ifdef EFFORT_CUT_FINE
-    if (dbg && tid == 0) { for (int i = 0; i < 10; i++) dbg[8 + i] = fine[i]; }
+    if (dbg && tid == 0) { for (int i = 3; i < 7; i++) dbg[8 + i] = fine[i]; }     // ([16..19]: the kernel's entry stamps; [23..24]: the reduction's)
 #endif
     if (dbg && tid == 0) { dbg[3] = wall_clock64(); dbg[4] = dbg[3]; dbg[5] = (unsigned long long)loops * 1000ull + nPasses; dbg[7] = clock64(); }
     return newBound;

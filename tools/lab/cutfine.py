@@ -8,20 +8,33 @@ import effort_amd as ea
 from bench import make_weights
 dev = torch.device("cuda", 0)
 g = ea.gpu(0)
-names = ["values+adds", "dpp min/max", "barrier A", "range read", "table read+sum", "T(k)", "rounds", "tail", "exchange"]
+names = ["entry stamp", "values+adds", "dpp min/max + barrier A", "range read", "table read+sum", "T(k)", "rounds", "tail", "exchange"]
 for shape in ((4096, 11008),):
     ews = make_weights(ea, 4, shape[0], shape[1], 1234, dev, keep_core=False)
     gen = torch.Generator(device=dev); gen.manual_seed(42)
     v = torch.randn(shape[0], generator=gen, device=dev)
     out = torch.zeros(shape[1], device=dev)
     for effort in (0.25, 0.5, 1.0):
-        for rep in range(4):
-            g.enable_kernel_timing(2)
-            ea.bucketMul(v, ews[rep], None, out, effort)
-            g.eval()
-            st = g.debug_stamps()
-            g.enable_kernel_timing(0)
+        # as the decode loop and the bench issue it: lone calls on rotating matrices, captured into a hipGraph, replayed
+        g.enable_kernel_timing(2)
+        def run():
+            for rep in range(4):
+                ea.bucketMul(v, ews[rep], None, out, effort)
+        run(); torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            run()
+        g._bind_stream()
+        for _ in range(5):
+            gr.replay()
+        torch.cuda.synchronize()
+        st = g.debug_stamps()
+        g.enable_kernel_timing(0)
         c = st[0:8]; f = st[8:18]
         seq = [c[6]] + [x for x in f[:9]]
         d = [seq[i + 1] - seq[i] for i in range(9)]
+        pz = st[18:23]
+        en = st[8:11]
+        print(f"   entry: touched {en[0] - pz[0]}, before locate_item {en[1] - pz[0]}, located {en[2] - pz[0]}")
+        print(f"   prologue (cycles from kernel entry): item start {pz[1] - pz[0]}, stage issued {pz[2] - pz[0]}, cut inputs asked {pz[3] - pz[0]}, all landed {pz[4] - pz[0]}, cutoff entry {c[6] - pz[0]}")
         print(f"{shape} effort {effort}: total {seq[-1] - seq[0]} cycles; " + "; ".join(f"{n} {x}" for n, x in zip(names, d)) + f"; loops {c[5] // 1000}")
