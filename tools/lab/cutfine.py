@@ -30,11 +30,10 @@ for shape in ((4096, 11008),):
         torch.cuda.synchronize()
         st = g.debug_stamps()
         g.enable_kernel_timing(0)
-        c = st[0:8]; f = st[8:18]
-        seq = [c[6]] + [x for x in f[:9]]
-        d = [seq[i + 1] - seq[i] for i in range(9)]
-        pz = st[18:23]
-        en = st[8:11]
-        print(f"   entry: touched {en[0] - pz[0]}, before locate_item {en[1] - pz[0]}, located {en[2] - pz[0]}")
-        print(f"   prologue (cycles from kernel entry): item start {pz[1] - pz[0]}, stage issued {pz[2] - pz[0]}, cut inputs asked {pz[3] - pz[0]}, all landed {pz[4] - pz[0]}, cutoff entry {c[6] - pz[0]}")
-        print(f"{shape} effort {effort}: total {seq[-1] - seq[0]} cycles; " + "; ".join(f"{n} {x}" for n, x in zip(names, d)) + f"; loops {c[5] // 1000}")
+        # host32[k] = tstamp[8 + k]: [6] clock at the cutoff's entry; [8..10] kernel entry (after the touch loads), before / after locate_item;
+        # [11..14] inside the cutoff: range known, histogram read + summed, order statistics found, rounds done; [18..22] kernel entry (before the
+        # touch), item start, stage issued, cut inputs asked, all landed
+        c, en, f, pz = st[0:8], st[8:11], st[11:15], st[18:23]
+        print(f"{shape} effort {effort} (cycles): kernel entry -> touched {en[0] - pz[0]} -> locate_item {en[1] - pz[0]} -> located {en[2] - pz[0]} -> item start {pz[1] - pz[0]} "
+              f"-> stage issued {pz[2] - pz[0]} -> cut inputs asked {pz[3] - pz[0]} -> all landed {pz[4] - pz[0]} -> cutoff entry {c[6] - pz[0]} -> range known {f[0] - pz[0]} "
+              f"-> histogram read and summed +{f[1] - f[0]} -> order statistics +{f[2] - f[1]} -> rounds +{f[3] - f[2]} ({c[5] // 1000} rounds)")
