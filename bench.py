@@ -1334,5 +1334,38 @@ def main():
         dist.destroy_process_group()
 
 
+def guarded():
+    """N = 1: the measurement runs in a CHILD process and this one relays its line.  The record has ~20 auxiliary sections behind
+    the headline (profiler children, four contexts, RCCL, a decode loop ...); should one of them ever take the process down -- one
+    run in this round's ~40 ended in glibc's `free(): invalid pointer` somewhere behind the headline -- the driver would get no
+    line at all.  If the child dies or prints no record, the contract-complete subset (headline + roofline + cpu_baseline:
+    --no-sweep --no-pmc) is run instead, then the headline alone; what was dropped is named in the line's `note`."""
+    import subprocess
+    env = dict(os.environ, BENCH_CHILD="1")
+    note = None
+    for extra in ([], ["--no-sweep", "--no-pmc"], ["--headline-only"]):
+        p = subprocess.run([sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + extra, env=env, stdout=subprocess.PIPE)
+        line = None
+        for cand in reversed(p.stdout.decode(errors="replace").strip().split("\n")):
+            try:
+                d = json.loads(cand)
+                if isinstance(d, dict) and "metric" in d and "value" in d:
+                    line = d
+                    break
+            except ValueError:
+                continue
+        if line is not None:
+            if note:
+                line["note"] = note
+            print(json.dumps(line, separators=(",", ":")), flush=True)
+            return 0
+        note = (note + "; " if note else "") + f"the run with flags {extra or ['(default)']} ended with exit code {p.returncode} and no record"
+        log("bench.py: " + note + " -- falling back")
+    return 1
+
+
 if __name__ == "__main__":
-    main()
+    if os.environ.get("BENCH_CHILD") or os.environ.get("BENCH_NO_GUARD") or int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("BENCH_FORCE_DIST") or "--headline-only" in sys.argv:
+        main()
+    else:
+        sys.exit(guarded())

@@ -48,6 +48,8 @@ struct effort_ctx {
     int numCU = 256;
     Lane lane[kMaxLanes];
     int nLanes = 1, lastLane = 0, nextLane = 0;
+    int busyStreak = 0;               // overlap mode: consecutive launches of a dependent chain that found the context's stream "busy" (see the lane choice)
+    bool migrated = false;            // ... and the chain was moved to another lane for it (once between joins)
     hipEvent_t forkEv = nullptr;      // overlap mode: "everything enqueued on the context's stream so far"
     size_t slabBytes = 0;
     uint32_t* d_blockScratch = nullptr;
@@ -252,6 +254,7 @@ static int join_lanes(effort_ctx* c) {
         if (e != hipSuccess) { snprintf(c->err, sizeof(c->err), "join: %s", hipGetErrorString(e)); return EFFORT_ERR_HIP; }
         L.pending = false; L.reads.clear(); L.writes.clear();
     }
+    c->busyStreak = 0; c->migrated = false;
     return EFFORT_OK;
 }
 static bool overlaps(const std::vector<Lane::Range>& a, const std::vector<Lane::Range>& b) {
@@ -728,6 +731,19 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
             if (L.pending && (overlaps(rd, L.writes) || overlaps(wr, L.writes) || overlaps(wr, L.reads))) hazard[nh++] = i;
         }
         li = nh ? hazard[0] : c->nextLane;
+        // A chain of dependent launches lives on ONE lane and forks from the context's stream only when that stream is busy
+        // (fork_lane).  HIP multiplexes streams over a few hardware queues, and a lane that happens to share its queue with the
+        // context's stream makes hipStreamQuery(context's stream) say "busy" while the LANE works: every link of the chain then
+        // pays the event-record-and-wait fork, +8 us per call (tools/lab/lane_probe.py with EXTRA_CONTEXTS=1: one lane of four;
+        // round 5's bench record showed it at three of five efforts).  Four busy answers in a row on a pure chain: the chain MOVES
+        // to an idle lane -- one cross-lane edge, the ordinary hazard wait below -- where the stream's answer is its own again.
+        // Once between joins: if the busy answers were true (the caller really enqueues between the calls) nothing is lost but that edge.
+        if (nh == 1 && c->busyStreak >= 4 && !c->migrated) {
+            for (int k = 1; k < c->nLanes; k++) {
+                const int cand = (hazard[0] + k) % c->nLanes;
+                if (!c->lane[cand].pending) { li = cand; c->migrated = true; c->busyStreak = 0; break; }
+            }
+        }
     } else if (c->nLanes > 1) {
         if (join_lanes(c) != EFFORT_OK) return EFFORT_ERR_HIP;        // timing modes: one launch at a time, on lane 0
     }
@@ -759,9 +775,8 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
             HIP_TRY(c, hipEventRecord(c->forkEv, c->stream));
             HIP_TRY(c, hipStreamWaitEvent(L.own, c->forkEv, 0));
         }
+        c->busyStreak = (wait && nh == 1 && hazard[0] == li) ? c->busyStreak + 1 : 0;     // (a dependent chain's link that had to fork)
         guard.forked = true;
-        for (int k = 0; k < nh; k++) if (hazard[k] != li) { HIP_TRY(c, lane_mark(c->lane[hazard[k]])); HIP_TRY(c, hipStreamWaitEvent(L.own, c->lane[hazard[k]].done, 0)); }
-        if (!nh) c->nextLane = (c->nextLane + 1) % c->nLanes;
         // (a range the lane holds already is not recorded twice: a loop that multiplies into the same vectors over and over --
         //  the reference's timing loop -- would otherwise grow the lists to their cap, and every call scan thousands of ranges)
         auto add_new = [](std::vector<Lane::Range>& have, const std::vector<Lane::Range>& more) {
@@ -771,6 +786,16 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
                 if (!seen) have.push_back(x);
             }
         };
+        // a lane this launch waits for: from here on this lane's order covers everything that lane has enqueued, so its ranges move
+        // here and it is no longer pending (a join need not wait for it, a later launch that touches those ranges follows THIS lane)
+        for (int k = 0; k < nh; k++) if (hazard[k] != li) {
+            Lane& H = c->lane[hazard[k]];
+            HIP_TRY(c, lane_mark(H));
+            HIP_TRY(c, hipStreamWaitEvent(L.own, H.done, 0));
+            add_new(L.reads, H.reads); add_new(L.writes, H.writes);
+            H.reads.clear(); H.writes.clear(); H.pending = false;
+        }
+        if (!nh) c->nextLane = (c->nextLane + 1) % c->nLanes;
         add_new(L.reads, rd);
         add_new(L.writes, wr);
         return EFFORT_OK;

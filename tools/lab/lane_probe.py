@@ -9,6 +9,10 @@ from bench import make_weights
 dev = torch.device("cuda", 0)
 g = ea.gpu(0)
 lib = ea.lib()
+extra = []
+for _ in range(int(os.environ.get("EXTRA_CONTEXTS", "0"))):      # other contexts' lanes shift which hardware queue a lane's stream lands on
+    x = ea.Gpu(0); x.set_overlap(4); extra.append(x)
+side = [torch.cuda.Stream() for _ in range(int(os.environ.get("EXTRA_STREAMS", "0")))]
 ws = make_weights(ea, 32, 4096, 14336, 777, dev, keep_core=False)
 hs = [C.c_void_p(ew.handle) if not isinstance(ew.handle, C.c_void_p) else ew.handle for ew in ws]
 v = torch.randn(4096, device=dev); t = torch.zeros(14336, device=dev)
@@ -20,9 +24,9 @@ def loop(n, s):
     for i in range(n):
         rc |= fn(ctx, hs[i & 31], vp, None, tp, s)
     return rc
-for lanes in (1, 4):
+for lanes in (4,):
     g.set_overlap(lanes)
-    for s in (1.0, 0.5, 0.25):
+    for s in (0.5,):
         row = []
         for k in range(8):
             assert loop(300, s) == 0 if k == 0 else True
