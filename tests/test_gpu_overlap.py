@@ -211,6 +211,46 @@ def test_long_dependent_chains_without_a_join(ea, oracle_cpu):
     ctx.close()
 
 
+def test_a_chain_moves_lanes_when_the_stream_keeps_answering_busy(ea, oracle_cpu):
+    """A dependent chain lives on one lane and forks from the context's stream only when that stream is busy; four busy answers in
+    a row (a lane that shares its hardware queue with the caller's stream makes the idle test lie: DESIGN 4.2 iv) and the chain
+    MOVES to an idle lane, which takes the old lane's address ranges over.  Here the stream IS busy -- the caller parks a sleep
+    kernel on it before every call -- so every link forks and the move happens; a second chain and a launch that depends on both run
+    beside it.  Bit-identical with one lane; the order after the caller's own work is kept (the input is written by a copy the caller
+    enqueues on the stream between the calls)."""
+    inDim = outDim = 4096
+    W, b, s, p = converted(oracle_cpu, outDim, inDim, scale=1.0 / 64.0)
+    W2, b2, s2, p2 = converted(oracle_cpu, outDim, inDim, seed=77, scale=1.0 / 64.0)
+    ewA, ewB = gpu_weights(ea, W, b, s, p), gpu_weights(ea, W2, b2, s2, p2)
+    ctx = ea.Gpu(0)
+    x0, u0 = devf(make_v(inDim, seed=5)), devf(make_v(inDim, seed=6))
+    x, y, u, w, z, k = (torch.zeros(inDim, device=DEV) for _ in range(6))
+
+    def run():
+        x.copy_(x0); u.copy_(u0)
+        for i in range(12):
+            torch.cuda._sleep(200_000)                                          # the caller's stream is busy when the call arrives
+            k.copy_(x if i % 2 == 0 else y)                                     # ... with work the launch must follow: its input
+            ea.bucketMul(k, ewA, None, y if i % 2 == 0 else x, 0.5, gpu=ctx)    # one chain, ping-pong through x / y
+            if i % 3 == 0:
+                ea.bucketMul(u, ewB, None, w, 0.5, gpu=ctx)                     # another chain, elsewhere
+                ea.bucketMul(w, ewB, None, u, 0.5, gpu=ctx)
+        ea.bucketMul(x, ewB, None, z, 0.5, gpu=ctx)                             # depends on the moved chain
+        ctx.eval()
+        return x.clone(), y.clone(), u.clone(), z.clone()
+    ctx._bind_stream()
+    ctx.set_overlap(1)
+    one = run()
+    ctx.set_overlap(4)
+    four = run()
+    again = run()                                                               # (the move is allowed once between joins: a second batch moves again)
+    for a_, b_, c_ in zip(one, four, again):
+        assert torch.isfinite(a_).all() and float(a_.abs().max()) > 0
+        assert torch.equal(a_, b_) and torch.equal(a_, c_)
+    ctx.set_overlap(1)
+    ctx.close()
+
+
 def test_timed_configuration_as_a_whole(ea, oracle_cpu):
     """bench.py's timed job, as a whole: 4096 x 11008 matrices converted on line-aligned rows (pitch 1408), 32 calls per
     launch at 25 % effort on the heuristic geometry (persistent workgroups, cutoff jobs, COMPACT means, E = 4), ONE context
