@@ -3,7 +3,10 @@ LOOKUPS") against the oracle's findCutoff32.  The device code replaces every use
 the steering comparison and the two count-driven exit tests -- with comparisons of the threshold's bf16 CELL against five
 order statistics of the values; this restates that control flow in numpy f32 arithmetic -- including the hand-over to the
 closed-form tail and the ballot rounds for value ranges wider than the table -- asserts every shortcut against the count
-it stands for, and compares the float BITS with the C oracle over seeded inputs that leave the loop through every exit.  (The device code itself is compared with the oracle by the -m gpu tests: test_cutoff_*.)"""
+it stands for, and compares the float BITS with the C oracle over seeded inputs that leave the loop through every exit.  The five
+order statistics are also found the way the device finds them since round 5 -- from the HISTOGRAM of the cells, one wave, two
+levels (`_device_order_statistic`), over the cells between the bounds and over the fixed window plain grids count into before the
+value range is known -- and must be the same cells.  (The device code itself is compared with the oracle by the -m gpu tests: test_cutoff_*.)"""
 import numpy as np
 import pytest
 
@@ -37,6 +40,29 @@ def _cell_edge_tail(nb, lo, hi, X, loops):
 
 
 K_BLK = 16
+WINDOW_BASE = (127 - 10) << 7          # kCutoffWindowBase: the cell of 2^-10
+
+
+def _device_order_statistic(hist, base, above, k):
+    """T(k) as wave 0 computes it from the histogram (cutoff_device.h, "one wave turns the histogram into the five order
+    statistics"): lane L sums its CAP / 64 consecutive cells; a suffix scan over the lanes gives the count above each lane's last
+    cell; whole lanes whose last cell still reaches k count in full, the boundary lane's cells are scanned the same way."""
+    seg = CAP // 64
+    lanes = hist.reshape(64, seg).sum(axis=1)
+    total = int(lanes.sum())
+    c1 = above + total - np.cumsum(lanes)                          # count(last cell of lane L) = everything in later lanes, + above
+    allGE = above + total
+    sgAll = int((c1 >= k).sum())                                   # (the counts fall with the lane: a prefix)
+    assert all(c1[i] >= c1[i + 1] for i in range(63))
+    sg = min(sgAll, 63)
+    cells = hist[sg * seg:(sg + 1) * seg]
+    cnt = int(c1[sg]) + int(cells.sum()) - np.cumsum(cells)        # count(cell) = later cells of the lane + what lies behind the lane
+    n = sg * seg + int((cnt >= k).sum())
+    if k <= 0 or sgAll >= 64:
+        return 0xFFFFFFFF
+    if k > 4096 or allGE < k:
+        return 0
+    return base + n
 
 
 def _bits(f):
@@ -138,6 +164,13 @@ def model_cutoff(v, probes_u16, q):
         return 0xFFFFFFFF if n == CAP else base + n
     m = effort
     tM2, tM1, tM, tP1, tP2 = (first_cell_below(m + d) for d in (-2, -1, 0, 1, 2))
+    # the device finds the same five cells from the HISTOGRAM, one wave, two levels (cutoff_device.h, round 5) -- from the cells
+    # [base, top], or, on plain grids, from a fixed window counted before the range was known
+    hist = np.bincount((vp[(vp >= base) & (vp <= tp)] - base).astype(np.int64), minlength=CAP)[:CAP]
+    assert [_device_order_statistic(hist, base, above, m + d) for d in (-2, -1, 0, 1, 2)] == [tM2, tM1, tM, tP1, tP2]
+    if pLo == NO_LO and pHi == NO_HI and pminNZ >= WINDOW_BASE and pmax - WINDOW_BASE < CAP:
+        win = np.bincount((vp[vp >= WINDOW_BASE] - WINDOW_BASE).astype(np.int64), minlength=CAP)[:CAP]
+        assert [_device_order_statistic(win, WINDOW_BASE, 0, m + d) for d in (-2, -1, 0, 1, 2)] == [tM2, tM1, tM, tP1, tP2]
     # count(hi) as "how many of m-1, m-2 it reaches", count(lo) as "how many of m+1, m+2": |maxCount - minCount| < 3 <=> catHi > catLo
     catHi = int(pHi < tM1) + int(pHi < tM2) if pHi != NO_HI else int(maxC >= m - 1) + int(maxC >= m - 2)
     catLo = int(pLo < tP1) + int(pLo < tP2) if pLo != NO_LO else int(minC >= m + 1) + int(minC >= m + 2)
