@@ -225,3 +225,56 @@ def test_bench_guard_relays_the_record_or_falls_back(monkeypatch, capsys):
     line = json.loads(out[0])
     assert line["value"] == 1.0 and "exit code -6" in line["note"]
     assert "--no-sweep" in calls[1] and "--no-sweep" not in calls[0]
+
+
+def _run_bench(args, env_extra, timeout=180):
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "BENCH_CHILD", "BENCH_NO_GUARD")}
+    env.update(env_extra)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` with no launcher around it starts its N ranks itself (one process each, RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* set) and relays rank 0's ONE line with n_gpus = N.  Run here over gloo with the stub step
+    (BENCH_STUB=1: the launch contract -- rendezvous, warm-up, barrier, K steps, barrier, max over ranks -- without a GPU)."""
+    import json
+    p = _run_bench(["--gpus", "2", "--steps", "5", "--warmup", "2"], {"BENCH_STUB": "1"})
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.strip().split("\n") if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["steps"] == 5 and d["warmup"] == 2
+    assert d["config"]["partition"] == "matrices" and "launch_ranks" in d["launched_by"] and d["value"] > 0
+    for k in ("metric", "value", "unit", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in d, k
+
+
+def test_bench_honours_an_external_launcher():
+    """Under torch.distributed.run (the driver's N > 1 command) the launcher's environment is used as it is: no second level of ranks."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "BENCH_CHILD")}
+    env["BENCH_STUB"] = "1"
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1"], env=env, capture_output=True, text=True, timeout=240)
+    assert p.returncode == 0, p.stderr[-2000:]
+    recs = [json.loads(ln) for ln in p.stdout.strip().split("\n") if ln.startswith("{")]
+    assert len(recs) == 1 and recs[0]["n_gpus"] == 2 and "launched_by" not in recs[0]
+
+
+def test_bench_launcher_reports_failures_in_one_line():
+    """Fewer GPUs than asked for, or a rank that dies: ONE contract-shaped JSON line with `error` and a null value, never a hang."""
+    import json
+
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("a multi-GPU box would really launch")
+    p = _run_bench(["--gpus", "2"], {})
+    d = json.loads(p.stdout.strip().split("\n")[-1])
+    assert p.returncode == 2 and d["value"] is None and d["n_gpus"] == 2 and "GPU(s) visible" in d["error"]
+    p = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1"], {"BENCH_STUB": "1", "BENCH_STUB_FAIL_RANK": "1", "BENCH_LAUNCH_TIMEOUT_S": "60"})
+    d = json.loads(p.stdout.strip().split("\n")[-1])
+    assert p.returncode == 1 and d["value"] is None and "rank 1 exited with code 3" in d["error"]
