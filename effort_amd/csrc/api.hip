@@ -27,6 +27,7 @@ struct Lane {
     hipStream_t own = nullptr;        // internal stream (overlap mode); with one lane the launches go to the context's stream
     hipEvent_t done = nullptr;        // "everything enqueued on the lane so far": recorded LAZILY, when somebody is about to wait for the lane (lane_mark)
     bool dirty = false;               // launches were enqueued on `own` since `done` was last recorded
+    unsigned long long capId = 0;     // the hipGraph capture the lane's pending launches were enqueued in (0: none -- real work on the queue)
     float* d_cutoff = nullptr;        // BucketMul.cutoff
     uint32_t* d_count = nullptr;      // dispatch.size
     float* d_slabs = nullptr;         // partial tiles (replaces tmpMulVec)
@@ -243,16 +244,43 @@ static hipError_t lane_mark(Lane& L) {
     if (e == hipSuccess) L.dirty = false;
     return e;
 }
+// The capture the context's stream is in (0: none).
+static unsigned long long capture_of(hipStream_t st) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    unsigned long long id = 0;
+    if (hipStreamGetCaptureInfo(st, &cap, &id) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return cap == hipStreamCaptureStatusActive ? (id ? id : ~0ull) : 0ull;
+}
+// Lanes and hipGraph captures.  A lane's pending launches are either real work on its queue or nodes of ONE capture, the one its fork
+// edge came from (Lane::capId).  Two mixtures cannot be ordered and are refused / cleaned up here instead of surfacing as a HIP error in the
+// middle of a launch: (a) real work pending when the context's stream is capturing -- the capture would have to wait on an event recorded
+// outside it, which stream capture forbids: the caller joins BEFORE beginning the capture (returns false, c->err says so); (b) nodes of a
+// capture that has ended (or of another one): the graph's own edges order them; the bookkeeping is dropped.
+static bool lanes_match_capture(effort_ctx* c, unsigned long long now) {
+    for (int i = 0; i < c->nLanes; i++) {
+        Lane& L = c->lane[i];
+        if (!L.pending || L.capId == now) continue;
+        if (L.capId == 0) {
+            snprintf(c->err, sizeof(c->err), "lanes hold launches enqueued BEFORE this hipGraph capture began: call effort_join (or effort_sync) before beginning the capture");
+            return false;
+        }
+        L.pending = false; L.dirty = false; L.capId = 0; L.reads.clear(); L.writes.clear();
+    }
+    return true;
+}
 // The context's stream waits for every lane's launches; from here on the context's stream order covers them.
 static int join_lanes(effort_ctx* c) {
     if (c->nLanes <= 1) return EFFORT_OK;
+    bool any = false;
+    for (int i = 0; i < c->nLanes; i++) any = any || c->lane[i].pending;
+    if (any && !lanes_match_capture(c, capture_of(c->stream))) return EFFORT_ERR_ARG;
     for (int i = 0; i < c->nLanes; i++) {
         Lane& L = c->lane[i];
         if (!L.pending) continue;
         hipError_t e = lane_mark(L);
         if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, L.done, 0);
         if (e != hipSuccess) { snprintf(c->err, sizeof(c->err), "join: %s", hipGetErrorString(e)); return EFFORT_ERR_HIP; }
-        L.pending = false; L.reads.clear(); L.writes.clear();
+        L.pending = false; L.capId = 0; L.reads.clear(); L.writes.clear();
     }
     c->busyStreak = 0; c->migrated = false;
     return EFFORT_OK;
@@ -308,7 +336,7 @@ extern "C" int effort_set_stream(effort_ctx* c, void* stream) {
 
 extern "C" int effort_sync(effort_ctx* c) {
     if (!c) return EFFORT_ERR_ARG;
-    if (join_lanes(c) != EFFORT_OK) return EFFORT_ERR_HIP;
+    { const int jrc = join_lanes(c); if (jrc != EFFORT_OK) return jrc; }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return EFFORT_OK;
 }
@@ -425,7 +453,7 @@ static int copy_aligned(effort_w* w) {
     return EFFORT_OK;
 }
 extern "C" int effort_weights_refresh(effort_w* w) {
-    if (!w || !w->ctx) return EFFORT_ERR_ARG;
+    if (!w || !w->ctx || w->dead) return EFFORT_ERR_ARG;
     if (w->view) return fail(w->ctx, EFFORT_ERR_ARG, "effort_weights_refresh: a column shard takes its bound from the full handle -- refresh that one and shard again");
     hipSetDevice(w->ctx->device);
     int rc = join_lanes(w->ctx);                 // multiplies still in flight on the lanes read what is recomputed here
@@ -440,7 +468,7 @@ extern "C" int effort_weights_refresh(effort_w* w) {
 // reads the copy, and the caller's buffer is no longer read (it may be freed; effort_weights_refresh re-reads it, so
 // keep it if the weights are going to change).  No-op when the pitch is line-aligned already.  Results are bit-identical.
 extern "C" int effort_weights_align_rows(effort_w* w) {
-    if (!w || !w->ctx) return EFFORT_ERR_ARG;
+    if (!w || !w->ctx || w->dead) return EFFORT_ERR_ARG;
     if (w->aligned || w->rowPitch % 128u == 0u) return EFFORT_OK;        // (already on whole lines: as converted with effort_convert_fp16_pitched, or 2*cols % 128 == 0)
     hipSetDevice(w->ctx->device);
     const uint32_t pitch = (w->cols * 2u + 127u) / 128u * 128u;
@@ -461,24 +489,32 @@ extern "C" int effort_weights_get_bound(effort_w* w, float* host_out) {
     return EFFORT_OK;
 }
 extern "C" int effort_weights_set_bound(effort_w* w, const float* host_in) {
-    if (!w || !w->ctx || !host_in || !w->rankBound) return EFFORT_ERR_ARG;
+    if (!w || !w->ctx || !host_in || !w->rankBound || w->dead) return EFFORT_ERR_ARG;
     for (uint32_t e = 0; e < w->numExperts; e++) if (!(host_in[e] >= 0.0f)) return EFFORT_ERR_ARG;
-    if (join_lanes(w->ctx) != EFFORT_OK) return EFFORT_ERR_HIP;
+    { const int jrc = join_lanes(w->ctx); if (jrc != EFFORT_OK) return jrc; }
     HIP_TRY(w->ctx, hipStreamSynchronize(w->ctx->stream));
     HIP_TRY(w->ctx, hipMemcpy(w->rankBound, host_in, (size_t)w->numExperts * 4, hipMemcpyHostToDevice));
     return EFFORT_OK;
 }
 
+// A full handle's `views` / `dead` are touched from whichever threads shard and free (one context per rank-thread is a pattern the
+// multi-GPU path invites): one process-wide mutex orders those few words.
+static std::mutex g_viewMutex;
 extern "C" void effort_weights_free(effort_w* w) {
     if (!w) return;
     if (w->view) {                               // a column shard owns its bound only; the last view of a freed parent takes the parent along
         effort_w* const par = w->parent;
         hipFree(w->rankBound);
         delete w;
-        if (par && --par->views == 0 && par->dead) { par->dead = false; effort_weights_free(par); }
+        bool last = false;
+        if (par) { std::lock_guard<std::mutex> lk(g_viewMutex); last = --par->views == 0 && par->dead; if (last) par->dead = false; }
+        if (last) effort_weights_free(par);
         return;
     }
-    if (w->views > 0) { w->dead = true; return; }   // views still read these buffers (the header says: free the shards first -- but do not dangle if not)
+    {   // views still read these buffers (the header says: free the shards first -- but do not dangle if not)
+        std::lock_guard<std::mutex> lk(g_viewMutex);
+        if (w->views > 0) { w->dead = true; return; }
+    }
     hipFree(w->olBlockPtr); hipFree(w->olEntry); hipFree(w->olMeta);
     hipFree(w->aligned); hipFree(w->rankBound); hipFree(w->means16);
     delete w;
@@ -502,7 +538,11 @@ extern "C" effort_w* effort_weights_column_shard(const effort_w* full, int rank,
         fail(c, EFFORT_ERR_SHAPE, "effort_weights_column_shard: the shard must hold whole blocks of the outlier index"); return nullptr; }
     effort_w* w = new (std::nothrow) effort_w();
     if (!w) return nullptr;
-    if (full->view || full->dead) { fail(c, EFFORT_ERR_ARG, "effort_weights_column_shard: shard a full, live handle"); delete w; return nullptr; }
+    {   // (`dead` and `views` under the mutex: a concurrent effort_weights_free(full) either sees this view or is seen here)
+        std::lock_guard<std::mutex> lk(g_viewMutex);
+        if (full->view || full->dead) { fail(c, EFFORT_ERR_ARG, "effort_weights_column_shard: shard a full, live handle"); delete w; return nullptr; }
+        const_cast<effort_w*>(full)->views++;
+    }
     *w = *full;
     w->view = true; w->parent = const_cast<effort_w*>(full); w->views = 0; w->dead = false;
     w->aligned = nullptr; w->rankBound = nullptr;
@@ -515,8 +555,13 @@ extern "C" effort_w* effort_weights_column_shard(const effort_w* full, int rank,
     hipSetDevice(c->device);
     if (hipMalloc(&w->rankBound, (size_t)w->numExperts * 4) != hipSuccess ||
         hipMemcpy(w->rankBound, full->rankBound, (size_t)w->numExperts * 4, hipMemcpyDeviceToDevice) != hipSuccess) {
-        fail(c, EFFORT_ERR_HIP, "effort_weights_column_shard: bound"); hipFree(w->rankBound); delete w; return nullptr; }
-    w->parent->views++;
+        fail(c, EFFORT_ERR_HIP, "effort_weights_column_shard: bound"); hipFree(w->rankBound);
+        effort_w* const par = w->parent;
+        delete w;
+        bool last;
+        { std::lock_guard<std::mutex> lk(g_viewMutex); last = --par->views == 0 && par->dead; if (last) par->dead = false; }
+        if (last) effort_weights_free(par);
+        return nullptr; }
     if (full->nOutliers) {
         w->olBlockPtr = full->olBlockPtr + (size_t)rank * outDim / 64u;                       // block bounds index the SHARED entry array
         w->olMeta = full->olMeta + (size_t)rank * outDim;                                     // (64 meta words per block of 64 outputs)
@@ -553,7 +598,7 @@ extern "C" int effort_comm_world(effort_ctx* c) { return c ? c->commWorld : EFFO
 extern "C" int effort_allgather_outputs(effort_ctx* c, const float* send, float* recv, int count) {
     if (!c || !send || !recv || count < 1) return fail(c, EFFORT_ERR_ARG, "allgather_outputs: bad argument");
     if (!c->comm) return fail(c, EFFORT_ERR_ARG, "allgather_outputs: no communicator (effort_comm_create)");
-    if (join_lanes(c) != EFFORT_OK) return EFFORT_ERR_HIP;
+    { const int jrc = join_lanes(c); if (jrc != EFFORT_OK) return jrc; }
     const ncclResult_t r = rccl().AllGather(send, recv, (size_t)count, ncclFloat, c->comm, c->stream);
     if (r != ncclSuccess) { snprintf(c->err, sizeof(c->err), "ncclAllGather: %s", rccl().GetErrorString(r)); return EFFORT_ERR_COMM; }
     return EFFORT_OK;
@@ -656,7 +701,7 @@ static int choose_geom(const effort_ctx* c, const effort_w* w, int groupSize, in
         g->slices = (w->inDim + g->sliceRows - 1) / g->sliceRows;
         g->sliceLog2 = 0; while ((1u << g->sliceLog2) < g->sliceRows) g->sliceLog2++;
         g->slots = w->fmt == kFp16 ? (g->rowsPerIn << g->sliceLog2) : g->sliceRows * 8u;
-        const size_t lds = bucket_mul_lds_bytes(w->fmt, W, E, *g);
+        const size_t lds = bucket_mul_lds_bytes(w->fmt, W, E, *g, true);    // (whether the launch will be a lean plain grid is known only once all its calls are: budget for the larger plan, the lean one's)
         const bool fits = lds <= ldsMax && g->slots <= maxCand && (size_t)g->slots * 4 + (size_t)g->sliceRows * 8 + 1024 <= 65536 &&   // staged regions below 64 KB
                           (w->fmt == kFp16 ? (1u << g->sliceLog2) <= 64u * (uint32_t)W : g->sliceRows <= 128u * (uint32_t)W);   // a thread stages one (Q4: two) inputs of the slice
         const size_t slab = (size_t)g->slices * g->tiles * tileFloats * 4;
@@ -691,6 +736,7 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
 #endif
     for (int i = 0; i < n; i++) {                      // every argument first: nothing is launched for a group with a bad call
         if (!ws[i] || !vs[i] || !outs[i]) return fail(c, EFFORT_ERR_ARG, "bucketmul: null argument");
+        if (ws[i]->dead) return fail(c, EFFORT_ERR_ARG, "bucketmul: the handle was freed (its buffers live on only for its column shards)");
         if (ws[i]->fmt != fmt) return fail(c, EFFORT_ERR_KIND, "bucketmul: weight handle of the wrong kind");
         if (!(efforts[i] >= 0.0 && efforts[i] <= 1.0)) return fail(c, EFFORT_ERR_EFFORT, "bucketmul: effort outside [0,1]");
         const int pre = prologues ? prologues[i] : 0;
@@ -711,13 +757,16 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
     const bool laned = c->nLanes > 1 && !c->timing && !c->clock;
     std::vector<Lane::Range> rd, wr;
     int hazard[effort_ctx::kMaxLanes], nh = 0;
+    unsigned long long capNow = 0;
     if (laned) {
+        capNow = capture_of(c->stream);
+        if (!lanes_match_capture(c, capNow)) return EFFORT_ERR_ARG;
         // bounded bookkeeping: a caller may enqueue arbitrarily many multiplies between joins (helpers/gpu.swift:109-119: one
         // eval() per token); once a lane has recorded kMaxRanges ranges the lanes are JOINED -- the context's stream waits for
         // all of them, and every later launch forks from that stream -- never forgotten
         bool full = false;
         for (int i = 0; i < c->nLanes; i++) full = full || c->lane[i].reads.size() + c->lane[i].writes.size() > effort_ctx::kMaxRanges;
-        if (full && join_lanes(c) != EFFORT_OK) return EFFORT_ERR_HIP;
+        if (full) { const int jrc = join_lanes(c); if (jrc != EFFORT_OK) return jrc; }
         auto add = [](std::vector<Lane::Range>& v, const void* p, size_t bytes) { if (p && bytes) v.push_back({(uintptr_t)p, (uintptr_t)p + bytes}); };
         for (int i = 0; i < n; i++) {
             add(rd, vs[i], (size_t)ws[i]->inDim * 4);
@@ -745,7 +794,7 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
             }
         }
     } else if (c->nLanes > 1) {
-        if (join_lanes(c) != EFFORT_OK) return EFFORT_ERR_HIP;        // timing modes: one launch at a time, on lane 0
+        { const int jrc = join_lanes(c); if (jrc != EFFORT_OK) return jrc; }        // timing modes: one launch at a time, on lane 0
     }
     Lane& L = c->lane[li];
     const hipStream_t st = laned ? L.own : c->stream;
@@ -762,21 +811,21 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
         // edge per call made that loop 45 % SLOWER with lanes than without (round 4: 32.5 against 22.5 us per call).  A capturing
         // stream cannot be queried (and "idle" means nothing inside a capture): there the fork is a graph edge, as before.
         bool wait = true;
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusActive;
-        if (hipStreamIsCapturing(c->stream, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) {
+        if (capNow == 0) {
             const hipError_t q = hipStreamQuery(c->stream);
             if (q == hipSuccess) wait = false;
             else {
                 (void)hipGetLastError();                    // ("not ready" must not linger as the thread's last error: the launchers read it after their kernels)
                 if (q != hipErrorNotReady) return fail(c, EFFORT_ERR_HIP, "hipStreamQuery", q);
             }
-        } else (void)hipGetLastError();
+        }
         if (wait) {
             HIP_TRY(c, hipEventRecord(c->forkEv, c->stream));
             HIP_TRY(c, hipStreamWaitEvent(L.own, c->forkEv, 0));
         }
         c->busyStreak = (wait && nh == 1 && hazard[0] == li) ? c->busyStreak + 1 : 0;     // (a dependent chain's link that had to fork)
         guard.forked = true;
+        L.capId = capNow;
         // (a range the lane holds already is not recorded twice: a loop that multiplies into the same vectors over and over --
         //  the reference's timing loop -- would otherwise grow the lists to their cap, and every call scan thousands of ranges)
         auto add_new = [](std::vector<Lane::Range>& have, const std::vector<Lane::Range>& more) {
@@ -937,9 +986,9 @@ extern "C" int effort_bucketmul_q4_group(effort_ctx* c, int n, const effort_w* c
 
 extern "C" int effort_calc_dispatch(effort_ctx* c, const effort_w* w, const float* v, const uint32_t* expNo, double effort,
                                     float* dispatch, uint32_t* count) {
-    if (!c || !w || !v || !dispatch) return fail(c, EFFORT_ERR_ARG, "calc_dispatch: null argument");
+    if (!c || !w || !v || !dispatch || w->dead) return fail(c, EFFORT_ERR_ARG, "calc_dispatch: null argument (or a freed handle)");
     if (!(effort >= 0.0 && effort <= 1.0)) return fail(c, EFFORT_ERR_EFFORT, "calc_dispatch: effort outside [0,1]");
-    if (join_lanes(c) != EFFORT_OK) return EFFORT_ERR_HIP;
+    { const int jrc = join_lanes(c); if (jrc != EFFORT_OK) return jrc; }
     Lane& L = c->lane[0];
     c->lastLane = 0;
     MulGeom g; int W, E;
@@ -954,7 +1003,7 @@ extern "C" int effort_calc_dispatch(effort_ctx* c, const effort_w* w, const floa
 
 extern "C" int effort_group_dispatch_count(effort_ctx* c, int idx, uint32_t* host_out) {
     if (!c || !host_out || idx < 0 || (uint32_t)idx >= c->lane[c->lastLane].lastCalls) return EFFORT_ERR_ARG;
-    if (join_lanes(c) != EFFORT_OK) return EFFORT_ERR_HIP;
+    { const int jrc = join_lanes(c); if (jrc != EFFORT_OK) return jrc; }
     Lane& L = c->lane[c->lastLane];
     if (L.lastSlices[idx] == 0) {
         HIP_TRY(c, hipMemcpyAsync(host_out, L.d_count, 4, hipMemcpyDeviceToHost, c->stream));
@@ -971,7 +1020,7 @@ extern "C" int effort_group_dispatch_count(effort_ctx* c, int idx, uint32_t* hos
 }
 extern "C" int effort_debug_slice_counts(effort_ctx* c, int idx, uint32_t* host, int maxSlices) {
     if (!c || !host || idx < 0 || (uint32_t)idx >= c->lane[c->lastLane].lastCalls || maxSlices < 1) return EFFORT_ERR_ARG;
-    if (join_lanes(c) != EFFORT_OK) return EFFORT_ERR_HIP;
+    { const int jrc = join_lanes(c); if (jrc != EFFORT_OK) return jrc; }
     Lane& L = c->lane[c->lastLane];
     const uint32_t n = L.lastSlices[idx] < (uint32_t)maxSlices ? L.lastSlices[idx] : (uint32_t)maxSlices;
     if (n) HIP_TRY(c, hipMemcpyAsync(host, L.d_sliceCounts + L.lastSliceOff[idx], (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
@@ -980,7 +1029,7 @@ extern "C" int effort_debug_slice_counts(effort_ctx* c, int idx, uint32_t* host,
 }
 extern "C" int effort_group_cutoff(effort_ctx* c, int idx, float* host_out) {
     if (!c || !host_out || idx < 0 || (uint32_t)idx >= c->lane[c->lastLane].lastCalls) return EFFORT_ERR_ARG;
-    if (join_lanes(c) != EFFORT_OK) return EFFORT_ERR_HIP;
+    { const int jrc = join_lanes(c); if (jrc != EFFORT_OK) return jrc; }
     Lane& L = c->lane[c->lastLane];
     HIP_TRY(c, hipMemcpyAsync(host_out, L.d_cutoff + idx, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -997,7 +1046,7 @@ extern "C" int effort_set_dense_backend(effort_ctx* c, int rocblas) {
 }
 extern "C" int effort_dense_gemv(effort_ctx* c, const void* W, const float* v, float* out, int inDim, int outDim) {
     if (!c || !W || !v || !out || inDim <= 0 || outDim <= 0) return fail(c, EFFORT_ERR_ARG, "dense_gemv: bad argument");
-    if (join_lanes(c) != EFFORT_OK) return EFFORT_ERR_HIP;
+    { const int jrc = join_lanes(c); if (jrc != EFFORT_OK) return jrc; }
     if (inDim % 16) return fail(c, EFFORT_ERR_SHAPE, "dense_gemv: inDim % 16 != 0 (helpers/mps.swift:18)");
     if (!c->denseRocblas && dense_gemv_supported((uint32_t)inDim, (uint32_t)outDim)) {
         HIP_TRY(c, launch_dense_gemv(static_cast<const uint16_t*>(W), v, out, (uint32_t)inDim, (uint32_t)outDim, c->stream));
@@ -1027,7 +1076,7 @@ extern "C" int effort_dense_gemv(effort_ctx* c, const void* W, const float* v, f
 // ---- converter -----------------------------------------------------------------------------------
 extern "C" int effort_convert_fp16_pitched(effort_ctx* c, const void* W, int outDim, int inDim, void* buckets, int rowPitchBytes, void* stats, void* probes) {
     if (!c || !W || !buckets || !stats || !probes) return fail(c, EFFORT_ERR_ARG, "convert_fp16: null argument");
-    if (join_lanes(c) != EFFORT_OK) return EFFORT_ERR_HIP;
+    { const int jrc = join_lanes(c); if (jrc != EFFORT_OK) return jrc; }
     // convert.swift:210-215,239 + the 16384-wide limit of the multiply (bucketMul.swift:52)
     if (outDim <= 0 || inDim < kProbes || !(outDim >= kProbes || kProbes % outDim == 0) || outDim > 16384 || inDim > 32000 ||
         outDim % 16 || (outDim / 16) % 4)
@@ -1057,7 +1106,7 @@ extern "C" int64_t effort_q4_outlier_count(int inDim, int outDim, double perc) {
 extern "C" int effort_convert_q4(effort_ctx* c, const void* core2, int inDim, int outDim, double perc, void* buckets, void* stats, void* probes,
                                  void* outliers) {
     if (!c || !core2 || !buckets || !stats || !probes) return fail(c, EFFORT_ERR_ARG, "convert_q4: null argument");
-    if (join_lanes(c) != EFFORT_OK) return EFFORT_ERR_HIP;
+    { const int jrc = join_lanes(c); if (jrc != EFFORT_OK) return jrc; }
     if (inDim <= 0 || outDim <= 0 || outDim % 32 || (int64_t)inDim * outDim >= (1ll << 32) || !(perc >= 0.0 && perc <= 1.0))
         return fail(c, EFFORT_ERR_CONVERT, "convert_q4: outDim % 32 != 0 (q4_draft.py:299), or a matrix of 2^32 elements or more");
     const int64_t cnt = effort_q4_outlier_count(inDim, outDim, perc);
@@ -1071,7 +1120,7 @@ extern "C" int effort_convert_q4(effort_ctx* c, const void* core2, int inDim, in
 
 extern "C" int effort_cosine(effort_ctx* c, const float* a, const float* b, int n, float* host_out) {
     if (!c || !a || !b || !host_out || n <= 0) return EFFORT_ERR_ARG;
-    if (join_lanes(c) != EFFORT_OK) return EFFORT_ERR_HIP;
+    { const int jrc = join_lanes(c); if (jrc != EFFORT_OK) return jrc; }
     HIP_TRY(c, launch_cosine(a, b, n, c->d_cos, c->stream));
     HIP_TRY(c, hipMemcpyAsync(host_out, c->d_cos, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1081,14 +1130,14 @@ extern "C" int effort_cosine(effort_ctx* c, const float* a, const float* b, int 
 // ---- decode-loop glue (runNetwork.swift:68-316; kernels in decode.hip) ---------------------------------------
 extern "C" int effort_add_rmsnorm_mul(effort_ctx* c, float* h, const float* delta, const void* w, float* out, int n) {
     if (!c || !h || !w || !out || n <= 0) return fail(c, EFFORT_ERR_ARG, "add_rmsnorm_mul: bad argument");
-    if (join_lanes(c) != EFFORT_OK) return EFFORT_ERR_HIP;
+    { const int jrc = join_lanes(c); if (jrc != EFFORT_OK) return jrc; }
     HIP_TRY(c, launch_add_rmsnorm_mul(h, delta, static_cast<const uint16_t*>(w), out, (uint32_t)n, c->stream));
     return EFFORT_OK;
 }
 extern "C" int effort_rope_kv(effort_ctx* c, const float* xq, const float* xk, const float* xv, float* qOut, float* kCache,
                               float* vCache, const uint32_t* pos, int numHeads, int numHeadsKV, int headDim, int maxTokens, float ropeBase) {
     if (!c || !xq || !xk || !xv || !qOut || !kCache || !vCache || !pos) return fail(c, EFFORT_ERR_ARG, "rope_kv: null argument");
-    if (join_lanes(c) != EFFORT_OK) return EFFORT_ERR_HIP;
+    { const int jrc = join_lanes(c); if (jrc != EFFORT_OK) return jrc; }
     if (numHeads <= 0 || numHeadsKV <= 0 || numHeads % numHeadsKV || headDim < 2 || headDim > 1024 || headDim % 2 || !(ropeBase > 1.0f) || maxTokens <= 0)
         return fail(c, EFFORT_ERR_SHAPE, "rope_kv: bad head geometry");
     HIP_TRY(c, launch_rope_kv(xq, xk, xv, qOut, kCache, vCache, pos, numHeads, numHeadsKV, headDim, ropeBase, (uint32_t)maxTokens, c->d_status + 1, c->stream));
@@ -1097,7 +1146,7 @@ extern "C" int effort_rope_kv(effort_ctx* c, const float* xq, const float* xk, c
 extern "C" int effort_attention(effort_ctx* c, const float* q, const float* kCache, const float* vCache, const uint32_t* pos,
                                 float* out, int numHeads, int headDim, int maxTokens) {
     if (!c || !q || !kCache || !vCache || !pos || !out) return fail(c, EFFORT_ERR_ARG, "attention: null argument");
-    if (join_lanes(c) != EFFORT_OK) return EFFORT_ERR_HIP;
+    { const int jrc = join_lanes(c); if (jrc != EFFORT_OK) return jrc; }
     if (numHeads <= 0 || maxTokens <= 0 || maxTokens > 8192 || (headDim != 64 && headDim != 128 && headDim != 256))
         return fail(c, EFFORT_ERR_SHAPE, "attention: headDim 64/128/256, maxTokens <= 8192");
     HIP_TRY(c, launch_attention(q, kCache, vCache, pos, out, numHeads, headDim, maxTokens, c->stream));
@@ -1106,7 +1155,7 @@ extern "C" int effort_attention(effort_ctx* c, const float* q, const float* kCac
 extern "C" int effort_rope_attention(effort_ctx* c, const float* xq, const float* xk, const float* xv, float* kCache, float* vCache,
                                      const uint32_t* pos, float* out, int numHeads, int numHeadsKV, int headDim, int maxTokens, float ropeBase) {
     if (!c || !xq || !xk || !xv || !kCache || !vCache || !pos || !out) return fail(c, EFFORT_ERR_ARG, "rope_attention: null argument");
-    if (join_lanes(c) != EFFORT_OK) return EFFORT_ERR_HIP;
+    { const int jrc = join_lanes(c); if (jrc != EFFORT_OK) return jrc; }
     if (numHeads <= 0 || numHeadsKV <= 0 || numHeads % numHeadsKV || maxTokens <= 0 || maxTokens > 8192 || !(ropeBase > 1.0f) ||
         (headDim != 64 && headDim != 128 && headDim != 256))
         return fail(c, EFFORT_ERR_SHAPE, "rope_attention: headDim 64/128/256, maxTokens <= 8192");
@@ -1115,31 +1164,31 @@ extern "C" int effort_rope_attention(effort_ctx* c, const float* xq, const float
 }
 extern "C" int effort_silu_mul(effort_ctx* c, const float* x1, const float* x3, float* out, int n) {
     if (!c || !x1 || !x3 || !out || n <= 0) return fail(c, EFFORT_ERR_ARG, "silu_mul: bad argument");
-    if (join_lanes(c) != EFFORT_OK) return EFFORT_ERR_HIP;
+    { const int jrc = join_lanes(c); if (jrc != EFFORT_OK) return jrc; }
     HIP_TRY(c, launch_silu_mul(x1, x3, out, (uint32_t)n, c->stream));
     return EFFORT_OK;
 }
 extern "C" int effort_fetch_row(effort_ctx* c, const void* emb, const uint32_t* id, float* out, int n) {
     if (!c || !emb || !id || !out || n <= 0) return fail(c, EFFORT_ERR_ARG, "fetch_row: bad argument");
-    if (join_lanes(c) != EFFORT_OK) return EFFORT_ERR_HIP;
+    { const int jrc = join_lanes(c); if (jrc != EFFORT_OK) return jrc; }
     HIP_TRY(c, launch_fetch_row(static_cast<const uint16_t*>(emb), id, out, (uint32_t)n, c->stream));
     return EFFORT_OK;
 }
 extern "C" int effort_top2_softmax(effort_ctx* c, const float* gate, int n, uint32_t* idx2, float* val2) {
     if (!c || !gate || !idx2 || !val2 || n < 1) return fail(c, EFFORT_ERR_ARG, "top2_softmax: bad argument");
-    if (join_lanes(c) != EFFORT_OK) return EFFORT_ERR_HIP;
+    { const int jrc = join_lanes(c); if (jrc != EFFORT_OK) return jrc; }
     HIP_TRY(c, launch_top2_softmax(gate, (uint32_t)n, idx2, val2, c->stream));
     return EFFORT_OK;
 }
 extern "C" int effort_mix2(effort_ctx* c, const float* f0, const float* f1, const float* val2, float* out, int n) {
     if (!c || !f0 || !f1 || !val2 || !out || n <= 0) return fail(c, EFFORT_ERR_ARG, "mix2: bad argument");
-    if (join_lanes(c) != EFFORT_OK) return EFFORT_ERR_HIP;
+    { const int jrc = join_lanes(c); if (jrc != EFFORT_OK) return jrc; }
     HIP_TRY(c, launch_mix2(f0, f1, val2, out, (uint32_t)n, c->stream));
     return EFFORT_OK;
 }
 extern "C" int effort_argmax(effort_ctx* c, const float* logits, int n, uint32_t* idOut, uint32_t* pos, uint32_t* history, int historyLen) {
     if (!c || !logits || !idOut || !pos || n <= 0 || (history && historyLen <= 0)) return fail(c, EFFORT_ERR_ARG, "argmax: bad argument");
-    if (join_lanes(c) != EFFORT_OK) return EFFORT_ERR_HIP;
+    { const int jrc = join_lanes(c); if (jrc != EFFORT_OK) return jrc; }
     HIP_TRY(c, launch_argmax(logits, (uint32_t)n, idOut, pos, history, (uint32_t)(history ? historyLen : 0), c->d_status + 1, c->stream));
     return EFFORT_OK;
 }
@@ -1148,7 +1197,7 @@ extern "C" int effort_argmax(effort_ctx* c, const float* logits, int n, uint32_t
 // logits (token 0 returned).  Reads and clears the word.
 extern "C" int effort_decode_status(effort_ctx* c, int* host_out) {
     if (!c || !host_out) return EFFORT_ERR_ARG;
-    if (join_lanes(c) != EFFORT_OK) return EFFORT_ERR_HIP;
+    { const int jrc = join_lanes(c); if (jrc != EFFORT_OK) return jrc; }
     HIP_TRY(c, hipMemcpyAsync(host_out, c->d_status + 1, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_status + 1, 0, 4, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1158,7 +1207,7 @@ extern "C" int effort_decode_status(effort_ctx* c, int* host_out) {
 // tying with real zeros, convert.metal:40-61: the reference drops those elements silently).  Reads and clears the count.
 extern "C" int effort_convert_status(effort_ctx* c, int* host_out) {
     if (!c || !host_out) return EFFORT_ERR_ARG;
-    if (join_lanes(c) != EFFORT_OK) return EFFORT_ERR_HIP;
+    { const int jrc = join_lanes(c); if (jrc != EFFORT_OK) return jrc; }
     HIP_TRY(c, hipMemcpyAsync(host_out, c->d_status, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_status, 0, 4, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));

@@ -156,8 +156,10 @@ template <int E> __host__ __device__ inline uint32_t ol_scratch_bytes(const MulG
 // means / vblk are filled by LDS-direct buffer loads (stage_issue), whose destination (M0) is kept below 64 KB.  Q4: after
 // the streaming phase means | vblk are dead and hold the outlier phase's scratch (sums | whole v); Q4 items are not
 // pipelined and use vblk[0] only.
+// `lean`: the plan of a plain grid's lean instantiation (launch_mul_t) -- the only one whose Q4 items read offO, the region of their
+// own for the whole input vector (kOlMerge); the persistent / generic kernels and the other workgroup sizes do not carry it.
 template <int FMT, int E, int W>
-__host__ __device__ inline LdsPlan plan_lds(const MulGeom* geoms, int nGeoms) {
+__host__ __device__ inline LdsPlan plan_lds(const MulGeom* geoms, int nGeoms, bool lean) {
     uint32_t slots = 0, vrows = 0, ol = 0, vEarly = 0;
     for (int i = 0; i < nGeoms; i++) {
         const MulGeom& g = geoms[i];
@@ -167,7 +169,7 @@ __host__ __device__ inline LdsPlan plan_lds(const MulGeom* geoms, int nGeoms) {
         vrows = vrows > vr ? vrows : vr;
         if (FMT != kFp16) {
             const uint32_t x = ol_scratch_bytes<E>(g); ol = ol > x ? ol : x;
-            if (g.inDim <= kOlEarlyFloats) vEarly = vEarly > g.inDim * 4u ? vEarly : g.inDim * 4u;
+            if (lean && W == 8 && g.inDim <= kOlEarlyFloats) vEarly = vEarly > g.inDim * 4u ? vEarly : g.inDim * 4u;
         }
     }
     LdsPlan p;
@@ -1317,7 +1319,11 @@ __global__ __launch_bounds__(64 * W, (W <= 8 ? EFFORT_MIN_WAVES_PER_EU : 4)) voi
 template <int FMT, int E, int W>
 static hipError_t launch_mul_t(const GroupKArgs& gaIn, hipStream_t st) {
     GroupKArgs ga = gaIn;
-    const LdsPlan lp = ga.lp = plan_lds<FMT, E, W>(ga.geom, kMaxGeoms);
+    // plain grids of the product path (no stamps, no ablation switches) run the lean instantiation (PERSIST = false, see above);
+    // built for 8-wave workgroups, the only size the heuristics choose
+    constexpr bool kLean = W == 8;
+    const bool lean = kLean && !ga.persistent && !ga.tstamp && !ga.ablate;
+    const LdsPlan lp = ga.lp = plan_lds<FMT, E, W>(ga.geom, kMaxGeoms, lean);
     uint32_t lds = lp.total;
     if (lp.offA > 65536u && FMT == kFp16) return hipErrorInvalidValue;     // stage_issue's destinations sit below offA
     for (uint32_t i = 0; i < ga.count; i++) {
@@ -1338,13 +1344,9 @@ static hipError_t launch_mul_t(const GroupKArgs& gaIn, hipStream_t st) {
     bool fusedAny = false;
     for (uint32_t i = 0; i < ga.count; i++) fusedAny = fusedAny || ga.call[i].pre || ga.call[i].resid;
     if (fusedAny && FMT != kFp16) return hipErrorInvalidValue;
-    // plain grids of the product path (no stamps, no ablation switches) run the lean instantiation (PERSIST = false, see above);
-    // built for 8-wave workgroups, the only size the heuristics choose
-    constexpr bool kLean = W == 8;
     // (every instantiation may use the whole LDS: bucket_mul_prepare_device, once per device at effort_create)
     if (lds > kMaxLdsBytes) return hipErrorInvalidValue;
     const bool compact = (ga.split & 4u) != 0u;                   // (api.hip: persistent FP16 launches of plain calls)
-    const bool lean = kLean && !ga.persistent && !ga.tstamp && !ga.ablate;
     if (compact && (FMT != kFp16 || (fusedAny && !lean))) return hipErrorInvalidValue;
     const dim3 gd(grid), bd(64 * W);
     if constexpr (kLean) {
@@ -1405,10 +1407,10 @@ hipError_t launch_bucket_mul(Format fmt, int W, int E, const GroupKArgs& a, hipS
     return fmt == kFp16 ? launch_mul_fmt<kFp16>(W, E, a, st) : launch_mul_fmt<kQ4>(W, E, a, st);
 }
 
-size_t bucket_mul_lds_bytes(Format fmt, int W, int E, const MulGeom& g) {
+size_t bucket_mul_lds_bytes(Format fmt, int W, int E, const MulGeom& g, bool lean) {
 #define EFFORT_CASE(w, e)                                                                     \
     if (W == w && E == e)                                                                     \
-        return fmt == kFp16 ? plan_lds<kFp16, e, w>(&g, 1).total : plan_lds<kQ4, e, w>(&g, 1).total;
+        return fmt == kFp16 ? plan_lds<kFp16, e, w>(&g, 1, lean).total : plan_lds<kQ4, e, w>(&g, 1, lean).total;
     EFFORT_GEOMS(EFFORT_CASE)
 #undef EFFORT_CASE
     return 0;

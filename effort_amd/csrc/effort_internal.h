@@ -212,7 +212,7 @@ hipError_t launch_find_cutoff(const float* v, const uint16_t* probes, const uint
 hipError_t launch_bucket_mul(Format fmt, int wavesPerGroup, int elemsPerLane, const GroupKArgs& ga, hipStream_t st);
 hipError_t bucket_mul_prepare_device();     // once per device: the kernels may use the whole LDS (hipFuncSetAttribute)
 hipError_t launch_find_cutoff_group(const GroupKArgs& ga, hipStream_t st);    // ga.cutoff[i] of every call
-size_t bucket_mul_lds_bytes(Format fmt, int wavesPerGroup, int elemsPerLane, const MulGeom& g);
+size_t bucket_mul_lds_bytes(Format fmt, int wavesPerGroup, int elemsPerLane, const MulGeom& g, bool lean);    // lean: with the lean Q4 kernels' region for v (plan_lds)
 uint32_t bucket_mul_max_candidates(int wavesPerGroup);
 int bucket_mul_occupancy(Format fmt, int wavesPerGroup, int elemsPerLane, size_t ldsBytes);
   // rowsPerIn*sliceRows must not exceed this

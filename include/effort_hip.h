@@ -58,7 +58,15 @@ EFFORT_API int effort_sync(effort_ctx* ctx);
 /* Overlap of independent launches (the reference's command queue lets independent kernels overlap too, helpers/gpu.swift:
  * 135-196).  lanes = 1 (default): every call is enqueued on the context's stream, in order.  lanes = 2..4: the context owns
  * that many internal streams, each with its own scratch, and every effort_bucketmul* call goes to one of them, ordered
- *   - after everything enqueued on the context's stream BEFORE the call, and
+ *   - after everything enqueued ON THE CONTEXT'S STREAM before the call -- exactly that: outside a capture the lane forks from the
+ *     stream only if the stream still has work (hipStreamQuery); when it answers "idle" everything enqueued on it has completed and
+ *     no edge is recorded.  Work the caller keeps on OTHER streams is ordered against a multiply only through the context's stream:
+ *     make that stream wait for it (hipStreamWaitEvent) before the call -- a wait enqueued on the stream keeps it "busy" until
+ *     the event fires, so the fork happens -- and do not rely on an earlier, already completed wait.  Inside a capture the fork
+ *     is always a graph edge; a lane's completion event is recorded lazily, when something first waits for the lane (a join, a
+ *     dependent launch on another lane), which may be inside a capture that began after the lane's launches: the event then becomes a
+ *     node of that graph and orders the graph's work after launches enqueued BEFORE the capture (a join at the top of the
+ *     capture is the explicit form) -- and
  *   - after earlier multiplies of this context whose outputs it reads or overwrites, or whose inputs it overwrites (address
  *     ranges of v / expNo / aux / resid / out are compared);
  * otherwise it runs beside the multiplies still in flight: the head of one launch (staging, cutoffs, selection: HBM idle)
@@ -148,7 +156,13 @@ EFFORT_API int effort_bucketmul(effort_ctx* ctx, const effort_w* w, const float*
                      float* out_dev, double effort);
 
 /* func bucketMulQ4(...) -- bucketMulQ4.swift:11-17 -> fullMul (:54-63), INCLUDING the caller's
- * out.zero() (expertMul.swift:27) and the calcOutliers pass (bucketMulQ4.metal:13-21). */
+ * out.zero() (expertMul.swift:27) and the calcOutliers pass (bucketMulQ4.metal:13-21).
+ * Determinism: the bucket rows are accumulated in fixed point like effort_bucketmul's (order-free).  The OUTLIER sums are f32, as the
+ * reference's float atomics are: an output's entries are added in the table's order, and an item whose share of the outputs is thin
+ * splits them among the waves of its workgroup, the partial sums added in wave order.  How they are split follows the launch geometry
+ * (group size, the device's CU count, a column shard against the full handle), so a bundle WITH outliers gives bit-identical results
+ * run to run for one geometry, and results that may differ in the last bits between a lone call, a grouped call and a column shard
+ * (all within the 2e-5 * max|out| bar).  Without outliers Q4 is as order-free as FP16. */
 EFFORT_API int effort_bucketmul_q4(effort_ctx* ctx, const effort_w* w, const float* v_dev, const uint32_t* expNo_dev,
                         float* out_dev, double effort);
 

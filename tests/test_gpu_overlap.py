@@ -162,6 +162,54 @@ def test_overlap_orders_dependent_launches(ea, oracle_cpu):
     ctx.close()
 
 
+def test_a_capture_that_begins_with_launches_pending_on_the_lanes(ea, oracle_cpu):
+    """Lanes and hipGraph captures (effort_hip.h, effort_set_overlap).  Launches enqueued on the lanes BEFORE a capture of the
+    context's own stream begins are real work on the lanes' queues; a launch inside the capture that depends on them would have to
+    wait, from a capturing stream, on an event recorded outside the capture -- which stream capture forbids.  The library refuses it
+    with a message that names the remedy (join before beginning the capture) instead of failing somewhere inside HIP, touches no stream
+    doing so (the capture stays valid), and after the join the same capture goes through, bit-identical with one lane.  Lanes left
+    pending by a capture that ENDED are dropped from the bookkeeping (the graph's own edges order them)."""
+    inDim = outDim = 4096
+    W, b, s, p = converted(oracle_cpu, outDim, inDim)
+    ewA = gpu_weights(ea, W, b, s, p)
+    st = torch.cuda.Stream(device=DEV)
+    v0 = devf(make_v(inDim, seed=13, heavy=True))
+    x, y, z = (torch.zeros(inDim, device=DEV) for _ in range(3))
+    torch.cuda.synchronize()
+    with torch.cuda.stream(st):
+        ctx = ea.Gpu(0)                                                          # bound to `st`: the stream that is going to capture
+        ctx.set_overlap(1)
+        ea.bucketMul(v0, ewA, None, x, 0.25, gpu=ctx)
+        ea.bucketMul(x, ewA, None, y, 0.5, gpu=ctx)
+        ctx.eval()
+        want_x, want_y = x.clone(), y.clone()
+        ctx.set_overlap(4)
+        x.zero_(); y.zero_()
+        ea.bucketMul(v0, ewA, None, x, 0.25, gpu=ctx)                            # lane 0 now holds real work, not joined
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=st, capture_error_mode="thread_local"):
+            with pytest.raises(ea.EffortError, match="before beginning the capture"):
+                ea.bucketMul(x, ewA, None, y, 0.5, gpu=ctx)                      # RAW on x: would need lane 0's pre-capture work
+            with pytest.raises(ea.EffortError, match="before beginning the capture"):
+                ctx.join()                                                       # ... and so would a join inside the capture
+            z.zero_()                                                            # (something to capture: the refused calls left the capture untouched and valid)
+        del graph
+        ctx.join()                                                               # the remedy, outside the capture
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=st, capture_error_mode="thread_local"):
+            ea.bucketMul(x, ewA, None, y, 0.5, gpu=ctx)
+            ctx.join()
+        y.fill_(float("nan"))
+        graph.replay()
+        ctx.eval()
+        assert torch.equal(x, want_x) and torch.equal(y, want_y)
+        # a capture that ended with its lanes joined leaves nothing behind; one more eager launch and a join are ordinary
+        ea.bucketMul(v0, ewA, None, z, 0.25, gpu=ctx)
+        ctx.eval()
+        assert torch.equal(z, want_x)
+        ctx.close()
+
+
 def test_long_dependent_chains_without_a_join(ea, oracle_cpu):
     """The reference's style is one gpu.eval() after arbitrarily many enqueues (helpers/gpu.swift:109-119).  Two interleaved
     chains x <- A x of 800 dependent lone calls each (1 600 launches, no effort_join in between) under effort_set_overlap(4):
