@@ -9,7 +9,9 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("EFFORT_HIP_LIB") or os.path.join(_HERE, "libeffort_hip.so")     # (the override: A/B builds of the kernels, tools/ only)
+LAB_LIB_PATH = os.path.join(_HERE, "libeffort_hip_lab.so")      # the lab bench: same sources built -DEFFORT_LAB (device-clock stamps, traces, ablation switches)
+# (the override: A/B builds of the kernels and the lab library, tools/ only; "lab" = the in-tree lab library)
+LIB_PATH = (LAB_LIB_PATH if os.environ.get("EFFORT_HIP_LIB") == "lab" else os.environ.get("EFFORT_HIP_LIB")) or os.path.join(_HERE, "libeffort_hip.so")
 
 ERRORS = {
     -1: "EFFORT_ERR_ARG", -2: "EFFORT_ERR_SHAPE", -3: "EFFORT_ERR_EFFORT", -4: "EFFORT_ERR_HIP",
@@ -92,6 +94,7 @@ _SIGS = {
     "effort_cosine": (C.c_int, [_P, _P, _P, C.c_int, C.POINTER(C.c_float)]),
     "effort_set_split_cutoff": (C.c_int, [_P, C.c_int]),
     "effort_set_tuning": (C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
+    "effort_is_lab_build": (C.c_int, []),
     "effort_enable_kernel_timing": (C.c_int, [_P, C.c_int]),
     "effort_debug_stamps": (C.c_int, [_P, C.POINTER(C.c_ulonglong)]),
     "effort_debug_slice_counts": (C.c_int, [_P, C.c_int, C.POINTER(C.c_uint32), C.c_int]),
@@ -118,7 +121,7 @@ def lib() -> C.CDLL:
         import torch  # noqa: F401
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
-            if name.startswith("effort_debug_") and os.environ.get("EFFORT_HIP_LIB") and not hasattr(l, name):
+            if (name.startswith("effort_debug_") or name == "effort_is_lab_build") and os.environ.get("EFFORT_HIP_LIB") and not hasattr(l, name):
                 continue                 # (an A/B build of an older tree may lack a profiling hook)
             fn = getattr(l, name)        # AttributeError if the ABI and the header drifted apart
             fn.restype = res

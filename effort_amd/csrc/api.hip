@@ -319,7 +319,7 @@ extern "C" void effort_destroy(effort_ctx* c) {
     hipStreamSynchronize(c->stream);
     if (c->comm) rccl().CommDestroy(c->comm);
     if (c->blas) rocblas_destroy_handle(c->blas);
-    if (c->ev) { for (int i = 0; i < effort_ctx::kMaxSamples * 4; i++) hipEventDestroy(c->ev[i]); delete[] c->ev; }
+    if (c->ev) { for (int i = 0; i < effort_ctx::kMaxSamples * 4; i++) if (c->ev[i]) hipEventDestroy(c->ev[i]); delete[] c->ev; }
     for (int i = 0; i < effort_ctx::kMaxLanes; i++) lane_free(c->device, c->lane[i]);
     pool_put(c->device, c->forkEv);
     hipFree(c->d_blockScratch); hipFree(c->d_vhalf); hipFree(c->d_cos); hipFree(c->d_convVals); hipFree(c->d_status); hipFree(c->d_tstamp);
@@ -715,7 +715,7 @@ static int choose_geom(const effort_ctx* c, const effort_w* w, int groupSize, in
 
 static int ensure_timing(effort_ctx* c) {
     if (c->ev) return EFFORT_OK;
-    c->ev = new (std::nothrow) hipEvent_t[effort_ctx::kMaxSamples * 4];
+    c->ev = new (std::nothrow) hipEvent_t[effort_ctx::kMaxSamples * 4]();       // (value-initialised: effort_destroy walks the whole array)
     if (!c->ev) return EFFORT_ERR_HIP;
     for (int i = 0; i < effort_ctx::kMaxSamples * 4; i++) HIP_TRY(c, hipEventCreate(&c->ev[i]));
     return EFFORT_OK;
@@ -1246,12 +1246,23 @@ extern "C" int effort_set_split_cutoff(effort_ctx* c, int split) {
     return EFFORT_OK;
 }
 
+// The device-clock stamps and the per-item trace live in the LAB library only (libeffort_hip_lab.so, -DEFFORT_LAB; csrc/Makefile): the
+// shipped kernels carry no stamp code at all.  In the shipped library mode 1 times launches with HIP events alone and modes 2 / 3 are refused.
+#ifdef EFFORT_LAB
+static constexpr bool kLabBuild = true;
+#else
+static constexpr bool kLabBuild = false;
+#endif
+static int lab_only(effort_ctx* c) { return fail(c, EFFORT_ERR_KIND, "device-clock stamps / traces are compiled into libeffort_hip_lab.so only (EFFORT_HIP_LIB=lab)"); }
+extern "C" int effort_is_lab_build(void) { return kLabBuild ? 1 : 0; }
+
 extern "C" int effort_enable_kernel_timing(effort_ctx* c, int enable) {
     if (!c) return EFFORT_ERR_ARG;
+    if (!kLabBuild && enable >= 2) return lab_only(c);
     if (enable == 1) { int rc = ensure_timing(c); if (rc != EFFORT_OK) return rc; }
     c->timing = enable == 1;      // 1: events + device clock, 2: device clock only (graph-capture safe), 3: 2 + per-item trace
-    c->clock = enable != 0;
-    c->trace = enable == 3;
+    c->clock = kLabBuild && enable != 0;
+    c->trace = kLabBuild && enable == 3;
     if (c->trace) HIP_TRY(c, hipMemsetAsync(c->d_tstamp + kTraceOff, 0, (size_t)kTraceItems * 96, c->stream));
     c->nSamples = 0;
     HIP_TRY(c, hipMemsetAsync(c->d_tstamp, 0, 4096, c->stream));
@@ -1261,6 +1272,7 @@ extern "C" int effort_enable_kernel_timing(effort_ctx* c, int enable) {
 
 extern "C" int effort_debug_stamps(effort_ctx* c, unsigned long long* host32) {
     if (!c || !host32) return EFFORT_ERR_ARG;
+    if (!kLabBuild) return lab_only(c);
     HIP_TRY(c, hipMemcpyAsync(host32, c->d_tstamp + 8, 192, hipMemcpyDeviceToHost, c->stream));
     unsigned long long lines[32 * 8];
     HIP_TRY(c, hipMemcpyAsync(lines, c->d_tstamp + 64, sizeof(lines), hipMemcpyDeviceToHost, c->stream));
@@ -1271,6 +1283,7 @@ extern "C" int effort_debug_stamps(effort_ctx* c, unsigned long long* host32) {
 
 extern "C" int effort_debug_trace(effort_ctx* c, unsigned long long* host, int maxRecords) {
     if (!c || !host || maxRecords < 1 || maxRecords > kTraceItems) return EFFORT_ERR_ARG;
+    if (!kLabBuild) return lab_only(c);
     HIP_TRY(c, hipMemcpyAsync(host, c->d_tstamp + kTraceOff, (size_t)maxRecords * 64, hipMemcpyDeviceToHost, c->stream));
     // (then, per item, four progress stamps of its streaming phase: wave 0 a quarter / half / three quarters through its rows)
     HIP_TRY(c, hipMemcpyAsync(host + (size_t)maxRecords * 8, c->d_tstamp + kTraceOff + (size_t)kTraceItems * 8, (size_t)maxRecords * 32, hipMemcpyDeviceToHost, c->stream));
@@ -1280,6 +1293,7 @@ extern "C" int effort_debug_trace(effort_ctx* c, unsigned long long* host, int m
 
 extern "C" int effort_kernel_clock(effort_ctx* c, double* mul_us_avg, int* n_launches) {
     if (!c) return EFFORT_ERR_ARG;
+    if (!kLabBuild) return lab_only(c);
     unsigned long long h[4] = {0, 0, 0, 0};
     HIP_TRY(c, hipMemcpyAsync(h, c->d_tstamp, 32, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));

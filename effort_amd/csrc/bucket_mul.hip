@@ -84,7 +84,19 @@ constexpr int kRowAux = EFFORT_ROW_AUX;
 // decode loop 267 -> 290 tokens/s (A/B on one box).  The generic instantiation serves persistent launches and the debug modes.
 #define GA_PERSISTENT(ga) (PERSIST ? (ga).persistent : 0u)
 #define GA_CUTJOBS(ga) (PERSIST ? (ga).cutJobs : 0u)
-#ifdef EFFORT_PRODUCT_ONLY               // A/B build: no stamps / ablation switches in ANY instantiation
+// Two libraries are built from this file (csrc/Makefile).  The SHIPPED one, libeffort_hip.so, is the product alone: no device-clock
+// stamps, no per-item trace, no ablation switches in ANY instantiation -- the macros below are constants and the code behind them is
+// gone (tests/test_abi.py disassembles the library: no s_memrealtime in bucket_mul_kernel).  libeffort_hip_lab.so (-DEFFORT_LAB) is
+// the lab bench the tools load (EFFORT_HIP_LIB=lab): the generic instantiation then carries the stamps / trace / ablation paths, and
+// the A/B macros (EFFORT_PAD_TEST, EFFORT_CUT_FINE, EFFORT_ABLATE_*, EFFORT_NO_TOUCH, ...) are accepted.  Round 6 A/B of the two
+// builds on the throughput launches: profiles/r06_ab_product_only.txt.
+#ifndef EFFORT_LAB
+#define EFFORT_PRODUCT_ONLY 1
+#if defined(EFFORT_PAD_TEST) || defined(EFFORT_CUT_FINE) || defined(EFFORT_NO_TOUCH) || defined(EFFORT_NO_STAMPS) || EFFORT_ABLATE_NOSCATTER || EFFORT_ABLATE_NOLOAD
+#error "lab switches need -DEFFORT_LAB (they belong in libeffort_hip_lab.so / build/variants, never in the shipped library)"
+#endif
+#endif
+#ifdef EFFORT_PRODUCT_ONLY
 #define GA_TSTAMP(ga) ((unsigned long long*)nullptr)
 #define GA_ABLATE(ga) 0u
 #define GA_TRACE(ga) 0u
@@ -1027,6 +1039,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     if (wstamp) ph[5] = wall_clock64();
     // the stamps are flushed off the critical path (after the ticket), spread over 32 cache lines
     auto flush_stamps = [&]() {
+#ifndef EFFORT_PRODUCT_ONLY
         if (!wstamp) return;
         if (GA_TRACE(ga) && item + GA_CUTJOBS(ga) < (uint32_t)kTraceItems) {           // one record per item: who / where / when
             unsigned long long* rec = GA_TSTAMP(ga) + kTraceOff + (size_t)(item + GA_CUTJOBS(ga)) * 8u;
@@ -1045,6 +1058,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
         atomicMax(&GA_TSTAMP(ga)[28], ph[5] - ph[0]);                               // longest workgroup (start .. slab drained)
         atomicMax(&GA_TSTAMP(ga)[29], ph[4] - ph[3]);                               // longest streaming phase
         atomicMax(&GA_TSTAMP(ga)[1], (unsigned long long)wall_clock64());
+#endif
     };
     {
         __syncthreads();
@@ -1145,7 +1159,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     if (rstamp) GA_TSTAMP(ga)[24] = wall_clock64();
     if (tid == 0) {
         __hip_atomic_store(&a_counters[t], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next call
-#ifndef EFFORT_CUT_FINE
+#if !defined(EFFORT_CUT_FINE) && !defined(EFFORT_PRODUCT_ONLY)
         if (GA_TSTAMP(ga)) {
             flush_stamps();
             const uint32_t done = __hip_atomic_fetch_add(ga.groupDone, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1179,10 +1193,11 @@ __device__ __forceinline__ void cutoff_job(const GroupKArgs& ga, uint32_t ci, ch
     float vj[VPT]; uint16_t prj[VPT];
 #pragma unroll
     for (int i = 0; i < VPT; i++) { vj[i] = a.v[tid + NT * i]; prj[i] = pr[tid + NT * i]; }
-    const unsigned long long tj0 = (ga.tstamp && ga.trace) ? wall_clock64() : 0ull;
+    [[maybe_unused]] constexpr bool PERSIST = true;              // (cutoff jobs exist in persistent launches only)
+    const unsigned long long tj0 = (GA_TSTAMP(ga) && GA_TRACE(ga)) ? wall_clock64() : 0ull;
     const float cutoff = block_find_cutoff<NT>(vj, prj, a.q, smem + cutoff_table_bytes(NT), reinterpret_cast<uint32_t*>(smem), []() {}, nullptr);
-    if (tid == 0 && ga.tstamp && ga.trace) {
-        unsigned long long* rec = ga.tstamp + kTraceOff + (size_t)ci * 8u;
+    if (tid == 0 && GA_TSTAMP(ga) && GA_TRACE(ga)) {
+        unsigned long long* rec = GA_TSTAMP(ga) + kTraceOff + (size_t)ci * 8u;
         rec[0] = (unsigned long long)ci | ((unsigned long long)blockIdx.x << 32) | (1ull << 63);
         rec[1] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 32);
         rec[2] = tj0; rec[3] = wall_clock64();

@@ -49,21 +49,37 @@ __global__ __launch_bounds__(1024) void q4_threshold_kernel(const uint32_t* __re
     }
 }
 
-// candidates: every element with magnitude >= m*, as key (32767 - mag) << 32 | flat index (ascending key = the table's order)
+// candidates: every element with magnitude >= m*, as key (32767 - mag) << 32 | flat index (ascending key = the table's order; the sort
+// that follows fixes the order, so where a candidate lands here is free).  A thread takes eight elements (one 16-byte load), the block
+// counts its candidates in LDS and reserves their places with ONE global atomic per 2048 elements.  (Round 5's version asked the global
+// counter once per wave and 64 elements -- half a million atomics on one address for a 4096 x 11008 matrix: 5.8 ms, two thirds of a
+// conversion's GPU time; profiles/r05_q4_rocprofv3_kernel_stats_16_per_launch.csv.)
 __global__ __launch_bounds__(256) void q4_collect_kernel(const uint16_t* __restrict__ core, size_t n, const uint32_t* __restrict__ res,
                                                          unsigned long long* __restrict__ keys, uint32_t* __restrict__ counter) {
+    __shared__ uint32_t s_cnt, s_base;
     const uint32_t mstar = res[0];
-    for (size_t i0 = (size_t)blockIdx.x * 256; i0 < n; i0 += (size_t)gridDim.x * 256) {
-        const size_t i = i0 + threadIdx.x;
-        const uint32_t mag = i < n ? (uint32_t)(core[i] & 0x7FFFu) : 0u;
-        const bool take = i < n && mag >= mstar;
-        const unsigned long long m = __ballot(take);
-        if (!m) continue;
-        uint32_t base = 0;
-        const int lane = threadIdx.x & 63;
-        if (lane == 0) base = atomicAdd(counter, (uint32_t)__popcll(m));
-        base = __shfl(base, 0);
-        if (take) keys[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = ((unsigned long long)(32767u - mag) << 32) | (unsigned long long)i;
+    constexpr size_t kChunk = 256 * 8;
+    for (size_t c0 = (size_t)blockIdx.x * kChunk; c0 < n; c0 += (size_t)gridDim.x * kChunk) {       // (n is a multiple of 32: outDim % 32 == 0)
+        if (threadIdx.x == 0) s_cnt = 0;
+        __syncthreads();
+        const size_t i = c0 + (size_t)threadIdx.x * 8;
+        uint32_t mag[8], t = 0;
+        if (i < n) {
+            const uint4 w = *reinterpret_cast<const uint4*>(core + i);
+            const uint32_t d[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int k = 0; k < 8; k++) { mag[k] = (d[k >> 1] >> (16 * (k & 1))) & 0x7FFFu; t += mag[k] >= mstar ? 1u : 0u; }
+        }
+        uint32_t my = t ? atomicAdd(&s_cnt, t) : 0u;
+        __syncthreads();
+        if (threadIdx.x == 0) s_base = s_cnt ? atomicAdd(counter, s_cnt) : 0u;
+        __syncthreads();
+        if (t) {
+            my += s_base;
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if (mag[k] >= mstar) keys[my++] = ((unsigned long long)(32767u - mag[k]) << 32) | (unsigned long long)(i + k);
+        }
     }
 }
 

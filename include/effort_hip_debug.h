@@ -29,6 +29,10 @@ EFFORT_API int effort_set_persistent(effort_ctx* ctx, int wgPerCU);
  * read the lane the most recent launch went to; this points them at another lane's last launch (0 .. lanes-1). */
 EFFORT_API int effort_debug_hook_lane(effort_ctx* ctx, int lane);
 
+/* 1 in libeffort_hip_lab.so (built with -DEFFORT_LAB: device-clock stamps, per-item trace, ablation switches, environment knobs), 0 in the
+ * shipped libeffort_hip.so, whose kernels carry none of that: there enable = 2 / 3 below, effort_kernel_clock, effort_debug_stamps and
+ * effort_debug_trace return EFFORT_ERR_KIND, and enable = 1 records HIP events only. */
+EFFORT_API int effort_is_lab_build(void);
 /* Timing hooks.  enable = 1: HIP events are recorded on the context's stream around each launch (not capturable into a
  * graph) AND the multiply kernel stamps the device wall clock at its first workgroup's start / last workgroup's end;
  * enable = 2: device clock only (works inside hipGraph replays); 3: 2 plus a per-item trace (effort_debug_trace); 0: off.

@@ -115,6 +115,41 @@ def test_shipped_library_reads_no_environment(hip_lib_built):
             assert "getenv" not in syms, obj
 
 
+def _multiply_kernel_disassembly(lib_path, tmp_path):
+    """Disassembly of the code object of `lib_path` that holds the bucket_mul_kernel instantiations (llvm-objdump --offloading)."""
+    import glob
+    import shutil
+    import subprocess
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not os.path.exists(os.path.join(llvm, "llvm-objdump")):
+        pytest.skip("no llvm-objdump in this image")
+    work = os.path.join(str(tmp_path), os.path.basename(lib_path))
+    shutil.copy(lib_path, work)
+    subprocess.run([os.path.join(llvm, "llvm-objdump"), "--offloading", work], capture_output=True, cwd=str(tmp_path), check=True)
+    for co in sorted(glob.glob(work + ".*gfx950")):
+        syms = subprocess.run([os.path.join(llvm, "llvm-readelf"), "-sW", co], capture_output=True, text=True).stdout
+        if "bucket_mul_kernel" in syms:
+            return subprocess.run([os.path.join(llvm, "llvm-objdump"), "-d", co], capture_output=True, text=True, check=True).stdout
+    raise AssertionError("no code object with bucket_mul_kernel in " + lib_path)
+
+
+def test_shipped_kernels_carry_no_lab_code(hip_lib_built, tmp_path):
+    """Round 5's review: the persistent headline instantiation kept runtime tests of the stamp / ablation / trace switches, and the lab
+    macros sat beside product code.  Since round 6 the shipped library is the product alone -- its multiply kernels read no clock
+    (`s_memrealtime`: the device-clock stamps) and no XCC / HW id (the per-item trace) anywhere in their code -- and the same sources
+    built -DEFFORT_LAB are libeffort_hip_lab.so, which does and which the tools load (EFFORT_HIP_LIB=lab)."""
+    import ctypes
+    import effort_amd._lib as L
+    prod = _multiply_kernel_disassembly(hip_lib_built, tmp_path)
+    assert prod.count("s_memrealtime") == 0 and "HW_REG_XCC_ID" not in prod and "HW_REG_HW_ID" not in prod
+    assert os.path.exists(L.LAB_LIB_PATH), "make all builds the lab library next to the product"
+    lab = _multiply_kernel_disassembly(L.LAB_LIB_PATH, tmp_path)
+    assert lab.count("s_memrealtime") > 100 and "HW_REG_XCC_ID" in lab
+    assert ctypes.CDLL(hip_lib_built).effort_is_lab_build() == 0
+    blob = open(L.LAB_LIB_PATH, "rb").read()
+    assert b"EFFORT_ABLATE" in blob                                  # (the environment knobs live there, and only there)
+
+
 def test_shipped_library_has_no_measured_dead_ends(hip_lib_built):
     """What round 4 built and measured SLOWER -- chain launches, the named reducer, byte-indexed Q4 accumulators -- lives on branch
     `chain-launch`, not in the drop-in header or the shipped library; and the library loads without RCCL (multi-GPU binds it at run

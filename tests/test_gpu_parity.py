@@ -1147,3 +1147,35 @@ def test_row_selection_across_exits_and_ties(ea, oracle_cpu, kind):
         for i, o in enumerate(outs):
             assert g.last_dispatch_count(i) == n and g.last_cutoff(i) == cutoff, (kind, effort, i)
             assert close(o.cpu().numpy(), want), (kind, effort, i)
+
+
+def test_timing_hooks_of_the_shipped_library(ea, oracle_cpu):
+    """The shipped kernels carry no stamp code (tests/test_abi.py::test_shipped_kernels_carry_no_lab_code): the device-clock modes are
+    refused with a message naming the lab library, the HIP-event mode still times launches, and results are what they are without it."""
+    if ea.lib().effort_is_lab_build():
+        pytest.skip("EFFORT_HIP_LIB points at a lab build")
+    outDim, inDim = 1024, 4096
+    W, b, s, p = converted(oracle_cpu, outDim, inDim)
+    ew = gpu_weights(ea, W, b, s, p)
+    g = ea.Gpu(0)
+    v = make_v(inDim, seed=21)
+    want, n, cutoff = oracle_cpu.bucket_mul(v, b, s, p, inDim, outDim, 0.25)
+    out = torch.zeros(outDim, device=DEV)
+    try:
+        for mode in (2, 3):
+            with pytest.raises(ea.EffortError, match="libeffort_hip_lab"):
+                g.enable_kernel_timing(mode)
+        with pytest.raises(ea.EffortError, match="libeffort_hip_lab"):
+            g.kernel_clock()
+        with pytest.raises(ea.EffortError, match="libeffort_hip_lab"):
+            g.debug_stamps()
+        g.enable_kernel_timing(1)
+        for _ in range(3):
+            ea.bucketMul(devf(v), ew, None, out, 0.25, gpu=g)
+        t = g.kernel_timing()
+        assert t["samples"] == 3 and 1.0 < t["mul_us"] < 1000.0
+        g.enable_kernel_timing(0)
+        g.eval()
+        assert close(out.cpu().numpy(), want) and g.last_dispatch_count() == n and g.last_cutoff() == cutoff
+    finally:
+        g.close()

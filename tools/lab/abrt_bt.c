@@ -27,6 +27,11 @@ static void on_sig(int sig, siginfo_t* si, void* uc) {
 }
 __attribute__((constructor)) static void init(void) {
     struct sigaction sa;
+    {   /* backtrace()'s first call loads libgcc_s (dlopen: malloc) -- done HERE, not inside a handler that runs while free() holds the
+         * allocator's lock (round 6's first hunt reproduced the abort and then hung exactly there) */
+        void* warm[4];
+        (void)backtrace(warm, 4);
+    }
     memset(&sa, 0, sizeof sa);
     sa.sa_sigaction = on_sig;
     sigemptyset(&sa.sa_mask);

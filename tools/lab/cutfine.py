@@ -2,6 +2,7 @@
 """Shader-clock stamps inside findCutoff32 of item 0 of a lone call (a -DEFFORT_CUT_FINE lab build: tools/build_variant_all.sh fine
 "-DEFFORT_CUT_FINE"; EFFORT_HIP_LIB=build/variants/fine.so python tools/lab/cutfine.py)."""
 import os, sys
+os.environ.setdefault("EFFORT_HIP_LIB", "lab")     # stamps / traces live in libeffort_hip_lab.so (the shipped kernels carry none)
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import effort_amd as ea

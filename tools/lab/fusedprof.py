@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Phase stamps of item 0 of a lone call, plain against fused prologues / epilogue (tools only)."""
 import os, sys
+os.environ.setdefault("EFFORT_HIP_LIB", "lab")     # stamps / traces live in libeffort_hip_lab.so (the shipped kernels carry none)
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import effort_amd as ea

@@ -8,6 +8,7 @@ the same bytes with a plain torch reduction so the box's achievable HBM rate is 
 """
 import json
 import os
+os.environ.setdefault("EFFORT_HIP_LIB", "lab")     # stamps / traces live in libeffort_hip_lab.so (the shipped kernels carry none)
 import sys
 import time
 

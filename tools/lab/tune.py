@@ -9,6 +9,7 @@ multiply kernel's own duration from the device wall clock.  Used to pick the heu
 import argparse
 import json
 import os
+os.environ.setdefault("EFFORT_HIP_LIB", "lab")     # stamps / traces live in libeffort_hip_lab.so (the shipped kernels carry none)
 import sys
 import time
 

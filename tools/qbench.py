@@ -38,6 +38,7 @@ def main():
     from bench import make_weights
     dev = torch.device("cuda", 0)
     g = ea.gpu(0)
+    lab = bool(getattr(ea.lib(), "effort_is_lab_build", lambda: 1)())     # (device-clock stamps exist in the lab library only; an older A/B build has them too)
     ews = make_weights(ea, args.mats, inDim, outDim, 1234, dev, keep_core=False, q4=bool(args.q4))
     if args.q4 and args.no_outliers:
         ews = [ea.ExpertWeights(e.buckets, e.stats, e.probes, inSize=inDim, outSize=outDim, q4=True) for e in ews]
@@ -109,7 +110,8 @@ def main():
                 for _ in range(30):
                     gr.replay()
                 torch.cuda.synchronize()
-                g.kernel_clock()
+                if lab:
+                    g.kernel_clock()
                 t0 = time.perf_counter()
                 for _ in range(n):
                     gr.replay()
@@ -117,11 +119,13 @@ def main():
                 return (time.perf_counter() - t0) / n / len(chunks) / args.steps_per_graph
             g.enable_kernel_timing(0)
             dt = timed(300)
-            g.enable_kernel_timing(2)
-            timed(50)
-            kc = g.kernel_clock()
-            g.enable_kernel_timing(0)
-            print(f"{args.tag} rep {rep} cfg {cfg:14s} effort {args.effort} group {args.group}: {dt * 1e6:8.2f} us/launch  device-clock span {kc['mul_us']:8.2f} us", flush=True)
+            span = "n/a (product library: EFFORT_HIP_LIB=lab has the stamps)"
+            if lab:
+                g.enable_kernel_timing(2)
+                timed(50)
+                span = f"{g.kernel_clock()['mul_us']:8.2f} us"
+                g.enable_kernel_timing(0)
+            print(f"{args.tag} rep {rep} cfg {cfg:14s} effort {args.effort} group {args.group}: {dt * 1e6:8.2f} us/launch  device-clock span {span}", flush=True)
 
 
 if __name__ == "__main__":

@@ -9,6 +9,7 @@ workgroups are in the streaming phase over time, and the per-item phase duration
 import argparse
 import json
 import os
+os.environ.setdefault("EFFORT_HIP_LIB", "lab")     # stamps / traces live in libeffort_hip_lab.so (the shipped kernels carry none)
 import sys
 
 import numpy as np
