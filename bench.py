@@ -224,17 +224,30 @@ def chunked(items, n):
     return [items[i:i + n] for i in range(0, len(items), n)]
 
 
+_EVENTS_FOR_LIFE = []       # see Job: events that took part in a capture are never destroyed
+
+
 class Job:
     """K independent steps as ONE hipGraph: step i is enqueued on stream i % S through context i % S (a context owns the
     scratch of its launches) into output set i % S; the streams fork from / join the capturing stream inside the graph.
     `step(ctx, slot)` enqueues one step's launches on the current stream.  S = 1: everything on the capturing stream.
-    (The N > 1 legs and tools/bench_extra.py's `four_contexts`; the one-GPU headline goes through LaneJob.)"""
+    (The N > 1 legs, the dense baseline and tools/bench_extra.py's `four_contexts`; the one-GPU headline goes through LaneJob.)
+
+    The fork / join edges go through events that live AS LONG AS THE PROCESS, not through Stream.wait_stream: wait_stream creates a
+    temporary event per call and destroys it at once -- inside a capture, while the graph it became part of is still being built --
+    and on this runtime (ROCm 7.x) an event destroyed after it took part in a capture leaves a dangling reference that a LATER
+    hipGraphLaunch trips over, or that surfaces as glibc's `free(): invalid pointer` a few frees later: round 5's one-in-forty bench
+    abort (round 6's hunts: tools/lab/graph_event_repro.py; the library's own lanes have pooled their events for the same
+    reason since round 3, api.hip)."""
 
     def __init__(self, ea, device, streams=1, tune=(0, 0, 0)):
         import torch
         self.ea, self.S = ea, max(1, streams)
         self.ctxs = [ea.gpu(device)] + [ea.Gpu(device) for _ in range(self.S - 1)]
         self.streams = [None] + [torch.cuda.Stream(device=device) for _ in range(self.S - 1)]
+        self.fork_ev = torch.cuda.Event()
+        self.join_ev = [torch.cuda.Event() for _ in range(self.S)]
+        _EVENTS_FOR_LIFE.extend([self.fork_ev] + self.join_ev + self.streams[1:])
         for c in self.ctxs:
             c.set_tuning(*tune)
 
@@ -242,8 +255,10 @@ class Job:
         import torch
         s0 = torch.cuda.current_stream()
         used = min(self.S, nsteps)
+        if used > 1:
+            self.fork_ev.record(s0)
         for k in range(1, used):
-            self.streams[k].wait_stream(s0)
+            self.streams[k].wait_event(self.fork_ev)
         for i in range(nsteps):
             k = i % self.S
             if k == 0:
@@ -252,7 +267,8 @@ class Job:
                 with torch.cuda.stream(self.streams[k]):
                     step(self.ctxs[k], k)
         for k in range(1, used):
-            s0.wait_stream(self.streams[k])
+            self.join_ev[k].record(self.streams[k])
+            s0.wait_event(self.join_ev[k])
 
     def capture(self, step, nsteps):
         import torch

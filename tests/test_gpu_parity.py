@@ -14,6 +14,8 @@ import torch
 
 from tests.util import cos, make_v, make_w
 
+_KEEP_ALIVE = []       # events / streams that took part in a hipGraph capture are never destroyed (see test_launches_in_flight_on_several_streams)
+
 pytestmark = pytest.mark.gpu
 
 ATOL_REL = 2e-5
@@ -1027,10 +1029,16 @@ def test_launches_in_flight_on_several_streams(ea, oracle_cpu):
     def step(i):
         ea.bucketMulGroup([(vs[i], ews[k], None, outs[i][k], efforts[(i + k) % 3]) for k in range(n_mats)], gpu=ctxs[i % S])
 
+    # (fork / join through events that outlive the graph, not Stream.wait_stream: its temporary events are destroyed inside the
+    #  capture they took part in, which this runtime does not survive reliably -- tools/lab/graph_event_repro.py)
+    fork_ev, join_ev = torch.cuda.Event(), [torch.cuda.Event() for _ in range(S)]
+    _KEEP_ALIVE.extend([fork_ev] + join_ev + streams[1:])
+
     def enqueue():
         s0 = torch.cuda.current_stream()
+        fork_ev.record(s0)
         for k in range(1, S):
-            streams[k].wait_stream(s0)
+            streams[k].wait_event(fork_ev)
         for i in range(steps):
             if i % S == 0:
                 step(i)
@@ -1038,7 +1046,8 @@ def test_launches_in_flight_on_several_streams(ea, oracle_cpu):
                 with torch.cuda.stream(streams[i % S]):
                     step(i)
         for k in range(1, S):
-            s0.wait_stream(streams[k])
+            join_ev[k].record(streams[k])
+            s0.wait_event(join_ev[k])
     try:
         enqueue()
         torch.cuda.synchronize()

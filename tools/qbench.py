@@ -69,6 +69,8 @@ def main():
             if K > 1 and not hasattr(main, "ctxs"):
                 main.ctxs = [ea.Gpu(0) for _ in range(K)]
                 main.sts = [torch.cuda.Stream() for _ in range(K)]
+                main.fork = torch.cuda.Event()                     # (events that outlive the graphs: bench.Job says why not wait_stream)
+                main.join = [torch.cuda.Event() for _ in range(K)]
             if K > 1:
                 for c in main.ctxs:
                     c.set_tuning(*(int(x) for x in tune.split(",")))
@@ -89,14 +91,17 @@ def main():
                     else:                                # step `rep_` of the graph goes to stream rep_ % K (own context: own scratch)
                         s0 = torch.cuda.current_stream()
                         st, cx = main.sts[rep_ % K], main.ctxs[rep_ % K]
+                        if rep_ == 0:
+                            main.fork.record(s0)
                         if rep_ < K:
-                            st.wait_stream(s0)
+                            st.wait_event(main.fork)
                         with torch.cuda.stream(st):
                             for ch in chunks:
                                 ea.bucketMulGroup([(v, ew, None, o, args.effort) for ew, o in ch], gpu=cx)
                 if K > 1:
-                    for st in main.sts:
-                        torch.cuda.current_stream().wait_stream(st)
+                    for st, ev in zip(main.sts, main.join):
+                        ev.record(st)
+                        torch.cuda.current_stream().wait_event(ev)
                 if args.overlap > 1:
                     g.join()
 
