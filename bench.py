@@ -225,6 +225,17 @@ def chunked(items, n):
 
 
 _EVENTS_FOR_LIFE = []       # see Job: events that took part in a capture are never destroyed
+_GRAPHS_FOR_LIFE = []       # ... and neither is a captured graph: keep() below
+
+
+def keep(graph):
+    """Every hipGraph this process captures lives until the process exits (and the process leaves through os._exit: main()).  Destroying
+    a graph exec shortly after its last launch is what took round 5's bench down once in ~40 runs (`free(): invalid pointer`): a
+    use-after-free inside the HIP runtime's graph code that plain torch ops reproduce without this library in the process
+    (tools/lab/graph_event_repro.py: capture -> replay -> destroy in a loop dies under the checking allocator, the same loop that KEEPS
+    its graphs does not).  A bench's few hundred graphs cost a few MB."""
+    _GRAPHS_FOR_LIFE.append(graph)
+    return graph
 
 
 class Job:
@@ -281,7 +292,7 @@ class Job:
             self._enqueue(step, nsteps)
         for c in self.ctxs:
             c._bind_stream()
-        return g
+        return keep(g)
 
     def last_dispatch_count(self, nsteps, idx):
         return self.ctxs[(nsteps - 1) % self.S].last_dispatch_count(idx)
@@ -313,7 +324,7 @@ class LaneJob:
         with torch.cuda.graph(g, capture_error_mode="thread_local"):
             self._enqueue(step, nsteps)
         self.ctx._bind_stream()
-        return g
+        return keep(g)
 
     def last_dispatch_count(self, nsteps, idx):
         return self.ctx.last_dispatch_count(idx)
@@ -479,7 +490,7 @@ def timeit_protocol(ea, g, dev, efforts=(1.0, 0.5, 0.25), repeats=3000, variants
                 g._bind_stream()                                                  # (the raw ABI calls go to the context's stream: the capturing one)
                 assert loop(320, s, 1) == 0
             g._bind_stream()
-            gr.replay()
+            keep(gr).replay()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(10):
@@ -553,7 +564,7 @@ def layer_latency(ea, g, dev, rank=0, world=1, effort=0.5, n_layers=8, reps=60, 
             with torch.cuda.graph(gr, capture_error_mode="thread_local"):
                 chain(G)
             g._bind_stream()
-            run = gr.replay
+            run = keep(gr).replay
         else:
             run = lambda: chain(G)                                                # noqa: E731
         for _ in range(3):
@@ -1097,6 +1108,7 @@ class Bench:
         g.set_dense_backend(True)                    # the dense path through rocBLAS (the north star's baseline) ...
         _, dt_r, _ = dec.run(prompt, ntok, dense=True)
         g.set_dense_backend(False)                   # ... and through the package's own GEMV (also the LM head of the effort runs)
+        _GRAPHS_FOR_LIFE.extend(dec._graphs.values())        # (keep(): no graph is destroyed before the process exits)
         dec._graphs.clear()
         ids_d, dt_d, lg_d = dec.run(prompt, ntok, dense=True, collect_logits=True)
         forced = prompt + ids_d[len(prompt) - 1:-1]
@@ -1108,6 +1120,7 @@ class Bench:
             dsec["effort"][str(e)] = {"tokens_per_s": round(1 / dt_e, 1), "ms_per_token": round(dt_e * 1e3, 3),
                                       "speedup_vs_dense_rocblas": round(dt_r / dt_e, 3), "speedup_vs_dense_hip_kernel": round(dt_d / dt_e, 3),
                                       "kl_vs_dense": round(kl_divergence(lg_d, lg_e), 5)}
+        _GRAPHS_FOR_LIFE.extend(dec._graphs.values())
         del dec, model
         self.g.set_tuning(*self.tune)
         return dsec
@@ -1306,6 +1319,14 @@ def main(argv=None):
     aux_done.set()
     if dist:
         dist.destroy_process_group()
+    # leave without tearing anything down: the graphs kept alive (keep()) are not destroyed at interpreter exit either
+    sys.stdout.flush()
+    sys.stderr.flush()
+    # (not under --headline-only: that is the job rocprofv3 wraps, and a profiler flushes its trace in exit handlers)
+    if (os.environ.get("BENCH_CHILD") or os.environ.get("BENCH_LAUNCHED") or int(os.environ.get("WORLD_SIZE", "1")) > 1) and not args.headline_only:
+        import atexit
+        atexit._run_exitfuncs()          # (Python-level exit hooks still run; what is skipped is the teardown of the CUDA objects)
+        os._exit(0)
     return 0
 
 

@@ -628,6 +628,17 @@ static uint32_t pick_slices(const effort_ctx* c, const effort_w* w, int groupSiz
     uint32_t S = (target / allTiles + 4u) / 8u * 8u;       // nearest multiple of 8
     if (S < lo) S = lo;
     if (S > hi) S = hi;
+    // A slice's candidate slots are laid out per rank in blocks of 2^ceil(log2(rows)): a row count that is not a power of two wastes the
+    // rest of the block in staging, selection and LDS (24 slices of a 4096-row input: 171 rows in blocks of 256, a third of the slots
+    // empty).  With a power-of-two input the count snaps to the next power of two when the bounds allow.  Round 6 re-sweep of the decode
+    // loop's launches and the lone FFN shapes (tools/lab/geosweep.py, profiles/r06_geosweep.txt): every launch was within 0.3 % of its best
+    // geometry except the lone 4096 -> 14336 call -- the shape of the reference's own timing loop (benchmarks/benchmark.swift:245-257) --
+    // where the rule above gave 24 slices: 20.0 -> 18.6 us at 25 % effort, 25.4 -> 23.4 at 50 %.
+    if ((w->inDim & (w->inDim - 1u)) == 0u && (S & (S - 1u)) != 0u) {
+        uint32_t up = 8u;
+        while (up < S) up <<= 1;
+        S = up <= hi ? up : up >> 1;
+    }
     return S;
 }
 

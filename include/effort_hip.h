@@ -75,7 +75,10 @@ EFFORT_API int effort_sync(effort_ctx* ctx);
  * once), and implicitly at effort_sync, at any other effort_* call on the context and at the test hooks.  A caller who
  * enqueues its OWN work on the stream to consume an output calls effort_join first; inside a hipGraph capture call
  * effort_join before ending the capture (the lanes fork from and must rejoin the capturing stream).
- * Costs 64 MiB of scratch per extra lane. */
+ * Costs 64 MiB of scratch per extra lane.
+ * Runtime note (HIP 7.0.x as bundled by torch 2.10+rocm7.0, found in round 6): DESTROYING a hipGraph that was captured across several
+ * streams -- which every capture of a context with lanes > 1 is -- corrupts the HIP runtime's heap (reproducible with plain torch ops,
+ * tools/lab/graph_event_repro.py); keep such graphs for the life of the process, or capture with lanes = 1. */
 EFFORT_API int effort_set_overlap(effort_ctx* ctx, int lanes);
 EFFORT_API int effort_join(effort_ctx* ctx);
 /* Text of the context's last error; with ctx == NULL: why the last effort_create returned NULL ("null context" if none did). */

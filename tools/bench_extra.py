@@ -189,6 +189,7 @@ def decode_quality(b, res):
     model = Model.random(MistralConfig(), seed=2, structured=True)
     ntq = 224
     dec = Decoder(model, maxTokens=ntq + 8)
+    B._GRAPHS_FOR_LIFE.append(dec._graphs)                        # (the dict itself: whatever it collects stays alive)
     ids_1, _, _ = dec.run(prompt, ntq, effort=1.0)
     forced = prompt + ids_1[len(prompt) - 1:-1]
     _, _, lg_dn = dec.run(forced, ntq, dense=True, forced=True, collect_logits=True)
@@ -248,7 +249,9 @@ def main():
     with open(os.path.join(ROOT, "gpurun_out", "bench_extra.json"), "w") as f:
         json.dump(res, f)
         f.write("\n")
-    print(json.dumps({k: (v if not isinstance(v, dict) or len(json.dumps(v)) < 300 else "...") for k, v in res.items()}))
+    print(json.dumps({k: (v if not isinstance(v, dict) or len(json.dumps(v)) < 300 else "...") for k, v in res.items()}), flush=True)
+    sys.stderr.flush()
+    os._exit(0)          # (bench.keep(): no captured graph is destroyed, at exit either)
 
 
 if __name__ == "__main__":

@@ -27,10 +27,13 @@ def main():
     ap.add_argument("--sync", default="wait_stream")
     ap.add_argument("--iters", type=int, default=3000)
     ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--keep", type=int, default=0, help="1: never destroy a graph (every one is kept until the process exits)")
+    ap.add_argument("--streams", type=int, default=4, help="1: no fork / join at all (everything on the capturing stream)")
+    ap.add_argument("--nograph", type=int, default=0, help="1: the same work eagerly, no capture at all")
     a = ap.parse_args()
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
-    S = 4
+    S = max(1, a.streams)
     streams = [None] + [torch.cuda.Stream(device=dev) for _ in range(S - 1)]
     fork_ev = torch.cuda.Event()
     join_ev = [torch.cuda.Event() for _ in range(S)]
@@ -77,9 +80,16 @@ def main():
                 join_ev[k].record(streams[k])
                 s0.wait_event(join_ev[k])
     t0 = time.time()
+    kept = []
+    tag = f"{a.work} {a.sync} streams={S} keep={a.keep} nograph={a.nograph}"
     for it in range(a.iters):
         enqueue(S)
         torch.cuda.synchronize()
+        if a.nograph:
+            for _ in range(5):
+                enqueue(a.steps)
+            torch.cuda.synchronize()
+            continue
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, capture_error_mode="thread_local"):
             enqueue(a.steps)
@@ -89,10 +99,15 @@ def main():
         for _ in range(4):
             g.replay()
         torch.cuda.synchronize()
+        if a.keep:
+            kept.append(g)
         del g
         if it % 500 == 499:
-            print(f"{a.work} {a.sync}: {it + 1} captures + replays + destroys, {time.time() - t0:.0f} s", flush=True)
-    print(f"{a.work} {a.sync}: done, {a.iters} iterations clean", flush=True)
+            print(f"{tag}: {it + 1} captures + replays{'' if a.keep else ' + destroys'}, {time.time() - t0:.0f} s", flush=True)
+    print(f"{tag}: done, {a.iters} iterations clean", flush=True)
+    sys.stdout.flush()
+    if a.keep:
+        os._exit(0)          # (the kept graphs are not destroyed at interpreter exit either)
 
 
 if __name__ == "__main__":
