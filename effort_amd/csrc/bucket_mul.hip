@@ -97,8 +97,17 @@ constexpr int kRowAux = EFFORT_ROW_AUX;
 #endif
 #endif
 #ifdef EFFORT_PRODUCT_ONLY
+constexpr bool kProductOnly = true;
+#else
+constexpr bool kProductOnly = false;
+#endif
+#ifdef EFFORT_PRODUCT_ONLY
 #define GA_TSTAMP(ga) ((unsigned long long*)nullptr)
 #define GA_ABLATE(ga) 0u
+#define GA_TRACE(ga) 0u
+#elif defined(EFFORT_LEAN_STAMPS)          // lab: the LEAN instantiations write the fine stamps too (with EFFORT_CUT_FINE; tools/lab/cutfine.py) -- timing only
+#define GA_TSTAMP(ga) ((ga).tstamp)
+#define GA_ABLATE(ga) (PERSIST ? (ga).ablate : 0u)
 #define GA_TRACE(ga) 0u
 #else
 #define GA_TSTAMP(ga) (PERSIST ? (ga).tstamp : nullptr)
@@ -168,10 +177,11 @@ template <int E> __host__ __device__ inline uint32_t ol_scratch_bytes(const MulG
 // means / vblk are filled by LDS-direct buffer loads (stage_issue), whose destination (M0) is kept below 64 KB.  Q4: after
 // the streaming phase means | vblk are dead and hold the outlier phase's scratch (sums | whole v); Q4 items are not
 // pipelined and use vblk[0] only.
-// `lean`: the plan of a plain grid's lean instantiation (launch_mul_t) -- the only one whose Q4 items read offO, the region of their
-// own for the whole input vector (kOlMerge); the persistent / generic kernels and the other workgroup sizes do not carry it.
+// `merge`: the plan of an instantiation whose Q4 items work their outliers inside the streaming loop (kOlMerge: the 8-wave kernels of the
+// shipped library, lean and persistent) and read offO, the region of their own for the whole input vector; the lab library's generic
+// kernels (stamps: no registers to spare) and the other workgroup sizes do not carry it.
 template <int FMT, int E, int W>
-__host__ __device__ inline LdsPlan plan_lds(const MulGeom* geoms, int nGeoms, bool lean) {
+__host__ __device__ inline LdsPlan plan_lds(const MulGeom* geoms, int nGeoms, bool merge) {
     uint32_t slots = 0, vrows = 0, ol = 0, vEarly = 0;
     for (int i = 0; i < nGeoms; i++) {
         const MulGeom& g = geoms[i];
@@ -181,7 +191,7 @@ __host__ __device__ inline LdsPlan plan_lds(const MulGeom* geoms, int nGeoms, bo
         vrows = vrows > vr ? vrows : vr;
         if (FMT != kFp16) {
             const uint32_t x = ol_scratch_bytes<E>(g); ol = ol > x ? ol : x;
-            if (lean && W == 8 && g.inDim <= kOlEarlyFloats) vEarly = vEarly > g.inDim * 4u ? vEarly : g.inDim * 4u;
+            if (merge && W == 8 && g.inDim <= kOlEarlyFloats) vEarly = vEarly > g.inDim * 4u ? vEarly : g.inDim * 4u;
         }
     }
     LdsPlan p;
@@ -375,7 +385,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     // Q4 outliers (phase O below): the share of this item, and -- lean kernels, v small enough for a region of its own -- what the
     // MERGED form needs, asked for now: the whole of v (eight loads per thread, written to LDS once the staged loads are awaited)
     // and the wave's first block's meta word and entry bounds.
-    constexpr bool kOlMerge = FMT != kFp16 && !PERSIST && W == 8;
+    constexpr bool kOlMerge = FMT != kFp16 && W == 8 && (!PERSIST || kProductOnly);      // (round 6: the persistent instantiation of the SHIPPED library too -- with the stamp code gone it has the registers: 124 VGPRs, no scratch)
     const uint32_t olPer = ol_outputs_per_item<E>(g);
     bool olAny = false, olEarly = false;
     uint32_t olParts = 1u, olStride = 0u;                              // partial sums of a thin share: [parts][olStride], olStride = its blocks * 64
@@ -1245,6 +1255,16 @@ __global__ __launch_bounds__(64 * W, (W <= 8 ? EFFORT_MIN_WAVES_PER_EU : 4)) voi
 #define EFFORT_ESTAMP(i)
 #endif
     EFFORT_ESTAMP(0)
+#ifdef EFFORT_Q4_STAGGER_US
+    // experiment (round 6): a CU's two persistent Q4 workgroups run their heads, streams and tails IN STEP (profiles/r06_q4_timelines.txt), so the
+    // LDS atomic pipe idles through every head and tail; the workgroups placed second (block >= numCU: speed only, never correctness) start late
+    if constexpr (PERSIST && FMT != kFp16) {
+        if (ga.persistent && blockIdx.x >= ga.numCU) {
+            const unsigned long long t0 = wall_clock64();
+            while (wall_clock64() - t0 < (unsigned long long)(EFFORT_Q4_STAGGER_US) * 100ull) __builtin_amdgcn_s_sleep(32);
+        }
+    }
+#endif
     const uint32_t total = ga.totalItems + GA_CUTJOBS(ga);
     uint32_t cachedCall = 0xFFFFFFFFu; float cachedCutoff = 0.0f;
     const uint32_t x = blockIdx.x & 7u;                    // block b sits on XCD b%8; item i wants XCD i%8
@@ -1337,8 +1357,12 @@ static hipError_t launch_mul_t(const GroupKArgs& gaIn, hipStream_t st) {
     // plain grids of the product path (no stamps, no ablation switches) run the lean instantiation (PERSIST = false, see above);
     // built for 8-wave workgroups, the only size the heuristics choose
     constexpr bool kLean = W == 8;
+#ifdef EFFORT_LEAN_STAMPS
+    const bool lean = kLean && !ga.persistent && !ga.ablate;
+#else
     const bool lean = kLean && !ga.persistent && !ga.tstamp && !ga.ablate;
-    const LdsPlan lp = ga.lp = plan_lds<FMT, E, W>(ga.geom, kMaxGeoms, lean);
+#endif
+    const LdsPlan lp = ga.lp = plan_lds<FMT, E, W>(ga.geom, kMaxGeoms, lean || (kLean && kProductOnly));
     uint32_t lds = lp.total;
     if (lp.offA > 65536u && FMT == kFp16) return hipErrorInvalidValue;     // stage_issue's destinations sit below offA
     for (uint32_t i = 0; i < ga.count; i++) {
