@@ -909,6 +909,12 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
             for (uint32_t i = 0; i < ga.count; i++) ga.call[i].stats = ws[first + i]->means16;
             ga.split |= 4u;
         }
+        // Persistent Q4 launches of a context WITHOUT lanes -- one launch on the chip at a time -- start the second workgroup of every CU ~10 us late,
+        // which takes a CU's pair out of step (bucket_mul_kernel; profiles/r06_ab_q4_stagger.txt: 32 calls per launch 109.5 -> 99.8 us).  With lanes the
+        // launches overlap, the CUs are busy anyway and the wait is a loss (2-5 %): off.  FP16 launches are bound by the CU's pull from memory, not
+        // by an LDS pipe, and their pairs fall out of step by themselves (the older workgroup wins the arbitration two to one): measured, no gain
+        // (profiles/r06_ab_fp16_stagger.txt): off.
+        ga.staggerSleeps = (ga.persistent && fmt == kQ4 && !laned) ? 11u : 0u;
         const int frc = fork_lane();
         if (frc != EFFORT_OK) return frc;
         if (c->splitCutoff && !(ablate & 1u)) HIP_TRY(c, launch_find_cutoff_group(ga, st));

@@ -1255,16 +1255,21 @@ __global__ __launch_bounds__(64 * W, (W <= 8 ? EFFORT_MIN_WAVES_PER_EU : 4)) voi
 #define EFFORT_ESTAMP(i)
 #endif
     EFFORT_ESTAMP(0)
-#ifdef EFFORT_Q4_STAGGER_US
-    // experiment (round 6): a CU's two persistent Q4 workgroups run their heads, streams and tails IN STEP (profiles/r06_q4_timelines.txt), so the
-    // LDS atomic pipe idles through every head and tail; the workgroups placed second (block >= numCU: speed only, never correctness) start late
-    if constexpr (PERSIST && FMT != kFp16) {
-        if (ga.persistent && blockIdx.x >= ga.numCU) {
-            const unsigned long long t0 = wall_clock64();
-            while (wall_clock64() - t0 < (unsigned long long)(EFFORT_Q4_STAGGER_US) * 100ull) __builtin_amdgcn_s_sleep(32);
-        }
-    }
+    // A CU's two persistent workgroups start together and -- their items being alike -- stay IN STEP: both in their heads (staging, cutoff wait,
+    // selection), both streaming, both in their tails (outliers, hand-off, reduction), so the pipe that bounds the stream (Q4: the LDS atomics; per-item
+    // traces profiles/r06_q4_timelines.txt) idles through every head and tail.  The workgroups placed second (block >= numCU: the dispatcher fills the
+    // CUs round-robin -- speed only, never correctness) start `staggerSleeps` x ~0.9 us late and the pair runs out of step from then on.  Measured, Q4 alone on the
+    // chip: 32 calls per launch 109.5 -> 99.8 us at 6-12 us, 16 calls as 768 items 85.4 -> 69.0; with four launches in flight it LOSES 2-5 % (the CU is
+    // busy anyway, the wait is just a wait), so the host asks for it only where launches do not overlap (api.hip: a context without lanes).
+#ifdef EFFORT_Q4_STAGGER_US                 // (lab A/B builds: a fixed delay whatever the host says)
+    const uint32_t staggerSleeps = (uint32_t)((EFFORT_Q4_STAGGER_US) * 10 / 9);
+#else
+    const uint32_t staggerSleeps = ga.staggerSleeps;
 #endif
+    if constexpr (PERSIST) {                    // (counted sleeps, not a clock: the shipped kernels read no clock at all)
+        if (GA_PERSISTENT(ga) && staggerSleeps && blockIdx.x >= ga.numCU)
+            for (uint32_t i = 0; i < staggerSleeps; i++) __builtin_amdgcn_s_sleep(32);
+    }
     const uint32_t total = ga.totalItems + GA_CUTJOBS(ga);
     uint32_t cachedCall = 0xFFFFFFFFu; float cachedCutoff = 0.0f;
     const uint32_t x = blockIdx.x & 7u;                    // block b sits on XCD b%8; item i wants XCD i%8

@@ -96,6 +96,7 @@ struct GroupKArgs {
     uint32_t trace;                // profiling only: 1 = every item leaves a 64-byte record (who ran it, where, its phase stamps) at tstamp + kTraceOff
     LdsPlan lp;                    // of the instantiation launched, over geom[] (launch_mul_t)
     uint32_t totalItems;           // = 8 * wgEnd8[count - 1]: items of the launch (without the cutoff jobs)
+    uint32_t staggerSleeps;        // persistent launches: the workgroups placed second on their CU (block >= numCU) start this many `s_sleep 32` (2048 cycles, ~0.9 us each) late; 0: at once -- bucket_mul_kernel
     uint32_t* groupDone;           // counter of finished tiles (zero between launches)
     uint32_t* queue;               // [9][16]: per-XCD item cursors (one cache line each), line 8 = exit counter;
                                    // then [32] cutoff words (value | ready bit) of the calls; all zero between launches
