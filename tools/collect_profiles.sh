@@ -2,7 +2,7 @@
 # Regenerates everything under profiles/ on a GPU box (run from the repo root through gpurun; outputs land in gpurun_out/).
 #   gpurun --timeout 2400 -- 'ROUND=r03 bash tools/collect_profiles.sh'   then copy gpurun_out/${ROUND}_* into profiles/
 set -u
-R=${ROUND:-r05}
+R=${ROUND:-r06}
 O=gpurun_out
 mkdir -p $O
 export TMPDIR=/tmp
@@ -37,6 +37,10 @@ rm -rf $O/prof_bench $O/prof_bench1 $O/prof_shared $O/prof_fetch $O/prof_write $
 # 5. the bench line as the driver runs it, and at the default length
 python bench.py --steps 20 --warmup 5 > $O/${R}_bench_driver_style.json 2> $O/bench_driver_style.log
 tail -c 400 $O/${R}_bench_driver_style.json
+cp $O/bench_full.json $O/${R}_bench_full.json
+# 5b. what the driver's command no longer runs (tools/bench_extra.py), and the N > 1 leg as a world of one through RCCL
+python tools/bench_extra.py --steps 20 --warmup 5 > /dev/null 2> $O/bench_extra.log; cp $O/bench_extra.json $O/${R}_bench_extra.json
+BENCH_FORCE_DIST=1 python bench.py --steps 20 --warmup 5 > $O/${R}_bench_forced_dist_world1.json 2> $O/bench_forced_dist.log
 # 6. decode loop: tokens/s and per-kernel summary
 python tools/decode_bench.py --tokens 64 > $O/${R}_decode_bench.json 2> $O/decode.log
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_dec -- python tools/decode_bench.py --tokens 64 --efforts 0.25 > $O/prof_dec.log 2>&1
@@ -48,4 +52,6 @@ python tools/layer_probe.py > $O/${R}_layer_probe_effort25.json 2>> $O/probe.log
 python tools/layer_probe.py --effort 0.5 > $O/${R}_layer_probe_effort50.json 2>> $O/probe.log
 [ -x build/rowbench ] && build/rowbench | grep "^mode" > $O/${R}_rowbench.txt
 [ -x build/rampbench ] && build/rampbench > $O/${R}_rampbench.txt
+# 8. Q4: kernel stats, ablation table (tools/q4_profile.sh)
+ROUND=$R bash tools/q4_profile.sh > $O/q4_profile.log 2>&1
 ls -la $O | grep ${R}_

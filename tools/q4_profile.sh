@@ -1,9 +1,9 @@
 #!/bin/bash
 # Q4 evidence for profiles/ (VERDICT round 3, item 5): run on a GPU box from the repo root AFTER building the lab variants HERE
-#   tools/build_variant_all.sh lab "-DEFFORT_LAB=1"; tools/build_variant_all.sh noscatter "-DEFFORT_LAB=1 -DEFFORT_ABLATE_NOSCATTER=1"
+#   tools/build_variant.sh noscatter "-DEFFORT_LAB -DEFFORT_ABLATE_NOSCATTER=1"     (the EFFORT_ABLATE switches live in the in-tree lab library: EFFORT_HIP_LIB=lab)
 #   gpurun --timeout 900 -- 'ROUND=r04 bash tools/q4_profile.sh'      then copy gpurun_out/${ROUND}_q4_* into profiles/
 set -u
-R=${ROUND:-r05}
+R=${ROUND:-r06}
 O=gpurun_out
 mkdir -p $O
 export TMPDIR=/tmp
@@ -19,8 +19,8 @@ WHOLE=$($Q --tag whole 2>&1 | us)
 LONE=$(timeout 200 python tools/qbench.py --q4 1 --group 1 --reps 1 --tag lone 2>&1 | us)
 G32=$(timeout 200 python tools/qbench.py --q4 1 --group 32 --reps 1 --tag g32 2>&1 | us)
 NOOL=$($Q --no-outliers 1 --tag no-outliers 2>&1 | us)
-NOSTREAM=$(EFFORT_HIP_LIB=build/variants/lab.so EFFORT_ABLATE=4 $Q --tag no-stream 2>&1 | us)
-NEITHER=$(EFFORT_HIP_LIB=build/variants/lab.so EFFORT_ABLATE=4 $Q --no-outliers 1 --tag neither 2>&1 | us)
+NOSTREAM=$(EFFORT_HIP_LIB=lab EFFORT_ABLATE=4 $Q --tag no-stream 2>&1 | us)
+NEITHER=$(EFFORT_HIP_LIB=lab EFFORT_ABLATE=4 $Q --no-outliers 1 --tag neither 2>&1 | us)
 NOSCATTER=$(EFFORT_HIP_LIB=build/variants/noscatter.so $Q --tag no-scatter 2>&1 | us)
 # 3. the LDS atomic rate the streaming phase is bound by
 [ -x tools/microbench ] && tools/microbench 2>&1 | grep -E "^device|^scatter" > $O/${R}_q4_microbench_scatter.txt
