@@ -615,13 +615,32 @@ static bool supported(int W, int E) {
 // (tools/lab/tune.py, 4096x4096 .. 14336x4096, 10-100 % effort): a workgroup's life is mostly fixed-latency steps (staging,
 // cutoff, selection, hand-off), so FEWER, fatter items win even when they leave CUs idle -- about 3/4 of an item per CU
 // for small groups, with slices between 128 and 512 input rows; from 8 calls on, the fattest slices (512 rows).
+// Q4 groups of about 10 to 16 calls on a context WITHOUT lanes (one launch on the chip at a time): the launch as ONE round of workgroups -- just
+// under two items per CU -- of 64-column tiles and tall slices.  A Q4 item's stream is bound by its CU's LDS atomic pipe, a CU's two workgroups
+// run their heads, streams and tails in step (profiles/r06_q4_timelines.txt), and what a launch then costs is one head + the CU's share of the
+// atomics + one tail: the unbalanced 384 items of the general rule (E = 2, 8 slices: half the CUs two items, half one) 65.4 us per 16-call
+// launch, 480 items (E = 1, 5 slices) 58.3; 12 calls: 57.1 -> 50.2 at 6 slices (profiles/r06_q4_one_round_sweep.txt).  With several launches in
+// flight the other launches fill the idle CUs anyway and the tall items only delay them (four in flight: 45.9 against 40.6 us): lanes keep the
+// general rule.  Returns the slices per call, or 0 when the rule does not apply (the slices would be taller than two workgroups' LDS allows).
+static uint32_t q4_one_round(const effort_ctx* c, uint32_t inDim, uint32_t groupTiles1) {
+    if (c->nLanes > 1 || c->tuneS || !groupTiles1) return 0;
+    const uint32_t sMin = (inDim + 831u) / 832u;                  // <= 832 rows per slice: 6656 candidate slots, ~78 KB of LDS, two workgroups per CU
+    const uint32_t S = (uint32_t)c->numCU * 15u / 8u / groupTiles1;      // 480 items on 256 CUs
+    return S >= sMin && S >= 2u ? S : 0u;
+}
 static uint32_t pick_slices(const effort_ctx* c, const effort_w* w, int groupSize, int E, uint32_t groupTiles = 0) {
     const uint32_t tiles = (w->cols + 64 * E - 1) / (64 * E);
     const uint32_t lo = ((w->inDim + 511) / 512 + 7) / 8 * 8, hi = ((w->inDim + 127) / 128 + 7) / 8 * 8;
+    if (w->fmt != kFp16 && E == 1 && groupSize >= 8 && groupTiles) {       // (pick_elems chose E = 1 for this Q4 group: q4_one_round)
+        const uint32_t S = q4_one_round(c, w->inDim, groupTiles);
+        if (S) return S;
+    }
     if (groupSize >= 8) return lo;
     // (64-column tiles -- narrow matrices, see pick_elems -- are worked best at one item per CU: measured, 14336 -> 4096 lone, 64 slices
     //  26.9 us against 29.2 at 48)
-    const uint32_t target = E == 1 ? (uint32_t)c->numCU : (uint32_t)c->numCU * 3u / 4u;
+    // (Q4 small groups are worked at E = 1 whatever the shape and want the 3/4 too -- round 6, a pair of 4096x11008 calls: 16 slices = 192 items 23.2 us
+    //  against 25.4 at the 24 the full-CU target gave; lone and four per launch land on 192 items either way)
+    const uint32_t target = (E == 1 && w->fmt == kFp16) ? (uint32_t)c->numCU : (uint32_t)c->numCU * 3u / 4u;
     // the launch's items come from ALL its calls: with the column tiles of the whole group known (Wq | Wk | Wv: 4 + 1 + 1 at
     // E = 1) every call takes target / tiles slices; without, the calls are taken as equals
     const uint32_t allTiles = groupTiles ? groupTiles : (uint32_t)groupSize * tiles;
@@ -649,7 +668,15 @@ static uint32_t pick_slices(const effort_ctx* c, const effort_w* w, int groupSiz
 // 4096x11008: 8 calls 7.9 vs 8.4 us/call, 16 calls 7.2 vs 6.6, 32 calls 5.7 vs 6.3).  Q4 (a word = 4 sub-buckets): 1, or 2 from 8 calls on.
 static int pick_elems(const effort_ctx* c, Format fmt, int n, const effort_w* const* ws) {
     if (c->tuneE) return c->tuneE;
-    if (fmt != kFp16) return n >= 8 ? 2 : 1;        // measured, 4096x11008 Q4: 32 calls 5.3 vs 6.4 us/call, 8 calls 8.3 vs 8.3, 2 calls 20.8 vs 18.8
+    if (fmt != kFp16) {      // measured, 4096x11008 Q4: 32 calls 5.3 vs 6.4 us/call, 8 calls 8.3 vs 8.3, 2 calls 20.8 vs 18.8
+        if (n < 8) return 1;
+        if (n >= 10) {       // (one round of narrow, tall items where that fits: q4_one_round)
+            uint32_t t1 = 0, inDim = 0;
+            for (int i = 0; i < n; i++) if (ws[i]) { t1 += (ws[i]->cols + 63u) / 64u; inDim = inDim > ws[i]->inDim ? inDim : ws[i]->inDim; }
+            if (q4_one_round(c, inDim, t1)) return 1;
+        }
+        return 2;
+    }
     if (c->tuneS) return 2;
     auto group_tiles = [&](int E) {
         uint32_t t = 0;
@@ -864,7 +891,7 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
     if (tm) HIP_TRY(c, hipEventRecord(ev[0], st));
     GroupKArgs ga;
     int W = 0, E = 0;
-    uint32_t nGeoms = 0, wg = 0, first = 0;
+    uint32_t nGeoms = 0, wg = 0, realItems = 0, first = 0;
     size_t slabOff = 0; uint32_t tileOff = 0, sliceOff = 0;
     auto begin = [&](uint32_t firstCall) {
         memset(&ga, 0, sizeof(ga));
@@ -873,12 +900,12 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
         ga.tstamp = c->clock ? c->d_tstamp : nullptr;
         ga.ablate = ablate; ga.split = c->splitCutoff ? 1u : 0u; ga.trace = (c->clock && c->trace) ? 1u : 0u;
         ga.numCU = (uint32_t)c->numCU; ga.queue = L.d_queue;
-        nGeoms = 0; wg = 0; first = firstCall;
+        nGeoms = 0; wg = 0; realItems = 0; first = firstCall;
     };
     auto flush = [&]() -> int {                        // one kernel launch for the calls gathered so far
         // grid: persistent workgroups once the items outnumber what the chip holds at R per CU
         const uint32_t R = c->persistent < 0 ? 2u : (uint32_t)c->persistent;
-        ga.persistent = (R && wg > ga.numCU * R) ? R : 0u;
+        ga.persistent = (R && realItems > ga.numCU * R) ? R : 0u;      // (the items that exist: the grid's padding -- slices are dealt in rounds of 8 -- exits at once)
         // persistent launches evaluate every call's cutoff ONCE, in a job of its own at the head of the item queues, instead
         // of once per workgroup and call (measured: 6.8 of the ~90 us of an item at 32 calls per launch)
         bool plain = true;
@@ -967,6 +994,7 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
         a.pre = (uint16_t)pre; a.vAux = pre ? vAux[i] : nullptr; a.resid = resids ? resids[i] : nullptr;
         a.slabOff = (uint32_t)(slabOff / 256); a.tileOff = (uint16_t)tileOff; a.sliceOff = (uint16_t)sliceOff; a.geom = (uint16_t)gi;
         wg += g.tiles * ((g.slices + 7) / 8 * 8);
+        realItems += g.tiles * g.slices;
         if (wg / 8u > 0xFFFFu) return fail(c, EFFORT_ERR_SHAPE, "bucketmul: group exceeds the launch descriptor's item range");
         ga.wgEnd8[(uint32_t)i - first] = (uint16_t)(wg / 8u); ga.totalItems = wg;
         ga.count = (uint32_t)i - first + 1u;

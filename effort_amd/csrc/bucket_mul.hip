@@ -330,7 +330,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     uint32_t* const a_counters = ga.counters + a.tileOff;
     uint32_t* const a_sliceCounts = ga.sliceCounts + a.sliceOff;
     float* const a_cutoff = ga.cutoff + ci;
-    const uint32_t b = item - (ci ? (uint32_t)ga.wgEnd8[ci - 1] * 8u : 0u);
+    (void)item;
 
     int tid0 = threadIdx.x;
     asm volatile("" : "+v"(tid0));      // opaque per item: keeps the compiler from hoisting every tid-derived value out of the item loop (+50 VGPRs)
@@ -1024,7 +1024,8 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
         }
         return r;
     };
-    if (fused && b == 0 && tid == 0 && !GA_CUTJOBS(ga)) a_cutoff[0] = cutoff;       // BucketMul.cutoff (bucketMul.swift:22) of a call without a cutoff job
+    if (fused && t == 0 && s == 0 && tid == 0 && !GA_CUTJOBS(ga)) a_cutoff[0] = cutoff;       // BucketMul.cutoff (bucketMul.swift:22) of a call without a cutoff job
+    // (the item of tile 0, slice 0 -- not the call's first BLOCK: with a slice count that is not a multiple of 8 that block may be padding of the item grid)
     // (Round 4 built this hand-off WITHOUT ticket and drain -- a reducer named up front polling sentinel slabs -- and measured it
     //  slower on plain grids: branch `chain-launch`)
     {   // (a fixed trip count, the tile read back in ONE LDS round trip: `for (o = tid * 2; o < TILE_F; ...)` compiled to a loop of dependent ones)

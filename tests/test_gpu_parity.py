@@ -180,7 +180,7 @@ def test_launch_geometries_agree_and_are_deterministic(ea, oracle_cpu, waves, el
     want, n, _ = oracle_cpu.bucket_mul(v, b, s, p, inDim, outDim, 0.3)
     g = ea.gpu()
     try:
-        for slices in (0, 8, 64, 512):
+        for slices in (0, 8, 12, 20, 64, 512):                        # (12, 20: not multiples of 8 -- the item grid is padded, the call's first block may be padding)
             g.set_tuning(waves, elems, slices)
             o1 = torch.zeros(outDim, device=DEV)
             o2 = torch.zeros(outDim, device=DEV)
@@ -1187,4 +1187,44 @@ def test_timing_hooks_of_the_shipped_library(ea, oracle_cpu):
         g.eval()
         assert close(out.cpu().numpy(), want) and g.last_dispatch_count() == n and g.last_cutoff() == cutoff
     finally:
+        g.close()
+
+
+def test_slice_counts_that_are_not_multiples_of_eight(ea, oracle_cpu, q4_11008):
+    """Slices are dealt to the XCDs in rounds of 8, so a count like 5 or 12 pads the item grid, and the FIRST block of a call can be padding
+    (it is for a call whose rotation puts slices >= the count there).  Round 6's Q4 rule launches 10..16 calls as one round of 5-8 tall slices
+    (api.hip q4_one_round), so such counts are the default path now: every call's dispatch.size, BucketMul.cutoff (the hook is written by the
+    item of tile 0 / slice 0, which used to be taken for the first block) and product against the oracle -- Q4 groups of 10, 13 and 16 on the
+    default geometry, then forced slice counts, lone and grouped, FP16 too."""
+    W, L, inDim, outDim = q4_11008
+    ew = ea.ExpertWeights(dev16(L["buckets"]), devf(L["bucket.stats"]), dev16(L["probes"]), inSize=inDim, outSize=outDim,
+                          outliers=devf(L["outliers"]), q4=True)
+    g = ea.Gpu(0)
+    efforts = (0.1, 0.25, 0.5)
+    hv = [make_v(inDim, seed=700 + i, heavy=bool(i & 1)) for i in range(16)]
+    wants = [oracle_cpu.bucket_mul_q4(hv[i], L["buckets"], L["bucket.stats"], L["probes"], L["outliers"], inDim, outDim, efforts[i % 3]) for i in range(16)]
+    try:
+        for tune, n in (((0, 0, 0), 16), ((0, 0, 0), 13), ((0, 0, 0), 10), ((8, 1, 5), 16), ((8, 2, 10), 7), ((8, 1, 21), 3), ((8, 1, 5), 1), ((8, 2, 12), 1)):
+            g.set_tuning(*tune)
+            outs = [torch.full((outDim,), float("nan"), device=DEV) for _ in range(n)]
+            ea.bucketMulGroup([(devf(hv[i]), ew, None, outs[i], efforts[i % 3]) for i in range(n)], gpu=g)
+            g.eval()
+            for i in range(n):
+                want, cnt, cutoff = wants[i]
+                assert g.last_dispatch_count(i) == cnt and g.last_cutoff(i) == cutoff, (tune, n, i)
+                assert close(outs[i].cpu().numpy(), want), (tune, n, i)
+        # FP16: 12 and 20 slices (a 4096-row input cannot go below 8 with 8-wave workgroups), a group whose calls rotate through every XCD offset
+        oD, iD = 1024, 4096
+        Wf, b, s, p = converted(oracle_cpu, oD, iD)
+        ewf = gpu_weights(ea, Wf, b, s, p)
+        for tune in ((8, 1, 12), (8, 2, 20), (8, 4, 12)):
+            g.set_tuning(*tune)
+            outs = [torch.full((oD,), float("nan"), device=DEV) for _ in range(9)]
+            ea.bucketMulGroup([(devf(hv[i]), ewf, None, outs[i], efforts[i % 3]) for i in range(9)], gpu=g)
+            g.eval()
+            for i in range(9):
+                want, cnt, cutoff = oracle_cpu.bucket_mul(hv[i], b, s, p, iD, oD, efforts[i % 3])
+                assert g.last_dispatch_count(i) == cnt and g.last_cutoff(i) == cutoff and close(outs[i].cpu().numpy(), want), (tune, i)
+    finally:
+        g.set_tuning(0, 0, 0)
         g.close()
