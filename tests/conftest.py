@@ -34,10 +34,9 @@ def hip_lib_built():
 # multi-stream test) is a use-after-free inside the HIP runtime bundled with this torch wheel (HIP 7.0.51831): a capture -> replay ->
 # destroy loop of plain torch ops dies in 3 runs of 4, the same loop that keeps its graphs never does (tools/lab/graph_event_repro.py,
 # profiles/r06_heap_hunt.txt).  A test session destroys a few hundred such graphs; so every torch.cuda.CUDAGraph made while
-# the suite runs on a GPU is held until the session ends, and the session then leaves through os._exit with pytest's own exit status
-# -- after the summary has been printed -- instead of destroying them during interpreter shutdown.
+# the suite runs on a GPU takes one reference that is never given back: its destructor never runs, not during the session and not during
+# interpreter shutdown -- the process ends like any program that still holds its graphs when it exits, through the ordinary exit path.
 _GRAPHS_FOR_LIFE = []
-_EXIT = {"status": None}
 
 
 def pytest_sessionstart(session):
@@ -47,24 +46,12 @@ def pytest_sessionstart(session):
         return
     if not torch.cuda.is_available():
         return
+    import ctypes
     orig_new = torch.cuda.CUDAGraph.__new__
 
     def keeping_new(cls, *a, **k):
         g = orig_new(cls, *a, **k)
+        ctypes.pythonapi.Py_IncRef(ctypes.py_object(g))          # (leaked on purpose: see above)
         _GRAPHS_FOR_LIFE.append(g)
         return g
     torch.cuda.CUDAGraph.__new__ = staticmethod(keeping_new)
-    _EXIT["armed"] = True
-
-
-def pytest_sessionfinish(session, exitstatus):
-    _EXIT["status"] = int(exitstatus)
-
-
-def pytest_unconfigure(config):
-    if _EXIT.get("armed") and _GRAPHS_FOR_LIFE and _EXIT["status"] is not None:
-        import atexit
-        atexit._run_exitfuncs()          # (whatever registered itself for the end of the process -- a harness's hooks included -- still runs)
-        sys.stdout.flush()
-        sys.stderr.flush()
-        os._exit(_EXIT["status"])
