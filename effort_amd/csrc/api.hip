@@ -993,7 +993,7 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
         const int pre = prologues ? prologues[i] : 0;
         a.pre = (uint16_t)pre; a.vAux = pre ? vAux[i] : nullptr; a.resid = resids ? resids[i] : nullptr;
         a.slabOff = (uint32_t)(slabOff / 256); a.tileOff = (uint16_t)tileOff; a.sliceOff = (uint16_t)sliceOff; a.geom = (uint16_t)gi;
-        wg += g.tiles * ((g.slices + 7) / 8 * 8);
+        wg += (g.tiles * g.slices + 7u) / 8u * 8u;            // the call's item range: a multiple of 8 (item % 8 = the XCD; locate_item)
         realItems += g.tiles * g.slices;
         if (wg / 8u > 0xFFFFu) return fail(c, EFFORT_ERR_SHAPE, "bucketmul: group exceeds the launch descriptor's item range");
         ga.wgEnd8[(uint32_t)i - first] = (uint16_t)(wg / 8u); ga.totalItems = wg;

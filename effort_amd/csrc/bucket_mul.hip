@@ -225,7 +225,18 @@ __device__ __forceinline__ bool locate_item(const GroupKArgs& ga, const uint32_t
     const uint32_t b = item - (ci ? (uint32_t)ga.wgEnd8[ci - 1] * 8u : 0u), xcd = b & 7u, k = b >> 3;
     // (the slice <-> XCD assignment rotates with the call: calls sharing an input vector -- Wq|Wk|Wv, or a batch on one v --
     //  have the same heavy and light slices, and an XCD that got the same slice of every call would finish 15 % late)
-    r.ci = ci; r.s = (k / g.tiles) * 8u + ((xcd + ci) & 7u); r.t = k % g.tiles;
+    r.ci = ci;
+    if ((g.slices & 7u) == 0u) {               // slices dealt to the XCDs in rounds of 8: every block of the call's range is an item
+        r.s = (k / g.tiles) * 8u + ((xcd + ci) & 7u); r.t = k % g.tiles;
+        return true;
+    }
+    // A slice count that is not a multiple of 8 (round 6: Q4's one-round launches, 5-7 tall slices): dealing slices in rounds of 8 would leave
+    // three blocks of every eight as padding -- a 16-call launch 768 blocks for 480 items.  The call's tiles x slices items are numbered
+    // slice-major and every XCD takes a CONTIGUOUS eighth of them (its items then belong to one or two slices: the same locality), the range
+    // padded to a multiple of 8 at its end only: 512 blocks for those 480 items.
+    const uint32_t per = (uint32_t)ga.wgEnd8[ci] - (ci ? (uint32_t)ga.wgEnd8[ci - 1] : 0u);      // items per XCD of this call
+    const uint32_t idx = ((xcd + ci) & 7u) * per + k;
+    r.s = idx / g.tiles; r.t = idx - r.s * g.tiles;
     return r.s < g.slices;
 }
 
@@ -1375,7 +1386,7 @@ static hipError_t launch_mul_t(const GroupKArgs& gaIn, hipStream_t st) {
         const MulGeom& g = ga.geom[ga.call[i].geom];
         if (g.slots > (uint32_t)kRounds * 64 * W || g.slots != (FMT == kFp16 ? (g.rowsPerIn << g.sliceLog2) : g.sliceRows * 8u)) return hipErrorInvalidValue;
         if (FMT == kFp16 ? (1u << g.sliceLog2) > 64u * W : g.sliceRows > 128u * W) return hipErrorInvalidValue;       // stage_issue: a thread lands one (Q4: two) inputs of the slice
-        if (((uint32_t)ga.wgEnd8[i] - (i ? (uint32_t)ga.wgEnd8[i - 1] : 0u)) * 8u != g.tiles * align_up(g.slices, 8)) return hipErrorInvalidValue;
+        if (((uint32_t)ga.wgEnd8[i] - (i ? (uint32_t)ga.wgEnd8[i - 1] : 0u)) * 8u != align_up(g.tiles * g.slices, 8)) return hipErrorInvalidValue;
     }
     if (ga.totalItems != (uint32_t)ga.wgEnd8[ga.count - 1] * 8u) return hipErrorInvalidValue;
     uint32_t grid = ga.totalItems;
