@@ -1228,3 +1228,38 @@ def test_slice_counts_that_are_not_multiples_of_eight(ea, oracle_cpu, q4_11008):
     finally:
         g.set_tuning(0, 0, 0)
         g.close()
+
+
+def test_geometry_rules_of_round_six(ea, oracle_cpu, q4_11008):
+    """The launch-geometry rules round 6 added, pinned through the slice-count hook (effort_debug_slice_counts): a lone 4096 -> 14336 call --
+    the reference's timed shape -- takes 32 slices (24 = 171 rows in blocks of 256 slots before: pick_slices' power-of-two rule); a 16-call
+    Q4 group on a context WITHOUT lanes launches as one round of 5 tall slices per call, on a context WITH lanes as 8 (api.hip q4_one_round);
+    a pair of Q4 calls 16 slices.  Every product against the oracle."""
+    W, L, inDim, outDim = q4_11008
+    ew = ea.ExpertWeights(dev16(L["buckets"]), devf(L["bucket.stats"]), dev16(L["probes"]), inSize=inDim, outSize=outDim,
+                          outliers=devf(L["outliers"]), q4=True)
+    g = ea.Gpu(0)
+    v = make_v(inDim, seed=41)
+    want, cnt, cutoff = oracle_cpu.bucket_mul_q4(v, L["buckets"], L["bucket.stats"], L["probes"], L["outliers"], inDim, outDim, 0.25)
+    try:
+        for lanes, n, slices in ((1, 16, 5), (4, 16, 8), (1, 2, 16), (1, 12, 6), (1, 32, 8)):
+            g.set_overlap(lanes)
+            outs = [torch.full((outDim,), float("nan"), device=DEV) for _ in range(n)]
+            ea.bucketMulGroup([(devf(v), ew, None, o, 0.25) for o in outs], gpu=g)
+            g.eval()
+            assert len(g.slice_counts(n - 1)) == slices, (lanes, n, len(g.slice_counts(n - 1)))
+            for i in (0, n - 1):
+                assert g.last_dispatch_count(i) == cnt and g.last_cutoff(i) == cutoff and close(outs[i].cpu().numpy(), want), (lanes, n, i)
+        g.set_overlap(1)
+        oD, iD = 14336, 4096
+        Wf, b, s, p = converted(oracle_cpu, oD, iD, seed=77)
+        ewf = gpu_weights(ea, Wf, b, s, p)
+        out = torch.zeros(oD, device=DEV)
+        ea.bucketMul(devf(v), ewf, None, out, 0.25, gpu=g)
+        g.eval()
+        assert len(g.slice_counts(0)) == 32
+        wantf, cntf, cutf = oracle_cpu.bucket_mul(v, b, s, p, iD, oD, 0.25)
+        assert g.last_dispatch_count() == cntf and g.last_cutoff() == cutf and close(out.cpu().numpy(), wantf)
+    finally:
+        g.set_overlap(1)
+        g.close()
