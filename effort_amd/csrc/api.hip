@@ -905,7 +905,7 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
     auto flush = [&]() -> int {                        // one kernel launch for the calls gathered so far
         // grid: persistent workgroups once the items outnumber what the chip holds at R per CU
         const uint32_t R = c->persistent < 0 ? 2u : (uint32_t)c->persistent;
-        ga.persistent = (R && realItems > ga.numCU * R) ? R : 0u;      // (the items that exist: the grid's padding -- slices are dealt in rounds of 8 -- exits at once)
+        ga.persistent = (R && realItems > ga.numCU * R) ? R : 0u;      // (the items that exist, not the padded item range)
         // persistent launches evaluate every call's cutoff ONCE, in a job of its own at the head of the item queues, instead
         // of once per workgroup and call (measured: 6.8 of the ~90 us of an item at 32 calls per launch)
         bool plain = true;
