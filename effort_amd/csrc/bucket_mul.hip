@@ -69,12 +69,33 @@ constexpr int kRounds = 16;  // selection rounds of NT candidate slots a workgro
 #define EFFORT_MIN_WAVES_PER_EU 4
 #endif
 
-// Cache policy of the bucket-row stream.  0 = default.  nt (2) measured WORSE from 16 calls per launch on (6.8 vs 6.6 us/call,
-// 100 % effort 22 vs 18): neighbouring tiles' pieces share the 128-byte lines a 1376-byte row pitch straddles, and nt drops them.
+// Cache policy of the bucket-row stream: NON-TEMPORAL (aux bit 1, `nt`; -DEFFORT_ROW_AUX=0 builds the temporal policy).  A kept row is
+// read once per call and a model's weights are tens of times the chip's caches (Mistral-7B at 25 % effort reads 3.5 GB per token against
+// 32 MB of L2 and 256 MB of Infinity Cache): marked nt, the stream does not push the row means, the partial tiles and the other
+// workgroups' lines out on its way through.  Round 6, second session, A/B builds on rows that sit on whole 128-byte lines
+// (profiles/r06_ab_row_stream_nt.txt): one 32-call launch 160 -> 150 us, four in flight on disjoint matrices 133 -> 127, a lone call
+// 18.1 -> 17.75, 50 % effort 286 -> 264, 4096 -> 14336 lone 18.8 -> 18.3; sc0 / sc1 beside nt change nothing, sc1 alone nothing; rows
+// 1376 bytes apart (not line-aligned) 169 -> 167.  (Round 2 had measured nt WORSE -- 6.8 vs 6.6 us per call at 16 per launch -- on those
+// unaligned rows with that round's kernel: neighbouring tiles' pieces share the lines a row straddles.)  What nt gives up is reuse
+// BETWEEN launches: four launches in flight over the SAME 32 matrices (a batch of inputs on one set of weights, in lockstep within the
+// Infinity Cache's 256 MB) 117 -> 130 us per launch; and 32 calls on 4096 x 4096 matrices re-read every launch (270 MB, the Infinity
+// Cache's size) 62 -> 64.  A RUN-TIME switch was built too -- a uniform branch between two batches of eight loads, counted waits intact --
+// and measured: a lone call 18.1 -> 19.8 us, a group of three 30.5 -> 36.7, one 32-call launch 160 -> 165 (the scheduler no longer
+// interleaves the loads with the other batch's scatter): the policy stays a compile-time constant.
 #ifndef EFFORT_ROW_AUX
-#define EFFORT_ROW_AUX 0
+#define EFFORT_ROW_AUX 2
 #endif
 constexpr int kRowAux = EFFORT_ROW_AUX;
+// (Q4: the outlier entries are read once per call too, but nt on THEIR loads measured slower -- 16 calls per launch 58.8 -> 63.7 us, 32:
+//  100.4 -> 106.3 -- and stays off: -DEFFORT_OL_NT=1 builds it.)
+#ifndef EFFORT_OL_NT
+#define EFFORT_OL_NT 0
+#endif
+#if EFFORT_OL_NT
+#define EFFORT_OL_LOAD(p) __builtin_nontemporal_load(p)
+#else
+#define EFFORT_OL_LOAD(p) (*(p))
+#endif
 // PERSIST (template parameter of the kernel and of mul_item) = false: the LEAN instantiation for PLAIN grids -- one item per
 // workgroup, no item queues, no cutoff jobs, no staging of a next item, no stamps or ablation switches.  It is the same kernel
 // with those compiled out: 4300 instead of 8000 instructions and 116 instead of 128 VGPRs.  A plain grid's workgroup runs its
@@ -867,7 +888,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     auto ol_fetch = [&](uint32_t (&ent)[kOlMerged]) {              // the entries of the next kOlMerged steps asked for (branch-free: lanes past a step's population read on into the next entries)
 #pragma unroll
         for (int u = 0; u < kOlMerged; u++) {
-            ent[u] = (a.ol.entry + olCur)[lane];                   // (a uniform base + 4 * lane: no address arithmetic per step; the array ends in 64 entries of padding)
+            ent[u] = EFFORT_OL_LOAD((a.ol.entry + olCur) + lane);                   // (a uniform base + 4 * lane: no address arithmetic per step; the array ends in 64 entries of padding)
             olCur += (uint32_t)__popcll(__ballot(olLen > olKf + (uint32_t)u));
         }
         olKf += (uint32_t)kOlMerged;
@@ -975,7 +996,7 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
                     auto fetch = [&](uint32_t (&ent)[kOlBatch], uint32_t kk) {             // the entries of steps kk .. kk + kOlBatch - 1 asked for (clamped, branch-free)
 #pragma unroll
                         for (int u = 0; u < kOlBatch; u++) {
-                            ent[u] = (ol.entry + cur)[lane];
+                            ent[u] = EFFORT_OL_LOAD((ol.entry + cur) + lane);
                             cur += (uint32_t)__popcll(__ballot(myLen > kk + (uint32_t)u));
                         }
                     };

@@ -7,11 +7,17 @@
 namespace effort {
 
 constexpr int kGemvWaves = 4;          // waves per workgroup
+// Cache policy of the weight stream (AUX, an immediate of the load): a matrix of more than kGemvKeepBytes is streamed NON-TEMPORALLY
+// (every element is read once and nothing of it will still be cached when it is read again; 4096 x 11008, 32 matrices rotated: 17.55 ->
+// 17.0 us per call, the decode loop's dense line 291 -> 310 tokens/s, round 6 -- the baseline gets what the bucket-row stream got); a
+// smaller one keeps the ordinary policy: the reference's dense benchmark line multiplies ONE 4096 x 4096 matrix three times in a row
+// (benchmarks/benchmark.swift:237-241), and its second and third pass come from the Infinity Cache (360 projected tokens/s against 264 nt).
+constexpr size_t kGemvKeepBytes = 64u << 20;
 
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 
 // ROWS = rows a wave works on at once (they share the LDS reads of v): 2, or 1 when the matrix has too few rows to fill the chip
-template <int kGemvRows>                // eight 16-byte loads in flight per lane: 8 / ROWS 1 KB chunks of each row
+template <int kGemvRows, int AUX>       // eight 16-byte loads in flight per lane: 8 / ROWS 1 KB chunks of each row
 __global__ __launch_bounds__(64 * kGemvWaves) void dense_gemv_kernel(const uint16_t* __restrict__ W, const float* __restrict__ v,
                                                                      float* __restrict__ out, uint32_t inDim, uint32_t outDim) {
     extern __shared__ __attribute__((aligned(16))) uint16_t vh[];              // f16(v), padded with zeros to a multiple of 512
@@ -53,7 +59,7 @@ __global__ __launch_bounds__(64 * kGemvWaves) void dense_gemv_kernel(const uint1
             const uint32_t e = min(c0 + u * 512u + lane * 8u, inDim - 8u);      // clamped, branch-free (inDim % 16 == 0)
 #pragma unroll
             for (int r = 0; r < kGemvRows; r++) {
-                const auto t = __builtin_amdgcn_raw_buffer_load_b128(rs, e * 2u, rowOff[r], 0);
+                const auto t = __builtin_amdgcn_raw_buffer_load_b128(rs, e * 2u, rowOff[r], AUX);
                 w[r][u][0] = t[0]; w[r][u][1] = t[1]; w[r][u][2] = t[2]; w[r][u][3] = t[3];
             }
         }
@@ -90,20 +96,22 @@ bool dense_gemv_supported(uint32_t inDim, uint32_t outDim) {
     return inDim % 16 == 0 && inDim >= 16 && inDim <= 65536 && (size_t)outDim * inDim * 2 <= 0xFFFFFFFFull;
 }
 
-template <int ROWS>
+template <int ROWS, int AUX>
 static hipError_t launch_dense_gemv_t(const uint16_t* W, const float* v, float* out, uint32_t inDim, uint32_t outDim, hipStream_t st) {
     const uint32_t lds = (inDim + 511u) / 512u * 512u * 2u;
     if (lds > 48u * 1024u) {
-        hipError_t e = allow_full_lds(reinterpret_cast<const void*>(&dense_gemv_kernel<ROWS>));
+        hipError_t e = allow_full_lds(reinterpret_cast<const void*>(&dense_gemv_kernel<ROWS, AUX>));
         if (e != hipSuccess) return e;
     }
     const uint32_t rowsPerWg = kGemvWaves * ROWS;
-    hipLaunchKernelGGL(dense_gemv_kernel<ROWS>, dim3((outDim + rowsPerWg - 1) / rowsPerWg), dim3(64 * kGemvWaves), lds, st, W, v, out, inDim, outDim);
+    hipLaunchKernelGGL((dense_gemv_kernel<ROWS, AUX>), dim3((outDim + rowsPerWg - 1) / rowsPerWg), dim3(64 * kGemvWaves), lds, st, W, v, out, inDim, outDim);
     return hipGetLastError();
 }
 
 hipError_t launch_dense_gemv(const uint16_t* W, const float* v, float* out, uint32_t inDim, uint32_t outDim, hipStream_t st) {
-    return outDim <= 8192u ? launch_dense_gemv_t<1>(W, v, out, inDim, outDim, st) : launch_dense_gemv_t<2>(W, v, out, inDim, outDim, st);
+    const bool nt = (size_t)inDim * outDim * 2u > kGemvKeepBytes;
+    if (outDim <= 8192u) return nt ? launch_dense_gemv_t<1, 2>(W, v, out, inDim, outDim, st) : launch_dense_gemv_t<1, 0>(W, v, out, inDim, outDim, st);
+    return nt ? launch_dense_gemv_t<2, 2>(W, v, out, inDim, outDim, st) : launch_dense_gemv_t<2, 0>(W, v, out, inDim, outDim, st);
 }
 
 }  // namespace effort

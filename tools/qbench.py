@@ -31,11 +31,15 @@ def main():
     ap.add_argument("--overlap", type=int, default=1, help="K > 1: ONE context with effort_set_overlap(K); the steps of a graph write K rotating output sets")
     ap.add_argument("--no-outliers", type=int, default=0, help="Q4: register the bundles without their outlier tables")
     ap.add_argument("--fused", default="", help="comma list of gate,norm,resid: every call derives its input / adds its residual in the launch (effort_bucketmul_group_fused)")
+    ap.add_argument("--no-align", type=int, default=0, help="1: the reference's dense rows (2 * cols bytes apart) instead of rows on whole 128-byte lines")
     ap.add_argument("--split", type=int, default=0, help="1: the cutoffs in a kernel of their own before the multiply (the device-clock span then covers the multiply alone)")
     args = ap.parse_args()
     inDim, outDim = (int(x) for x in args.shape.split("x"))
     import effort_amd as ea
+    import bench
     from bench import make_weights
+    if args.no_align:
+        bench.ALIGN_ROWS = False
     dev = torch.device("cuda", 0)
     g = ea.gpu(0)
     lab = bool(getattr(ea.lib(), "effort_is_lab_build", lambda: 1)())     # (device-clock stamps exist in the lab library only; an older A/B build has them too)
