@@ -150,6 +150,24 @@ def test_shipped_kernels_carry_no_lab_code(hip_lib_built, tmp_path):
     assert b"EFFORT_ABLATE" in blob                                  # (the environment knobs live there, and only there)
 
 
+def test_shipped_kernels_stream_the_bucket_rows_non_temporally(hip_lib_built, tmp_path):
+    """Round 6: every load of the bucket-row stream carries `nt` (bucket_mul.hip, EFFORT_ROW_AUX: a kept row is read once per call; one
+    32-call launch 160 -> 150 us) -- in every multiply kernel of the shipped library: the 8-byte (E = 4) and 4-byte
+    (E = 2) row pieces are the only buffer loads of those widths the kernels issue besides LDS-direct staging (which carries `lds`)."""
+    import re
+    prod = _multiply_kernel_disassembly(hip_lib_built, tmp_path)
+    body, name = {}, None
+    for line in prod.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+        if m:
+            name = m.group(1)
+        elif name and "bucket_mul_kernel" in name and "buffer_load_dwordx2" in line:
+            body.setdefault(name, []).append(line)
+    assert len(body) >= 10, "no 8-byte row loads found in the multiply kernels?"
+    for k, lines in body.items():
+        assert all(" nt" in l for l in lines), (k, [l for l in lines if " nt" not in l][:3])
+
+
 def test_shipped_library_has_no_measured_dead_ends(hip_lib_built):
     """What round 4 built and measured SLOWER -- chain launches, the named reducer, byte-indexed Q4 accumulators -- lives on branch
     `chain-launch`, not in the drop-in header or the shipped library; and the library loads without RCCL (multi-GPU binds it at run
