@@ -905,13 +905,15 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
     auto flush = [&]() -> int {                        // one kernel launch for the calls gathered so far
         // grid: persistent workgroups once the items outnumber what the chip holds at R per CU
         const uint32_t R = c->persistent < 0 ? 2u : (uint32_t)c->persistent;
-        // FP16 on a context WITHOUT lanes -- one launch on the chip at a time -- stays a PLAIN grid up to three items per CU: the lean kernel (half the
+        // FP16 on a context WITHOUT lanes -- one launch on the chip at a time -- stays a PLAIN grid: the lean kernel (half the
         // instructions, every workgroup evaluates its cutoff at once instead of awaiting a job), and the dispatcher hands the third round of workgroups
         // to whichever CU frees a slot.  Round 6, 4096x11008, us per launch persistent -> plain: 12 calls 80.0 -> 74.9, 16: 89.9 -> 87.4, 20: 111.9 -> 103.2,
         // 16 at 50 % effort 157.6 -> 145.8, 16 x (4096 -> 14336) 108.9 -> 101.8, 24 / 32 calls level (122.2 / 122.4, 153.0 / 152.2), 32 at 10 % +2 %;
         // with four launches in flight the persistent grid wins (16 calls 66.9 against 67.6, 32: 127.2 against 130.1): lanes keep it from 2 per CU on
         // (profiles/r06_plain_vs_persistent.txt).
-        const uint32_t perCU = (c->persistent < 0 && fmt == kFp16 && !laned) ? 3u : R;
+        // (1024 items -- 32 calls of 4096 -> 14336 -- 205.4 -> 197.7; 1536 -- 32 calls at E = 2 -- plain 0.98 x the heuristic's launch where persistent was 1.04 x:
+        //  plain up to six items per CU, as far as was measured)
+        const uint32_t perCU = (c->persistent < 0 && fmt == kFp16 && !laned) ? 6u : R;
         ga.persistent = (R && realItems > ga.numCU * perCU) ? R : 0u;      // (the items that exist, not the padded item range)
         // persistent launches evaluate every call's cutoff ONCE, in a job of its own at the head of the item queues, instead
         // of once per workgroup and call (measured: 6.8 of the ~90 us of an item at 32 calls per launch)
