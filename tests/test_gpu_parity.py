@@ -537,6 +537,43 @@ def test_group_launch_persistent_workgroups(ea, oracle_cpu, per_cu, n_calls):
         g.set_tuning(0, 0, 0)
 
 
+def test_plain_and_persistent_forms_of_one_launch_agree(ea, oracle_cpu):
+    """Round 6: on a context without lanes an FP16 launch stays a PLAIN grid (lean kernel, every workgroup its own cutoff) up to six items
+    per CU -- 20 calls on a 4096 x 11008 matrix: 960 items, the third and fourth round of workgroups placed by the dispatcher -- where it
+    used to go persistent from two per CU on.  Same geometry, integer accumulation: the two forms give the SAME BITS, launch after launch,
+    and both match the oracle."""
+    outDim, inDim, n_calls = 11008, 4096, 20
+    W, b, s, p = converted(oracle_cpu, outDim, inDim)
+    ew = gpu_weights(ea, W, b, s, p)
+    g = ea.gpu()
+    hv = [make_v(inDim, seed=300 + i, heavy=bool(i & 1)) for i in range(n_calls)]
+    efforts = [(0.1, 0.25, 0.5, 1.0)[i % 4] for i in range(n_calls)]
+    calls = [(devf(hv[i]), ew, None, torch.full((outDim,), float("nan"), device=DEV), efforts[i]) for i in range(n_calls)]
+    got = {}
+    try:
+        for form, per_cu in (("heuristic", -1), ("persistent", 2), ("plain", 0)):
+            g.set_persistent(per_cu)
+            for rep in range(2):
+                for c in calls:
+                    c[3].fill_(float("nan"))
+                ea.bucketMulGroup(calls)
+                g.eval()
+                outs = [c[3].cpu().numpy().copy() for c in calls]
+                meta = [(g.last_dispatch_count(i), g.last_cutoff(i)) for i in range(n_calls)]
+                if form in got:
+                    assert all(np.array_equal(a, b_) for a, b_ in zip(outs, got[form][0])), form       # launch after launch
+                got[form] = (outs, meta)
+    finally:
+        g.set_persistent(-1)
+    for form in ("persistent", "plain"):
+        assert got[form][1] == got["heuristic"][1], form
+        assert all(np.array_equal(a, b_) for a, b_ in zip(got[form][0], got["heuristic"][0])), form
+    for i in (0, 1, 6, 19):
+        want, n, cutoff = oracle_cpu.bucket_mul(hv[i], b, s, p, inDim, outDim, efforts[i])
+        assert got["heuristic"][1][i] == (n, cutoff), i
+        assert close(got["heuristic"][0][i], want), i
+
+
 def test_cutoff_jobs_under_graph_replay(ea, oracle_cpu):
     """A persistent 32-call launch evaluates each call's cutoff once, in a job its items wait for (flag in device memory,
     lowered by the last workgroup out).  Replayed from ONE hipGraph with the inputs changed in place between replays, every
