@@ -122,7 +122,7 @@ def compact_line(result: dict) -> str:
     rf = result.get("roofline")
     if isinstance(rf, dict):
         r = _pick(rf, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "traffic_measured_in_run",
-                       "bytes_per_launch", "calls_per_launch", "launches_in_flight", "kernel_us", "frac_moved_bytes"))
+                       "bytes_per_launch", "calls_per_launch", "launches_in_flight", "kernel_us", "frac_moved_bytes", "scope"))
         if isinstance(rf.get("single_stream"), dict):
             r["single_stream"] = _pick(rf["single_stream"], ("frac", "kernel_us", "kernel_us_hip_events_outside_graph"))
         out["roofline"] = r
@@ -1288,6 +1288,13 @@ def main(argv=None):
         result["multi_gpu"] = {"partition": "matrices (weak scaling: every rank its own 32 matrices per step; north_star's partition: `value`)",
                                "ms_per_step_kernel_only": round(b.dt_kernel * 1e3, 5), "ms_per_step_with_all_gather": round(dt * 1e3, 5),
                                "steps_per_round": 16 * S, "all_gather_bytes_per_rank_per_round": 16 * S * N_MATS * OUT_DIM * 4}
+        # the dominant kernel's roofline on N > 1: PER RANK (every rank streams its own matrices from its own HBM), from the kernel-only
+        # time of the timed rounds; traffic is measured at N = 1 only (a rocprofv3 child per rank would outlive the driver's patience)
+        kbl, t_launch = G * kb, b.dt_kernel / b.launches_per_step
+        result["roofline"] = {"bound": "hbm", "kernel": "bucket_mul_kernel", "achieved": round(kbl / t_launch / 1e9, 1), "peak": HBM_PEAK_GBPS,
+                              "unit": "GB/s", "frac": round(kbl / t_launch / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None,
+                              "bytes_per_launch": kbl, "calls_per_launch": G, "launches_in_flight": b.in_flight, "kernel_us": round(t_launch * 1e6, 3),
+                              "scope": "per rank (one GPU's HBM), slowest rank, kernel-only time of the timed rounds; the all-gather of the outputs is in ms_per_step"}
         if not args.headline_only:
             b.multi_gpu_legs(result)
 
