@@ -41,6 +41,7 @@ _SIGS = {
     "effort_set_stream": (C.c_int, [_P, _P]),
     "effort_sync": (C.c_int, [_P]),
     "effort_set_overlap": (C.c_int, [_P, C.c_int]),
+    "effort_set_row_reuse": (C.c_int, [_P, C.c_int]),
     "effort_join": (C.c_int, [_P]),
     "effort_last_error": (C.c_char_p, [_P]),
     "effort_version": (C.c_char_p, []),

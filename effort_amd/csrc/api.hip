@@ -72,6 +72,7 @@ struct effort_ctx {
     // tuning overrides (0 = heuristic)
     int tuneW = 0, tuneE = 0, tuneS = 0;
     bool splitCutoff = false;     // run findCutoff32 as its own 1-workgroup kernel instead of inside every workgroup
+    bool rowReuse = false;        // effort_set_row_reuse: the bucket-row stream with the ordinary cache policy instead of nt (GroupKArgs::split bit 3)
     // optional per-kernel timing
     bool timing = false;          // HIP events around each kernel
     bool clock = false;           // device wall-clock stamps inside the multiply kernel
@@ -898,7 +899,7 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
         ga.groupDone = L.d_counters + effort_ctx::kMaxTiles - 1;
         ga.slabs = L.d_slabs; ga.counters = L.d_counters; ga.sliceCounts = L.d_sliceCounts; ga.cutoff = L.d_cutoff + firstCall;
         ga.tstamp = c->clock ? c->d_tstamp : nullptr;
-        ga.ablate = ablate; ga.split = c->splitCutoff ? 1u : 0u; ga.trace = (c->clock && c->trace) ? 1u : 0u;
+        ga.ablate = ablate; ga.split = (c->splitCutoff ? 1u : 0u) | (c->rowReuse ? 8u : 0u); ga.trace = (c->clock && c->trace) ? 1u : 0u;
         ga.numCU = (uint32_t)c->numCU; ga.queue = L.d_queue;
         nGeoms = 0; wg = 0; realItems = 0; first = firstCall;
     };
@@ -1291,6 +1292,12 @@ extern "C" int effort_set_persistent(effort_ctx* c, int wgPerCU) {
 extern "C" int effort_debug_hook_lane(effort_ctx* c, int lane) {
     if (!c || lane < 0 || lane >= c->nLanes) return EFFORT_ERR_ARG;
     c->lastLane = lane;
+    return EFFORT_OK;
+}
+
+extern "C" int effort_set_row_reuse(effort_ctx* c, int reuse) {
+    if (!c) return EFFORT_ERR_ARG;
+    c->rowReuse = reuse != 0;
     return EFFORT_OK;
 }
 

@@ -79,9 +79,11 @@ constexpr int kRounds = 16;  // selection rounds of NT candidate slots a workgro
 // unaligned rows with that round's kernel: neighbouring tiles' pieces share the lines a row straddles.)  What nt gives up is reuse
 // BETWEEN launches: four launches in flight over the SAME 32 matrices (a batch of inputs on one set of weights, in lockstep within the
 // Infinity Cache's 256 MB) 117 -> 130 us per launch; and 32 calls on 4096 x 4096 matrices re-read every launch (270 MB, the Infinity
-// Cache's size) 62 -> 64.  A RUN-TIME switch was built too -- a uniform branch between two batches of eight loads, counted waits intact --
-// and measured: a lone call 18.1 -> 19.8 us, a group of three 30.5 -> 36.7, one 32-call launch 160 -> 165 (the scheduler no longer
-// interleaves the loads with the other batch's scatter): the policy stays a compile-time constant.
+// Cache's size) 62 -> 64.  Such a caller asks for the ordinary policy at RUN TIME (effort_set_row_reuse -> GroupKArgs::split bit 3): the two policies
+// are two copies of the whole streaming loop, chosen once per item (mul_item: `stream`).  The first form of the switch -- a uniform branch between two
+// batches of eight loads inside ONE loop -- cost a lone call 18.1 -> 19.8 us and a 32-call launch 160 -> 165: at the join hipcc's wait-count pass
+// assumed the worse of the two paths and every `s_waitcnt vmcnt(15..8)` of the accumulate became `vmcnt(7..0)` -- a batch waited for the batch
+// issued AFTER it, i.e. no software pipeline at all.
 #ifndef EFFORT_ROW_AUX
 #define EFFORT_ROW_AUX 2
 #endif
@@ -156,20 +158,20 @@ template <> struct MeanT<kQ4> { typedef float type; };        // f32 (stats lane
 template <int E> struct Piece;
 template <> struct Piece<1> {
     uint32_t w;
-    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) { w = __builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, kRowAux); }
+    template <int AUX> __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) { w = __builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, AUX); }
     __device__ __forceinline__ uint32_t word(int) const { return w & 0xFFFFu; }
     __device__ __forceinline__ uint32_t dword(int) const { return w; }
 };
 template <> struct Piece<2> {
     uint32_t w;
-    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) { w = __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, kRowAux); }
+    template <int AUX> __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) { w = __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, AUX); }
     __device__ __forceinline__ uint32_t word(int j) const { return (w >> (16 * j)) & 0xFFFFu; }
     __device__ __forceinline__ uint32_t dword(int) const { return w; }
 };
 template <> struct Piece<4> {
     uint32_t w[2];
-    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
-        auto t = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, kRowAux); w[0] = t[0]; w[1] = t[1];
+    template <int AUX> __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+        auto t = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, AUX); w[0] = t[0]; w[1] = t[1];
     }
     __device__ __forceinline__ uint32_t word(int j) const { return (w[j >> 1] >> (16 * (j & 1))) & 0xFFFFu; }
     __device__ __forceinline__ uint32_t dword(int j) const { return w[j >> 1]; }
@@ -775,9 +777,11 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
         boff = 0; dv = 0.0f;
         if (lane < KB && nU) decode_code(i0 + (uint32_t)lane < nU ? code0 : (uint32_t)__builtin_amdgcn_readfirstlane((int)code0), boff, dv);
     };
-    auto issue = [&](Piece<E> (&piece)[KB], uint32_t boff) {
+    // (`aux`: the cache policy of the batch's loads, an immediate of the instruction -- std::integral_constant: the two policies are two copies of
+    //  the whole streaming loop below, chosen ONCE per item; a branch per batch breaks hipcc's counted waits, see EFFORT_ROW_AUX above)
+    auto issue = [&](auto aux, Piece<E> (&piece)[KB], uint32_t boff) {
 #pragma unroll
-        for (int u = 0; u < KB; u++) piece[u].load(rsrc, voff, EFFORT_ABLATE_NOLOAD ? 0u : __builtin_amdgcn_readlane(boff, u));
+        for (int u = 0; u < KB; u++) piece[u].template load<decltype(aux)::value>(rsrc, voff, EFFORT_ABLATE_NOLOAD ? 0u : __builtin_amdgcn_readlane(boff, u));
     };
     // One row piece -> E (Q4: 4E) integer LDS atomics on the workgroup's tile.  Why fixed point: a float
     // read-add-write needs a PRIVATE tile per wave (W x the LDS, so two workgroups per CU at best) and two LDS
@@ -904,13 +908,13 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
     };
     // (measured: raising the wave priority of this loop -- s_setprio 2 -- so that a co-resident workgroup's selection does not
     //  take its issue slots is 8 % SLOWER per launch: the other workgroup's head then takes that much longer)
-    auto stream_rows = [&](auto withOl) {
+    auto stream_rows = [&](auto withOl, auto aux) {
         constexpr bool OL = decltype(withOl)::value;
         Piece<E> pa[KB], pb[KB];
         uint32_t entA[OL ? kOlMerged : 1], entB[OL ? kOlMerged : 1];
         uint32_t boffA, boffB; float dvA, dvB;
         uint32_t baseA = (uint32_t)(wave * KB), baseB;             // (no LDS atomic for the first batch: the cursor starts at W * KB)
-        if (baseA < nU) { decode_first(baseA, boffA, dvA); issue(pa, boffA); }
+        if (baseA < nU) { decode_first(baseA, boffA, dvA); issue(aux, pa, boffA); }
         if constexpr (OL) ol_fetch(entA);
         while (baseA < nU) {
             if (!asked && nU - baseA <= 4u * KB * W) asked = prefetch();
@@ -920,13 +924,13 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
             }
             baseB = grab();
             decode(baseB, boffB, dvB);
-            issue(pb, boffB);
+            issue(aux, pb, boffB);
             if constexpr (OL) ol_fetch(entB);
             accumulate(pa, dvA, __builtin_amdgcn_readfirstlane(min((uint32_t)KB, nU - baseA)));
             if constexpr (OL) ol_add(entA);
             baseA = grab();
             decode(baseA, boffA, dvA);
-            issue(pa, boffA);
+            issue(aux, pa, boffA);
             if constexpr (OL) ol_fetch(entA);
             accumulate(pb, dvB, __builtin_amdgcn_readfirstlane(baseB < nU ? min((uint32_t)KB, nU - baseB) : 0u));
             if constexpr (OL) ol_add(entB);
@@ -939,8 +943,14 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
             }
         }
     };
-    if constexpr (kOlMerge) { if (olEarly) stream_rows(std::true_type{}); else stream_rows(std::false_type{}); }
-    else stream_rows(std::false_type{});
+    // the rows' cache policy: non-temporal, or -- the host says the launches in flight read the SAME matrices (effort_set_row_reuse) -- the ordinary one
+    const bool rowsReused = kRowAux != 0 && (ga.split & 8u) != 0u;                 // uniform per launch
+    auto stream = [&](auto withOl) {
+        if constexpr (kRowAux != 0) { if (rowsReused) { stream_rows(withOl, std::integral_constant<int, 0>{}); return; } }
+        stream_rows(withOl, std::integral_constant<int, kRowAux>{});
+    };
+    if constexpr (kOlMerge) { if (olEarly) stream(std::true_type{}); else stream(std::false_type{}); }
+    else stream(std::false_type{});
     // (measured too: everything BUT this loop at raised priority -- no effect, 173.9 vs 173.5 us per 32-call launch)
     if (!asked) asked = prefetch();            // (a wave without rows; wave 0 always gets an answer: it is the one that pulls)
     __syncthreads();                           // every wave's atomics have landed in the tile

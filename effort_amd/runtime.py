@@ -69,6 +69,12 @@ class Gpu:
     def join(self):
         self.check(self._lib.effort_join(self.ctx), "join")
 
+    def set_row_reuse(self, reuse: bool = True):
+        """Cache policy of the bucket-row stream (effort_set_row_reuse): non-temporal by default (a row is read once per call);
+        ``reuse=True`` keeps the ordinary policy for launches in flight that read the SAME matrices (a batch on one set of
+        weights).  Speed only."""
+        self.check(self._lib.effort_set_row_reuse(self.ctx, int(bool(reuse))), "set_row_reuse")
+
     # -- multi-GPU: one process per GPU, RCCL over xGMI (effort_comm_*) -----------------------------------------------------
     @staticmethod
     def comm_unique_id() -> bytes:

@@ -81,6 +81,15 @@ EFFORT_API int effort_sync(effort_ctx* ctx);
  * tools/lab/graph_event_repro.py); keep such graphs for the life of the process, or capture with lanes = 1. */
 EFFORT_API int effort_set_overlap(effort_ctx* ctx, int lanes);
 EFFORT_API int effort_join(effort_ctx* ctx);
+/* Cache policy of the bucket-row stream.  reuse = 0 (default): the kept rows are read NON-TEMPORALLY -- a row is read once per call and a
+ * model's weights are tens of times the chip's caches (Mistral-7B at 25 % effort reads 3.5 GB per token against 32 MB of L2 and 256 MB of
+ * Infinity Cache), so the stream should not push the row means, the partial tiles and the other launches' lines out on its way through
+ * (one 32-call launch 160 -> 150 us, four in flight 133 -> 127, a lone call 18.1 -> 17.75: DESIGN.md 4.1).  reuse = 1: the ordinary policy,
+ * for a caller whose launches in flight read the SAME matrices within a few hundred MB of one another (a batch of inputs on one set of
+ * weights, through effort_set_overlap lanes or several contexts): the later launches then hit in the Infinity Cache (four launches in flight
+ * on one set of 32 matrices: 117 us per launch against 130).  Speed only: results are bit-identical either way.  Takes effect with the next
+ * launch (a captured launch keeps the policy it was captured with). */
+EFFORT_API int effort_set_row_reuse(effort_ctx* ctx, int reuse);
 /* Text of the context's last error; with ctx == NULL: why the last effort_create returned NULL ("null context" if none did). */
 EFFORT_API const char* effort_last_error(effort_ctx* ctx);
 EFFORT_API const char* effort_version(void);

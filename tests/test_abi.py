@@ -151,21 +151,30 @@ def test_shipped_kernels_carry_no_lab_code(hip_lib_built, tmp_path):
 
 
 def test_shipped_kernels_stream_the_bucket_rows_non_temporally(hip_lib_built, tmp_path):
-    """Round 6: every load of the bucket-row stream carries `nt` (bucket_mul.hip, EFFORT_ROW_AUX: a kept row is read once per call; one
-    32-call launch 160 -> 150 us) -- in every multiply kernel of the shipped library: the 8-byte (E = 4) and 4-byte
-    (E = 2) row pieces are the only buffer loads of those widths the kernels issue besides LDS-direct staging (which carries `lds`)."""
+    """Round 6: the bucket-row stream is read with `nt` (bucket_mul.hip, EFFORT_ROW_AUX: a kept row is read once per call; one 32-call
+    launch 160 -> 150 us) -- in every multiply kernel of the shipped library; and since effort_set_row_reuse every kernel
+    holds a SECOND copy of the streaming loop with the ordinary policy, chosen once per item (a caller whose launches in flight read the
+    same matrices).  The 8-byte (E = 4) row pieces are the only buffer loads of that width the kernels issue besides LDS-direct staging
+    (which carries `lds`): half of them carry nt, half do not, and the counted waits of the software pipeline (vmcnt 15 .. 8) survive
+    in both copies -- the first form of the switch, a branch per batch, lost them."""
     import re
     prod = _multiply_kernel_disassembly(hip_lib_built, tmp_path)
-    body, name = {}, None
+    body, waits, name = {}, {}, None
     for line in prod.splitlines():
         m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
         if m:
             name = m.group(1)
-        elif name and "bucket_mul_kernel" in name and "buffer_load_dwordx2" in line:
-            body.setdefault(name, []).append(line)
+        elif name and "bucket_mul_kernel" in name:
+            if "buffer_load_dwordx2" in line:
+                body.setdefault(name, []).append(line)
+            w = re.search(r"s_waitcnt vmcnt\((\d+)\)", line)
+            if w:
+                waits.setdefault(name, []).append(int(w.group(1)))
     assert len(body) >= 10, "no 8-byte row loads found in the multiply kernels?"
     for k, lines in body.items():
-        assert all(" nt" in l for l in lines), (k, [l for l in lines if " nt" not in l][:3])
+        nt = sum(" nt" in l for l in lines)
+        assert nt > 0 and 2 * nt == len(lines), (k, nt, len(lines))
+        assert waits[k].count(15) >= 2 and waits[k].count(12) >= 2, (k, sorted(set(waits[k])))
 
 
 def test_shipped_library_has_no_measured_dead_ends(hip_lib_built):

@@ -574,6 +574,68 @@ def test_plain_and_persistent_forms_of_one_launch_agree(ea, oracle_cpu):
         assert close(got["heuristic"][0][i], want), i
 
 
+def test_row_reuse_policy_changes_no_bit(ea, oracle_cpu):
+    """effort_set_row_reuse: the bucket-row stream with the ordinary cache policy instead of nt -- a second copy of the streaming loop,
+    chosen per item.  Speed only: a lone call, a plain group and a persistent group give the same bits under either policy (and the
+    oracle's dispatch count and cutoff)."""
+    outDim, inDim, n_calls = 11008, 4096, 12
+    W, b, s, p = converted(oracle_cpu, outDim, inDim)
+    ew = gpu_weights(ea, W, b, s, p)
+    g = ea.gpu()
+    hv = [make_v(inDim, seed=700 + i, heavy=bool(i & 1)) for i in range(n_calls)]
+    efforts = [(0.1, 0.25, 0.5, 1.0)[i % 4] for i in range(n_calls)]
+    calls = [(devf(hv[i]), ew, None, torch.full((outDim,), float("nan"), device=DEV), efforts[i]) for i in range(n_calls)]
+    got = {}
+    try:
+        for reuse in (False, True, False):
+            g.set_row_reuse(reuse)
+            for form, per_cu, k in (("lone", -1, 1), ("plain", 0, n_calls), ("persistent", 2, n_calls)):
+                g.set_persistent(per_cu)
+                for c in calls:
+                    c[3].fill_(float("nan"))
+                ea.bucketMulGroup(calls[:k])
+                g.eval()
+                outs = [c[3].cpu().numpy().copy() for c in calls[:k]]
+                meta = [(g.last_dispatch_count(i), g.last_cutoff(i)) for i in range(k)]
+                if form in got:
+                    assert meta == got[form][1], (form, reuse)
+                    assert all(np.array_equal(a, b_) for a, b_ in zip(outs, got[form][0])), (form, reuse)
+                got[form] = (outs, meta)
+    finally:
+        g.set_persistent(-1)
+        g.set_row_reuse(False)
+    for i in (0, 1, 6):
+        want, n, cutoff = oracle_cpu.bucket_mul(hv[i], b, s, p, inDim, outDim, efforts[i])
+        assert got["plain"][1][i] == (n, cutoff), i
+        assert close(got["plain"][0][i], want), i
+
+
+def test_row_reuse_policy_changes_no_bit_q4(ea, oracle_cpu, q4_case):
+    """The Q4 kernels hold the two copies of the streaming loop too (same launch geometry -> same bits, outliers included)."""
+    W, L, inDim, outDim = q4_case
+    ew = ea.ExpertWeights(dev16(L["buckets"]), devf(L["bucket.stats"]), dev16(L["probes"]), inSize=inDim, outSize=outDim,
+                          outliers=devf(L["outliers"]), q4=True)
+    g = ea.gpu()
+    calls = [(devf(make_v(inDim, seed=720 + k, heavy=k == 2)), ew, None, torch.full((outDim,), float("nan"), device=DEV), effort)
+             for k, effort in enumerate((0.25, 0.5, 1.0, 0.1))]
+    got = None
+    try:
+        for reuse in (False, True, False):
+            g.set_row_reuse(reuse)
+            for c in calls:
+                c[3].fill_(float("nan"))
+            ea.bucketMulGroup(calls)
+            g.eval()
+            cur = ([c[3].cpu().numpy().copy() for c in calls], [(g.last_dispatch_count(i), g.last_cutoff(i)) for i in range(len(calls))])
+            if got is not None:
+                assert cur[1] == got[1], reuse
+                assert all(np.array_equal(a, b_) for a, b_ in zip(cur[0], got[0])), reuse
+            got = cur
+    finally:
+        g.set_row_reuse(False)
+    assert all(np.isfinite(o).all() for o in got[0])
+
+
 def test_cutoff_jobs_under_graph_replay(ea, oracle_cpu):
     """A persistent 32-call launch evaluates each call's cutoff once, in a job its items wait for (flag in device memory,
     lowered by the last workgroup out).  Replayed from ONE hipGraph with the inputs changed in place between replays, every

@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--no-outliers", type=int, default=0, help="Q4: register the bundles without their outlier tables")
     ap.add_argument("--fused", default="", help="comma list of gate,norm,resid: every call derives its input / adds its residual in the launch (effort_bucketmul_group_fused)")
     ap.add_argument("--no-align", type=int, default=0, help="1: the reference's dense rows (2 * cols bytes apart) instead of rows on whole 128-byte lines")
+    ap.add_argument("--row-reuse", type=int, default=0, help="1: effort_set_row_reuse(1), the ordinary cache policy on the row stream (default: nt)")
     ap.add_argument("--split", type=int, default=0, help="1: the cutoffs in a kernel of their own before the multiply (the device-clock span then covers the multiply alone)")
     args = ap.parse_args()
     inDim, outDim = (int(x) for x in args.shape.split("x"))
@@ -55,6 +56,8 @@ def main():
     osets = [[torch.zeros(outDim, device=dev) for _ in ews] for _ in range(max(1, args.overlap))]
     if args.overlap > 1:
         g.set_overlap(args.overlap)
+    if args.row_reuse:
+        g.set_row_reuse(True)
     fz = {}
     if "gate" in args.fused:
         fz["gate"] = torch.randn(inDim, generator=gen, device=dev)
