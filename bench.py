@@ -640,6 +640,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-decode", action="store_true", help="skip the end-to-end decode section (BASELINE.json configs[4])")
     ap.add_argument("--headline-only", action="store_true", help="only the timed job (for rocprofv3 passes: every bucket_mul_kernel dispatch is then the timed configuration)")
     ap.add_argument("--headline-shared", action="store_true", help="round 2's job: every step in flight on the SAME 32 matrices")
+    ap.add_argument("--row-reuse", action="store_true", help="effort_set_row_reuse(1) on the timed job's context: the ordinary cache policy on the row stream (what a --headline-shared caller asks for; default nt)")
     ap.add_argument("--no-align", action="store_true", help="stream the converter's rows as they are (2*cols bytes apart) instead of on whole 128-byte lines")
     ap.add_argument("--tune", default="0,0,0", help="waves,elems,slices of the multiply kernel (0,0,0 = heuristic)")
     return ap.parse_args(argv)
@@ -683,6 +684,9 @@ class Bench:
         # contexts on four streams) under the all-gather pipeline.
         self.job = Job(ea, local, self.S, self.tune) if dist else LaneJob(ea, local, self.S, self.tune)
         self.one = LaneJob(ea, local, 1, self.tune, ctx=self.g)
+        if getattr(args, "row_reuse", False):
+            for cx in self.job.ctxs:
+                cx.set_row_reuse(True)
         self.launches_per_step = (N_MATS + self.G - 1) // self.G
 
     def barrier(self):

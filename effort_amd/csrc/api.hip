@@ -960,20 +960,57 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
     };
     uint32_t groupTiles = 0;
     for (int i = 0; i < n; i++) groupTiles += (ws[i]->cols + 64 * groupE - 1) / (64 * groupE);
+    // Thin slices for the LAST TWO calls of an FP16 launch whose last round of workgroups would be nearly empty (round 6, third session;
+    // profiles/r06_tail_slices.txt).  A plain grid's workgroups are handed out in call order, two per CU at a time: 11 calls of 48 items are 528 items --
+    // one round of 512 and 16 stragglers that start when the others END, a whole item's duration for 3 % of the work.  With the last two calls cut into twice the
+    // slices the tail of the launch is made of half-height items: the first of them finish while the round is still running and hand their slots on.  us per
+    // launch, 4096x11008 at 25 %, without / with the rule: 11 calls 72.8 -> 66.0 (-9.4 %), 12: 74.5 -> 69.3 (-7 %), 22: 114.2 -> 108.4 (-5 %), 23: 115.6 -> 110.9
+    // (-4 %), 12 at 10 / 50 / 100 % effort -5.7 / -9.1 / -11.5 %, 11 at 100 % -13.7 %, 19 x (4096 -> 14336) -4.8 %, 11 x (4096 -> 14336) -6 %.  The gain shrinks as
+    // the last round fills -- 13 calls (112 of 512 slots) -2.5 %, 24 calls or 18 x (14336 -> 4096) (128) 0 / +3 % -- so the rule ends at 7/32 of a round.  Applied
+    // to EVERY mid-size launch (its first form) it was level or worse from a quarter-full last round on: 14 / 15 calls +2 / +3 %, 16 at 50 / 100 % effort +2.5 /
+    // +4.5 %, 16 calls of a 4096x4096 matrix (256 items: not even one round) +12 %.  More than
+    // two thin calls, or four times the slices: never better (a thin item pays the same head and hand-off for half the rows); E = 4 launches (32 calls: 149.0 ->
+    // 150.8), persistent grids (151 -> 157) and launches in flight on lanes (a launch's tail runs under the next one's head; round 2: 124.3 -> 125.8): worse, off.
+    int thinFrom = n;                                     // calls [thinFrom, n) take twice the slices
+    if (fmt == kFp16 && groupE == 2 && n >= 11 && !laned && !c->tuneS && c->persistent < 0) {
+        uint32_t base = 0, extra = 0;
+        MulGeom seen[kMaxGeoms + 1];                       // the launch descriptor holds kMaxGeoms shapes: the thin ones must not split the launch
+        uint32_t nSeen = 0;
+        bool ok = true;
+        auto note = [&](const MulGeom& g) {
+            uint32_t k = 0;
+            while (k < nSeen && memcmp(&seen[k], &g, sizeof(g)) != 0) k++;
+            if (k == nSeen) { if (nSeen == kMaxGeoms) ok = false; else seen[nSeen++] = g; }
+        };
+        for (int i = 0; ok && i < n; i++) {
+            MulGeom g1, g2; int Wi, Ei;
+            memset(&g1, 0, sizeof(g1)); memset(&g2, 0, sizeof(g2));
+            ok = choose_geom(c, ws[i], n, groupE, &g1, &Wi, &Ei, 1, groupTiles) == EFFORT_OK;
+            const uint32_t it1 = (g1.tiles * g1.slices + 7u) / 8u * 8u;
+            base += it1;
+            if (ok && i >= n - 2) {
+                ok = choose_geom(c, ws[i], n, groupE, &g2, &Wi, &Ei, 2, groupTiles) == EFFORT_OK && g2.slices > g1.slices;
+                extra += (g2.tiles * g2.slices + 7u) / 8u * 8u - it1;
+                if (ok) note(g2);
+            } else if (ok) note(g1);
+        }
+        const uint32_t round = 2u * (uint32_t)c->numCU;
+        if (ok && base > round && base + extra <= 6u * (uint32_t)c->numCU && base % round != 0u && base % round * 32u <= round * 7u) thinFrom = n - 2;
+    }
     begin(0);
     for (int i = 0; i < n; i++) {
         const effort_w* w = ws[i];
         MulGeom g;
         memset(&g, 0, sizeof(g));
         int Wi, Ei;
-        // (knob, off by default) The calls at the END of a big group can be cut into thinner slices: their items are the last
-        // ones the persistent workgroups pull, and the launch ends when the last item does.
-        uint32_t mult = 1;
+        // the calls at the END of a mid-size group are cut into thinner slices (thinFrom, above): their items are the last ones handed out, and
+        // the launch ends when the last item does
+        uint32_t mult = i >= thinFrom ? 2u : 1u;
 #ifdef EFFORT_LAB
-        if (n >= 8 && !c->tuneS) {
-            static const int tailCalls = getenv("EFFORT_TAIL_CALLS") ? atoi(getenv("EFFORT_TAIL_CALLS")) : -1;     // profiling knobs
-            static const int tailMult = getenv("EFFORT_TAIL_MULT") ? atoi(getenv("EFFORT_TAIL_MULT")) : 2;
-            const int tc = tailCalls >= 0 ? tailCalls : 0;     // measured (r02): with several launches in flight the tail of one launch runs under the next one's head, and thin slices only add items: 125.8 vs 124.3 us per step; kept as a knob
+        if (n >= 8 && !c->tuneS && getenv("EFFORT_TAIL_CALLS")) {       // profiling knobs (read at every call: tools/qbench.py --tails sweeps them in one process): the rule above replaced by "the last tc calls at tailMult x the slices"
+            const int tc = atoi(getenv("EFFORT_TAIL_CALLS"));
+            const int tailMult = getenv("EFFORT_TAIL_MULT") ? atoi(getenv("EFFORT_TAIL_MULT")) : 2;
+            mult = 1;
             if (i >= n - tc) mult = (uint32_t)tailMult;
             if (tailMult >= 4 && i >= n - tc && i < n - tc / 2) mult = (uint32_t)tailMult / 2;      // two steps: ... x2 x2 x4 x4
         }

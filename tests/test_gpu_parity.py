@@ -1082,8 +1082,8 @@ def test_aligned_row_pitch_is_bit_identical(ea, oracle_cpu, q4_11008):
     ea.bucketMulGroup([(vd, padded if i & 1 else plain, None, outs[i], 0.25) for i in range(12)])
     g.eval()
     want, n, cutoff = oracle_cpu.bucket_mul(v, b, s, p, inDim, outDim, 0.25)
-    for i in range(12):                              # (the last quarter of a big group is cut into thinner slices: its own rounding grid)
-        assert g.last_dispatch_count(i) == n and torch.equal(outs[i], outs[0 if i < 9 else 9]) and close(outs[i].cpu().numpy(), want), i
+    for i in range(12):                              # (the last two calls of this launch are cut into thinner slices, api.hip thinFrom: their own rounding grid)
+        assert g.last_dispatch_count(i) == n and torch.equal(outs[i], outs[0 if i < 10 else 10]) and close(outs[i].cpu().numpy(), want), i
     o2 = torch.zeros(outDim, device=DEV)
     ea.bucketMul(vd, padded, None, o2, 0.25)
     g.eval()
@@ -1333,7 +1333,8 @@ def test_geometry_rules_of_round_six(ea, oracle_cpu, q4_11008):
     """The launch-geometry rules round 6 added, pinned through the slice-count hook (effort_debug_slice_counts): a lone 4096 -> 14336 call --
     the reference's timed shape -- takes 32 slices (24 = 171 rows in blocks of 256 slots before: pick_slices' power-of-two rule); a 16-call
     Q4 group on a context WITHOUT lanes launches as one round of 5 tall slices per call, on a context WITH lanes as 8 (api.hip q4_one_round);
-    a pair of Q4 calls 16 slices.  Every product against the oracle."""
+    a pair of Q4 calls 16 slices; an FP16 launch without lanes whose last round of workgroups would be nearly empty cuts its last two calls into twice
+    the slices.  Every product against the oracle."""
     W, L, inDim, outDim = q4_11008
     ew = ea.ExpertWeights(dev16(L["buckets"]), devf(L["bucket.stats"]), dev16(L["probes"]), inSize=inDim, outSize=outDim,
                           outliers=devf(L["outliers"]), q4=True)
@@ -1359,6 +1360,23 @@ def test_geometry_rules_of_round_six(ea, oracle_cpu, q4_11008):
         assert len(g.slice_counts(0)) == 32
         wantf, cntf, cutf = oracle_cpu.bucket_mul(v, b, s, p, iD, oD, 0.25)
         assert g.last_dispatch_count() == cntf and g.last_cutoff() == cutf and close(out.cpu().numpy(), wantf)
+        # FP16, third session: a launch that has the chip to itself and whose last round of workgroups would be nearly empty (at most 7/32 full: 11 / 12 / 13 / 23 calls of
+        # 48 items are 16 / 64 / 112 / 80 items over a multiple of 512; 14 and 24 calls, 160 and 128, are not) cuts its LAST TWO calls into twice the slices (api.hip do_group: thinFrom); not with lanes
+        oD, iD = 11008, 4096
+        Wf, b, s, p = converted(oracle_cpu, oD, iD)
+        ewf = gpu_weights(ea, Wf, b, s, p)
+        hv = [make_v(iD, seed=900 + i, heavy=bool(i & 1)) for i in range(3)]
+        wants = [oracle_cpu.bucket_mul(hv[i], b, s, p, iD, oD, e) for i, e in enumerate((0.25, 0.5, 0.1))]
+        for lanes, n, first, last in ((1, 11, 8, 16), (1, 12, 8, 16), (1, 13, 8, 16), (1, 23, 8, 16), (1, 14, 8, 8), (1, 16, 8, 8), (1, 24, 8, 8), (4, 12, 8, 8), (1, 10, 8, 8)):
+            g.set_overlap(lanes)
+            outs = [torch.full((oD,), float("nan"), device=DEV) for _ in range(n)]
+            ea.bucketMulGroup([(devf(hv[i % 3]), ewf, None, outs[i], (0.25, 0.5, 0.1)[i % 3]) for i in range(n)], gpu=g)
+            g.eval()
+            got = [len(g.slice_counts(i)) for i in range(n)]
+            assert got == [first] * (n - 2) + [last] * 2, (lanes, n, got)
+            for i in (0, 1, n - 3, n - 2, n - 1):
+                wantf, cntf, cutf = wants[i % 3]
+                assert g.last_dispatch_count(i) == cntf and g.last_cutoff(i) == cutf and close(outs[i].cpu().numpy(), wantf), (lanes, n, i)
     finally:
         g.set_overlap(1)
         g.close()

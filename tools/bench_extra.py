@@ -43,6 +43,13 @@ def shared_matrices(b, res):
     kb = B.mul_kernel_bytes(b.D, B.IN_DIM, B.OUT_DIM)
     gn = b.job.capture(b.mul_step(b.args.effort), 192)
     res["shared_matrices"] = b.rate(B.time_graph(gn, None) / 192 / B.N_MATS, kb)
+    # ... and with the row stream's ordinary cache policy, what such a caller asks for (effort_set_row_reuse: the policy is captured with the launch)
+    b.job.ctx.set_row_reuse(True)
+    try:
+        gr = b.job.capture(b.mul_step(b.args.effort), 192)
+    finally:
+        b.job.ctx.set_row_reuse(False)
+    res["shared_matrices_row_reuse"] = b.rate(B.time_graph(gr, None) / 192 / B.N_MATS, kb)
 
 
 def four_contexts(b, res):

@@ -21,6 +21,9 @@ python tools/span.py --trace $O/prof_bench1 --bytes-per-launch $BPL --out $O/${R
 # 3. round 2's job (every step in flight on the SAME 32 matrices) for the comparison
 rocprofv3 --kernel-trace --output-format csv -d $O/prof_shared -- $H --headline-shared > $O/prof_shared.json 2> $O/prof_shared.log
 python tools/span.py --trace $O/prof_shared --bytes-per-launch $BPL --out $O/${R}_span_shared_matrices.json --label "4 launches in flight on the SAME 32 matrices (round 2's job)"
+rocprofv3 --kernel-trace --output-format csv -d $O/prof_shared_r -- $H --headline-shared --row-reuse > $O/prof_shared_r.json 2> $O/prof_shared_r.log
+python tools/span.py --trace $O/prof_shared_r --bytes-per-launch $BPL --out $O/${R}_span_shared_matrices_row_reuse.json --label "4 launches in flight on the SAME 32 matrices, effort_set_row_reuse(1): the ordinary cache policy on the row stream"
+rm -rf $O/prof_shared_r
 # 4. HBM-side traffic and L2 hit / miss counters (separate --pmc passes, kernel-trace only: MI355X_MICROARCH.md)
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/prof_fetch -- $H > /dev/null 2> $O/pmc_fetch.log
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/prof_write -- $H > /dev/null 2> $O/pmc_write.log

@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--fused", default="", help="comma list of gate,norm,resid: every call derives its input / adds its residual in the launch (effort_bucketmul_group_fused)")
     ap.add_argument("--no-align", type=int, default=0, help="1: the reference's dense rows (2 * cols bytes apart) instead of rows on whole 128-byte lines")
     ap.add_argument("--row-reuse", type=int, default=0, help="1: effort_set_row_reuse(1), the ordinary cache policy on the row stream (default: nt)")
+    ap.add_argument("--tails", default="", help="lab library: comma list of EFFORT_TAIL_CALLS values (the last k calls of a group at EFFORT_TAIL_MULT x the slices), each timed in turn")
     ap.add_argument("--split", type=int, default=0, help="1: the cutoffs in a kernel of their own before the multiply (the device-clock span then covers the multiply alone)")
     args = ap.parse_args()
     inDim, outDim = (int(x) for x in args.shape.split("x"))
@@ -66,7 +67,11 @@ def main():
     resid = torch.randn(outDim, generator=gen, device=dev) if "resid" in args.fused else None
     items = list(zip(ews, outs))
     chunks = [items[i:i + args.group] for i in range(0, len(items), args.group)]
+    tails = [t for t in args.tails.split(",") if t] or [None]
     for rep in range(args.reps):
+      for tail in tails:
+        if tail is not None:
+            os.environ["EFFORT_TAIL_CALLS"] = tail           # (read by the lab library at every call)
         for cfg in args.configs.split(";"):
             tune, per = cfg.split(":")
             g.set_tuning(*(int(x) for x in tune.split(",")))
@@ -137,7 +142,7 @@ def main():
                 timed(50)
                 span = f"{g.kernel_clock()['mul_us']:8.2f} us"
                 g.enable_kernel_timing(0)
-            print(f"{args.tag} rep {rep} cfg {cfg:14s} effort {args.effort} group {args.group}: {dt * 1e6:8.2f} us/launch  device-clock span {span}", flush=True)
+            print(f"{args.tag}{'' if tail is None else '-tc' + tail} rep {rep} cfg {cfg:14s} effort {args.effort} group {args.group}: {dt * 1e6:8.2f} us/launch  device-clock span {span}", flush=True)
 
 
 if __name__ == "__main__":
