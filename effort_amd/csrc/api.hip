@@ -629,14 +629,18 @@ static uint32_t q4_one_round(const effort_ctx* c, uint32_t inDim, uint32_t group
     const uint32_t S = (uint32_t)c->numCU * 15u / 8u / groupTiles1;      // 480 items on 256 CUs
     return S >= sMin && S >= 2u ? S : 0u;
 }
-static uint32_t pick_slices(const effort_ctx* c, const effort_w* w, int groupSize, int E, uint32_t groupTiles = 0) {
+static uint32_t pick_slices(const effort_ctx* c, const effort_w* w, int groupSize, int E, uint32_t groupTiles = 0, bool fill = true) {
     const uint32_t tiles = (w->cols + 64 * E - 1) / (64 * E);
     const uint32_t lo = ((w->inDim + 511) / 512 + 7) / 8 * 8, hi = ((w->inDim + 127) / 128 + 7) / 8 * 8;
     if (w->fmt != kFp16 && E == 1 && groupSize >= 8 && groupTiles) {       // (pick_elems chose E = 1 for this Q4 group: q4_one_round)
         const uint32_t S = q4_one_round(c, w->inDim, groupTiles);
         if (S) return S;
     }
-    if (groupSize >= 8) return lo;
+    // Groups of >= 8 calls: the fewest slices (fat items: less fixed work per byte) -- unless the launch then leaves CUs WITHOUT an item: 8 calls on 4096x4096
+    // matrices are 8 x 2 tiles x 8 slices = 128 items on 256 CUs.  FP16 groups then take the small groups' rule below (about 3/4 of an item per CU; it
+    // never goes under `lo`): 8 x 4096x4096 31.8 -> 24.8 us per launch at 16 slices (32 slices: 28.7; E = 1 x 16: 27.6; E = 4 x 32: 29.7 -- round 6, third
+    // session, profiles/r06_small_matrix_groups.txt).  `fill` = false: the count pick_elems prices its choice of E with (unchanged: E is chosen as before).
+    if (groupSize >= 8 && (w->fmt != kFp16 || !fill)) return lo;
     // (64-column tiles -- narrow matrices, see pick_elems -- are worked best at one item per CU: measured, 14336 -> 4096 lone, 64 slices
     //  26.9 us against 29.2 at 48)
     // (Q4 small groups are worked at E = 1 whatever the shape and want the 3/4 too -- round 6, a pair of 4096x11008 calls: 16 slices = 192 items 23.2 us
@@ -687,7 +691,7 @@ static int pick_elems(const effort_ctx* c, Format fmt, int n, const effort_w* co
     auto items = [&](int E) {
         uint32_t t = 0;
         const uint32_t gt = group_tiles(E);
-        for (int i = 0; i < n; i++) if (ws[i]) t += (ws[i]->cols + 64 * E - 1) / (64 * E) * pick_slices(c, ws[i], n, E, gt);
+        for (int i = 0; i < n; i++) if (ws[i]) t += (ws[i]->cols + 64 * E - 1) / (64 * E) * pick_slices(c, ws[i], n, E, gt, false);
         return t;
     };
     const uint32_t numCU = (uint32_t)c->numCU;

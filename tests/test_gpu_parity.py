@@ -1377,6 +1377,20 @@ def test_geometry_rules_of_round_six(ea, oracle_cpu, q4_11008):
             for i in (0, 1, n - 3, n - 2, n - 1):
                 wantf, cntf, cutf = wants[i % 3]
                 assert g.last_dispatch_count(i) == cntf and g.last_cutoff(i) == cutf and close(outs[i].cpu().numpy(), wantf), (lanes, n, i)
+        # FP16, third session: a group of >= 8 calls on a SMALL matrix takes enough slices to give every CU an item (api.hip pick_slices: fill) --
+        # 8 calls on 4096 x 4096: 16 slices (8 x 2 tiles x 16 = 256 items; 8 slices left half the CUs idle); 9 calls stay at 8
+        oD, iD = 4096, 4096
+        Ws, bs, ss, ps = converted(oracle_cpu, oD, iD)
+        ews = gpu_weights(ea, Ws, bs, ss, ps)
+        wants = [oracle_cpu.bucket_mul(hv[i], bs, ss, ps, iD, oD, e) for i, e in enumerate((0.25, 0.5, 0.1))]
+        for n, slices in ((8, 16), (9, 8), (16, 8)):
+            outs = [torch.full((oD,), float("nan"), device=DEV) for _ in range(n)]
+            ea.bucketMulGroup([(devf(hv[i % 3]), ews, None, outs[i], (0.25, 0.5, 0.1)[i % 3]) for i in range(n)], gpu=g)
+            g.eval()
+            assert [len(g.slice_counts(i)) for i in range(n)] == [slices] * n, (n, len(g.slice_counts(0)))
+            for i in (0, 1, 2, n - 1):
+                wantf, cntf, cutf = wants[i % 3]
+                assert g.last_dispatch_count(i) == cntf and g.last_cutoff(i) == cutf and close(outs[i].cpu().numpy(), wantf), (n, i)
     finally:
         g.set_overlap(1)
         g.close()
