@@ -663,6 +663,19 @@ static uint32_t pick_slices(const effort_ctx* c, const effort_w* w, int groupSiz
         while (up < S) up <<= 1;
         S = up <= hi ? up : up >> 1;
     }
+    // Groups of >= 3 FP16 calls that fit ONE round of CUs: as many slices as keep the launch at one item per CU, any count, instead of the nearest power of two
+    // under 3/4 of the CUs.  A launch of one round lasts as long as its tallest item: 3 calls of 4096x11008 at 8 slices are 144 items of 512 rows, at 13 slices
+    // 234 of 316 (30.7 -> 25.3 us per launch).  "One item per CU" is counted the way the items are DEALT: a call's item range is padded to a multiple of 8 and item
+    // % 8 is the XCD, so each call puts ceil(items / 8) on XCD 0 -- 7 calls of 33 items are 231 items but 35 on XCD 0's 32 CUs, and the launch takes 69 us
+    // where 30 items per call take 45 (round 6, third session, profiles/r06_one_round_groups.txt).  Lone calls and pairs -- the decode loop's launches,
+    // re-swept in round 6 -- keep the rule above.
+    if (w->fmt == kFp16 && fill && groupSize >= 3) {
+        const bool same = allTiles == (uint32_t)groupSize * tiles;          // (a mixed group: every call's padding bounded by 7)
+        auto fits = [&](uint32_t s) {
+            return same ? (uint32_t)groupSize * ((tiles * s + 7u) / 8u * 8u) <= (uint32_t)c->numCU : allTiles * s + 7u * (uint32_t)groupSize <= (uint32_t)c->numCU;
+        };
+        while (S < hi && fits(S + 1u)) S++;
+    }
     return S;
 }
 
@@ -710,6 +723,16 @@ static int pick_elems(const effort_ctx* c, Format fmt, int n, const effort_w* co
     }
     const uint32_t i2 = items(2);
     if (f2 < 0.8 * best) return 1;
+    // 3..7 calls of BIG matrices whose E = 2 items overflow one round of CUs even at the fewest slices (6 calls of 4096x11008: 6 x 6 tiles x 8 = 288 items, the 32
+    // over the 256 CUs run as a round of their own) while E = 4 items fit: E = 4, and pick_slices then fills the round (18 tiles x 13 slices = 234 items)
+    if (n >= 3 && f4 >= 0.8 * best) {
+        uint32_t lo2 = 0, lo4 = 0;
+        for (int i = 0; i < n; i++) if (ws[i]) {
+            const uint32_t lo = ((ws[i]->inDim + 511u) / 512u + 7u) / 8u * 8u;
+            lo2 += (ws[i]->cols + 127u) / 128u * lo; lo4 += (ws[i]->cols + 255u) / 256u * lo;
+        }
+        if (lo2 > numCU && lo4 <= numCU * 15u / 16u) return 4;
+    }
     // narrow matrices (<= 256 bucket columns: 4096 outputs) in small groups: 64-column tiles -- more tiles, each reduced by its
     // own last arriver (measured, us per launch at 25 %: Wq|Wk|Wv 21.2 vs 23.8, 14336 -> 4096 lone 26.6-27.5 vs 29.7)
     bool narrow = true;

@@ -1378,17 +1378,31 @@ def test_geometry_rules_of_round_six(ea, oracle_cpu, q4_11008):
                 wantf, cntf, cutf = wants[i % 3]
                 assert g.last_dispatch_count(i) == cntf and g.last_cutoff(i) == cutf and close(outs[i].cpu().numpy(), wantf), (lanes, n, i)
         # FP16, third session: a group of >= 8 calls on a SMALL matrix takes enough slices to give every CU an item (api.hip pick_slices: fill) --
-        # 8 calls on 4096 x 4096: 16 slices (8 x 2 tiles x 16 = 256 items; 8 slices left half the CUs idle); 9 calls stay at 8
+        # 8 calls on 4096 x 4096: 16 slices (8 x 2 tiles x 16 = 256 items; 8 slices left half the CUs idle); and a group of >= 3 calls that fits one round of CUs
+        # takes as many slices as keep it at one item per CU, counted as the items are dealt to the XCDs (a call's range padded to a multiple of 8): 9 calls 12
+        # slices (9 x 24 = 216), 11 calls 8 (12 slices would be 264)
         oD, iD = 4096, 4096
         Ws, bs, ss, ps = converted(oracle_cpu, oD, iD)
         ews = gpu_weights(ea, Ws, bs, ss, ps)
         wants = [oracle_cpu.bucket_mul(hv[i], bs, ss, ps, iD, oD, e) for i, e in enumerate((0.25, 0.5, 0.1))]
-        for n, slices in ((8, 16), (9, 8), (16, 8)):
+        for n, slices in ((8, 16), (9, 12), (11, 8), (16, 8)):
             outs = [torch.full((oD,), float("nan"), device=DEV) for _ in range(n)]
             ea.bucketMulGroup([(devf(hv[i % 3]), ews, None, outs[i], (0.25, 0.5, 0.1)[i % 3]) for i in range(n)], gpu=g)
             g.eval()
             assert [len(g.slice_counts(i)) for i in range(n)] == [slices] * n, (n, len(g.slice_counts(0)))
             for i in (0, 1, 2, n - 1):
+                wantf, cntf, cutf = wants[i % 3]
+                assert g.last_dispatch_count(i) == cntf and g.last_cutoff(i) == cutf and close(outs[i].cpu().numpy(), wantf), (n, i)
+        # ... 3 / 4 calls of 4096 x 11008: 13 / 10 slices (E = 2: 3 x 80 = 240, 4 x 64 = 256 padded items); 6 / 7 calls: E = 4 (their E = 2 items overflow one round
+        # even at 8 slices) at 13 / 10 slices; 5 calls stay at E = 2 x 8 (240 items)
+        oD, iD = 11008, 4096
+        wants = [oracle_cpu.bucket_mul(hv[i], b, s, p, iD, oD, e) for i, e in enumerate((0.25, 0.5, 0.1))]
+        for n, slices in ((3, 13), (4, 10), (5, 8), (6, 13), (7, 10)):
+            outs = [torch.full((oD,), float("nan"), device=DEV) for _ in range(n)]
+            ea.bucketMulGroup([(devf(hv[i % 3]), ewf, None, outs[i], (0.25, 0.5, 0.1)[i % 3]) for i in range(n)], gpu=g)
+            g.eval()
+            assert [len(g.slice_counts(i)) for i in range(n)] == [slices] * n, (n, len(g.slice_counts(0)))
+            for i in range(n):
                 wantf, cntf, cutf = wants[i % 3]
                 assert g.last_dispatch_count(i) == cntf and g.last_cutoff(i) == cutf and close(outs[i].cpu().numpy(), wantf), (n, i)
     finally:
