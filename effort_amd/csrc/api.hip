@@ -629,9 +629,31 @@ static uint32_t q4_one_round(const effort_ctx* c, uint32_t inDim, uint32_t group
     const uint32_t S = (uint32_t)c->numCU * 15u / 8u / groupTiles1;      // 480 items on 256 CUs
     return S >= sMin && S >= 2u ? S : 0u;
 }
+// Q4 groups of 3 .. 9 calls on a context without lanes: ONE item per CU -- the tallest slices (>= the slices a workgroup's LDS allows) whose items, counted on the
+// padded ranges the XCDs are dealt from (a call's range is a multiple of 8; item % 8 is the XCD), still number at most the CUs.  A launch of one round lasts as long
+// as its tallest item, and the first item past one per CU shares its CU for the whole launch: 3 calls of 4096x11008 at 8 slices (144 items of 512 rows) 30.2 us,
+// 12 slices (216 of 342) 26.2, 14 slices (252 items, 264 padded) 30.9; 6 calls at 8 slices (288 items) 40.1, at 6 (240 padded) 35.5; 8 calls at E = 2 x 8 (192 fat items)
+// 43.7, at E = 1 x 5 (256 padded) 39.5; 8 calls of 4096x4096 at E = 2 x 8 (64 items!) 42.5, at E = 1 x 16 (256) 24.8; 5 x (14336 -> 4096) at 32 slices (320 items) 56.5,
+// at 24 (240) 37.9 (round 6, third session, profiles/r06_one_round_groups.txt).  Returns the slices per call, or 0 when such a round does not exist.
+static uint32_t q4_one_per_cu(const effort_ctx* c, uint32_t inDim, uint32_t tiles1, int n, uint32_t groupTiles1) {
+    if (c->nLanes > 1 || c->tuneS || n < 3 || n > 9) return 0;
+    const uint32_t sMin = (inDim + 831u) / 832u, hi = ((inDim + 127u) / 128u + 7u) / 8u * 8u;
+    const bool same = !groupTiles1 || groupTiles1 == (uint32_t)n * tiles1;          // (a mixed group: every call's padding bounded by 7)
+    auto fits = [&](uint32_t s) {
+        return same ? (uint32_t)n * ((tiles1 * s + 7u) / 8u * 8u) <= (uint32_t)c->numCU : groupTiles1 * s + 7u * (uint32_t)n <= (uint32_t)c->numCU;
+    };
+    uint32_t S = sMin > 2u ? sMin : 2u;
+    if (!fits(S)) return 0;
+    while (S < hi && fits(S + 1u)) S++;
+    return S;
+}
 static uint32_t pick_slices(const effort_ctx* c, const effort_w* w, int groupSize, int E, uint32_t groupTiles = 0, bool fill = true) {
     const uint32_t tiles = (w->cols + 64 * E - 1) / (64 * E);
     const uint32_t lo = ((w->inDim + 511) / 512 + 7) / 8 * 8, hi = ((w->inDim + 127) / 128 + 7) / 8 * 8;
+    if (w->fmt != kFp16 && E == 1 && fill) {
+        const uint32_t S = q4_one_per_cu(c, w->inDim, tiles, groupSize, groupTiles);
+        if (S) return S;
+    }
     if (w->fmt != kFp16 && E == 1 && groupSize >= 8 && groupTiles) {       // (pick_elems chose E = 1 for this Q4 group: q4_one_round)
         const uint32_t S = q4_one_round(c, w->inDim, groupTiles);
         if (S) return S;
@@ -640,7 +662,7 @@ static uint32_t pick_slices(const effort_ctx* c, const effort_w* w, int groupSiz
     // matrices are 8 x 2 tiles x 8 slices = 128 items on 256 CUs.  FP16 groups then take the small groups' rule below (about 3/4 of an item per CU; it
     // never goes under `lo`): 8 x 4096x4096 31.8 -> 24.8 us per launch at 16 slices (32 slices: 28.7; E = 1 x 16: 27.6; E = 4 x 32: 29.7 -- round 6, third
     // session, profiles/r06_small_matrix_groups.txt).  `fill` = false: the count pick_elems prices its choice of E with (unchanged: E is chosen as before).
-    if (groupSize >= 8 && (w->fmt != kFp16 || !fill)) return lo;
+    if (groupSize >= 8 && (w->fmt != kFp16 || !fill || c->nLanes > 1)) return lo;     // (with launches in flight on lanes the other launches fill the idle CUs: fat items stay -- 8 x 4096x4096, four in flight: 14.7 us per launch at 8 slices, 15.7 at 16)
     // (64-column tiles -- narrow matrices, see pick_elems -- are worked best at one item per CU: measured, 14336 -> 4096 lone, 64 slices
     //  26.9 us against 29.2 at 48)
     // (Q4 small groups are worked at E = 1 whatever the shape and want the 3/4 too -- round 6, a pair of 4096x11008 calls: 16 slices = 192 items 23.2 us
@@ -669,7 +691,7 @@ static uint32_t pick_slices(const effort_ctx* c, const effort_w* w, int groupSiz
     // % 8 is the XCD, so each call puts ceil(items / 8) on XCD 0 -- 7 calls of 33 items are 231 items but 35 on XCD 0's 32 CUs, and the launch takes 69 us
     // where 30 items per call take 45 (round 6, third session, profiles/r06_one_round_groups.txt).  Lone calls and pairs -- the decode loop's launches,
     // re-swept in round 6 -- keep the rule above.
-    if (w->fmt == kFp16 && fill && groupSize >= 3) {
+    if (w->fmt == kFp16 && fill && groupSize >= 3 && c->nLanes <= 1) {          // (four launches in flight: 3 calls of 4096x11008 13.4 us per launch at 8 slices, 15.0 at 13)
         const bool same = allTiles == (uint32_t)groupSize * tiles;          // (a mixed group: every call's padding bounded by 7)
         auto fits = [&](uint32_t s) {
             return same ? (uint32_t)groupSize * ((tiles * s + 7u) / 8u * 8u) <= (uint32_t)c->numCU : allTiles * s + 7u * (uint32_t)groupSize <= (uint32_t)c->numCU;
@@ -688,6 +710,15 @@ static int pick_elems(const effort_ctx* c, Format fmt, int n, const effort_w* co
     if (c->tuneE) return c->tuneE;
     if (fmt != kFp16) {      // measured, 4096x11008 Q4: 32 calls 5.3 vs 6.4 us/call, 8 calls 8.3 vs 8.3, 2 calls 20.8 vs 18.8
         if (n < 8) return 1;
+        if (n < 10) {        // (8 / 9 calls: one E = 1 item per CU where that fits: q4_one_per_cu)
+            uint32_t t1 = 0, inDim = 0, tMax = 0;
+            bool same = true;
+            for (int i = 0; i < n; i++) if (ws[i]) {
+                const uint32_t t = (ws[i]->cols + 63u) / 64u;
+                t1 += t; same = same && (tMax == 0 || t == tMax); tMax = tMax > t ? tMax : t; inDim = inDim > ws[i]->inDim ? inDim : ws[i]->inDim;
+            }
+            if (q4_one_per_cu(c, inDim, tMax, n, same ? 0u : t1)) return 1;
+        }
         if (n >= 10) {       // (one round of narrow, tall items where that fits: q4_one_round)
             uint32_t t1 = 0, inDim = 0;
             for (int i = 0; i < n; i++) if (ws[i]) { t1 += (ws[i]->cols + 63u) / 64u; inDim = inDim > ws[i]->inDim ? inDim : ws[i]->inDim; }
@@ -725,7 +756,7 @@ static int pick_elems(const effort_ctx* c, Format fmt, int n, const effort_w* co
     if (f2 < 0.8 * best) return 1;
     // 3..7 calls of BIG matrices whose E = 2 items overflow one round of CUs even at the fewest slices (6 calls of 4096x11008: 6 x 6 tiles x 8 = 288 items, the 32
     // over the 256 CUs run as a round of their own) while E = 4 items fit: E = 4, and pick_slices then fills the round (18 tiles x 13 slices = 234 items)
-    if (n >= 3 && f4 >= 0.8 * best) {
+    if (n >= 3 && f4 >= 0.8 * best && c->nLanes <= 1) {
         uint32_t lo2 = 0, lo4 = 0;
         for (int i = 0; i < n; i++) if (ws[i]) {
             const uint32_t lo = ((ws[i]->inDim + 511u) / 512u + 7u) / 8u * 8u;

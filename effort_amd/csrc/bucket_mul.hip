@@ -944,9 +944,12 @@ __device__ __forceinline__ void mul_item(const GroupKArgs& ga, const uint32_t it
         }
     };
     // the rows' cache policy: non-temporal, or -- the host says the launches in flight read the SAME matrices (effort_set_row_reuse) -- the ordinary one
-    const bool rowsReused = kRowAux != 0 && (ga.split & 8u) != 0u;                 // uniform per launch
+    // (the second copy lives in the kernels that serve GROUP launches -- the persistent instantiations and the E = 4 plain ones; the lean E = 1 / E = 2 kernels a
+    //  lone call runs keep one policy: with two copies they were 0.1-0.3 us slower per call on the default path, profiles/r06_ab_row_reuse.txt)
+    constexpr bool kRowSwitch = kRowAux != 0 && (PERSIST || E == 4);
+    const bool rowsReused = kRowSwitch && (ga.split & 8u) != 0u;                   // uniform per launch
     auto stream = [&](auto withOl) {
-        if constexpr (kRowAux != 0) { if (rowsReused) { stream_rows(withOl, std::integral_constant<int, 0>{}); return; } }
+        if constexpr (kRowSwitch) { if (rowsReused) { stream_rows(withOl, std::integral_constant<int, 0>{}); return; } }
         stream_rows(withOl, std::integral_constant<int, kRowAux>{});
     };
     if constexpr (kOlMerge) { if (olEarly) stream(std::true_type{}); else stream(std::false_type{}); }

@@ -88,7 +88,9 @@ EFFORT_API int effort_join(effort_ctx* ctx);
  * for a caller whose launches in flight read the SAME matrices within a few hundred MB of one another (a batch of inputs on one set of
  * weights, through effort_set_overlap lanes or several contexts): the later launches then hit in the Infinity Cache (four launches in flight
  * on one set of 32 matrices: 117 us per launch against 130).  Speed only: results are bit-identical either way.  Takes effect with the next
- * launch (a captured launch keeps the policy it was captured with). */
+ * launch (a captured launch keeps the policy it was captured with).  The second policy lives in the kernels that serve GROUP launches (persistent grids,
+ * and plain grids of 256-column tiles): lone calls, pairs and plain launches of narrower tiles ignore the hint (two copies of the loop cost them 0.1-0.3 us
+ * per call on the default path). */
 EFFORT_API int effort_set_row_reuse(effort_ctx* ctx, int reuse);
 /* Text of the context's last error; with ctx == NULL: why the last effort_create returned NULL ("null context" if none did). */
 EFFORT_API const char* effort_last_error(effort_ctx* ctx);

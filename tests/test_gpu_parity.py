@@ -1342,7 +1342,9 @@ def test_geometry_rules_of_round_six(ea, oracle_cpu, q4_11008):
     v = make_v(inDim, seed=41)
     want, cnt, cutoff = oracle_cpu.bucket_mul_q4(v, L["buckets"], L["bucket.stats"], L["probes"], L["outliers"], inDim, outDim, 0.25)
     try:
-        for lanes, n, slices in ((1, 16, 5), (4, 16, 8), (1, 2, 16), (1, 12, 6), (1, 32, 8)):
+        # (third session: Q4 groups of 3 .. 9 calls without lanes take one E = 1 item per CU, counted on the padded item ranges: 3 calls 13 slices, 6 calls 6, 8 calls 5;
+        #  9 calls do not fit such a round and stay at E = 2 x 8; with lanes 3 calls keep 8)
+        for lanes, n, slices in ((1, 16, 5), (4, 16, 8), (1, 2, 16), (1, 12, 6), (1, 32, 8), (1, 3, 13), (1, 6, 6), (1, 8, 5), (1, 9, 8), (4, 3, 8)):
             g.set_overlap(lanes)
             outs = [torch.full((outDim,), float("nan"), device=DEV) for _ in range(n)]
             ea.bucketMulGroup([(devf(v), ew, None, o, 0.25) for o in outs], gpu=g)
@@ -1397,7 +1399,9 @@ def test_geometry_rules_of_round_six(ea, oracle_cpu, q4_11008):
         # even at 8 slices) at 13 / 10 slices; 5 calls stay at E = 2 x 8 (240 items)
         oD, iD = 11008, 4096
         wants = [oracle_cpu.bucket_mul(hv[i], b, s, p, iD, oD, e) for i, e in enumerate((0.25, 0.5, 0.1))]
-        for n, slices in ((3, 13), (4, 10), (5, 8), (6, 13), (7, 10)):
+        for n, slices in ((3, 13), (4, 10), (5, 8), (6, 13), (7, 10), (-3, 8)):          # (-3: three calls on a context WITH lanes keep the 8 fat slices)
+            g.set_overlap(4 if n < 0 else 1)
+            n = abs(n)
             outs = [torch.full((oD,), float("nan"), device=DEV) for _ in range(n)]
             ea.bucketMulGroup([(devf(hv[i % 3]), ewf, None, outs[i], (0.25, 0.5, 0.1)[i % 3]) for i in range(n)], gpu=g)
             g.eval()
