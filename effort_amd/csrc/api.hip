@@ -696,7 +696,13 @@ static uint32_t pick_slices(const effort_ctx* c, const effort_w* w, int groupSiz
         auto fits = [&](uint32_t s) {
             return same ? (uint32_t)groupSize * ((tiles * s + 7u) / 8u * 8u) <= (uint32_t)c->numCU : allTiles * s + 7u * (uint32_t)groupSize <= (uint32_t)c->numCU;
         };
-        while (S < hi && fits(S + 1u)) S++;
+        if (fits(S)) while (S < hi && fits(S + 1u)) S++;
+        else {      // the rule above went OVER one item per CU (the power-of-two snap: 9 x (8192 -> 4096) 24 -> 32 slices = 288 items, 62.9 us against 46.1 at 24; the `hi`
+                    // bound: 9 x (4096 -> 1024) at 32 slices 20.6 us, at 24 18.9): the most slices that fit, if any do
+            uint32_t s2 = S;
+            while (s2 > lo && !fits(s2)) s2--;
+            if (fits(s2)) S = s2;
+        }
     }
     return S;
 }
@@ -1030,7 +1036,7 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
     // two thin calls, or four times the slices: never better (a thin item pays the same head and hand-off for half the rows); E = 4 launches (32 calls: 149.0 ->
     // 150.8), persistent grids (151 -> 157) and launches in flight on lanes (a launch's tail runs under the next one's head; round 2: 124.3 -> 125.8): worse, off.
     int thinFrom = n;                                     // calls [thinFrom, n) take twice the slices
-    if (fmt == kFp16 && groupE == 2 && n >= 11 && !laned && !c->tuneS && c->persistent < 0) {
+    if (fmt == kFp16 && groupE == 2 && n >= 8 && !laned && !c->tuneS && c->persistent < 0) {
         uint32_t base = 0, extra = 0;
         MulGeom seen[kMaxGeoms + 1];                       // the launch descriptor holds kMaxGeoms shapes: the thin ones must not split the launch
         uint32_t nSeen = 0;
