@@ -650,8 +650,8 @@ static uint32_t q4_one_per_cu(const effort_ctx* c, uint32_t inDim, uint32_t tile
 static uint32_t pick_slices(const effort_ctx* c, const effort_w* w, int groupSize, int E, uint32_t groupTiles = 0, bool fill = true) {
     const uint32_t tiles = (w->cols + 64 * E - 1) / (64 * E);
     const uint32_t lo = ((w->inDim + 511) / 512 + 7) / 8 * 8, hi = ((w->inDim + 127) / 128 + 7) / 8 * 8;
-    if (w->fmt != kFp16 && E == 1 && fill) {
-        const uint32_t S = q4_one_per_cu(c, w->inDim, tiles, groupSize, groupTiles);
+    if (w->fmt != kFp16 && (E == 1 || groupSize >= 8) && fill) {       // (8 / 9 calls that do not fit one E = 1 item per CU run at E = 2: one of THOSE per CU then -- 9 x (14336 ->
+        const uint32_t S = q4_one_per_cu(c, w->inDim, tiles, groupSize, groupTiles);     //  4096): 32 slices = 288 items 78.4 us, 24 = 216 items 56.1; 9 x (4096 -> 14336): 8 slices 64.4, 6: 54.8)
         if (S) return S;
     }
     if (w->fmt != kFp16 && E == 1 && groupSize >= 8 && groupTiles) {       // (pick_elems chose E = 1 for this Q4 group: q4_one_round)
