@@ -774,7 +774,11 @@ static int pick_elems(const effort_ctx* c, Format fmt, int n, const effort_w* co
     // own last arriver (measured, us per launch at 25 %: Wq|Wk|Wv 21.2 vs 23.8, 14336 -> 4096 lone 26.6-27.5 vs 29.7)
     bool narrow = true;
     for (int i = 0; i < n; i++) narrow = narrow && (!ws[i] || ws[i]->cols <= 256u);
-    if (narrow && f1 >= 0.8 * best) return 1;
+    // (... for launches that have the chip to themselves, and for lone calls.  GROUPS on a context with lanes -- launches in flight beside one another, the CUs
+    //  never short of items -- want the fatter 128-column tiles: four in flight, us per launch E = 1 / E = 2: 14336 -> 4096 x 2 / 3 / 4 / 6 calls 14.7 / 13.0, 21.6 / 16.9,
+    //  28.6 / 22.3, 44.6 / 31.7; 4096x4096 x 2 / 3 / 4 / 6: 7.7 / 6.7, 10.9 / 7.8, 10.7 / 10.2, 13.1 / 11.8; lone calls 9.7 / 10.0 and 5.4 / 5.9 -- round 6, third session,
+    //  profiles/r06_one_round_groups.txt)
+    if (narrow && f1 >= 0.8 * best && !(c->nLanes > 1 && n >= 3)) return 1;      // (pairs keep the lone calls' tiles: -11 % left on the table, and a pair's bits do not depend on the lanes)
     return (i2 * 10u < numCU * 3u / 4u * 6u && items(1) > i2) ? 1 : 2;
 }
 

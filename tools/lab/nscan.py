@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--ns", default="1,2,3,4,5,6,7,8,9,10,11,12,14,16,20,24,28,32")
     ap.add_argument("--q4", type=int, default=0)
     ap.add_argument("--mats", type=int, default=0)
+    ap.add_argument("--overlap", type=int, default=1, help="K > 1: effort_set_overlap(K) -- the launches of a replay are independent and up to K are in flight")
     args = ap.parse_args()
     inDim, outDim = (int(x) for x in args.shape.split("x"))
     import effort_amd as ea
@@ -35,12 +36,16 @@ def main():
     v = torch.randn(inDim, generator=gen, device=dev)
     outs = [torch.zeros(outDim, device=dev) for _ in ews]
     keep = []
+    if args.overlap > 1:
+        g.set_overlap(args.overlap)
     for n in ns:
         chunks = [list(range(i, i + n)) for i in range(0, nm - n + 1, n)]
 
         def run():
             for ch in chunks:
                 ea.bucketMulGroup([(v, ews[k], None, outs[k], args.effort) for k in ch])
+            if args.overlap > 1:
+                g.join()
         run()
         torch.cuda.synchronize()
         gr = torch.cuda.CUDAGraph()
@@ -58,7 +63,7 @@ def main():
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / reps / len(chunks)
         sl = len(g.slice_counts(0)), len(g.slice_counts(n - 1))
-        print(f"{args.shape} effort {args.effort} q4 {args.q4} n {n:2d}: {dt * 1e6:8.2f} us/launch {dt * 1e6 / n:7.2f} us/call  slices {sl[0]}/{sl[1]}", flush=True)
+        print(f"{args.shape} effort {args.effort} q4 {args.q4}{' lanes ' + str(args.overlap) if args.overlap > 1 else ''} n {n:2d}: {dt * 1e6:8.2f} us/launch {dt * 1e6 / n:7.2f} us/call  slices {sl[0]}/{sl[1]}", flush=True)
 
 
 if __name__ == "__main__":
