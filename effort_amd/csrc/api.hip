@@ -778,6 +778,16 @@ static int pick_elems(const effort_ctx* c, Format fmt, int n, const effort_w* co
     //  never short of items -- want the fatter 128-column tiles: four in flight, us per launch E = 1 / E = 2: 14336 -> 4096 x 2 / 3 / 4 / 6 calls 14.7 / 13.0, 21.6 / 16.9,
     //  28.6 / 22.3, 44.6 / 31.7; 4096x4096 x 2 / 3 / 4 / 6: 7.7 / 6.7, 10.9 / 7.8, 10.7 / 10.2, 13.1 / 11.8; lone calls 9.7 / 10.0 and 5.4 / 5.9 -- round 6, third session,
     //  profiles/r06_one_round_groups.txt)
+    if (narrow && f1 >= 0.8 * best && n >= 3 && c->nLanes <= 1 && f2 >= 0.8 * best) {
+        // ... unless the 64-column tiles overflow ONE round of CUs even at the fewest slices while the 128-column tiles fit it (tall narrow matrices: 3 calls of 11008 -> 4096
+        // are 3 x 4 tiles x 24 slices = 288 items, at E = 2 144 -- and pick_slices then fills the round: 35.6 -> 27.9 us per launch, 4 / 5 calls -15 / -7 %, 3 x (14336 -> 4096) -12 %)
+        uint32_t p1 = 0, p2 = 0;
+        for (int i = 0; i < n; i++) if (ws[i]) {
+            const uint32_t lo = ((ws[i]->inDim + 511u) / 512u + 7u) / 8u * 8u;
+            p1 += ((ws[i]->cols + 63u) / 64u * lo + 7u) / 8u * 8u; p2 += ((ws[i]->cols + 127u) / 128u * lo + 7u) / 8u * 8u;
+        }
+        if (p1 > numCU && p2 <= numCU) return 2;
+    }
     if (narrow && f1 >= 0.8 * best && !(c->nLanes > 1 && n >= 3)) return 1;      // (pairs keep the lone calls' tiles: -11 % left on the table, and a pair's bits do not depend on the lanes)
     return (i2 * 10u < numCU * 3u / 4u * 6u && items(1) > i2) ? 1 : 2;
 }
