@@ -1049,31 +1049,46 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
     // +4.5 %, 16 calls of a 4096x4096 matrix (256 items: not even one round) +12 %.  More than
     // two thin calls, or four times the slices: never better (a thin item pays the same head and hand-off for half the rows); E = 4 launches (32 calls: 149.0 ->
     // 150.8), persistent grids (151 -> 157) and launches in flight on lanes (a launch's tail runs under the next one's head; round 2: 124.3 -> 125.8): worse, off.
+    // HOW MANY calls: enough that the thin calls' items cover the stragglers (the items past the last whole round), at least two, at most four -- 24 Q4 calls of 24
+    // items are 64 over a round: two thin calls (48 items) 93.7 -> 92.6 us, four (96) 86.3.  Q4 (E = 2 launches past one round of two workgroups per CU are PERSISTENT
+    // grids on a context without lanes: the queue hands the items out in call order just the same): 22 / 24 calls of 4096x11008 93.0 -> 84.9 / 93.7 -> 86.3 us, 17 / 18 x
+    // (4096 -> 14336) 90.0 -> 83.1 / 91.0 -> 83.8, 24 calls at 50 % effort 139.6 -> 128.7; 26 calls (112 over) level.
     int thinFrom = n;                                     // calls [thinFrom, n) take twice the slices
-    if (fmt == kFp16 && groupE == 2 && n >= 8 && !laned && !c->tuneS && c->persistent < 0) {
-        uint32_t base = 0, extra = 0;
-        MulGeom seen[kMaxGeoms + 1];                       // the launch descriptor holds kMaxGeoms shapes: the thin ones must not split the launch
-        uint32_t nSeen = 0;
+    if (groupE == 2 && n >= 8 && !laned && !c->tuneS && c->persistent < 0) {
+        uint32_t base = 0, it1[kMaxGroup];
         bool ok = true;
-        auto note = [&](const MulGeom& g) {
-            uint32_t k = 0;
-            while (k < nSeen && memcmp(&seen[k], &g, sizeof(g)) != 0) k++;
-            if (k == nSeen) { if (nSeen == kMaxGeoms) ok = false; else seen[nSeen++] = g; }
-        };
         for (int i = 0; ok && i < n; i++) {
-            MulGeom g1, g2; int Wi, Ei;
-            memset(&g1, 0, sizeof(g1)); memset(&g2, 0, sizeof(g2));
+            MulGeom g1; int Wi, Ei;
+            memset(&g1, 0, sizeof(g1));
             ok = choose_geom(c, ws[i], n, groupE, &g1, &Wi, &Ei, 1, groupTiles) == EFFORT_OK;
-            const uint32_t it1 = (g1.tiles * g1.slices + 7u) / 8u * 8u;
-            base += it1;
-            if (ok && i >= n - 2) {
-                ok = choose_geom(c, ws[i], n, groupE, &g2, &Wi, &Ei, 2, groupTiles) == EFFORT_OK && g2.slices > g1.slices;
-                extra += (g2.tiles * g2.slices + 7u) / 8u * 8u - it1;
-                if (ok) note(g2);
-            } else if (ok) note(g1);
+            it1[i] = (g1.tiles * g1.slices + 7u) / 8u * 8u;
+            base += it1[i];
         }
-        const uint32_t round = 2u * (uint32_t)c->numCU;
-        if (ok && base > round && base + extra <= 6u * (uint32_t)c->numCU && base % round != 0u && base % round * 32u <= round * 7u) thinFrom = n - 2;
+        const uint32_t round = 2u * (uint32_t)c->numCU, over = ok ? base % round : 0u;
+        // (FP16 stays a plain grid up to six items per CU; Q4 past one round is a persistent grid whatever its size)
+        if (ok && base > round && over != 0u && over * 32u <= round * 7u && (fmt != kFp16 || base <= 6u * (uint32_t)c->numCU)) {
+            int tc = 0;
+            uint32_t thin = 0;
+            while (tc < n && tc < 4 && (tc < 2 || thin < over)) thin += it1[n - 1 - tc++];
+            // the thin geometries: they must exist (more slices than the call has) and fit the launch descriptor's kMaxGeoms shapes beside the others
+            MulGeom seen[kMaxGeoms + 1];
+            uint32_t nSeen = 0, extra = 0;
+            auto note = [&](const MulGeom& g) {
+                uint32_t k = 0;
+                while (k < nSeen && memcmp(&seen[k], &g, sizeof(g)) != 0) k++;
+                if (k == nSeen) { if (nSeen == kMaxGeoms) ok = false; else seen[nSeen++] = g; }
+            };
+            ok = thin >= over;
+            for (int i = 0; ok && i < n; i++) {
+                MulGeom g; int Wi, Ei;
+                memset(&g, 0, sizeof(g));
+                const bool t = i >= n - tc;
+                ok = choose_geom(c, ws[i], n, groupE, &g, &Wi, &Ei, t ? 2u : 1u, groupTiles) == EFFORT_OK;
+                if (ok && t) { const uint32_t it2 = (g.tiles * g.slices + 7u) / 8u * 8u; ok = it2 > it1[i]; extra += it2 - it1[i]; }
+                if (ok) note(g);
+            }
+            if (ok && (fmt != kFp16 || base + extra <= 6u * (uint32_t)c->numCU)) thinFrom = n - tc;
+        }
     }
     begin(0);
     for (int i = 0; i < n; i++) {
