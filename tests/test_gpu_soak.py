@@ -42,7 +42,7 @@ def test_randomized_soak(ea, oracle_cpu):
     try:
         while time.time() < t_end or trials < 4:
             q4 = bool(rng.integers(3) == 0)
-            n = int(rng.choice([1, 1, 2, 3, 5, 9, 12, 16, 17, 32]))       # (12, 16: Q4's one-round rule -- slice counts that are not multiples of 8)
+            n = int(rng.choice([1, 1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 12, 13, 16, 17, 22, 24, 32]))       # (12, 16: Q4's one-round rule; 3 .. 9: the one-item-per-CU rounds, any slice count; 8 .. 13, 22, 24: thin last calls)
             tune = [(0, 0, 0), (0, 0, 0), (0, 0, 0), (8, 1, 0), (8, 2, 24), (16, 2, 0)][int(rng.integers(6))]
             lanes = int(rng.choice([1, 1, 4]))
             g.set_overlap(lanes)
