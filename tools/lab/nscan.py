@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--ns", default="1,2,3,4,5,6,7,8,9,10,11,12,14,16,20,24,28,32")
     ap.add_argument("--q4", type=int, default=0)
     ap.add_argument("--mats", type=int, default=0)
+    ap.add_argument("--mix", default="", help="comma list of shapes sharing one inDim (e.g. 4096x4096,4096x1024,4096x1024 = Wq | Wk | Wv): a launch of n calls cycles through them")
     ap.add_argument("--overlap", type=int, default=1, help="K > 1: effort_set_overlap(K) -- the launches of a replay are independent and up to K are in flight")
     args = ap.parse_args()
     inDim, outDim = (int(x) for x in args.shape.split("x"))
@@ -30,11 +31,22 @@ def main():
     g = ea.gpu(0)
     ns = [int(x) for x in args.ns.split(",")]
     nm = args.mats or max(32, min(96, (1 << 31) // (inDim * outDim * 2)))          # enough matrices that a launch does not find its rows in the caches
-    ews = make_weights(ea, nm, inDim, outDim, 1234, dev, keep_core=False, q4=bool(args.q4))
+    if args.mix:
+        shapes = [tuple(int(x) for x in sh.split("x")) for sh in args.mix.split(",")]
+        assert all(sh[0] == shapes[0][0] for sh in shapes)
+        inDim = shapes[0][0]
+        nm = args.mats or 48
+        per = [make_weights(ea, (nm + len(shapes) - 1) // len(shapes), sh[0], sh[1], 1234 + 100 * k, dev, keep_core=False, q4=bool(args.q4)) for k, sh in enumerate(shapes)]
+        ews = [per[i % len(shapes)][i // len(shapes)] for i in range(nm)]
+        outs_dim = [shapes[i % len(shapes)][1] for i in range(nm)]
+        args.shape = "mix(" + args.mix + ")"
+    else:
+        ews = make_weights(ea, nm, inDim, outDim, 1234, dev, keep_core=False, q4=bool(args.q4))
+        outs_dim = [outDim] * nm
     gen = torch.Generator(device=dev)
     gen.manual_seed(42)
     v = torch.randn(inDim, generator=gen, device=dev)
-    outs = [torch.zeros(outDim, device=dev) for _ in ews]
+    outs = [torch.zeros(outs_dim[i], device=dev) for i in range(len(ews))]
     keep = []
     if args.overlap > 1:
         g.set_overlap(args.overlap)
