@@ -756,7 +756,19 @@ static int pick_elems(const effort_ctx* c, Format fmt, int n, const effort_w* co
     if (n >= 8) {
         const uint32_t i4 = items(4);
         if (((i4 > numCU / 2 && i4 <= numCU) || i4 >= 3u * numCU) && f4 >= 0.8 * best) return 4;
-        return f2 >= 0.8 * best ? 2 : 1;
+        if (f2 >= 0.8 * best) return 2;
+        // 64-column tiles because 128-column ones would leave lanes idle (k sequences' Wq | Wk | Wv: 4096 + 1024 + 1024 outputs fill 3/4 of their 128-column tiles) --
+        // unless the 64-column items outnumber the CUs at the fewest slices and the 128-column ones do not: a launch of one item per CU at 3/4 lane fill beats a
+        // second round (6 / 7 / 8 sequences, 18 / 21 / 24 calls: 37.6 -> 32.7 / 39.3 -> 33.8 / 39.7 -> 34.0 us per launch; 10 sequences overflow either way and stay)
+        if (c->nLanes <= 1 && f2 >= 0.7 * best) {
+            uint32_t p1 = 0, p2 = 0;
+            for (int i = 0; i < n; i++) if (ws[i]) {
+                const uint32_t lo = ((ws[i]->inDim + 511u) / 512u + 7u) / 8u * 8u;
+                p1 += ((ws[i]->cols + 63u) / 64u * lo + 7u) / 8u * 8u; p2 += ((ws[i]->cols + 127u) / 128u * lo + 7u) / 8u * 8u;
+            }
+            if (p1 > numCU && p2 <= numCU) return 2;
+        }
+        return 1;
     }
     const uint32_t i2 = items(2);
     if (f2 < 0.8 * best) return 1;

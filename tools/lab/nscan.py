@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--q4", type=int, default=0)
     ap.add_argument("--mats", type=int, default=0)
     ap.add_argument("--mix", default="", help="comma list of shapes sharing one inDim (e.g. 4096x4096,4096x1024,4096x1024 = Wq | Wk | Wv): a launch of n calls cycles through them")
+    ap.add_argument("--tune", default="0,0,0", help="waves,elems,slices (effort_set_tuning; 0 = the heuristic)")
     ap.add_argument("--overlap", type=int, default=1, help="K > 1: effort_set_overlap(K) -- the launches of a replay are independent and up to K are in flight")
     args = ap.parse_args()
     inDim, outDim = (int(x) for x in args.shape.split("x"))
@@ -48,6 +49,7 @@ def main():
     v = torch.randn(inDim, generator=gen, device=dev)
     outs = [torch.zeros(outs_dim[i], device=dev) for i in range(len(ews))]
     keep = []
+    g.set_tuning(*(int(x) for x in args.tune.split(",")))
     if args.overlap > 1:
         g.set_overlap(args.overlap)
     for n in ns:
