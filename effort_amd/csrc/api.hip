@@ -72,6 +72,9 @@ struct effort_ctx {
     // tuning overrides (0 = heuristic)
     int tuneW = 0, tuneE = 0, tuneS = 0;
     bool splitCutoff = false;     // run findCutoff32 as its own 1-workgroup kernel instead of inside every workgroup
+    mutable bool thinEffort = false;   // the launch being cut streams next to nothing (mean effort under 8 %): the rules that RAISE the slice count of a group stand down
+                                       // (do_group sets it before the geometry is chosen; at 2 % effort 3 / 6 / 8 calls of 4096x11008 at 13 / 13 / 10 slices are 9 / 14 / 10 % SLOWER
+                                       // than at 8 -- more slabs and heads, nothing to stream -- where at 10 % they are 6 / 5 / 0 % faster and at 100 % 28 / 28 / 6 %)
     bool rowReuse = false;        // effort_set_row_reuse: the bucket-row stream with the ordinary cache policy instead of nt (GroupKArgs::split bit 3)
     // optional per-kernel timing
     bool timing = false;          // HIP events around each kernel
@@ -644,7 +647,8 @@ static uint32_t q4_one_per_cu(const effort_ctx* c, uint32_t inDim, uint32_t tile
     };
     uint32_t S = sMin > 2u ? sMin : 2u;
     if (!fits(S)) return 0;
-    while (S < hi && fits(S + 1u)) S++;
+    const uint32_t top = c->thinEffort ? ((inDim + 511u) / 512u + 7u) / 8u * 8u : hi;      // (next to nothing to stream: no more slices than the small groups' minimum)
+    while (S < top && S < hi && fits(S + 1u)) S++;
     return S;
 }
 static uint32_t pick_slices(const effort_ctx* c, const effort_w* w, int groupSize, int E, uint32_t groupTiles = 0, bool fill = true) {
@@ -662,7 +666,7 @@ static uint32_t pick_slices(const effort_ctx* c, const effort_w* w, int groupSiz
     // matrices are 8 x 2 tiles x 8 slices = 128 items on 256 CUs.  FP16 groups then take the small groups' rule below (about 3/4 of an item per CU; it
     // never goes under `lo`): 8 x 4096x4096 31.8 -> 24.8 us per launch at 16 slices (32 slices: 28.7; E = 1 x 16: 27.6; E = 4 x 32: 29.7 -- round 6, third
     // session, profiles/r06_small_matrix_groups.txt).  `fill` = false: the count pick_elems prices its choice of E with (unchanged: E is chosen as before).
-    if (groupSize >= 8 && (w->fmt != kFp16 || !fill || c->nLanes > 1)) return lo;     // (with launches in flight on lanes the other launches fill the idle CUs: fat items stay -- 8 x 4096x4096, four in flight: 14.7 us per launch at 8 slices, 15.7 at 16)
+    if (groupSize >= 8 && (w->fmt != kFp16 || !fill || c->nLanes > 1 || c->thinEffort)) return lo;     // (with launches in flight on lanes the other launches fill the idle CUs: fat items stay -- 8 x 4096x4096, four in flight: 14.7 us per launch at 8 slices, 15.7 at 16)
     // (64-column tiles -- narrow matrices, see pick_elems -- are worked best at one item per CU: measured, 14336 -> 4096 lone, 64 slices
     //  26.9 us against 29.2 at 48)
     // (Q4 small groups are worked at E = 1 whatever the shape and want the 3/4 too -- round 6, a pair of 4096x11008 calls: 16 slices = 192 items 23.2 us
@@ -696,7 +700,7 @@ static uint32_t pick_slices(const effort_ctx* c, const effort_w* w, int groupSiz
         auto fits = [&](uint32_t s) {
             return same ? (uint32_t)groupSize * ((tiles * s + 7u) / 8u * 8u) <= (uint32_t)c->numCU : allTiles * s + 7u * (uint32_t)groupSize <= (uint32_t)c->numCU;
         };
-        if (fits(S)) while (S < hi && fits(S + 1u)) S++;
+        if (fits(S)) { if (!c->thinEffort) while (S < hi && fits(S + 1u)) S++; }
         else {      // the rule above went OVER one item per CU (the power-of-two snap: 9 x (8192 -> 4096) 24 -> 32 slices = 288 items, 62.9 us against 46.1 at 24; the `hi`
                     // bound: 9 x (4096 -> 1024) at 32 slices 20.6 us, at 24 18.9): the most slices that fit, if any do
             uint32_t s2 = S;
@@ -872,6 +876,7 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
         if (pre < 0 || pre > 2 || (pre && (!vAux || !vAux[i]))) return fail(c, EFFORT_ERR_ARG, "bucketmul: bad input prologue");
         if (pre && (fmt != kFp16 || c->splitCutoff)) return fail(c, EFFORT_ERR_KIND, "bucketmul: input prologues need FP16 weights and the fused cutoff");
     }
+    { double sum = 0.0; for (int i = 0; i < n; i++) sum += efforts[i]; c->thinEffort = sum < 0.08 * n; }
     const int groupE = pick_elems(c, fmt, n, ws);         // columns per lane: one choice for a group launch
     const bool tm = c->timing && c->nSamples < effort_ctx::kMaxSamples;
     hipEvent_t* ev = tm ? c->ev + 4 * c->nSamples : nullptr;
@@ -1066,7 +1071,7 @@ static int do_group(effort_ctx* c, Format fmt, int n, const effort_w* const* ws,
     // grids on a context without lanes: the queue hands the items out in call order just the same): 22 / 24 calls of 4096x11008 93.0 -> 84.9 / 93.7 -> 86.3 us, 17 / 18 x
     // (4096 -> 14336) 90.0 -> 83.1 / 91.0 -> 83.8, 24 calls at 50 % effort 139.6 -> 128.7; 26 calls (112 over) level.
     int thinFrom = n;                                     // calls [thinFrom, n) take twice the slices
-    if (groupE == 2 && n >= 8 && !laned && !c->tuneS && c->persistent < 0) {
+    if (groupE == 2 && n >= 8 && !laned && !c->tuneS && c->persistent < 0 && !c->thinEffort) {
         uint32_t base = 0, it1[kMaxGroup];
         bool ok = true;
         for (int i = 0; ok && i < n; i++) {
